@@ -1,0 +1,270 @@
+/*
+ * mvs.h — C-ABI of the MI355X-native SRT + node-driven deformation engine.
+ *
+ * Drop-in boundary for the three solver classes the reference's Processor
+ * uses by value (there is no FFI layer upstream):
+ *
+ *   SRTSolver      R/Solver/SRTSolver.h:8-39      -> mvs_srt_*
+ *   Camera         R/Camera/Camera.h:44-49        -> struct mvs_camera, mvs_depth_*
+ *   Deformation    R/Deformation/Deformation.h:224-252 -> mvs_deform_*
+ *   SRT glue       R/Processor/Processor.cpp:819-823,979-982,1021-1027,1183-1184
+ *                                                 -> mvs_srt_compose / _relative / _apply
+ *
+ * (R/ = /root/reference/MultiViewStitch/.)  Plain pointers and sizes only; no
+ * C++ / torch types.  Every entry returns an int status (MVS_OK == 0,
+ * negatives enumerated below) where the reference prints to std::cerr and
+ * calls exit(-1) (R/Deformation/Deformation.cpp:41-45,393-397).
+ *
+ * Buffer conventions (SURVEY.md §8b "Buffer layout / ownership"):
+ *   - points / normals : AoS double[3] per element, 24-byte stride — the
+ *     memory of std::vector<Eigen::Vector3d>::data().
+ *   - faces            : int32[3*F], 0-based (R/Deformation/Deformation.h:72-78).
+ *   - matches          : double[6] per match = {p.xyz, q.xyz}, the memory of
+ *     std::vector<std::pair<Vector3d,Vector3d>> (R/Solver/SRTSolver.h:36).
+ *   - 3x3 matrices     : ROW-major double[9], M[3*i+j] = M(i,j), i.e. the
+ *     `double R[3][3]` overload (R/Solver/SRTSolver.cpp:266-268).
+ *   - the caller owns every buffer; the callee copies inputs to HBM at the
+ *     call and writes outputs into caller buffers.
+ * Pointers named *_dev are DEVICE (HBM) pointers, everything else is host.
+ *
+ * The library needs a gfx950 GPU; with none present every compute entry
+ * returns MVS_E_NO_DEVICE.  There is no CPU fallback.
+ */
+#ifndef MVS_H_
+#define MVS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVS_ABI_VERSION 1
+
+enum mvs_status {
+    MVS_OK            =  0,
+    MVS_E_INVALID_ARG = -1,  /* null pointer, negative size, bad enum          */
+    MVS_E_BAD_MESH    = -2,  /* index out of range / degenerate facet          */
+    MVS_E_NONMANIFOLD = -3,  /* CGAL builder would reject: Deformation.cpp:38-45 */
+    MVS_E_NO_DEVICE   = -4,  /* no HIP device                                   */
+    MVS_E_HIP         = -5,  /* HIP runtime error, see mvs_last_error()         */
+    MVS_E_OOM         = -6,
+    MVS_E_SOLVER      = -7,  /* global solve failed (Deformation.cpp:393-397)   */
+    MVS_E_STATE       = -8,  /* call order violated (e.g. no target set)        */
+    MVS_E_DEGENERATE  = -9   /* fewer than 3 matches etc.                       */
+};
+
+const char* mvs_last_error(void);     /* thread-local message of the last failure */
+int  mvs_abi_version(void);
+int  mvs_device_count(void);          /* 0 when no GPU; never fails               */
+int  mvs_set_device(int device);      /* device used by handles created afterwards */
+int  mvs_device_name(char* buf, int buflen);
+
+/* ---------------------------------------------------------------- camera -- */
+/* R/Camera/Camera.h:44-49.  Only fx,fy,cx,cy of K are read by the path
+ * (R/Camera/Camera.cpp:40-48).  R row-major as Camera.cpp:68-72 indexes it:
+ * Xc = R*Xw + t. */
+typedef struct mvs_camera {
+    double  fx, fy, cx, cy;
+    double  R[9];
+    double  t[3];
+    int32_t w, h;
+} mvs_camera;
+
+/* ------------------------------------------------------------ depth (a2) -- */
+/* Depth2Model::SaveModel (R/Depth2Model/Depth2Model.cpp:7-81) followed by
+ * Mesh::CalculateVertexNormals (R/PlyObj/PlyObj.cpp:139-185):
+ * float32 inverse-depth raster (R/Common/Utils.h:166-176) -> compacted world
+ * points (row-major pixel order), their PlyObj-style vertex normals, pixel
+ * index per point (texIndex) and the <=2 triangles per 2x2 quad.
+ * min_dsp/max_dsp = Depth2Model ctor args; smooth = m_fSmoothThreshold.
+ * Call with out_* == NULL to get the counts only.  faces may be NULL. */
+int mvs_depth_to_model(const float* inv_depth, const mvs_camera* cam,
+                       double min_dsp, double max_dsp, double smooth,
+                       int64_t* n_points, int64_t* n_faces,
+                       double* out_points, double* out_normals,
+                       int32_t* out_tex_index, int32_t* out_faces);
+
+/* Image3D::SolveUnProjectionD (R/Image3D/Image3D.cpp:92-106): dense w*h
+ * points + valid mask, no compaction. */
+int mvs_depth_unproject(const float* inv_depth, const mvs_camera* cam,
+                        double min_dsp, double max_dsp,
+                        double* out_points /* w*h*3 */, uint8_t* out_valid /* w*h */);
+
+/* ------------------------------------------------------------ SRT (a3-a9) -- */
+enum mvs_srt_mode {
+    MVS_SRT_CLOSED_FORM = 0,  /* EstimateTransform(double&,Matrix3d&,Vector3d&)  SRTSolver.cpp:272-275 */
+    MVS_SRT_RANSAC      = 1   /* EstimateTransformRansac / array overload        SRTSolver.cpp:256-270,277-280 */
+};
+
+/* One fit.  `triples` = iters*3 match indices replacing the reference's
+ * rand()-driven Shuffle (R/Common/Utils.h:25-34); NULL
+ * -> generated from `seed` with the MSVC rand() LCG + Shuffle.  Cameras are
+ * read only by the RANSAC score / residual (SRTSolver.cpp:6-29).
+ * residual (optional) = ResidualError(scale,R,t) of the returned transform. */
+int mvs_srt_fit(const double* matches, int64_t n,
+                const mvs_camera* cam1, const mvs_camera* cam2,
+                int mode, const int32_t* triples, int iters, uint32_t seed,
+                double* scale, double* R /*9*/, double* t /*3*/, double* residual);
+
+/* SRTSolver::ResidualError (SRTSolver.cpp:6-29); per_match (optional, n*2)
+ * receives err1,err2 per match — what Processor::RemoveOutliers thresholds
+ * (R/Processor/Processor.cpp:207-246). */
+int mvs_srt_residual(const double* matches, int64_t n,
+                     const mvs_camera* cam1, const mvs_camera* cam2,
+                     double scale, const double* R, const double* t,
+                     double* mean_err, double* per_match);
+
+/* Processor::RemoveOutliers (Processor.cpp:177-269): <=3 rounds of
+ * RANSAC(iters) -> per-match pixel errors -> keep both <= pixel_err*ratio.
+ * keep (n bytes) receives the surviving mask.  Each round draws its triples
+ * from the MSVC rand() LCG + Shuffle (R/Common/Utils.h:25-34); rand_state is
+ * the LCG state (srand seed) in, advanced state out. */
+int mvs_srt_remove_outliers(const double* matches, int64_t n,
+                            const mvs_camera* cam1, const mvs_camera* cam2,
+                            int iters, double pixel_err, double adapt_ratio,
+                            uint32_t* rand_state,
+                            uint8_t* keep, int64_t* n_keep, double* err);
+
+/* Fill triples with the reference's generator: MSVC rand() LCG driving
+ * Shuffle(idx, n, 3) (R/Common/Utils.h:25-34).  state in/out. */
+int mvs_srt_make_triples(int64_t n, int iters, uint32_t* state, int32_t* triples);
+
+/* Chain composition, Processor.cpp:819-823: (s0,R0,t0) <- (sk,Rk,tk) o (s0,R0,t0). */
+int mvs_srt_compose(double sk, const double* Rk, const double* tk,
+                    double* s0, double* R0, double* t0);
+/* Cross-sequence map k -> k0, Processor.cpp:979-982. */
+int mvs_srt_relative(double s_k0, const double* R_k0, const double* t_k0,
+                     double s_k,  const double* R_k,  const double* t_k,
+                     double* s, double* R, double* t);
+/* Point map over P points (+normals, may be NULL):
+ * forward  v = s R p + t, n' = R n          (Processor.cpp:1021-1027)
+ * inverse  p = (1/s) R^T (v - t), n' = R^T n (Processor.cpp:1183-1184). */
+int mvs_srt_apply(const double* pts, const double* normals, int64_t P,
+                  double s, const double* R, const double* t, int inverse,
+                  double* out_pts, double* out_normals);
+/* Same map, device pointers (zero-copy from mvs_depth_* device output). */
+int mvs_srt_apply_dev(const double* pts_dev, const double* normals_dev, int64_t P,
+                      double s, const double* R, const double* t, int inverse,
+                      double* out_pts_dev, double* out_normals_dev, void* hip_stream);
+
+/* ----------------------------------------------------- Deformation (a16-a22) */
+typedef struct mvs_deform_s* mvs_deform_t;
+
+typedef struct mvs_deform_params {
+    double  proj_len_err;    /* Deform(...,projLenErr,...)  = 100.0  Processor.cpp:1136 */
+    double  proj_dist_err;   /* Deform(...,projDistErr)     = 100.0                      */
+    double  min_cos;         /* 0.1     Deformation.cpp:353                               */
+    int32_t max_result;      /* 10000   Deformation.cpp:244                               */
+    int32_t top_k;           /* 8       Deformation.cpp:338 (<= 8)                        */
+    int32_t graph_k;         /* 8  -> 9-NN incl. self, w = 1/9   Deformation.cpp:359,143  */
+    int32_t smooth_sweeps;   /* 2       Deformation.cpp:362                               */
+    int32_t arap_iters;      /* 5       Deformation.cpp:398                               */
+    double  arap_tol;        /* 1e-4    Deformation.cpp:398                               */
+    double  cg_tol;          /* relative residual of the global solve (build's own; the
+                                reference factorises with SparseLU inside CGAL)          */
+    int32_t cg_max_iters;    /* safety cap                                                */
+    int32_t update_normals;  /* 0: keep ctor normals for every outer iteration as the
+                                reference does (Deformation.cpp:34,304); 1: recompute
+                                (Deformation.h:86-128) after each outer iteration        */
+} mvs_deform_params;
+
+void mvs_deform_default_params(mvs_deform_params* p);
+
+typedef struct mvs_deform_stats {
+    int32_t outer_done;
+    int32_t arap_iters_run;   /* of the last outer iteration           */
+    int32_t cg_iters;         /* per global solve (fixed per handle)   */
+    int32_t n_valid;          /* nodes with isValid (Deformation.cpp:355) */
+    double  energy[8];        /* ARAP energy after each iteration      */
+    double  cg_rel_residual;  /* worst over the solves of the last outer iteration */
+} mvs_deform_stats;
+
+/* Deformation(points,normals,facets)  R/Deformation/Deformation.cpp:29-46.
+ * Validity: indices in range, no repeated vertex in a facet, no directed edge
+ * used twice and no edge with >2 facets (what Polyhedron_incremental_builder_3
+ * + is_valid() reject, Deformation.h:65-79) -> MVS_E_BAD_MESH / _NONMANIFOLD. */
+int mvs_deform_create(int64_t V, const double* points, const double* normals,
+                      int64_t F, const int32_t* faces, mvs_deform_t* out);
+int mvs_deform_destroy(mvs_deform_t h);
+
+/* UniformSampling()  Deformation.cpp:63-106 (knn = 16). Exact NN on float32
+ * coordinates.  K receives sampIdx.size(). */
+int mvs_deform_sample_nodes(mvs_deform_t h, int knn, int64_t* K);
+int mvs_deform_set_nodes(mvs_deform_t h, const int32_t* vertex_idx, int64_t K);
+int mvs_deform_get_nodes(mvs_deform_t h, int32_t* vertex_idx /*K*/);
+int mvs_deform_sizes(mvs_deform_t h, int64_t* V, int64_t* F, int64_t* K, int64_t* P);
+
+/* Target point set of this rank (Deform(tpts,tnormals,..) arguments,
+ * Deformation.cpp:232-246): float32 spatial index built on the GPU.
+ * index_base = global index of pts[0] (ties between equal keys break on the
+ * global index so a sharded run reproduces the single-device result). */
+int mvs_deform_set_target(mvs_deform_t h, int64_t P, const double* pts,
+                          const double* normals, int64_t index_base);
+int mvs_deform_set_target_dev(mvs_deform_t h, int64_t P, const double* pts_dev,
+                              const double* normals_dev, int64_t index_base);
+
+/* One or more passes of the while(counter--) body, Deformation.cpp:253-401:
+ * associate -> 9-NN graph -> 2 Jacobi sweeps -> ARAP(arap_iters, arap_tol) ->
+ * overwrite_initial_geometry. */
+int mvs_deform_iterate(mvs_deform_t h, const mvs_deform_params* p, int n_outer,
+                       mvs_deform_stats* stats);
+
+/* The same body split at its exchange points for view-sharded targets
+ * (one process per GPU).  All *_dev buffers are caller-owned
+ * HBM (torch tensors) so the collective runs on them directly:
+ *   1. _assoc_dmin   : d2min_dev[K] float  <- local 1-NN squared distance  (then all-reduce MIN)
+ *   2. _assoc_select : local best <=top_k candidates inside the global ball
+ *                      -> records_dev[K*8] (mvs_cand), counts_dev[K*2] int32
+ *                      {ball population, survivors of the normal test}     (then all-gather)
+ *   3. _assoc_merge  : merge nranks record sets -> node targets + isValid
+ *   4. _solve        : graph smoothing + ARAP + geometry update (replicated) */
+typedef struct mvs_cand {      /* 48 bytes */
+    double  proj_dist;
+    double  proj_len;
+    double  pos[3];
+    int64_t index;             /* global target index, -1 = empty slot */
+} mvs_cand;
+
+int mvs_deform_assoc_dmin(mvs_deform_t h, const mvs_deform_params* p, float* d2min_dev);
+int mvs_deform_assoc_select(mvs_deform_t h, const mvs_deform_params* p,
+                            const float* d2min_dev, mvs_cand* records_dev, int32_t* counts_dev);
+int mvs_deform_assoc_merge(mvs_deform_t h, const mvs_deform_params* p,
+                           const mvs_cand* records_all_dev, const int32_t* counts_all_dev,
+                           int nranks);
+int mvs_deform_solve(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stats* stats);
+int mvs_deform_sync(mvs_deform_t h);            /* wait for the handle's stream */
+void* mvs_deform_stream(mvs_deform_t h);        /* hipStream_t of the handle     */
+
+/* Read-back (host buffers). */
+int mvs_deform_get_vertices(mvs_deform_t h, double* pts /*V*3*/);
+int mvs_deform_get_normals(mvs_deform_t h, double* normals /*V*3*/);
+int mvs_deform_get_rotations(mvs_deform_t h, double* R /*V*9 row-major*/);
+/* controls[] / isValid[] after association (+ smoothing if smoothed != 0),
+ * Deformation.cpp:262-264,355-356,378-380.  Optional debug outputs:
+ * d2min (K float), counts (K*2 int32), top_idx (K*8 int64, -1 padded). */
+int mvs_deform_get_node_targets(mvs_deform_t h, int smoothed, double* controls /*K*3*/,
+                                uint8_t* valid /*K*/, float* d2min, int32_t* counts,
+                                int64_t* top_idx);
+int mvs_deform_get_node_graph(mvs_deform_t h, int32_t* nbr /*K*(graph_k+1)*/);
+/* exportOBJ's normals (Deformation.h:86-150,174-191) for the current geometry. */
+int mvs_deform_compute_normals(mvs_deform_t h, double* normals /*V*3*/);
+
+/* Stand-alone pieces of the body (parity tests / callers that only need one):
+ * KNearestNeighbor on arbitrary points (Deformation.cpp:108-153) and the
+ * CGAL-equivalent ARAP solve with explicit constraints (Deformation.cpp:383-400). */
+int mvs_knn_points(const double* pts, int64_t n, int k, int32_t* out_idx /*n*k*/);
+int mvs_deform_arap(mvs_deform_t h, const mvs_deform_params* p,
+                    const double* ctrl_targets /*K*3, for the handle's nodes*/,
+                    mvs_deform_stats* stats);
+
+/* Kernel timing of the last mvs_deform_iterate / _solve call, measured with
+ * hipEvents on the handle's stream (bench.py's roofline object).  names:
+ * "assoc", "graph", "smooth", "weights", "rhs", "cg", "local", "finalize". */
+int mvs_deform_kernel_time(mvs_deform_t h, const char* name, double* total_ms, int64_t* launches);
+int mvs_deform_enable_timing(mvs_deform_t h, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVS_H_ */

@@ -1,0 +1,353 @@
+"""ctypes binding of the CPU oracle (oracle/libmvs_oracle.so).
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("R", C.c_double * 9), ("t", C.c_double * 3), ("w", C.c_int32), ("h", C.c_int32)]
+
+    @classmethod
+    def of(cls, cam):
+        c = cls()
+        c.fx, c.fy, c.cx, c.cy, c.w, c.h = cam.fx, cam.fy, cam.cx, cam.cy, cam.w, cam.h
+        c.R[:] = list(np.asarray(cam.R, dtype=np.float64).reshape(9))
+        c.t[:] = list(np.asarray(cam.t, dtype=np.float64).reshape(3))
+        return c
+
+
+class Params(C.Structure):
+    _fields_ = [("proj_len_err", C.c_double), ("proj_dist_err", C.c_double), ("min_cos", C.c_double),
+                ("max_result", C.c_int32), ("top_k", C.c_int32), ("graph_k", C.c_int32),
+                ("smooth_sweeps", C.c_int32), ("arap_iters", C.c_int32),
+                ("arap_tol", C.c_double), ("cg_tol", C.c_double),
+                ("cg_max_iters", C.c_int32), ("update_normals", C.c_int32)]
+
+    @classmethod
+    def default(cls, **kw):
+        p = cls(100.0, 100.0, 0.1, 10000, 8, 8, 2, 5, 1e-4, 1e-10, 2000, 0)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+
+CAND_DTYPE = np.dtype([("proj_dist", "<f8"), ("proj_len", "<f8"), ("pos", "<f8", (3,)), ("index", "<i8")])
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libmvs_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        L = _LIB
+        L.orc_target_create.restype = C.c_void_p
+        L.orc_deform_create.restype = C.c_void_p
+        L.orc_uniform_sampling.restype = C.c_int64
+        L.orc_deform_sample_nodes.restype = C.c_int64
+        L.orc_srt_residual.restype = C.c_double
+    return _LIB
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+# ---------------------------------------------------------------- math ----
+def svd3(A):
+    A = _c(A, np.float64)
+    U, S, V = np.empty((3, 3)), np.empty(3), np.empty((3, 3))
+    lib().orc_svd3(_p(A), _p(U), _p(S), _p(V))
+    return U, S, V
+
+
+def closest_rotation(cov):
+    cov = _c(cov, np.float64)
+    R = np.empty((3, 3))
+    lib().orc_closest_rotation(_p(cov), _p(R))
+    return R
+
+
+# --------------------------------------------------------------- depth ----
+def depth_to_model(dsp, cam, min_dsp, max_dsp, smooth):
+    dsp = _c(dsp, np.float32)
+    cc = Camera.of(cam)
+    npnt, nf = C.c_int64(), C.c_int64()
+    L = lib()
+    L.orc_depth_to_model(_p(dsp), C.byref(cc), C.c_double(min_dsp), C.c_double(max_dsp), C.c_double(smooth),
+                         C.byref(npnt), C.byref(nf), None, None, None, None)
+    P, F = npnt.value, nf.value
+    pts, nrm = np.empty((P, 3)), np.empty((P, 3))
+    tex, faces = np.empty(P, np.int32), np.empty((F, 3), np.int32)
+    L.orc_depth_to_model(_p(dsp), C.byref(cc), C.c_double(min_dsp), C.c_double(max_dsp), C.c_double(smooth),
+                         C.byref(npnt), C.byref(nf), _p(pts), _p(nrm), _p(tex), _p(faces))
+    return pts, nrm, tex, faces
+
+
+def depth_unproject(dsp, cam, min_dsp, max_dsp):
+    dsp = _c(dsp, np.float32)
+    cc = Camera.of(cam)
+    pts = np.empty((cam.h * cam.w, 3))
+    valid = np.empty(cam.h * cam.w, np.uint8)
+    lib().orc_depth_unproject(_p(dsp), C.byref(cc), C.c_double(min_dsp), C.c_double(max_dsp), _p(pts), _p(valid))
+    return pts, valid
+
+
+def vertex_normals(pts, faces, kind="cgal"):
+    pts, faces = _c(pts, np.float64), _c(faces, np.int32)
+    out = np.empty_like(pts)
+    fn = lib().orc_vertex_normals_cgal if kind == "cgal" else lib().orc_vertex_normals_plyobj
+    fn(C.c_int64(len(pts)), _p(pts), C.c_int64(len(faces)), _p(faces), _p(out))
+    return out
+
+
+# ----------------------------------------------------------------- SRT ----
+def srt_make_triples(n, iters, state):
+    st = C.c_uint32(state)
+    tri = np.empty((iters, 3), np.int32)
+    lib().orc_srt_make_triples(C.c_int64(n), C.c_int(iters), C.byref(st), _p(tri))
+    return tri, st.value
+
+
+def srt_fit(matches, cam1, cam2, mode=0, triples=None, iters=0):
+    m = _c(matches, np.float64)
+    c1, c2 = Camera.of(cam1), Camera.of(cam2)
+    s, res = C.c_double(), C.c_double()
+    R, t = np.empty((3, 3)), np.empty(3)
+    tri = _c(triples, np.int32) if triples is not None else None
+    rc = lib().orc_srt_fit(_p(m), C.c_int64(len(m)), C.byref(c1), C.byref(c2), C.c_int(mode), _p(tri),
+                           C.c_int(iters), C.byref(s), _p(R), _p(t), C.byref(res))
+    if rc:
+        raise RuntimeError(f"orc_srt_fit -> {rc}")
+    return s.value, R, t, res.value
+
+
+def srt_residual(matches, cam1, cam2, s, R, t):
+    m = _c(matches, np.float64)
+    c1, c2 = Camera.of(cam1), Camera.of(cam2)
+    pm = np.empty((len(m), 2))
+    R, t = _c(R, np.float64), _c(t, np.float64)
+    e = lib().orc_srt_residual(_p(m), C.c_int64(len(m)), C.byref(c1), C.byref(c2), C.c_double(s), _p(R), _p(t), _p(pm))
+    return e, pm
+
+
+def srt_remove_outliers(matches, cam1, cam2, iters, pixel_err, adapt_ratio, state):
+    m = _c(matches, np.float64)
+    c1, c2 = Camera.of(cam1), Camera.of(cam2)
+    st, nk, err = C.c_uint32(state), C.c_int64(), C.c_double()
+    keep = np.zeros(len(m), np.uint8)
+    lib().orc_srt_remove_outliers(_p(m), C.c_int64(len(m)), C.byref(c1), C.byref(c2), C.c_int(iters),
+                                  C.c_double(pixel_err), C.c_double(adapt_ratio), C.byref(st), _p(keep),
+                                  C.byref(nk), C.byref(err))
+    return keep, nk.value, err.value, st.value
+
+
+def srt_compose(sk, Rk, tk, s0, R0, t0):
+    Rk, tk = _c(Rk, np.float64), _c(tk, np.float64)
+    R0, t0 = _c(R0, np.float64).copy(), _c(t0, np.float64).copy()
+    s = C.c_double(s0)
+    lib().orc_srt_compose(C.c_double(sk), _p(Rk), _p(tk), C.byref(s), _p(R0), _p(t0))
+    return s.value, R0, t0
+
+
+def srt_relative(s_k0, R_k0, t_k0, s_k, R_k, t_k):
+    a = [_c(x, np.float64) for x in (R_k0, t_k0, R_k, t_k)]
+    s, R, t = C.c_double(), np.empty((3, 3)), np.empty(3)
+    lib().orc_srt_relative(C.c_double(s_k0), _p(a[0]), _p(a[1]), C.c_double(s_k), _p(a[2]), _p(a[3]),
+                           C.byref(s), _p(R), _p(t))
+    return s.value, R, t
+
+
+def srt_apply(pts, nrm, s, R, t, inverse=False):
+    pts = _c(pts, np.float64)
+    nrm = _c(nrm, np.float64) if nrm is not None else None
+    R, t = _c(R, np.float64), _c(t, np.float64)
+    op = np.empty_like(pts)
+    on = np.empty_like(pts) if nrm is not None else None
+    lib().orc_srt_apply(_p(pts), _p(nrm), C.c_int64(len(pts)), C.c_double(s), _p(R), _p(t), C.c_int(int(inverse)),
+                        _p(op), _p(on))
+    return op, on
+
+
+# ---------------------------------------------------------- deformation ----
+def mesh_check(V, faces):
+    faces = _c(faces, np.int32)
+    return lib().orc_mesh_check(C.c_int64(V), C.c_int64(len(faces)), _p(faces))
+
+
+def uniform_sampling(pts, knn=16):
+    pts = _c(pts, np.float64)
+    out = np.empty(len(pts), np.int32)
+    K = lib().orc_uniform_sampling(C.c_int64(len(pts)), _p(pts), C.c_int(knn), _p(out))
+    return out[:K].copy()
+
+
+def knn_points(pts, k):
+    pts = _c(pts, np.float64)
+    out = np.empty((len(pts), k), np.int32)
+    lib().orc_knn_points(_p(pts), C.c_int64(len(pts)), C.c_int(k), _p(out))
+    return out
+
+
+class Target:
+    def __init__(self, pts, nrm, index_base=0):
+        self.pts, self.nrm = _c(pts, np.float64), _c(nrm, np.float64)
+        self.h = C.c_void_p(lib().orc_target_create(C.c_int64(len(self.pts)), _p(self.pts), _p(self.nrm),
+                                                    C.c_int64(index_base)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_target_destroy(self.h)
+            self.h = None
+
+    def associate(self, node_pts, node_nrm, params):
+        node_pts, node_nrm = _c(node_pts, np.float64), _c(node_nrm, np.float64)
+        K = len(node_pts)
+        ctrl, valid = np.empty((K, 3)), np.empty(K, np.uint8)
+        d2, cnt, top = np.empty(K, np.float32), np.empty((K, 2), np.int32), np.empty((K, 8), np.int64)
+        lib().orc_associate(self.h, C.c_int64(K), _p(node_pts), _p(node_nrm), C.byref(params), _p(ctrl),
+                            _p(valid), _p(d2), _p(cnt), _p(top))
+        return dict(controls=ctrl, valid=valid, d2min=d2, counts=cnt, top_idx=top)
+
+    def dmin(self, node_pts):
+        node_pts = _c(node_pts, np.float64)
+        d2 = np.empty(len(node_pts), np.float32)
+        lib().orc_assoc_dmin(self.h, C.c_int64(len(node_pts)), _p(node_pts), _p(d2))
+        return d2
+
+    def select(self, node_pts, node_nrm, params, d2min):
+        node_pts, node_nrm, d2min = _c(node_pts, np.float64), _c(node_nrm, np.float64), _c(d2min, np.float32)
+        K = len(node_pts)
+        rec = np.zeros((K, 8), CAND_DTYPE)
+        cnt = np.empty((K, 2), np.int32)
+        lib().orc_assoc_select(self.h, C.c_int64(K), _p(node_pts), _p(node_nrm), C.byref(params), _p(d2min),
+                               _p(rec), _p(cnt))
+        return rec, cnt
+
+
+def assoc_merge(node_pts, node_nrm, params, records_all, counts_all):
+    node_pts, node_nrm = _c(node_pts, np.float64), _c(node_nrm, np.float64)
+    rec = np.ascontiguousarray(records_all)
+    cnt = _c(counts_all, np.int32)
+    nranks, K = rec.shape[0], len(node_pts)
+    ctrl, valid, top = np.empty((K, 3)), np.empty(K, np.uint8), np.empty((K, 8), np.int64)
+    lib().orc_assoc_merge(C.c_int64(K), _p(node_pts), _p(node_nrm), C.byref(params), _p(rec), _p(cnt),
+                          C.c_int(nranks), _p(ctrl), _p(valid), _p(top))
+    return dict(controls=ctrl, valid=valid, top_idx=top)
+
+
+def smooth(orig, controls, nbr, sweeps=2):
+    orig, controls, nbr = _c(orig, np.float64), _c(controls, np.float64), _c(nbr, np.int32)
+    out = np.empty_like(orig)
+    lib().orc_smooth(C.c_int64(len(orig)), _p(orig), _p(controls), _p(nbr), C.c_int(nbr.shape[1]), C.c_int(sweeps), _p(out))
+    return out
+
+
+def cot_weights(pts, faces):
+    pts, faces = _c(pts, np.float64), _c(faces, np.int32)
+    V, F = len(pts), len(faces)
+    rowptr = np.empty(V + 1, np.int64)
+    col, w = np.empty(6 * F, np.int32), np.empty(6 * F)
+    lib().orc_cot_weights(C.c_int64(V), _p(pts), C.c_int64(F), _p(faces), _p(rowptr), _p(col), _p(w))
+    nnz = rowptr[-1]
+    return rowptr, col[:nnz].copy(), w[:nnz].copy()
+
+
+def arap(pts, faces, ctrl_idx, ctrl_targets, iters=5, tol=1e-4):
+    pts, faces = _c(pts, np.float64), _c(faces, np.int32)
+    ctrl_idx, ctrl_targets = _c(ctrl_idx, np.int32), _c(ctrl_targets, np.float64)
+    out, rot, en = np.empty_like(pts), np.empty((len(pts), 3, 3)), np.zeros(max(iters, 1))
+    it = lib().orc_arap(C.c_int64(len(pts)), _p(pts), C.c_int64(len(faces)), _p(faces), C.c_int64(len(ctrl_idx)),
+                        _p(ctrl_idx), _p(ctrl_targets), C.c_int(iters), C.c_double(tol), _p(out), _p(rot), _p(en))
+    if it < 0:
+        raise RuntimeError(f"orc_arap -> {it}")
+    return dict(pts=out, rot=rot, energies=en, iters=it)
+
+
+class Deform:
+    def __init__(self, pts, nrm, faces):
+        pts, nrm, faces = _c(pts, np.float64), _c(nrm, np.float64), _c(faces, np.int32)
+        self.V = len(pts)
+        h = lib().orc_deform_create(C.c_int64(len(pts)), _p(pts), _p(nrm), C.c_int64(len(faces)), _p(faces))
+        if not h:
+            raise ValueError("invalid mesh")
+        self.h = C.c_void_p(h)
+        self.K = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_deform_destroy(self.h)
+            self.h = None
+
+    def sample_nodes(self, knn=16):
+        self.K = lib().orc_deform_sample_nodes(self.h, C.c_int(knn))
+        return self.K
+
+    def set_nodes(self, idx):
+        idx = _c(idx, np.int32)
+        lib().orc_deform_set_nodes(self.h, _p(idx), C.c_int64(len(idx)))
+        self.K = len(idx)
+
+    def nodes(self):
+        out = np.empty(self.K, np.int32)
+        lib().orc_deform_get_nodes(self.h, _p(out))
+        return out
+
+    def set_target(self, pts, nrm):
+        pts, nrm = _c(pts, np.float64), _c(nrm, np.float64)
+        lib().orc_deform_set_target(self.h, C.c_int64(len(pts)), _p(pts), _p(nrm))
+
+    def iterate(self, params, n_outer=1):
+        it, nv = C.c_int32(), C.c_int32()
+        en = np.zeros(8)
+        rc = lib().orc_deform_iterate(self.h, C.byref(params), C.c_int(n_outer), C.byref(it), _p(en), C.byref(nv))
+        if rc:
+            raise RuntimeError(f"orc_deform_iterate -> {rc}")
+        return dict(arap_iters_run=it.value, energy=en, n_valid=nv.value)
+
+    def vertices(self):
+        out = np.empty((self.V, 3))
+        lib().orc_deform_get_vertices(self.h, _p(out))
+        return out
+
+    def normals(self):
+        out = np.empty((self.V, 3))
+        lib().orc_deform_get_normals(self.h, _p(out))
+        return out
+
+    def rotations(self):
+        out = np.empty((self.V, 3, 3))
+        lib().orc_deform_get_rotations(self.h, _p(out))
+        return out
+
+    def node_targets(self, smoothed=False):
+        c, v = np.empty((self.K, 3)), np.empty(self.K, np.uint8)
+        lib().orc_deform_get_node_targets(self.h, C.c_int(int(smoothed)), _p(c), _p(v))
+        return c, v

@@ -1,0 +1,446 @@
+// orc_geom.cpp — oracle: 3x3 SVD, camera, depth->model, normals, SRT.
+// TEST INFRASTRUCTURE ONLY (see mvs_oracle.h).  R/ = /root/reference/MultiViewStitch/.
+#include "mvs_oracle.h"
+#include "orc_math.h"
+#include <vector>
+#include <algorithm>
+#include <cstring>
+
+namespace orc {
+
+// ---------------------------------------------------------------- svd3 ----
+void svd3(const double* A, double* U, double* S, double* Vm) {
+    double B[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 9; ++i) B[i] = A[i];
+    static const int PQ[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        bool rotated = false;
+        for (int k = 0; k < 3; ++k) {
+            const int p = PQ[k][0], q = PQ[k][1];
+            double al = 0, be = 0, ga = 0;
+            for (int r = 0; r < 3; ++r) {
+                al += B[3 * r + p] * B[3 * r + p];
+                be += B[3 * r + q] * B[3 * r + q];
+                ga += B[3 * r + p] * B[3 * r + q];
+            }
+            if (ga == 0.0 || std::fabs(ga) <= 1e-17 * std::sqrt(al * be)) continue;
+            rotated = true;
+            const double zeta = (be - al) / (2.0 * ga);
+            const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+            for (int r = 0; r < 3; ++r) {
+                const double bp = B[3 * r + p], bq = B[3 * r + q];
+                B[3 * r + p] = c * bp - s * bq;
+                B[3 * r + q] = s * bp + c * bq;
+                const double vp = V[3 * r + p], vq = V[3 * r + q];
+                V[3 * r + p] = c * vp - s * vq;
+                V[3 * r + q] = s * vp + c * vq;
+            }
+        }
+        if (!rotated) break;
+    }
+    double sg[3];
+    int ord[3] = {0, 1, 2};
+    for (int j = 0; j < 3; ++j)
+        sg[j] = std::sqrt((B[j] * B[j] + B[3 + j] * B[3 + j]) + B[6 + j] * B[6 + j]);
+    // stable descending sort of three
+    if (sg[ord[0]] < sg[ord[1]]) std::swap(ord[0], ord[1]);
+    if (sg[ord[1]] < sg[ord[2]]) std::swap(ord[1], ord[2]);
+    if (sg[ord[0]] < sg[ord[1]]) std::swap(ord[0], ord[1]);
+    V3 b[3], v[3];
+    for (int j = 0; j < 3; ++j) {
+        const int c = ord[j];
+        S[j] = sg[c];
+        b[j] = {B[c], B[3 + c], B[6 + c]};
+        v[j] = {V[c], V[3 + c], V[6 + c]};
+    }
+    V3 u[3];
+    const double tiny = 1e-300;
+    if (S[0] <= tiny) {
+        u[0] = {1, 0, 0}; u[1] = {0, 1, 0}; u[2] = {0, 0, 1};
+    } else {
+        u[0] = b[0] / S[0];
+        if (S[1] > 1e-14 * S[0]) {
+            u[1] = b[1] / S[1];
+            // re-orthogonalise against u0 (no-op to rounding for well-conditioned input)
+            u[1] = u[1] - dot(u[1], u[0]) * u[0];
+            u[1] = u[1] / norm(u[1]);
+        } else {
+            // rank 1: deterministic completion — cross with the axis of the smallest |u0| component
+            V3 e = {1, 0, 0};
+            double ax = std::fabs(u[0].x), ay = std::fabs(u[0].y), az = std::fabs(u[0].z);
+            if (ay < ax && ay <= az) e = {0, 1, 0};
+            else if (az < ax && az < ay) e = {0, 0, 1};
+            u[1] = cross(u[0], e);
+            u[1] = u[1] / norm(u[1]);
+        }
+        u[2] = cross(u[0], u[1]);
+        if (dot(u[2], b[2]) < 0) u[2] = -1.0 * u[2];
+    }
+    for (int j = 0; j < 3; ++j) {
+        U[j] = u[j].x; U[3 + j] = u[j].y; U[6 + j] = u[j].z;
+        Vm[j] = v[j].x; Vm[3 + j] = v[j].y; Vm[6 + j] = v[j].z;
+    }
+}
+
+static void rot_from_svd(const double* U, const double* Vm, bool flip, double* R) {
+    // R = V * diag(1,1,flip?-1:1) * U^T
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const double a = Vm[3 * i] * U[3 * j], b = Vm[3 * i + 1] * U[3 * j + 1],
+                         c = Vm[3 * i + 2] * U[3 * j + 2];
+            R[3 * i + j] = (a + b) + (flip ? -c : c);
+        }
+}
+
+void closest_rotation(const double* cov, double* R) {
+    double U[9], S[3], Vm[9];
+    svd3(cov, U, S, Vm);
+    rot_from_svd(U, Vm, false, R);
+    if (det3(R) < 0) rot_from_svd(U, Vm, true, R);
+}
+
+// R/Solver/SRTSolver.cpp:109-119 — R = V U^T, reflection test |det+1| <= 1e-9.
+static void kabsch_rotation(const double* Smat, double* R) {
+    double U[9], S[3], Vm[9];
+    svd3(Smat, U, S, Vm);
+    rot_from_svd(U, Vm, false, R);
+    if (std::fabs(det3(R) + 1.0) <= 1e-9) rot_from_svd(U, Vm, true, R);
+}
+
+// -------------------------------------------------------------- camera ----
+static inline V3 cam_from_img(const orc_camera* c, int u, int v, double d) {  // Camera.cpp:40-44
+    return {(u - c->cx) * d / c->fx, (v - c->cy) * d / c->fy, d};
+}
+static inline V3 world_from_cam(const orc_camera* c, V3 pc) {                 // Camera.cpp:61-67
+    V3 tmp = {pc.x - c->t[0], pc.y - c->t[1], pc.z - c->t[2]};
+    return mulMtv(c->R, tmp);
+}
+static inline V3 cam_from_world(const orc_camera* c, V3 pw) {                 // Camera.cpp:68-72
+    const double* R = c->R;
+    return {((R[0] * pw.x + R[1] * pw.y) + R[2] * pw.z) + c->t[0],
+            ((R[3] * pw.x + R[4] * pw.y) + R[5] * pw.z) + c->t[1],
+            ((R[6] * pw.x + R[7] * pw.y) + R[8] * pw.z) + c->t[2]};
+}
+static inline void img_from_cam(const orc_camera* c, V3 p, int* u, int* v) {  // Camera.cpp:45-48
+    *u = cvt_i32(c->fx * p.x / p.z + c->cx + 0.5);
+    *v = cvt_i32(c->fy * p.y / p.z + c->cy + 0.5);
+}
+static inline void img_from_world(const orc_camera* c, V3 pw, int* u, int* v) {
+    img_from_cam(c, cam_from_world(c, pw), u, v);
+}
+
+}  // namespace orc
+using namespace orc;
+
+extern "C" {
+
+void orc_svd3(const double* A, double* U, double* S, double* Vm) { svd3(A, U, S, Vm); }
+void orc_closest_rotation(const double* cov, double* R) { closest_rotation(cov, R); }
+
+void orc_cam_img_to_world(const orc_camera* c, int u, int v, double d, double* pw) {
+    put(pw, world_from_cam(c, cam_from_img(c, u, v, d)));
+}
+void orc_cam_world_to_img(const orc_camera* c, const double* pw, int* u, int* v) {
+    img_from_world(c, v3(pw), u, v);
+}
+
+// ---------------------------------------------------------------- depth ----
+void orc_depth_unproject(const float* dsp, const orc_camera* cam, double min_dsp, double max_dsp,
+                         double* out_points, uint8_t* out_valid) {
+    // R/Image3D/Image3D.cpp:92-106
+    const int w = cam->w, h = cam->h;
+    for (int j = 0; j < h; ++j)
+        for (int i = 0; i < w; ++i) {
+            const double d = (double)dsp[j * w + i];
+            const int64_t o = (int64_t)j * w + i;
+            if (d < min_dsp || d > max_dsp) {
+                out_valid[o] = 0;
+                out_points[3 * o] = out_points[3 * o + 1] = out_points[3 * o + 2] = 0.0;
+            } else {
+                out_valid[o] = 1;
+                put(out_points + 3 * o, world_from_cam(cam, cam_from_img(cam, i, j, 1.0 / d)));
+            }
+        }
+}
+
+static void tri_normal_plyobj(V3 p0, V3 p1, V3 p2, V3* out) {   // R/PlyObj/PlyObj.cpp:172-185
+    V3 v1 = p1 - p0, v2 = p2 - p1;
+    if (norm(v1) <= 1e-6) v1 = 1e+9 * p1 - 1e+9 * p0;
+    if (norm(v2) <= 1e-6) v2 = 1e+9 * p2 - 1e+9 * p1;
+    V3 n = cross(v1, v2);
+    *out = n / norm(n);
+}
+
+void orc_vertex_normals_plyobj(int64_t V, const double* pts, int64_t F, const int32_t* faces, double* out) {
+    // R/PlyObj/PlyObj.cpp:139-170: mean of unit facet normals over the adjacent
+    // facets (facet order), then normalised.  No adjacent facet -> 0/0 = NaN.
+    std::vector<V3> sum(V, V3{0, 0, 0});
+    std::vector<int> cnt(V, 0);
+    for (int64_t f = 0; f < F; ++f) {
+        const int a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
+        V3 n;
+        tri_normal_plyobj(v3(pts + 3 * a), v3(pts + 3 * b), v3(pts + 3 * c), &n);
+        sum[a] = sum[a] + n; cnt[a]++;
+        sum[b] = sum[b] + n; cnt[b]++;
+        sum[c] = sum[c] + n; cnt[c]++;
+    }
+    for (int64_t i = 0; i < V; ++i) {
+        V3 m = sum[i] / (double)cnt[i];
+        put(out + 3 * i, m / norm(m));
+    }
+}
+
+void orc_vertex_normals_cgal(int64_t V, const double* pts, int64_t F, const int32_t* faces, double* out) {
+    // R/Deformation/Deformation.h:86-128: unit facet normals summed, / sqrt(n.n)
+    std::vector<V3> sum(V, V3{0, 0, 0});
+    for (int64_t f = 0; f < F; ++f) {
+        const int a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
+        V3 p1 = v3(pts + 3 * a), p2 = v3(pts + 3 * b), p3 = v3(pts + 3 * c);
+        V3 n = cross(p2 - p1, p3 - p1);
+        n = n / std::sqrt(dot(n, n));
+        sum[a] = sum[a] + n; sum[b] = sum[b] + n; sum[c] = sum[c] + n;
+    }
+    for (int64_t i = 0; i < V; ++i) put(out + 3 * i, sum[i] / std::sqrt(dot(sum[i], sum[i])));
+}
+
+int orc_depth_to_model(const float* dsp, const orc_camera* cam, double min_dsp, double max_dsp,
+                       double smooth, int64_t* n_points, int64_t* n_faces, double* out_points,
+                       double* out_normals, int32_t* out_tex, int32_t* out_faces) {
+    // R/Depth2Model/Depth2Model.cpp:26-77
+    const int w = cam->w, h = cam->h;
+    std::vector<int32_t> tab((size_t)w * h, 0);
+    std::vector<double> pts;
+    std::vector<int32_t> tex, faces;
+    int32_t tabNum = 0;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const double d = (double)dsp[y * w + x];
+            if (d > 0) {
+                if (d > max_dsp || d < min_dsp) continue;
+                tab[(size_t)y * w + x] = ++tabNum;
+                V3 p = world_from_cam(cam, cam_from_img(cam, x, y, 1.0 / d));
+                pts.push_back(p.x); pts.push_back(p.y); pts.push_back(p.z);
+                tex.push_back(y * w + x);
+            }
+        }
+    const float threshold = (float)(smooth * (max_dsp - min_dsp) / 100);
+    auto D = [&](int y, int x) { return (double)dsp[y * w + x]; };
+    auto T = [&](int y, int x) { return tab[(size_t)y * w + x]; };
+    for (int y = 0; y < h - 1; ++y)
+        for (int x = 0; x < w - 1; ++x) {
+            if (T(y, x) != 0 && T(y + 1, x + 1) != 0) {
+                if (T(y + 1, x) != 0 && std::fabs(D(y, x) - D(y + 1, x)) <= threshold &&
+                    std::fabs(D(y + 1, x + 1) - D(y + 1, x)) <= threshold &&
+                    std::fabs(D(y, x) - D(y + 1, x + 1)) <= threshold) {
+                    faces.push_back(T(y, x) - 1); faces.push_back(T(y + 1, x) - 1); faces.push_back(T(y + 1, x + 1) - 1);
+                }
+                if (T(y, x + 1) != 0 && std::fabs(D(y, x) - D(y, x + 1)) <= threshold &&
+                    std::fabs(D(y + 1, x + 1) - D(y, x + 1)) <= threshold &&
+                    std::fabs(D(y + 1, x + 1) - D(y, x)) <= threshold) {
+                    faces.push_back(T(y, x) - 1); faces.push_back(T(y + 1, x + 1) - 1); faces.push_back(T(y, x + 1) - 1);
+                }
+            }
+        }
+    *n_points = tabNum;
+    *n_faces = (int64_t)faces.size() / 3;
+    if (out_points) std::memcpy(out_points, pts.data(), pts.size() * sizeof(double));
+    if (out_tex) std::memcpy(out_tex, tex.data(), tex.size() * sizeof(int32_t));
+    if (out_faces) std::memcpy(out_faces, faces.data(), faces.size() * sizeof(int32_t));
+    if (out_normals) orc_vertex_normals_plyobj(tabNum, pts.data(), *n_faces, faces.data(), out_normals);
+    return 0;
+}
+
+// ------------------------------------------------------------------ SRT ----
+static void barycentres(const double* m, int64_t n, V3* b1, V3* b2) {
+    V3 c1 = {0, 0, 0}, c2 = {0, 0, 0};
+    for (int64_t i = 0; i < n; ++i) { c1 = c1 + v3(m + 6 * i); c2 = c2 + v3(m + 6 * i + 3); }
+    *b1 = c1 / (double)n; *b2 = c2 / (double)n;
+}
+
+static double estimate_scale(const double* m, int64_t n) {     // SRTSolver.cpp:31-46
+    V3 b1, b2;
+    barycentres(m, n, &b1, &b2);
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) s += norm(v3(m + 6 * i + 3) - b2) / norm(v3(m + 6 * i) - b1);
+    return s / (double)n;
+}
+
+double orc_srt_residual(const double* m, int64_t n, const orc_camera* c1, const orc_camera* c2,
+                        double scale, const double* R, const double* t, double* per_match) {
+    // SRTSolver.cpp:6-29.  scale*R and (1/scale)*R^T are formed first, as Eigen
+    // evaluates `scale * R * p1`.
+    double sR[9], iRt[9], Rt[9];
+    transp(R, Rt);
+    const double inv = 1.0 / scale;
+    for (int i = 0; i < 9; ++i) { sR[i] = scale * R[i]; iRt[i] = inv * Rt[i]; }
+    const V3 tt = v3(t);
+    double err = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        V3 p1 = v3(m + 6 * i), p2 = v3(m + 6 * i + 3);
+        V3 tp = mulMv(sR, p1) + tt;
+        int u1, v1, u2, v2, u1_, v1_, u2_, v2_;
+        img_from_world(c2, tp, &u1, &v1);
+        img_from_world(c2, p2, &u2, &v2);
+        V3 tp_ = mulMv(iRt, p2 - tt);
+        img_from_world(c1, tp_, &u2_, &v2_);
+        img_from_world(c1, p1, &u1_, &v1_);
+        const double e1 = pix_dist(u1, v1, u2, v2), e2 = pix_dist(u1_, v1_, u2_, v2_);
+        if (per_match) { per_match[2 * i] = e1; per_match[2 * i + 1] = e2; }
+        err = err + (e1 + e2) * 0.5;
+    }
+    return err / (double)n;
+}
+
+static void rt_from_S(const double* S, double scale, V3 b1, V3 b2, double* R, double* t) {
+    kabsch_rotation(S, R);
+    double sR[9];
+    for (int i = 0; i < 9; ++i) sR[i] = scale * R[i];
+    put(t, b2 - mulMv(sR, b1));                               // SRTSolver.cpp:120,176
+}
+
+int orc_srt_fit(const double* m, int64_t n, const orc_camera* c1, const orc_camera* c2, int mode,
+                const int32_t* triples, int iters, double* scale, double* R, double* t, double* residual) {
+    if (n < 1) return -9;
+    const double s = estimate_scale(m, n);
+    *scale = s;
+    V3 b1, b2;
+    barycentres(m, n, &b1, &b2);
+    std::vector<V3> X(n), Y(n);
+    for (int64_t i = 0; i < n; ++i) {                        // SRTSolver.cpp:76-79,143-146
+        V3 d = v3(m + 6 * i) - b1;
+        X[i] = {d.x * s, d.y * s, d.z * s};
+        Y[i] = v3(m + 6 * i + 3) - b2;
+    }
+    auto accum = [&](double* S, int64_t i) {
+        const double x[3] = {X[i].x, X[i].y, X[i].z}, y[3] = {Y[i].x, Y[i].y, Y[i].z};
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) S[3 * a + b] += x[a] * y[b];
+    };
+    if (mode == 0) {                                         // SRTSolver.cpp:94-120
+        double S[9] = {0};
+        for (int64_t i = 0; i < n; ++i) accum(S, i);
+        rt_from_S(S, s, b1, b2, R, t);
+    } else {                                                 // SRTSolver.cpp:148-184
+        if (n < 3 || !triples) return -9;
+        double best = HUGE_VAL;
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        std::memcpy(R, I, sizeof I); t[0] = t[1] = t[2] = 0;  // reference leaves these uninitialised
+        for (int k = 0; k < iters; ++k) {
+            double S[9] = {0}, R_[9], t_[3];
+            for (int j = 0; j < 3; ++j) accum(S, triples[3 * k + j]);
+            rt_from_S(S, s, b1, b2, R_, t_);
+            const double e = orc_srt_residual(m, n, c1, c2, s, R_, t_, nullptr);
+            if (e < best) { best = e; std::memcpy(R, R_, sizeof R_); std::memcpy(t, t_, sizeof t_); }
+        }
+    }
+    if (residual) *residual = (c1 && c2) ? orc_srt_residual(m, n, c1, c2, s, R, t, nullptr) : 0.0;
+    return 0;
+}
+
+static inline int msvc_rand(uint32_t* st) {
+    *st = *st * 214013u + 2531011u;
+    return (int)((*st >> 16) & 0x7fff);
+}
+void orc_srt_make_triples(int64_t n, int iters, uint32_t* state, int32_t* triples) {
+    // R/Common/Utils.h:25-34 Shuffle(k, n, 3) driven by MSVC rand()
+    for (int it = 0; it < iters; ++it) {
+        int k[3];
+        for (int i = 0; i < 3; ++i) {
+            int r = msvc_rand(state) % (int)(n - i), j, j0;
+            for (j = 0; j < i && r >= k[j]; j++) r++;
+            j0 = j;
+            for (j = i; j > j0; j--) k[j] = k[j - 1];
+            k[j0] = r;
+        }
+        triples[3 * it] = k[0]; triples[3 * it + 1] = k[1]; triples[3 * it + 2] = k[2];
+    }
+}
+
+}  // extern "C"
+
+extern "C" int orc_srt_remove_outliers(const double* matches, int64_t n, const orc_camera* c1,
+                                              const orc_camera* c2, int iters, double pixel_err,
+                                              double adapt_ratio, uint32_t* state, uint8_t* keep,
+                                              int64_t* n_keep, double* err_out) {
+    std::vector<double> cur(matches, matches + 6 * n);
+    std::vector<int64_t> id(n);
+    for (int64_t i = 0; i < n; ++i) id[i] = i;
+    int64_t size = n;
+    double ratio = 1.0, err = HUGE_VAL;
+    for (int k = 0; k < 3; ++k) {
+        if (size < 3) break;                                   // Shuffle needs n-i > 0 (reference would divide by 0)
+        std::vector<int32_t> tri((size_t)iters * 3);
+        orc_srt_make_triples(size, iters, state, tri.data());
+        double s, R[9], t[3];
+        orc_srt_fit(cur.data(), size, c1, c2, 1, tri.data(), iters, &s, R, t, nullptr);
+        std::vector<double> pm((size_t)size * 2);
+        orc_srt_residual(cur.data(), size, c1, c2, s, R, t, pm.data());
+        double err_all = 0.0;
+        int64_t newSize = 0;
+        for (int64_t i = 0; i < size; ++i) {
+            const double e1 = pm[2 * i], e2 = pm[2 * i + 1];
+            err_all += (e1 + e2) * 0.5;
+            if (e1 <= pixel_err * ratio && e2 <= pixel_err * ratio) {
+                for (int c = 0; c < 6; ++c) cur[6 * newSize + c] = cur[6 * i + c];
+                id[newSize++] = id[i];
+            }
+        }
+        ratio *= adapt_ratio;
+        err = err_all / (double)size;
+        size = newSize;
+        if (newSize < 3) break;                                // inlier_ratio is never written: Processor.cpp:193,258
+    }
+    std::memset(keep, 0, (size_t)n);
+    for (int64_t i = 0; i < size; ++i) keep[id[i]] = 1;
+    *n_keep = size;
+    *err_out = err;
+    return 0;
+}
+
+extern "C" {
+
+void orc_srt_compose(double sk, const double* Rk, const double* tk, double* s0, double* R0, double* t0) {
+    // Processor.cpp:819-823 (order: R, then t with the OLD t0, then s)
+    double Rn[9], sRk[9];
+    mulMM(Rk, R0, Rn);
+    for (int i = 0; i < 9; ++i) sRk[i] = sk * Rk[i];
+    V3 tn = mulMv(sRk, v3(t0)) + v3(tk);
+    std::memcpy(R0, Rn, sizeof Rn);
+    put(t0, tn);
+    *s0 = sk * *s0;
+}
+
+void orc_srt_relative(double s_k0, const double* R_k0, const double* t_k0, double s_k, const double* R_k,
+                      const double* t_k, double* s, double* R, double* t) {
+    // Processor.cpp:979-982
+    double Rt[9], M[9];
+    transp(R_k0, Rt);
+    *s = 1.0 / s_k0 * s_k;
+    mulMM(Rt, R_k, R);
+    const double inv = 1.0 / s_k0;
+    for (int i = 0; i < 9; ++i) M[i] = inv * Rt[i];
+    put(t, mulMv(M, v3(t_k) - v3(t_k0)));
+}
+
+void orc_srt_apply(const double* pts, const double* nrm, int64_t P, double s, const double* R,
+                   const double* t, int inverse, double* out_pts, double* out_nrm) {
+    double M[9], Rt[9];
+    transp(R, Rt);
+    const V3 tt = v3(t);
+    if (!inverse) {                                           // Processor.cpp:1025-1026
+        for (int i = 0; i < 9; ++i) M[i] = s * R[i];
+        for (int64_t i = 0; i < P; ++i) {
+            put(out_pts + 3 * i, mulMv(M, v3(pts + 3 * i)) + tt);
+            if (nrm) put(out_nrm + 3 * i, mulMv(R, v3(nrm + 3 * i)));
+        }
+    } else {                                                  // Processor.cpp:1183-1184
+        const double inv = 1.0 / s;
+        for (int i = 0; i < 9; ++i) M[i] = inv * Rt[i];
+        for (int64_t i = 0; i < P; ++i) {
+            put(out_pts + 3 * i, mulMv(M, v3(pts + 3 * i) - tt));
+            if (nrm) put(out_nrm + 3 * i, mulMv(Rt, v3(nrm + 3 * i)));
+        }
+    }
+}
+
+}  // extern "C"
