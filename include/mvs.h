@@ -85,6 +85,14 @@ int mvs_depth_to_model(const float* inv_depth, const mvs_camera* cam,
                        double* out_points, double* out_normals,
                        int32_t* out_tex_index, int32_t* out_faces);
 
+/* Same contract with the raster and every output in HBM (zero-copy chain
+ * depth -> points -> mvs_srt_apply_dev -> mvs_deform_set_target_dev). */
+int mvs_depth_to_model_dev(const float* inv_depth_dev, const mvs_camera* cam,
+                           double min_dsp, double max_dsp, double smooth,
+                           int64_t* n_points, int64_t* n_faces,
+                           double* out_points_dev, double* out_normals_dev,
+                           int32_t* out_tex_index_dev, int32_t* out_faces_dev);
+
 /* Image3D::SolveUnProjectionD (R/Image3D/Image3D.cpp:92-106): dense w*h
  * points + valid mask, no compaction. */
 int mvs_depth_unproject(const float* inv_depth, const mvs_camera* cam,

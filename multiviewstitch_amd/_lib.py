@@ -1,0 +1,149 @@
+"""ctypes loader for libmvs_hip.so (the C-ABI of include/mvs.h).
+
+Fails loudly: a missing library is an ImportError-grade failure and a missing
+GPU turns every compute call into MvsError(MVS_E_NO_DEVICE).  There is no CPU
+fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvs_hip.so")
+
+MVS_OK = 0
+STATUS = {0: "MVS_OK", -1: "MVS_E_INVALID_ARG", -2: "MVS_E_BAD_MESH", -3: "MVS_E_NONMANIFOLD",
+          -4: "MVS_E_NO_DEVICE", -5: "MVS_E_HIP", -6: "MVS_E_OOM", -7: "MVS_E_SOLVER", -8: "MVS_E_STATE",
+          -9: "MVS_E_DEGENERATE"}
+
+
+class MvsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class CCamera(C.Structure):
+    """struct mvs_camera (include/mvs.h) — R/Camera/Camera.h:44-49."""
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("R", C.c_double * 9), ("t", C.c_double * 3), ("w", C.c_int32), ("h", C.c_int32)]
+
+    @classmethod
+    def of(cls, cam):
+        if isinstance(cam, cls):
+            return cam
+        c = cls()
+        c.fx, c.fy, c.cx, c.cy, c.w, c.h = cam.fx, cam.fy, cam.cx, cam.cy, int(cam.w), int(cam.h)
+        c.R[:] = list(np.asarray(cam.R, dtype=np.float64).reshape(9))
+        c.t[:] = list(np.asarray(cam.t, dtype=np.float64).reshape(3))
+        return c
+
+
+class CParams(C.Structure):
+    """struct mvs_deform_params."""
+    _fields_ = [("proj_len_err", C.c_double), ("proj_dist_err", C.c_double), ("min_cos", C.c_double),
+                ("max_result", C.c_int32), ("top_k", C.c_int32), ("graph_k", C.c_int32),
+                ("smooth_sweeps", C.c_int32), ("arap_iters", C.c_int32),
+                ("arap_tol", C.c_double), ("cg_tol", C.c_double),
+                ("cg_max_iters", C.c_int32), ("update_normals", C.c_int32)]
+
+
+class CStats(C.Structure):
+    """struct mvs_deform_stats."""
+    _fields_ = [("outer_done", C.c_int32), ("arap_iters_run", C.c_int32), ("cg_iters", C.c_int32),
+                ("n_valid", C.c_int32), ("energy", C.c_double * 8), ("cg_rel_residual", C.c_double)]
+
+
+CAND_DTYPE = np.dtype([("proj_dist", "<f8"), ("proj_len", "<f8"), ("pos", "<f8", (3,)), ("index", "<i8")])
+
+_lib = None
+
+# name -> (restype, argtypes); pointers are passed as c_void_p (numpy .ctypes.data or raw device addresses)
+_VP, _I64, _I32, _D, _U32 = C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_uint32
+_SIGS = {
+    "mvs_last_error": (C.c_char_p, []),
+    "mvs_abi_version": (C.c_int, []),
+    "mvs_device_count": (C.c_int, []),
+    "mvs_set_device": (C.c_int, [_I32]),
+    "mvs_device_name": (C.c_int, [C.c_char_p, _I32]),
+    "mvs_depth_to_model": (C.c_int, [_VP, _VP, _D, _D, _D, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "mvs_depth_to_model_dev": (C.c_int, [_VP, _VP, _D, _D, _D, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "mvs_depth_unproject": (C.c_int, [_VP, _VP, _D, _D, _VP, _VP]),
+    "mvs_srt_fit": (C.c_int, [_VP, _I64, _VP, _VP, _I32, _VP, _I32, _U32, _VP, _VP, _VP, _VP]),
+    "mvs_srt_residual": (C.c_int, [_VP, _I64, _VP, _VP, _D, _VP, _VP, _VP, _VP]),
+    "mvs_srt_remove_outliers": (C.c_int, [_VP, _I64, _VP, _VP, _I32, _D, _D, _VP, _VP, _VP, _VP]),
+    "mvs_srt_make_triples": (C.c_int, [_I64, _I32, _VP, _VP]),
+    "mvs_srt_compose": (C.c_int, [_D, _VP, _VP, _VP, _VP, _VP]),
+    "mvs_srt_relative": (C.c_int, [_D, _VP, _VP, _D, _VP, _VP, _VP, _VP, _VP]),
+    "mvs_srt_apply": (C.c_int, [_VP, _VP, _I64, _D, _VP, _VP, _I32, _VP, _VP]),
+    "mvs_srt_apply_dev": (C.c_int, [_VP, _VP, _I64, _D, _VP, _VP, _I32, _VP, _VP, _VP]),
+    "mvs_deform_default_params": (None, [_VP]),
+    "mvs_deform_create": (C.c_int, [_I64, _VP, _VP, _I64, _VP, _VP]),
+    "mvs_deform_destroy": (C.c_int, [_VP]),
+    "mvs_deform_sample_nodes": (C.c_int, [_VP, _I32, _VP]),
+    "mvs_deform_set_nodes": (C.c_int, [_VP, _VP, _I64]),
+    "mvs_deform_get_nodes": (C.c_int, [_VP, _VP]),
+    "mvs_deform_sizes": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "mvs_deform_set_target": (C.c_int, [_VP, _I64, _VP, _VP, _I64]),
+    "mvs_deform_set_target_dev": (C.c_int, [_VP, _I64, _VP, _VP, _I64]),
+    "mvs_deform_iterate": (C.c_int, [_VP, _VP, _I32, _VP]),
+    "mvs_deform_assoc_dmin": (C.c_int, [_VP, _VP, _VP]),
+    "mvs_deform_assoc_select": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "mvs_deform_assoc_merge": (C.c_int, [_VP, _VP, _VP, _VP, _I32]),
+    "mvs_deform_solve": (C.c_int, [_VP, _VP, _VP]),
+    "mvs_deform_sync": (C.c_int, [_VP]),
+    "mvs_deform_stream": (C.c_void_p, [_VP]),
+    "mvs_deform_get_vertices": (C.c_int, [_VP, _VP]),
+    "mvs_deform_get_normals": (C.c_int, [_VP, _VP]),
+    "mvs_deform_get_rotations": (C.c_int, [_VP, _VP]),
+    "mvs_deform_get_node_targets": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP]),
+    "mvs_deform_get_node_graph": (C.c_int, [_VP, _VP]),
+    "mvs_deform_compute_normals": (C.c_int, [_VP, _VP]),
+    "mvs_knn_points": (C.c_int, [_VP, _I64, _I32, _VP]),
+    "mvs_deform_arap": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "mvs_deform_kernel_time": (C.c_int, [_VP, C.c_char_p, _VP, _VP]),
+    "mvs_deform_enable_timing": (C.c_int, [_VP, _I32]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C multiviewstitch_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "multiviewstitch_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)          # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != MVS_OK:
+        raise MvsError(rc, lib().mvs_last_error().decode(errors="replace"))
+
+
+def device_count():
+    return lib().mvs_device_count()
+
+
+def arr(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def ptr(a):
+    """Host numpy array -> void*; None -> NULL; int -> raw (device) address."""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return C.c_void_p(int(a))
+    return C.c_void_p(a.ctypes.data)

@@ -1,0 +1,653 @@
+// api_deform.cpp — C-ABI of the deformation engine (include/mvs.h, mvs_deform_*):
+// the drop-in for class Deformation (R/Deformation/Deformation.h:224-252).
+// Host orchestration only; every per-point / per-vertex operation is a HIP kernel.
+#include "engine.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <tuple>
+
+// ------------------------------------------------------------------ errors ----
+static thread_local char g_err[512] = "";
+static int g_device = 0;
+
+void mvs_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+int mvs_check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return MVS_OK;
+    mvs_set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+    return e == hipErrorOutOfMemory ? MVS_E_OOM : MVS_E_HIP;
+}
+int mvs_current_device() { return g_device; }
+
+extern "C" {
+
+const char* mvs_last_error(void) { return g_err; }
+int mvs_abi_version(void) { return MVS_ABI_VERSION; }
+int mvs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+int mvs_set_device(int device) {
+    if (device < 0 || device >= mvs_device_count()) { mvs_set_error("no such device %d", device); return MVS_E_NO_DEVICE; }
+    HIPCHK(hipSetDevice(device));
+    g_device = device;
+    return MVS_OK;
+}
+int mvs_device_name(char* buf, int buflen) {
+    if (!buf || buflen <= 0) return MVS_E_INVALID_ARG;
+    if (mvs_device_count() == 0) { mvs_set_error("no HIP device"); return MVS_E_NO_DEVICE; }
+    hipDeviceProp_t pr;
+    HIPCHK(hipGetDeviceProperties(&pr, g_device));
+    snprintf(buf, buflen, "%s (%s)", pr.name, pr.gcnArchName);
+    return MVS_OK;
+}
+
+void mvs_deform_default_params(mvs_deform_params* p) {
+    if (!p) return;
+    p->proj_len_err = 100.0; p->proj_dist_err = 100.0; p->min_cos = 0.1;
+    p->max_result = 10000; p->top_k = 8; p->graph_k = 8; p->smooth_sweeps = 2;
+    p->arap_iters = 5; p->arap_tol = 1e-4; p->cg_tol = 1e-10; p->cg_max_iters = 2000;
+    p->update_normals = 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ helpers ----
+namespace {
+
+template <class T> int dmalloc(T** p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    return mvs_check_hip(hipMalloc((void**)p, n * sizeof(T)), "hipMalloc");
+}
+template <class T> void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+int need_device() {
+    if (mvs_device_count() == 0) { mvs_set_error("no HIP device: the MI355X engine has no CPU fallback"); return MVS_E_NO_DEVICE; }
+    return mvs_check_hip(hipSetDevice(g_device), "hipSetDevice");
+}
+
+int check_params(const mvs_deform_params* p) {
+    if (!p) { mvs_set_error("params is NULL"); return MVS_E_INVALID_ARG; }
+    if (p->top_k < 1 || p->top_k > 8 || p->graph_k < 0 || p->graph_k > 63 || p->smooth_sweeps < 0 ||
+        p->arap_iters < 1 || p->arap_iters > 8 || p->cg_max_iters < 1 || !(p->cg_tol > 0)) {
+        mvs_set_error("params out of range (top_k 1..8, graph_k 0..63, arap_iters 1..8, cg_tol > 0)");
+        return MVS_E_INVALID_ARG;
+    }
+    return MVS_OK;
+}
+
+// ---- timing ----
+hipEvent_t get_event(mvs_deform_s* h) {
+    if (!h->event_pool.empty()) { hipEvent_t e = h->event_pool.back(); h->event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct Tic { mvs_deform_s* h; const char* name; hipEvent_t a; };
+Tic tic(mvs_deform_s* h, const char* name) {
+    Tic t{h, name, nullptr};
+    if (h->timing) { t.a = get_event(h); (void)hipEventRecord(t.a, h->stream); }
+    return t;
+}
+void toc(Tic& t, int launches) {
+    if (!t.h->timing) return;
+    hipEvent_t b = get_event(t.h);
+    (void)hipEventRecord(b, t.h->stream);
+    t.h->pending.push_back({t.name, {t.a, b}});
+    t.h->pending_launches[t.name] += launches;
+}
+void collect_timers(mvs_deform_s* h) {
+    for (auto& pr : h->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pr.second.first, pr.second.second) == hipSuccess) h->timers[pr.first].total_ms += ms;
+        h->event_pool.push_back(pr.second.first);
+        h->event_pool.push_back(pr.second.second);
+    }
+    h->pending.clear();
+    for (auto& kv : h->pending_launches) h->timers[kv.first].launches += kv.second;
+    h->pending_launches.clear();
+}
+
+void free_nodes(mvs_deform_s* h) {
+    dfree(h->d_nodes); dfree(h->d_nbr); dfree(h->d_node_pts); dfree(h->d_node_nrm); dfree(h->d_ctrl_raw);
+    dfree(h->d_ctrl_a); dfree(h->d_ctrl_b); dfree(h->d_valid); dfree(h->d_d2min); dfree(h->d_counts);
+    dfree(h->d_records); dfree(h->d_top_idx);
+    h->d_ctrl_final = nullptr; h->K = 0; h->nbr_k = 0; h->h_nodes.clear();
+}
+
+int ensure_slots(mvs_deform_s* h, int arap_iters, int cg) {
+    const int64_t need = (int64_t)arap_iters * (cg + 2) * MVS_CG_SLOT;
+    if (need > h->slots_cap) {
+        dfree(h->d_slots);
+        int rc = dmalloc(&h->d_slots, (size_t)need);
+        if (rc) return rc;
+        h->slots_cap = need;
+    }
+    return MVS_OK;
+}
+
+// association of the handle's nodes against the handle's (local) target, nranks = 1
+void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
+    Tic t = tic(h, "assoc");
+    const int K = (int)h->K;
+    launch_assoc_dmin(h->grid, h->d_node_pts, K, h->d_d2min, h->stream);
+    launch_assoc_select(h->grid, h->d_node_pts, h->d_node_nrm, K, p.top_k, h->d_d2min, h->d_records, h->d_counts, h->stream);
+    launch_assoc_merge(h->d_node_pts, h->d_node_nrm, K, p, h->d_records, h->d_counts, 1, h->d_ctrl_raw, h->d_valid,
+                       h->d_top_idx, h->stream);
+    toc(t, 3);
+}
+
+// graph smoothing (optional) + ARAP + geometry update.  ctrl_src: K*3 node targets.
+int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctrl_src, bool graph_smooth, int cg) {
+    hipStream_t s = h->stream;
+    const int K = (int)h->K, V = (int)h->V;
+    const double* ctrl = ctrl_src;
+    if (graph_smooth) {
+        const int nn = p.graph_k + 1;
+        if (nn != h->nbr_k) {
+            dfree(h->d_nbr);
+            int rc = dmalloc(&h->d_nbr, (size_t)K * nn);
+            if (rc) return rc;
+            h->nbr_k = nn;
+        }
+        { Tic t = tic(h, "graph"); launch_knn(h->d_node_pts, K, nn, h->d_nbr, s); toc(t, 1); }   // Deformation.cpp:359
+        Tic t = tic(h, "smooth");
+        double* bufs[2] = {h->d_ctrl_a, h->d_ctrl_b};
+        for (int sw = 0; sw < p.smooth_sweeps; ++sw) {                                            // :362-381
+            launch_smooth(h->d_node_pts, ctrl, h->d_nbr, nn, K, bufs[sw & 1], s);
+            ctrl = bufs[sw & 1];
+        }
+        toc(t, p.smooth_sweeps);
+    }
+    h->d_ctrl_final = const_cast<double*>(ctrl);
+    int rc = ensure_slots(h, p.arap_iters, cg);
+    if (rc) return rc;
+    {
+        Tic t = tic(h, "weights");
+        HIPCHK(hipMemsetAsync(h->d_slots, 0, sizeof(double) * (size_t)p.arap_iters * (cg + 2) * MVS_CG_SLOT, s));
+        HIPCHK(hipMemsetAsync(h->d_energy, 0, sizeof(double) * 16, s));
+        launch_cot_weights(h->sell, h->d_pts, s);                                                 // preprocess(), :393
+        launch_arap_prepare(h->sell, h->d_pts, h->d_nodes, ctrl, K, h->d_sol, h->d_rot, s);      // :383-392
+        toc(t, 2);
+    }
+    for (int it = 0; it < p.arap_iters; ++it) {                                                   // deform(5, 1e-4), :398
+        double* slots = h->d_slots + (size_t)it * (cg + 2) * MVS_CG_SLOT;
+        {
+            Tic t = tic(h, "rhs");
+            launch_arap_rhs(h->sell, h->d_pts, h->d_sol, h->d_rot, it, p.arap_tol, h->d_energy, h->d_r[0], h->d_p, h->d_s[0], slots, s);
+            launch_cg_w0(h->sell, it, p.arap_tol, h->d_energy, h->d_r[0], h->d_wv[0], slots, s);
+            toc(t, 2);
+        }
+        {
+            Tic t = tic(h, "cg");
+            for (int i = 0; i < cg; ++i) {
+                const int a = i & 1, b = a ^ 1;
+                launch_cg_iter(h->sell, it, p.arap_tol, h->d_energy, i, p.cg_tol, slots, slots + (size_t)i * MVS_CG_SLOT,
+                               slots + (size_t)(i + 1) * MVS_CG_SLOT, h->d_r[a], h->d_wv[a], h->d_s[a], h->d_r[b],
+                               h->d_wv[b], h->d_s[b], h->d_p, h->d_sol, s);
+            }
+            toc(t, cg);
+        }
+        { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, h->d_sol, it, p.arap_tol, h->d_energy, h->d_rot, s); toc(t, 1); }
+    }
+    Tic t = tic(h, "finalize");
+    launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, h->d_sol, h->d_pts, h->d_info, s);   // :400
+    int n = 2;
+    if (p.update_normals) { launch_vertex_normals(h->d_pts, h->d_faces, h->d_vf_ptr, h->d_vf, V, h->d_nrm, s); ++n; }
+    launch_gather_nodes(h->d_pts, h->d_nrm, h->d_nodes, K, h->d_node_pts, h->d_node_nrm, s);
+    toc(t, n);
+    (void)V;
+    return MVS_OK;
+}
+
+// after a sync: read the CG slots of the last solve, fill stats, re-calibrate cg_iters
+int harvest(mvs_deform_s* h, const mvs_deform_params& p, int cg, mvs_deform_stats* st, bool* converged) {
+    const size_t n = (size_t)p.arap_iters * (cg + 2) * MVS_CG_SLOT;
+    std::vector<double> slots(n);
+    double energy[16];
+    int32_t info[8];
+    HIPCHK(hipMemcpyAsync(slots.data(), h->d_slots, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(energy, h->d_energy, sizeof energy, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(info, h->d_info, sizeof info, hipMemcpyDeviceToHost, h->stream));
+    std::vector<uint8_t> valid(h->K);
+    if (h->K) HIPCHK(hipMemcpyAsync(valid.data(), h->d_valid, (size_t)h->K, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int run = info[0];
+    int need = 0;
+    double worst = 0.0;
+    bool all_conv = true;
+    for (int it = 0; it < run; ++it) {
+        const double* S = slots.data() + (size_t)it * (cg + 2) * MVS_CG_SLOT;
+        int first = -1;
+        for (int i = 0; i <= cg; ++i) {
+            bool frozen = true;
+            for (int c = 0; c < 3; ++c) {
+                const double gam = S[(size_t)i * MVS_CG_SLOT + c], bn = S[9 + c];
+                if (gam > 0.0 && gam > p.cg_tol * p.cg_tol * bn) frozen = false;
+            }
+            if (frozen) { first = i; break; }
+        }
+        if (first < 0) { all_conv = false; first = cg; }
+        need = std::max(need, first);
+        for (int c = 0; c < 3; ++c) {
+            const double gam = S[(size_t)cg * MVS_CG_SLOT + c], bn = S[9 + c];
+            if (bn > 0) worst = std::max(worst, std::sqrt(std::max(0.0, gam) / bn));
+        }
+    }
+    if (converged) *converged = all_conv;
+    h->cg_iters = all_conv ? std::min(p.cg_max_iters, need + need / 4 + 4) : std::min(p.cg_max_iters, 2 * cg);
+    mvs_deform_stats out{};
+    out.arap_iters_run = run;
+    out.cg_iters = cg;
+    for (int i = 0; i < 8; ++i) out.energy[i] = i < p.arap_iters ? energy[i] : 0.0;
+    out.cg_rel_residual = worst;
+    int nv = 0;
+    for (uint8_t v : valid) nv += v;
+    out.n_valid = nv;
+    h->last = out;
+    if (st) *st = out;
+    collect_timers(h);
+    if (!all_conv && cg >= p.cg_max_iters) {
+        mvs_set_error("global solve did not reach cg_tol in cg_max_iters=%d (rel residual %.3e)", cg, worst);
+        return MVS_E_SOLVER;
+    }
+    return MVS_OK;
+}
+
+int probe_cg(const mvs_deform_s* h, const mvs_deform_params& p) {
+    return h->cg_iters > 0 ? std::min(h->cg_iters, p.cg_max_iters) : std::min(p.cg_max_iters, 192);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------- create ----
+int mvs_deform_create(int64_t V, const double* points, const double* normals, int64_t F, const int32_t* faces,
+                      mvs_deform_t* out) {
+    if (!out) { mvs_set_error("out is NULL"); return MVS_E_INVALID_ARG; }
+    *out = nullptr;
+    if (V <= 0 || F < 0 || !points || !normals || (F > 0 && !faces) || V > 0x7ffffff0LL || F > 0x2aaaaaa0LL) {
+        mvs_set_error("bad mesh arguments"); return MVS_E_INVALID_ARG;
+    }
+    // validity (what Polyhedron_incremental_builder_3 / is_valid reject, Deformation.cpp:36-45)
+    std::vector<std::tuple<int, int, int>> he;            // (i, j, opposite)
+    he.reserve((size_t)F * 6);
+    std::vector<std::pair<int, int>> dir;
+    dir.reserve((size_t)F * 3);
+    for (int64_t f = 0; f < F; ++f) {
+        const int v[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
+        for (int k = 0; k < 3; ++k)
+            if (v[k] < 0 || v[k] >= V) { mvs_set_error("facet %lld: vertex index out of range", (long long)f); return MVS_E_BAD_MESH; }
+        if (v[0] == v[1] || v[1] == v[2] || v[0] == v[2]) { mvs_set_error("facet %lld: repeated vertex", (long long)f); return MVS_E_BAD_MESH; }
+        for (int k = 0; k < 3; ++k) {
+            const int a = v[k], b = v[(k + 1) % 3], c = v[(k + 2) % 3];
+            dir.push_back({a, b});
+            he.push_back({a, b, c});
+            he.push_back({b, a, c});
+        }
+    }
+    std::sort(dir.begin(), dir.end());
+    for (size_t i = 1; i < dir.size(); ++i)
+        if (dir[i] == dir[i - 1]) { mvs_set_error("directed edge (%d,%d) used twice: non-manifold or inconsistently oriented", dir[i].first, dir[i].second); return MVS_E_NONMANIFOLD; }
+    int rc = need_device();
+    if (rc) return rc;
+
+    // adjacency rows: neighbours ascending, the (<=2) opposite vertices ascending
+    std::sort(he.begin(), he.end());
+    std::vector<int32_t> rowptr(V + 1, 0), col, o0, o1;
+    col.reserve(he.size() / 2); o0.reserve(he.size() / 2); o1.reserve(he.size() / 2);
+    {
+        size_t e = 0;
+        for (int64_t i = 0; i < V; ++i) {
+            while (e < he.size() && std::get<0>(he[e]) == i) {
+                const int j = std::get<1>(he[e]);
+                col.push_back(j); o0.push_back(std::get<2>(he[e])); o1.push_back(-1);
+                ++e;
+                if (e < he.size() && std::get<0>(he[e]) == i && std::get<1>(he[e]) == j) { o1.back() = std::get<2>(he[e]); ++e; }
+                while (e < he.size() && std::get<0>(he[e]) == i && std::get<1>(he[e]) == j) ++e;   // unreachable after the check above
+            }
+            rowptr[i + 1] = (int32_t)col.size();
+        }
+    }
+    // SELL-64
+    const int nslices = (int)((V + 63) / 64);
+    std::vector<int32_t> slice_off(nslices + 1, 0);
+    for (int sl = 0; sl < nslices; ++sl) {
+        int wmax = 0;
+        for (int64_t i = (int64_t)sl * 64; i < std::min<int64_t>(V, (int64_t)sl * 64 + 64); ++i) wmax = std::max(wmax, rowptr[i + 1] - rowptr[i]);
+        slice_off[sl + 1] = slice_off[sl] + wmax * 64;
+    }
+    const int64_t ne = slice_off[nslices];
+    std::vector<int32_t> scol(ne), sopp0(ne, -1), sopp1(ne, -1);
+    for (int sl = 0; sl < nslices; ++sl) {
+        const int wdt = (slice_off[sl + 1] - slice_off[sl]) / 64;
+        for (int l = 0; l < 64; ++l) {
+            const int64_t i = (int64_t)sl * 64 + l;
+            for (int k = 0; k < wdt; ++k) {
+                const int64_t e = slice_off[sl] + 64 * k + l;
+                if (i < V && k < rowptr[i + 1] - rowptr[i]) {
+                    scol[e] = col[rowptr[i] + k]; sopp0[e] = o0[rowptr[i] + k]; sopp1[e] = o1[rowptr[i] + k];
+                } else scol[e] = (int32_t)std::min<int64_t>(i, V - 1);
+            }
+        }
+    }
+    // vertex -> facet CSR (ascending facet index)
+    std::vector<int32_t> vf_ptr(V + 1, 0), vf((size_t)F * 3);
+    for (int64_t f = 0; f < 3 * F; ++f) vf_ptr[faces[f] + 1]++;
+    for (int64_t i = 0; i < V; ++i) vf_ptr[i + 1] += vf_ptr[i];
+    {
+        std::vector<int32_t> cur(vf_ptr.begin(), vf_ptr.end() - 1);
+        for (int64_t f = 0; f < F; ++f) for (int k = 0; k < 3; ++k) vf[cur[faces[3 * f + k]]++] = (int32_t)f;
+    }
+
+    mvs_deform_s* h = new mvs_deform_s;
+    h->device = g_device; h->V = V; h->F = F; h->n_entries = ne;
+#define TRY(x) do { rc = (x); if (rc) { mvs_deform_destroy(h); return rc; } } while (0)
+    TRY(mvs_check_hip(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate"));
+    TRY(dmalloc(&h->d_pts, (size_t)V * 3)); TRY(dmalloc(&h->d_nrm, (size_t)V * 3)); TRY(dmalloc(&h->d_sol, (size_t)V * 3));
+    TRY(dmalloc(&h->d_rot, (size_t)V * 9)); TRY(dmalloc(&h->d_faces, (size_t)F * 3));
+    TRY(dmalloc(&h->d_vf_ptr, (size_t)V + 1)); TRY(dmalloc(&h->d_vf, (size_t)F * 3));
+    TRY(dmalloc(&h->d_slice_off, (size_t)nslices + 1)); TRY(dmalloc(&h->d_col, (size_t)ne)); TRY(dmalloc(&h->d_opp0, (size_t)ne));
+    TRY(dmalloc(&h->d_opp1, (size_t)ne)); TRY(dmalloc(&h->d_w, (size_t)ne)); TRY(dmalloc(&h->d_diag, (size_t)V));
+    TRY(dmalloc(&h->d_is_ctrl, (size_t)V));
+    for (int k = 0; k < 2; ++k) { TRY(dmalloc(&h->d_r[k], (size_t)V * 3)); TRY(dmalloc(&h->d_wv[k], (size_t)V * 3)); TRY(dmalloc(&h->d_s[k], (size_t)V * 3)); }
+    TRY(dmalloc(&h->d_p, (size_t)V * 3)); TRY(dmalloc(&h->d_energy, 16)); TRY(dmalloc(&h->d_info, 8));
+    auto up = [&](void* d, const void* s, size_t n) { return mvs_check_hip(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, h->stream), "upload"); };
+    TRY(up(h->d_pts, points, sizeof(double) * V * 3)); TRY(up(h->d_nrm, normals, sizeof(double) * V * 3));
+    TRY(up(h->d_sol, points, sizeof(double) * V * 3));
+    if (F) { TRY(up(h->d_faces, faces, sizeof(int32_t) * F * 3)); TRY(up(h->d_vf, vf.data(), sizeof(int32_t) * F * 3)); }
+    TRY(up(h->d_vf_ptr, vf_ptr.data(), sizeof(int32_t) * (V + 1)));
+    TRY(up(h->d_slice_off, slice_off.data(), sizeof(int32_t) * (nslices + 1)));
+    if (ne) { TRY(up(h->d_col, scol.data(), sizeof(int32_t) * ne)); TRY(up(h->d_opp0, sopp0.data(), sizeof(int32_t) * ne)); TRY(up(h->d_opp1, sopp1.data(), sizeof(int32_t) * ne)); }
+    TRY(mvs_check_hip(hipMemsetAsync(h->d_is_ctrl, 0, sizeof(int32_t) * V, h->stream), "memset"));
+    TRY(mvs_check_hip(hipMemsetAsync(h->d_rot, 0, sizeof(double) * V * 9, h->stream), "memset"));
+    TRY(mvs_check_hip(hipMemsetAsync(h->d_info, 0, sizeof(int32_t) * 8, h->stream), "memset"));
+    TRY(mvs_check_hip(hipStreamSynchronize(h->stream), "sync"));
+#undef TRY
+    h->sell.V = (int32_t)V; h->sell.nslices = nslices; h->sell.slice_off = h->d_slice_off; h->sell.col = h->d_col;
+    h->sell.opp0 = h->d_opp0; h->sell.opp1 = h->d_opp1; h->sell.w = h->d_w; h->sell.diag = h->d_diag; h->sell.is_ctrl = h->d_is_ctrl;
+    *out = h;
+    return MVS_OK;
+}
+
+int mvs_deform_destroy(mvs_deform_t h) {
+    if (!h) return MVS_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_nodes(h);
+    dfree(h->d_pts); dfree(h->d_nrm); dfree(h->d_sol); dfree(h->d_rot); dfree(h->d_faces); dfree(h->d_vf_ptr); dfree(h->d_vf);
+    dfree(h->d_slice_off); dfree(h->d_col); dfree(h->d_opp0); dfree(h->d_opp1); dfree(h->d_is_ctrl); dfree(h->d_w); dfree(h->d_diag);
+    dfree(h->d_spos); dfree(h->d_tpos); dfree(h->d_tnrm); dfree(h->d_cell_start);
+    for (int k = 0; k < 2; ++k) { dfree(h->d_r[k]); dfree(h->d_wv[k]); dfree(h->d_s[k]); }
+    dfree(h->d_p); dfree(h->d_slots); dfree(h->d_energy); dfree(h->d_info);
+    for (auto& pr : h->pending) { (void)hipEventDestroy(pr.second.first); (void)hipEventDestroy(pr.second.second); }
+    for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MVS_OK;
+}
+
+// -------------------------------------------------------------------- nodes ----
+int mvs_deform_set_nodes(mvs_deform_t h, const int32_t* vertex_idx, int64_t K) {
+    if (!h || K < 0 || (K > 0 && !vertex_idx)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<int32_t> ctrl_id(h->V, 0);
+    for (int64_t k = 0; k < K; ++k) {
+        const int v = vertex_idx[k];
+        if (v < 0 || v >= h->V) { mvs_set_error("node %lld: vertex index out of range", (long long)k); return MVS_E_INVALID_ARG; }
+        if (ctrl_id[v]) { mvs_set_error("node %lld: vertex %d listed twice", (long long)k, v); return MVS_E_INVALID_ARG; }
+        ctrl_id[v] = (int32_t)k + 1;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    free_nodes(h);
+    h->K = K;
+    h->h_nodes.assign(vertex_idx, vertex_idx + K);
+    int rc;
+#define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+    TRY(dmalloc(&h->d_nodes, (size_t)K)); TRY(dmalloc(&h->d_node_pts, (size_t)K * 3)); TRY(dmalloc(&h->d_node_nrm, (size_t)K * 3));
+    TRY(dmalloc(&h->d_ctrl_raw, (size_t)K * 3)); TRY(dmalloc(&h->d_ctrl_a, (size_t)K * 3)); TRY(dmalloc(&h->d_ctrl_b, (size_t)K * 3));
+    TRY(dmalloc(&h->d_valid, (size_t)K)); TRY(dmalloc(&h->d_d2min, (size_t)K)); TRY(dmalloc(&h->d_counts, (size_t)K * 2));
+    TRY(dmalloc(&h->d_records, (size_t)K * 8)); TRY(dmalloc(&h->d_top_idx, (size_t)K * 8));
+#undef TRY
+    HIPCHK(hipMemcpyAsync(h->d_is_ctrl, ctrl_id.data(), sizeof(int32_t) * h->V, hipMemcpyHostToDevice, h->stream));
+    if (K) HIPCHK(hipMemcpyAsync(h->d_nodes, vertex_idx, sizeof(int32_t) * K, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_valid, 0, (size_t)std::max<int64_t>(K, 1), h->stream));
+    launch_gather_nodes(h->d_pts, h->d_nrm, h->d_nodes, (int)K, h->d_node_pts, h->d_node_nrm, h->stream);
+    if (K) HIPCHK(hipMemcpyAsync(h->d_ctrl_raw, h->d_node_pts, sizeof(double) * K * 3, hipMemcpyDeviceToDevice, h->stream));
+    h->d_ctrl_final = h->d_ctrl_raw;
+    h->cg_iters = 0;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MVS_OK;
+}
+
+int mvs_deform_sample_nodes(mvs_deform_t h, int knn, int64_t* K) {
+    // UniformSampling, Deformation.cpp:63-106: exact kNN table on the GPU, greedy suppression
+    // in vertex order on the host (inherently sequential).
+    if (!h || knn < 1 || knn > 64) { mvs_set_error("knn must be 1..64"); return MVS_E_INVALID_ARG; }
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t V = h->V;
+    int32_t* d_tab = nullptr;
+    int rc = dmalloc(&d_tab, (size_t)V * knn);
+    if (rc) return rc;
+    launch_knn(h->d_pts, (int)V, knn, d_tab, h->stream);
+    std::vector<int32_t> tab((size_t)V * knn);
+    rc = mvs_check_hip(hipMemcpyAsync(tab.data(), d_tab, sizeof(int32_t) * V * knn, hipMemcpyDeviceToHost, h->stream), "download");
+    if (!rc) rc = mvs_check_hip(hipStreamSynchronize(h->stream), "sync");
+    (void)hipFree(d_tab);
+    if (rc) return rc;
+    std::vector<char> removed(V, 0);
+    std::vector<int32_t> samp;
+    for (int64_t i = 0; i < V; ++i) {
+        if (removed[i]) continue;                           // :85
+        samp.push_back((int32_t)i);
+        for (int j = 0; j < knn; ++j) {
+            const int nb = tab[(size_t)i * knn + j];
+            if (nb >= 0 && nb != i) removed[nb] = 1;        // :98-102
+        }
+    }
+    rc = mvs_deform_set_nodes(h, samp.data(), (int64_t)samp.size());
+    if (rc) return rc;
+    if (K) *K = (int64_t)samp.size();
+    return MVS_OK;
+}
+
+int mvs_deform_get_nodes(mvs_deform_t h, int32_t* vertex_idx) {
+    if (!h || !vertex_idx) return MVS_E_INVALID_ARG;
+    std::memcpy(vertex_idx, h->h_nodes.data(), h->h_nodes.size() * sizeof(int32_t));
+    return MVS_OK;
+}
+int mvs_deform_sizes(mvs_deform_t h, int64_t* V, int64_t* F, int64_t* K, int64_t* P) {
+    if (!h) return MVS_E_INVALID_ARG;
+    if (V) *V = h->V; if (F) *F = h->F; if (K) *K = h->K; if (P) *P = h->P;
+    return MVS_OK;
+}
+
+// ------------------------------------------------------------------- target ----
+int mvs_deform_set_target_dev(mvs_deform_t h, int64_t P, const double* pts_dev, const double* normals_dev, int64_t index_base) {
+    if (!h || P < 0 || (P > 0 && (!pts_dev || !normals_dev))) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return grid_build(h, P, pts_dev, normals_dev, index_base);
+}
+int mvs_deform_set_target(mvs_deform_t h, int64_t P, const double* pts, const double* normals, int64_t index_base) {
+    if (!h || P < 0 || (P > 0 && (!pts || !normals))) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    HIPCHK(hipSetDevice(h->device));
+    double *dp = nullptr, *dn = nullptr;
+    int rc = dmalloc(&dp, (size_t)P * 3);
+    if (!rc) rc = dmalloc(&dn, (size_t)P * 3);
+    if (!rc && P) rc = mvs_check_hip(hipMemcpyAsync(dp, pts, sizeof(double) * P * 3, hipMemcpyHostToDevice, h->stream), "upload");
+    if (!rc && P) rc = mvs_check_hip(hipMemcpyAsync(dn, normals, sizeof(double) * P * 3, hipMemcpyHostToDevice, h->stream), "upload");
+    if (!rc) rc = mvs_deform_set_target_dev(h, P, dp, dn, index_base);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(dp); (void)hipFree(dn);
+    return rc;
+}
+
+// ------------------------------------------------------------------ iterate ----
+static int ready(mvs_deform_t h, const mvs_deform_params* p, bool need_target) {
+    if (!h) { mvs_set_error("handle is NULL"); return MVS_E_INVALID_ARG; }
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (need_target && !h->has_target) { mvs_set_error("no target set: call mvs_deform_set_target first"); return MVS_E_STATE; }
+    if (h->K == 0) { mvs_set_error("no nodes: call mvs_deform_sample_nodes / _set_nodes first"); return MVS_E_STATE; }
+    return mvs_check_hip(hipSetDevice(h->device), "hipSetDevice");
+}
+
+int mvs_deform_iterate(mvs_deform_t h, const mvs_deform_params* p, int n_outer, mvs_deform_stats* stats) {
+    int rc = ready(h, p, true);
+    if (rc) return rc;
+    if (n_outer < 0) return MVS_E_INVALID_ARG;
+    int done = 0;
+    mvs_deform_stats st = h->last;
+    while (done < n_outer) {
+        // enqueue as many outer iterations as the current calibration allows, then harvest once
+        const bool calibrated = h->cg_iters > 0;
+        const int cg = probe_cg(h, *p);
+        const int batch = calibrated ? (n_outer - done) : 1;
+        for (int o = 0; o < batch; ++o) {
+            enqueue_assoc_local(h, *p);
+            rc = enqueue_solve(h, *p, h->d_ctrl_raw, true, cg);
+            if (rc) return rc;
+        }
+        bool conv = true;
+        rc = harvest(h, *p, cg, &st, &conv);
+        if (rc) return rc;
+        done += batch;
+    }
+    st.outer_done = done;
+    h->last = st;
+    if (stats) *stats = st;
+    return MVS_OK;
+}
+
+int mvs_deform_assoc_dmin(mvs_deform_t h, const mvs_deform_params* p, float* d2min_dev) {
+    int rc = ready(h, p, true);
+    if (rc) return rc;
+    if (!d2min_dev) return MVS_E_INVALID_ARG;
+    Tic t = tic(h, "assoc");
+    launch_assoc_dmin(h->grid, h->d_node_pts, (int)h->K, d2min_dev, h->stream);
+    toc(t, 1);
+    return mvs_check_hip(hipGetLastError(), "assoc_dmin");
+}
+int mvs_deform_assoc_select(mvs_deform_t h, const mvs_deform_params* p, const float* d2min_dev, mvs_cand* records_dev,
+                            int32_t* counts_dev) {
+    int rc = ready(h, p, true);
+    if (rc) return rc;
+    if (!d2min_dev || !records_dev || !counts_dev) return MVS_E_INVALID_ARG;
+    Tic t = tic(h, "assoc");
+    launch_assoc_select(h->grid, h->d_node_pts, h->d_node_nrm, (int)h->K, p->top_k, d2min_dev, records_dev, counts_dev, h->stream);
+    toc(t, 1);
+    return mvs_check_hip(hipGetLastError(), "assoc_select");
+}
+int mvs_deform_assoc_merge(mvs_deform_t h, const mvs_deform_params* p, const mvs_cand* records_all_dev,
+                           const int32_t* counts_all_dev, int nranks) {
+    int rc = ready(h, p, false);
+    if (rc) return rc;
+    if (!records_all_dev || !counts_all_dev || nranks < 1) return MVS_E_INVALID_ARG;
+    Tic t = tic(h, "assoc");
+    launch_assoc_merge(h->d_node_pts, h->d_node_nrm, (int)h->K, *p, records_all_dev, counts_all_dev, nranks, h->d_ctrl_raw,
+                       h->d_valid, h->d_top_idx, h->stream);
+    toc(t, 1);
+    return mvs_check_hip(hipGetLastError(), "assoc_merge");
+}
+int mvs_deform_solve(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stats* stats) {
+    int rc = ready(h, p, false);
+    if (rc) return rc;
+    const int cg = probe_cg(h, *p);
+    rc = enqueue_solve(h, *p, h->d_ctrl_raw, true, cg);
+    if (rc) return rc;
+    return harvest(h, *p, cg, stats, nullptr);
+}
+int mvs_deform_arap(mvs_deform_t h, const mvs_deform_params* p, const double* ctrl_targets, mvs_deform_stats* stats) {
+    int rc = ready(h, p, false);
+    if (rc) return rc;
+    if (!ctrl_targets) return MVS_E_INVALID_ARG;
+    HIPCHK(hipMemcpyAsync(h->d_ctrl_a, ctrl_targets, sizeof(double) * h->K * 3, hipMemcpyHostToDevice, h->stream));
+    const int cg = probe_cg(h, *p);
+    rc = enqueue_solve(h, *p, h->d_ctrl_a, false, cg);
+    if (rc) return rc;
+    return harvest(h, *p, cg, stats, nullptr);
+}
+int mvs_deform_sync(mvs_deform_t h) {
+    if (!h) return MVS_E_INVALID_ARG;
+    return mvs_check_hip(hipStreamSynchronize(h->stream), "sync");
+}
+void* mvs_deform_stream(mvs_deform_t h) { return h ? (void*)h->stream : nullptr; }
+
+// ---------------------------------------------------------------- read-back ----
+static int download(mvs_deform_t h, void* dst, const void* src, size_t n) {
+    if (!h || !dst) return MVS_E_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    if (n) HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, h->stream));
+    return mvs_check_hip(hipStreamSynchronize(h->stream), "sync");
+}
+int mvs_deform_get_vertices(mvs_deform_t h, double* pts) { return download(h, pts, h ? h->d_pts : nullptr, h ? sizeof(double) * h->V * 3 : 0); }
+int mvs_deform_get_normals(mvs_deform_t h, double* n) { return download(h, n, h ? h->d_nrm : nullptr, h ? sizeof(double) * h->V * 3 : 0); }
+int mvs_deform_get_rotations(mvs_deform_t h, double* R) { return download(h, R, h ? h->d_rot : nullptr, h ? sizeof(double) * h->V * 9 : 0); }
+int mvs_deform_get_node_targets(mvs_deform_t h, int smoothed, double* controls, uint8_t* valid, float* d2min, int32_t* counts,
+                                int64_t* top_idx) {
+    if (!h || !controls) return MVS_E_INVALID_ARG;
+    const size_t K = (size_t)h->K;
+    int rc = download(h, controls, smoothed ? h->d_ctrl_final : h->d_ctrl_raw, sizeof(double) * K * 3);
+    if (!rc && valid) rc = download(h, valid, h->d_valid, K);
+    if (!rc && d2min) rc = download(h, d2min, h->d_d2min, sizeof(float) * K);
+    if (!rc && counts) rc = download(h, counts, h->d_counts, sizeof(int32_t) * K * 2);
+    if (!rc && top_idx) rc = download(h, top_idx, h->d_top_idx, sizeof(int64_t) * K * 8);
+    return rc;
+}
+int mvs_deform_get_node_graph(mvs_deform_t h, int32_t* nbr) {
+    if (!h || !nbr) return MVS_E_INVALID_ARG;
+    if (!h->d_nbr) { mvs_set_error("node graph not built yet"); return MVS_E_STATE; }
+    return download(h, nbr, h->d_nbr, sizeof(int32_t) * (size_t)h->K * h->nbr_k);
+}
+int mvs_deform_compute_normals(mvs_deform_t h, double* normals) {
+    if (!h || !normals) return MVS_E_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    double* d = nullptr;
+    int rc = dmalloc(&d, (size_t)h->V * 3);
+    if (rc) return rc;
+    launch_vertex_normals(h->d_pts, h->d_faces, h->d_vf_ptr, h->d_vf, (int)h->V, d, h->stream);
+    rc = download(h, normals, d, sizeof(double) * h->V * 3);
+    (void)hipFree(d);
+    return rc;
+}
+
+int mvs_knn_points(const double* pts, int64_t n, int k, int32_t* out_idx) {
+    if (!pts || !out_idx || n <= 0 || k < 1 || k > 64 || n > 0x7ffffff0LL) { mvs_set_error("bad arguments (k 1..64)"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    double* d = nullptr; int32_t* o = nullptr;
+    rc = dmalloc(&d, (size_t)n * 3);
+    if (!rc) rc = dmalloc(&o, (size_t)n * k);
+    if (!rc) rc = mvs_check_hip(hipMemcpy(d, pts, sizeof(double) * n * 3, hipMemcpyHostToDevice), "upload");
+    if (!rc) { launch_knn(d, (int)n, k, o, nullptr); rc = mvs_check_hip(hipDeviceSynchronize(), "knn"); }
+    if (!rc) rc = mvs_check_hip(hipMemcpy(out_idx, o, sizeof(int32_t) * n * k, hipMemcpyDeviceToHost), "download");
+    (void)hipFree(d); (void)hipFree(o);
+    return rc;
+}
+
+int mvs_deform_enable_timing(mvs_deform_t h, int on) {
+    if (!h) return MVS_E_INVALID_ARG;
+    h->timing = on != 0;
+    h->timers.clear();
+    return MVS_OK;
+}
+int mvs_deform_kernel_time(mvs_deform_t h, const char* name, double* total_ms, int64_t* launches) {
+    if (!h || !name) return MVS_E_INVALID_ARG;
+    auto it = h->timers.find(name);
+    if (total_ms) *total_ms = it == h->timers.end() ? 0.0 : it->second.total_ms;
+    if (launches) *launches = it == h->timers.end() ? 0 : it->second.launches;
+    return MVS_OK;
+}
+
+}  // extern "C"

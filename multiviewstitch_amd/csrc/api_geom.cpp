@@ -1,0 +1,288 @@
+// api_geom.cpp — C-ABI for the camera/depth entries and SRTSolver (include/mvs.h,
+// mvs_depth_*, mvs_srt_*).  Drop-in for SRTSolver (R/Solver/SRTSolver.h:8-39), the
+// Depth2Model / Image3D back-projection and the SRT glue of Processor.
+#include "engine.h"
+#include "geom.h"
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+int mvs_current_device();
+
+namespace {
+
+int need_device() {
+    if (mvs_device_count() == 0) { mvs_set_error("no HIP device: the MI355X engine has no CPU fallback"); return MVS_E_NO_DEVICE; }
+    return mvs_check_hip(hipSetDevice(mvs_current_device()), "hipSetDevice");
+}
+bool cam_ok(const mvs_camera* c) { return c && c->w > 0 && c->h > 0 && (int64_t)c->w * c->h < 0x7ffffff0LL; }
+
+struct DevBuf {               // RAII device scratch
+    void* p = nullptr;
+    int alloc(size_t bytes) { return mvs_check_hip(hipMalloc(&p, bytes ? bytes : 1), "hipMalloc"); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <class T> T* as() { return (T*)p; }
+};
+
+inline int msvc_rand(uint32_t* st) {          // MSVC rand(): SURVEY Appendix A.3
+    *st = *st * 214013u + 2531011u;
+    return (int)((*st >> 16) & 0x7fff);
+}
+
+}  // namespace
+
+extern "C" {
+
+// -------------------------------------------------------------------- depth ----
+int mvs_depth_to_model_dev(const float* inv_depth_dev, const mvs_camera* cam, double min_dsp, double max_dsp,
+                           double smooth, int64_t* n_points, int64_t* n_faces, double* out_points_dev,
+                           double* out_normals_dev, int32_t* out_tex_index_dev, int32_t* out_faces_dev) {
+    if (!inv_depth_dev || !cam_ok(cam) || !n_points || !n_faces) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    return depth_to_model_dev(inv_depth_dev, cam, min_dsp, max_dsp, smooth, n_points, n_faces, out_points_dev,
+                              out_normals_dev, out_tex_index_dev, out_faces_dev, nullptr);
+}
+
+int mvs_depth_to_model(const float* inv_depth, const mvs_camera* cam, double min_dsp, double max_dsp, double smooth,
+                       int64_t* n_points, int64_t* n_faces, double* out_points, double* out_normals,
+                       int32_t* out_tex_index, int32_t* out_faces) {
+    if (!inv_depth || !cam_ok(cam) || !n_points || !n_faces) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    const size_t n = (size_t)cam->w * cam->h;
+    DevBuf dsp, pts, nrm, tex, fcs;
+    if ((rc = dsp.alloc(n * sizeof(float)))) return rc;
+    HIPCHK(hipMemcpy(dsp.p, inv_depth, n * sizeof(float), hipMemcpyHostToDevice));
+    int64_t np = 0, nf = 0;
+    rc = depth_to_model_dev(dsp.as<float>(), cam, min_dsp, max_dsp, smooth, &np, &nf, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    *n_points = np; *n_faces = nf;
+    if (!out_points && !out_normals && !out_tex_index && !out_faces) return MVS_OK;
+    if (out_points && (rc = pts.alloc((size_t)np * 24))) return rc;
+    if (out_normals && (rc = nrm.alloc((size_t)np * 24))) return rc;
+    if (out_tex_index && (rc = tex.alloc((size_t)np * 4))) return rc;
+    if (out_faces && (rc = fcs.alloc((size_t)nf * 12))) return rc;
+    rc = depth_to_model_dev(dsp.as<float>(), cam, min_dsp, max_dsp, smooth, &np, &nf, pts.as<double>(), nrm.as<double>(),
+                            tex.as<int32_t>(), fcs.as<int32_t>(), nullptr);
+    if (rc) return rc;
+    if (out_points && np) HIPCHK(hipMemcpy(out_points, pts.p, (size_t)np * 24, hipMemcpyDeviceToHost));
+    if (out_normals && np) HIPCHK(hipMemcpy(out_normals, nrm.p, (size_t)np * 24, hipMemcpyDeviceToHost));
+    if (out_tex_index && np) HIPCHK(hipMemcpy(out_tex_index, tex.p, (size_t)np * 4, hipMemcpyDeviceToHost));
+    if (out_faces && nf) HIPCHK(hipMemcpy(out_faces, fcs.p, (size_t)nf * 12, hipMemcpyDeviceToHost));
+    return MVS_OK;
+}
+
+int mvs_depth_unproject(const float* inv_depth, const mvs_camera* cam, double min_dsp, double max_dsp,
+                        double* out_points, uint8_t* out_valid) {
+    if (!inv_depth || !cam_ok(cam) || !out_points || !out_valid) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    const size_t n = (size_t)cam->w * cam->h;
+    DevBuf dsp, pts, val;
+    if ((rc = dsp.alloc(n * 4)) || (rc = pts.alloc(n * 24)) || (rc = val.alloc(n))) return rc;
+    HIPCHK(hipMemcpy(dsp.p, inv_depth, n * 4, hipMemcpyHostToDevice));
+    launch_depth_unproject(dsp.as<float>(), cam, min_dsp, max_dsp, pts.as<double>(), val.as<uint8_t>(), nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_points, pts.p, n * 24, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_valid, val.p, n, hipMemcpyDeviceToHost));
+    return MVS_OK;
+}
+
+// ---------------------------------------------------------------------- SRT ----
+int mvs_srt_make_triples(int64_t n, int iters, uint32_t* state, int32_t* triples) {
+    // Shuffle(idx, n, 3) (R/Common/Utils.h:25-34) driven by MSVC rand()
+    if (n < 3 || iters < 0 || !state || !triples || n > 0x7fffffffLL) { mvs_set_error("need n >= 3"); return MVS_E_DEGENERATE; }
+    for (int it = 0; it < iters; ++it) {
+        int k[3];
+        for (int i = 0; i < 3; ++i) {
+            int r = msvc_rand(state) % (int)(n - i), j, j0;
+            for (j = 0; j < i && r >= k[j]; j++) r++;
+            j0 = j;
+            for (j = i; j > j0; j--) k[j] = k[j - 1];
+            k[j0] = r;
+        }
+        triples[3 * it] = k[0]; triples[3 * it + 1] = k[1]; triples[3 * it + 2] = k[2];
+    }
+    return MVS_OK;
+}
+
+int mvs_srt_fit(const double* matches, int64_t n, const mvs_camera* cam1, const mvs_camera* cam2, int mode,
+                const int32_t* triples, int iters, uint32_t seed, double* scale, double* R, double* t, double* residual) {
+    if (!matches || !scale || !R || !t || (mode != MVS_SRT_CLOSED_FORM && mode != MVS_SRT_RANSAC)) {
+        mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG;
+    }
+    if (n < 1 || (mode == MVS_SRT_RANSAC && (n < 3 || iters < 1))) { mvs_set_error("too few matches"); return MVS_E_DEGENERATE; }
+    if (mode == MVS_SRT_RANSAC && (!cam1 || !cam2)) { mvs_set_error("RANSAC scoring needs both cameras"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    std::vector<int32_t> gen;
+    if (mode == MVS_SRT_RANSAC) {
+        if (!triples) {
+            gen.resize((size_t)iters * 3);
+            uint32_t st = seed;
+            if ((rc = mvs_srt_make_triples(n, iters, &st, gen.data()))) return rc;
+            triples = gen.data();
+        }
+        for (int64_t i = 0; i < (int64_t)iters * 3; ++i)
+            if (triples[i] < 0 || triples[i] >= n) { mvs_set_error("triple index out of range"); return MVS_E_INVALID_ARG; }
+    }
+    DevBuf dm, dt, dout;
+    if ((rc = dm.alloc((size_t)n * 48)) || (rc = dout.alloc(14 * 8))) return rc;
+    HIPCHK(hipMemcpy(dm.p, matches, (size_t)n * 48, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dout.p, 0, 14 * 8));
+    if (mode == MVS_SRT_RANSAC) {
+        if ((rc = dt.alloc((size_t)iters * 12))) return rc;
+        HIPCHK(hipMemcpy(dt.p, triples, (size_t)iters * 12, hipMemcpyHostToDevice));
+    }
+    rc = srt_fit_dev(dm.as<double>(), n, cam1, cam2, mode, dt.as<int32_t>(), iters, dout.as<double>(), nullptr);
+    if (rc) return rc;
+    double out[14];
+    HIPCHK(hipMemcpy(out, dout.p, sizeof out, hipMemcpyDeviceToHost));
+    *scale = out[0];
+    std::memcpy(R, out + 1, 9 * sizeof(double));
+    std::memcpy(t, out + 10, 3 * sizeof(double));
+    if (residual) *residual = (cam1 && cam2) ? out[13] : 0.0;
+    return MVS_OK;
+}
+
+int mvs_srt_residual(const double* matches, int64_t n, const mvs_camera* cam1, const mvs_camera* cam2, double scale,
+                     const double* R, const double* t, double* mean_err, double* per_match) {
+    if (!matches || !cam1 || !cam2 || !R || !t || n < 1 || (!mean_err && !per_match)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    DevBuf dm, drt, dpm;
+    if ((rc = dm.alloc((size_t)n * 48)) || (rc = drt.alloc(12 * 8)) || (rc = dpm.alloc((size_t)n * 16))) return rc;
+    double Rt[12];
+    std::memcpy(Rt, R, 72); std::memcpy(Rt + 9, t, 24);
+    HIPCHK(hipMemcpy(dm.p, matches, (size_t)n * 48, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(drt.p, Rt, sizeof Rt, hipMemcpyHostToDevice));
+    launch_srt_residual(dm.as<double>(), n, make_camdev(cam1), make_camdev(cam2), scale, drt.as<double>(), dpm.as<double>(), nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<double> pm((size_t)n * 2);
+    HIPCHK(hipMemcpy(pm.data(), dpm.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (per_match) std::memcpy(per_match, pm.data(), (size_t)n * 16);
+    if (mean_err) {
+        double err = 0.0;                                       // summed in match order, SRTSolver.cpp:25-27
+        for (int64_t i = 0; i < n; ++i) err = err + (pm[2 * i] + pm[2 * i + 1]) * 0.5;
+        *mean_err = err / (double)n;
+    }
+    return MVS_OK;
+}
+
+int mvs_srt_remove_outliers(const double* matches, int64_t n, const mvs_camera* cam1, const mvs_camera* cam2, int iters,
+                            double pixel_err, double adapt_ratio, uint32_t* rand_state, uint8_t* keep, int64_t* n_keep,
+                            double* err_out) {
+    // Processor::RemoveOutliers, R/Processor/Processor.cpp:193-259.  The RANSAC fits and the
+    // per-match pixel errors run on the GPU; the (tiny) list compaction stays on the host.
+    if (!matches || !cam1 || !cam2 || !rand_state || !keep || !n_keep || !err_out || n < 0 || iters < 1) {
+        mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG;
+    }
+    int rc = need_device();
+    if (rc) return rc;
+    std::vector<double> cur(matches, matches + 6 * n);
+    std::vector<int64_t> id(n);
+    for (int64_t i = 0; i < n; ++i) id[i] = i;
+    int64_t size = n;
+    double ratio = 1.0, err = HUGE_VAL;
+    for (int k = 0; k < 3; ++k) {                               // :198
+        if (size < 3) break;
+        std::vector<int32_t> tri((size_t)iters * 3);
+        if ((rc = mvs_srt_make_triples(size, iters, rand_state, tri.data()))) return rc;
+        double s, R[9], t[3];
+        if ((rc = mvs_srt_fit(cur.data(), size, cam1, cam2, MVS_SRT_RANSAC, tri.data(), iters, 0, &s, R, t, nullptr))) return rc;   // :202-205
+        std::vector<double> pm((size_t)size * 2);
+        if ((rc = mvs_srt_residual(cur.data(), size, cam1, cam2, s, R, t, nullptr, pm.data()))) return rc;                        // :210-228
+        double err_all = 0.0;
+        int64_t newSize = 0;
+        for (int64_t i = 0; i < size; ++i) {
+            const double e1 = pm[2 * i], e2 = pm[2 * i + 1];
+            err_all += (e1 + e2) * 0.5;                         // :229
+            if (e1 <= pixel_err * ratio && e2 <= pixel_err * ratio) {   // :232
+                for (int c = 0; c < 6; ++c) cur[6 * newSize + c] = cur[6 * i + c];
+                id[newSize++] = id[i];
+            }
+        }
+        ratio *= adapt_ratio;                                   // :240
+        err = err_all / (double)size;                           // :244
+        size = newSize;
+        if (newSize < 3) break;                                 // :258 (inlier_ratio is never written)
+    }
+    std::memset(keep, 0, (size_t)n);
+    for (int64_t i = 0; i < size; ++i) keep[id[i]] = 1;
+    *n_keep = size;
+    *err_out = err;
+    return MVS_OK;
+}
+
+// 3x3 glue on the host: a handful of flops per sequence pair.
+static void mul33(const double* A, const double* B, double* C) {
+    double T[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) T[3 * i + j] = (A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j]) + A[3 * i + 2] * B[6 + j];
+    std::memcpy(C, T, sizeof T);
+}
+static void mv33(const double* M, const double* v, double* o) {
+    const double x = (M[0] * v[0] + M[1] * v[1]) + M[2] * v[2], y = (M[3] * v[0] + M[4] * v[1]) + M[5] * v[2],
+                 z = (M[6] * v[0] + M[7] * v[1]) + M[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+
+int mvs_srt_compose(double sk, const double* Rk, const double* tk, double* s0, double* R0, double* t0) {
+    if (!Rk || !tk || !s0 || !R0 || !t0) return MVS_E_INVALID_ARG;
+    double Rn[9], sRk[9], tn[3];                                // Processor.cpp:820-822
+    mul33(Rk, R0, Rn);
+    for (int i = 0; i < 9; ++i) sRk[i] = sk * Rk[i];
+    mv33(sRk, t0, tn);
+    for (int i = 0; i < 3; ++i) t0[i] = tn[i] + tk[i];
+    std::memcpy(R0, Rn, sizeof Rn);
+    *s0 = sk * *s0;
+    return MVS_OK;
+}
+
+int mvs_srt_relative(double s_k0, const double* R_k0, const double* t_k0, double s_k, const double* R_k, const double* t_k,
+                     double* s, double* R, double* t) {
+    if (!R_k0 || !t_k0 || !R_k || !t_k || !s || !R || !t) return MVS_E_INVALID_ARG;
+    const double Rt[9] = {R_k0[0], R_k0[3], R_k0[6], R_k0[1], R_k0[4], R_k0[7], R_k0[2], R_k0[5], R_k0[8]};
+    *s = 1.0 / s_k0 * s_k;                                      // Processor.cpp:979
+    mul33(Rt, R_k, R);                                          // :980
+    const double inv = 1.0 / s_k0;
+    double M[9], d[3] = {t_k[0] - t_k0[0], t_k[1] - t_k0[1], t_k[2] - t_k0[2]};
+    for (int i = 0; i < 9; ++i) M[i] = inv * Rt[i];
+    mv33(M, d, t);                                              // :981
+    return MVS_OK;
+}
+
+int mvs_srt_apply_dev(const double* pts_dev, const double* normals_dev, int64_t P, double s, const double* R,
+                      const double* t, int inverse, double* out_pts_dev, double* out_normals_dev, void* hip_stream) {
+    if (P < 0 || (P > 0 && (!pts_dev || !out_pts_dev)) || !R || !t || (normals_dev && !out_normals_dev)) {
+        mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG;
+    }
+    int rc = need_device();
+    if (rc) return rc;
+    launch_srt_apply(pts_dev, normals_dev, P, s, R, t, inverse, out_pts_dev, out_normals_dev, (hipStream_t)hip_stream);
+    return mvs_check_hip(hipGetLastError(), "srt_apply");
+}
+
+int mvs_srt_apply(const double* pts, const double* normals, int64_t P, double s, const double* R, const double* t,
+                  int inverse, double* out_pts, double* out_normals) {
+    if (P < 0 || (P > 0 && (!pts || !out_pts)) || !R || !t || (normals && !out_normals)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    if (P == 0) return MVS_OK;
+    DevBuf dp, dn, op, on;
+    if ((rc = dp.alloc((size_t)P * 24)) || (rc = op.alloc((size_t)P * 24))) return rc;
+    HIPCHK(hipMemcpy(dp.p, pts, (size_t)P * 24, hipMemcpyHostToDevice));
+    if (normals) {
+        if ((rc = dn.alloc((size_t)P * 24)) || (rc = on.alloc((size_t)P * 24))) return rc;
+        HIPCHK(hipMemcpy(dn.p, normals, (size_t)P * 24, hipMemcpyHostToDevice));
+    }
+    launch_srt_apply(dp.as<double>(), normals ? dn.as<double>() : nullptr, P, s, R, t, inverse, op.as<double>(),
+                     normals ? on.as<double>() : nullptr, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_pts, op.p, (size_t)P * 24, hipMemcpyDeviceToHost));
+    if (normals) HIPCHK(hipMemcpy(out_normals, on.p, (size_t)P * 24, hipMemcpyDeviceToHost));
+    return MVS_OK;
+}
+
+}  // extern "C"

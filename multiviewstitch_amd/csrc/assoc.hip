@@ -1,0 +1,295 @@
+// assoc.hip — node -> target correspondence search, the "HOT LOOP 1" of
+// Deformation::Deform (R/Deformation/Deformation.cpp:266-357), as three kernels
+// split at the exchange points of a view-sharded run:
+//
+//   k_assoc_dmin   : exact 1-NN squared distance (float32, FLANN's L2 order)     :283-284
+//   k_assoc_select : ball d2 <= 2*d2min (:288), normal filter (:304-315),
+//                    projLen/projDist (:330-335), best <= top_k by the total
+//                    order (projDist, |projLen|, index)  
+//   k_assoc_merge  : merge rank lists, means (:338-349), rejection tests (:350-353)
+//
+// One wave64 per node.  The dense grid is x-fastest, so every (y,z) row of a
+// search box is one contiguous, coalesced run of float4 points.  The running
+// top-k lives across lanes 0..top_k-1 of the wave (one element per lane) and is
+// updated by ballot/readlane/shfl_up — no LDS, no atomics, deterministic.
+#include "engine.h"
+#include "dev_common.h"
+#include "grid_dev.h"
+
+namespace {
+
+__device__ inline int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ inline double rl_d(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ inline long long rl_ll(long long b, int l) {
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ inline long long shfl_up_ll(long long b) {
+    const int lo = __shfl_up((int)(b & 0xffffffffLL), 1, 64);
+    const int hi = __shfl_up((int)(b >> 32), 1, 64);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+__device__ inline bool key_less(double pd_a, double apl_a, long long i_a, double pd_b, double apl_b, long long i_b) {
+    if (pd_a != pd_b) return pd_a < pd_b;
+    if (apl_a != apl_b) return apl_a < apl_b;
+    return i_a < i_b;
+}
+
+struct QCell {
+    float fx, fy, fz;
+    int cx, cy, cz;
+};
+__device__ inline QCell query_cell(const GridDev& g, float qx, float qy, float qz) {
+    QCell c;
+    c.fx = grid_cellf(qx, g.minx, g.inv_h); c.fy = grid_cellf(qy, g.miny, g.inv_h); c.fz = grid_cellf(qz, g.minz, g.inv_h);
+    c.cx = grid_axis(qx, g.minx, g.inv_h, g.nx); c.cy = grid_axis(qy, g.miny, g.inv_h, g.ny); c.cz = grid_axis(qz, g.minz, g.inv_h, g.nz);
+    return c;
+}
+
+// ------------------------------------------------------------------ dmin ----
+__global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __restrict__ node_pts, int K,
+                                                    float* __restrict__ d2min) {
+    const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= K) return;                       // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const float qx = (float)node_pts[3 * node], qy = (float)node_pts[3 * node + 1], qz = (float)node_pts[3 * node + 2];
+    float best = INFINITY;
+    if (g.P > 0) {
+        const QCell c = query_cell(g, qx, qy, qz);
+        float m = fminf(fminf(fminf(c.fx - c.cx, c.cx + 1 - c.fx), fminf(c.fy - c.cy, c.cy + 1 - c.fy)),
+                        fminf(c.fz - c.cz, c.cz + 1 - c.fz));
+        m = fmaxf(m, 0.0f);                      // query outside the grid (or NaN): no credit
+        const int smax = max(g.nx, max(g.ny, g.nz));
+        const int32_t* __restrict__ cs = g.cell_start;
+        for (int s = 0; s <= smax; ++s) {        // bounded: at s == smax every cell has been visited
+            const int side = 2 * s + 1, nrows = side * side;
+            for (int base = 0; base < nrows; base += 64) {
+                int a0 = 0, b0 = 0, a1 = 0, b1 = 0;
+                const int ridx = base + lane;
+                if (ridx < nrows) {
+                    const int dy = ridx / side - s, dz = ridx % side - s;
+                    const int y = c.cy + dy, z = c.cz + dz;
+                    if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+                        const int64_t rb = ((int64_t)z * g.ny + y) * g.nx;
+                        if (abs(dy) == s || abs(dz) == s) {          // face rows of the shell: whole x run
+                            const int x0 = max(c.cx - s, 0), x1 = min(c.cx + s, g.nx - 1);
+                            if (x0 <= x1) { a0 = cs[rb + x0]; b0 = cs[rb + x1 + 1]; }
+                        } else {                                      // interior rows: the two end cells
+                            if (c.cx - s >= 0) { a0 = cs[rb + c.cx - s]; b0 = cs[rb + c.cx - s + 1]; }
+                            if (c.cx + s < g.nx) { a1 = cs[rb + c.cx + s]; b1 = cs[rb + c.cx + s + 1]; }
+                        }
+                    }
+                }
+                unsigned long long mask = __ballot(b0 > a0 || b1 > a1);
+                while (mask) {
+                    const int l = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const int A0 = rl_i(a0, l), B0 = rl_i(b0, l), A1 = rl_i(a1, l), B1 = rl_i(b1, l);
+                    for (int i = A0 + lane; i < B0; i += 64) {
+                        const float4 p = g.spos[i];
+                        best = fminf(best, d2f(qx, qy, qz, p.x, p.y, p.z));
+                    }
+                    for (int i = A1 + lane; i < B1; i += 64) {
+                        const float4 p = g.spos[i];
+                        best = fminf(best, d2f(qx, qy, qz, p.x, p.y, p.z));
+                    }
+                }
+            }
+            const float wb = wave_min_f(best);
+            const float bound = ((float)s + m - 0.01f) * g.h;        // everything within `bound` has been seen
+            if (bound > 0.0f && wb <= bound * bound) break;
+        }
+    }
+    best = wave_min_f(best);
+    if (lane == 0) d2min[node] = best;
+}
+
+// ---------------------------------------------------------------- select ----
+__global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* __restrict__ node_pts,
+                                                      const double* __restrict__ node_nrm, int K, int top_k,
+                                                      const float* __restrict__ d2min, mvs_cand* __restrict__ rec,
+                                                      int32_t* __restrict__ counts) {
+    const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= K) return;
+    const int lane = threadIdx.x & 63;
+    const d3 orig = ld3(node_pts + 3 * node), nn = ld3(node_nrm + 3 * node);
+    const float qx = (float)orig.x, qy = (float)orig.y, qz = (float)orig.z;
+    const float dm = d2min[node];
+
+    // wave-resident sorted list: lane i (< len) holds the i-th best candidate
+    double L_pd = 0, L_pl = 0, L_x = 0, L_y = 0, L_z = 0;
+    long long L_idx = -1;
+    int len = 0;
+    double t_pd = 0, t_apl = 0; long long t_idx = 0;       // key of the current top_k-th element
+    int n_ball = 0, n_pass = 0;
+
+    if (g.P > 0 && dm < INFINITY) {
+        const float r2 = dm * 2.0f;                          // radiusSearch(..., minDist * 2.0f, ...)  :288
+        const double nlen = norm3(nn);
+        const QCell c = query_cell(g, qx, qy, qz);
+        const float rc = sqrtf(r2) * g.inv_h + 0.01f;
+        const float lx = floorf(c.fx - rc), hx = floorf(c.fx + rc);
+        const float ly = floorf(c.fy - rc), hy = floorf(c.fy + rc);
+        const float lz = floorf(c.fz - rc), hz = floorf(c.fz + rc);
+        const bool any = hx >= 0.f && lx <= (float)(g.nx - 1) && hy >= 0.f && ly <= (float)(g.ny - 1) &&
+                         hz >= 0.f && lz <= (float)(g.nz - 1);
+        if (any) {
+            const int x0 = (int)fmaxf(lx, 0.f), x1 = (int)fminf(hx, (float)(g.nx - 1));
+            const int y0 = (int)fmaxf(ly, 0.f), y1 = (int)fminf(hy, (float)(g.ny - 1));
+            const int z0 = (int)fmaxf(lz, 0.f), z1 = (int)fminf(hz, (float)(g.nz - 1));
+            const int ny_ = y1 - y0 + 1, nrows = ny_ * (z1 - z0 + 1);
+            const int32_t* __restrict__ cs = g.cell_start;
+            for (int base = 0; base < nrows; base += 64) {
+                int a = 0, b = 0;
+                const int ridx = base + lane;
+                if (ridx < nrows) {
+                    const int y = y0 + ridx % ny_, z = z0 + ridx / ny_;
+                    const int64_t rb = ((int64_t)z * g.ny + y) * g.nx;
+                    a = cs[rb + x0]; b = cs[rb + x1 + 1];
+                }
+                unsigned long long mask = __ballot(b > a);
+                while (mask) {
+                    const int l = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const int A = rl_i(a, l), B = rl_i(b, l);
+                    for (int cb = A; cb < B; cb += 64) {     // wave-uniform trip count
+                        const int i = cb + lane;
+                        bool has = false;
+                        double pd = 0, pl = 0; d3 tp = mk3(0, 0, 0); long long gi = 0;
+                        if (i < B) {
+                            const float4 p = g.spos[i];
+                            if (d2f(qx, qy, qz, p.x, p.y, p.z) <= r2) {
+                                ++n_ball;
+                                const d3 tn = ld3(g.tnrm + 3 * (int64_t)i);
+                                if (dot3(nn, tn) > 0) {                       // :307
+                                    ++n_pass;
+                                    tp = ld3(g.tpos + 3 * (int64_t)i);
+                                    const d3 dir = tp - orig;                 // :331
+                                    pl = dot3(dir, nn) / nlen;                // :332
+                                    const double x = sqn3(dir) - pl * pl;
+                                    pd = sqrt((0.0 < x) ? x : 0.0);           // :334, clamped (Appendix A.2)
+                                    gi = g.index_base + (long long)__float_as_int(p.w);
+                                    has = true;
+                                }
+                            }
+                        }
+                        const double apl = fabs(pl);
+                        unsigned long long pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
+                        while (pend) {
+                            const int src = __ffsll((long long)pend) - 1;
+                            const double c_pd = rl_d(pd, src), c_pl = rl_d(pl, src);
+                            const double c_x = rl_d(tp.x, src), c_y = rl_d(tp.y, src), c_z = rl_d(tp.z, src);
+                            const long long c_i = rl_ll(gi, src);
+                            const bool less = lane < len && key_less(L_pd, fabs(L_pl), L_idx, c_pd, fabs(c_pl), c_i);
+                            const int pos = __popcll(__ballot(less));
+                            const double u_pd = __shfl_up(L_pd, 1, 64), u_pl = __shfl_up(L_pl, 1, 64);
+                            const double u_x = __shfl_up(L_x, 1, 64), u_y = __shfl_up(L_y, 1, 64), u_z = __shfl_up(L_z, 1, 64);
+                            const long long u_i = shfl_up_ll(L_idx);
+                            if (lane > pos && lane <= len && lane < top_k) {
+                                L_pd = u_pd; L_pl = u_pl; L_x = u_x; L_y = u_y; L_z = u_z; L_idx = u_i;
+                            } else if (lane == pos) {
+                                L_pd = c_pd; L_pl = c_pl; L_x = c_x; L_y = c_y; L_z = c_z; L_idx = c_i;
+                            }
+                            len = min(len + 1, top_k);
+                            if (len == top_k) {
+                                t_pd = rl_d(L_pd, top_k - 1); t_apl = fabs(rl_d(L_pl, top_k - 1)); t_idx = rl_ll(L_idx, top_k - 1);
+                            }
+                            if (lane == src) has = false;
+                            pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    n_ball = wave_sum_i(n_ball);
+    n_pass = wave_sum_i(n_pass);
+    if (lane < 8) {
+        mvs_cand* o = rec + (int64_t)node * 8 + lane;
+        const bool live = lane < len;
+        o->proj_dist = live ? L_pd : 0.0;
+        o->proj_len = live ? L_pl : 0.0;
+        o->pos[0] = live ? L_x : 0.0; o->pos[1] = live ? L_y : 0.0; o->pos[2] = live ? L_z : 0.0;
+        o->index = live ? L_idx : -1;
+    }
+    if (lane == 0) { counts[2 * node] = n_ball; counts[2 * node + 1] = n_pass; }
+}
+
+// ----------------------------------------------------------------- merge ----
+__global__ void k_assoc_merge(const double* __restrict__ node_pts, const double* __restrict__ node_nrm, int K,
+                              mvs_deform_params p, const mvs_cand* __restrict__ rec_all,
+                              const int32_t* __restrict__ counts_all, int nranks, double* __restrict__ controls,
+                              uint8_t* __restrict__ valid, int64_t* __restrict__ top_idx) {
+    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= K) return;
+    const d3 orig = ld3(node_pts + 3 * node), nn = ld3(node_nrm + 3 * node);
+    double l_pd[8], l_pl[8], l_x[8], l_y[8], l_z[8];
+    long long l_i[8];
+    int len = 0;
+    long long ball = 0;
+    const int tk = p.top_k;
+    for (int r = 0; r < nranks; ++r) {
+        ball += counts_all[((int64_t)r * K + node) * 2];
+        for (int s = 0; s < 8; ++s) {
+            const mvs_cand c = rec_all[((int64_t)r * K + node) * 8 + s];
+            if (c.index < 0) continue;
+            int pos = len;
+            while (pos > 0 && key_less(c.proj_dist, fabs(c.proj_len), c.index, l_pd[pos - 1], fabs(l_pl[pos - 1]), l_i[pos - 1])) --pos;
+            if (pos >= tk) continue;
+            const int last = min(len, tk - 1);
+            for (int k = last; k > pos; --k) {
+                l_pd[k] = l_pd[k - 1]; l_pl[k] = l_pl[k - 1]; l_x[k] = l_x[k - 1]; l_y[k] = l_y[k - 1]; l_z[k] = l_z[k - 1]; l_i[k] = l_i[k - 1];
+            }
+            l_pd[pos] = c.proj_dist; l_pl[pos] = c.proj_len; l_x[pos] = c.pos[0]; l_y[pos] = c.pos[1]; l_z[pos] = c.pos[2]; l_i[pos] = c.index;
+            len = min(len + 1, tk);
+        }
+    }
+    bool ok = ball < (long long)p.max_result && len > 0;     // :286-297 (full result dropped), :315
+    d3 mp = orig;
+    if (top_idx)
+        for (int s = 0; s < 8; ++s) top_idx[(int64_t)node * 8 + s] = (ok && s < len) ? l_i[s] : -1;
+    if (ok) {
+        double m_pl = 0, m_pd = 0;
+        d3 acc = mk3(0, 0, 0);
+        for (int s = 0; s < len; ++s) {                       // :341-346, best first
+            m_pl += l_pl[s]; m_pd += l_pd[s];
+            acc = acc + mk3(l_x[s], l_y[s], l_z[s]);
+        }
+        const double dn = (double)len;
+        m_pl /= dn; m_pd /= dn; acc = acc / dn;               // :347-349
+        if (m_pl >= p.proj_len_err || m_pd >= p.proj_dist_err) ok = false;            // :350
+        if (ok) {
+            const d3 dir = acc - orig;                        // :352-353
+            if (fabs(dot3(dir, nn) / (norm3(dir) * norm3(nn))) < p.min_cos) ok = false;
+        }
+        if (ok) mp = acc;
+    }
+    valid[node] = ok ? 1 : 0;                                 // :355-356 (controls stay at orig otherwise, :271-272)
+    st3(controls + 3 * node, mp);
+}
+
+}  // namespace
+
+void launch_assoc_dmin(const GridDev& g, const double* node_pts, int K, float* d2min, hipStream_t s) {
+    if (K <= 0) return;
+    k_assoc_dmin<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, K, d2min);
+}
+void launch_assoc_select(const GridDev& g, const double* node_pts, const double* node_nrm, int K, int top_k,
+                         const float* d2min, mvs_cand* rec, int32_t* counts, hipStream_t s) {
+    if (K <= 0) return;
+    k_assoc_select<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, top_k, d2min, rec, counts);
+}
+void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
+                        const mvs_cand* rec_all, const int32_t* counts_all, int nranks, double* controls,
+                        uint8_t* valid, int64_t* top_idx, hipStream_t s) {
+    if (K <= 0) return;
+    k_assoc_merge<<<dim3((K + 127) / 128), dim3(128), 0, s>>>(node_pts, node_nrm, K, p, rec_all, counts_all, nranks,
+                                                             controls, valid, top_idx);
+}

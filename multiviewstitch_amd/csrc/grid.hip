@@ -1,0 +1,229 @@
+// grid.hip — float32 uniform grid over a rank's target points (replaces the
+// cv::flann KD-forest of R/Deformation/Deformation.cpp:238-246 with an EXACT
+// index).  Build = bbox reduce, cell histogram, exclusive
+// scan, scatter into cell-sorted SoA.  Runs once per mvs_deform_set_target.
+#include "engine.h"
+#include "dev_common.h"
+#include "grid_dev.h"
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr int TPB = 256;
+
+__global__ void k_bbox(const double* __restrict__ pts, int64_t P, float* __restrict__ part) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = (float)pts[3 * i + c];
+            mn[c] = fminf(mn[c], v);   // NaN coordinates are ignored by fminf/fmaxf
+            mx[c] = fmaxf(mx[c], v);
+        }
+    }
+    __shared__ float sm[6][TPB / 64];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float a = mn[c], b = mx[c];
+        for (int o = 32; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o, 64)); b = fmaxf(b, __shfl_xor(b, o, 64)); }
+        if ((threadIdx.x & 63) == 0) { sm[c][threadIdx.x >> 6] = a; sm[3 + c][threadIdx.x >> 6] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float r = sm[threadIdx.x][0];
+        for (int w = 1; w < TPB / 64; ++w) r = threadIdx.x < 3 ? fminf(r, sm[threadIdx.x][w]) : fmaxf(r, sm[threadIdx.x][w]);
+        part[blockIdx.x * 6 + threadIdx.x] = r;
+    }
+}
+
+__global__ void k_cell_count(const double* __restrict__ pts, int64_t P, GridGeom g, int32_t* __restrict__ counts,
+                             int32_t* __restrict__ cell_of_pt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int c = grid_cell(g, (float)pts[3 * i], (float)pts[3 * i + 1], (float)pts[3 * i + 2]);
+    if (cell_of_pt) cell_of_pt[i] = c;
+    atomicAdd(&counts[c], 1);
+}
+
+__global__ void k_count_nonzero(const int32_t* __restrict__ counts, int64_t n, unsigned long long* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nz = (i < n && counts[i] != 0) ? 1 : 0;
+    const int s = wave_sum_i(nz);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, (unsigned long long)s);
+}
+
+// ---- exclusive scan of int32 counts (3 phases, 1024 elements per block) ----
+constexpr int SCAN_ELEMS = 1024;
+
+__global__ void k_scan_block_sums(const int32_t* __restrict__ in, int64_t n, int32_t* __restrict__ bsum) {
+    const int64_t base = (int64_t)blockIdx.x * SCAN_ELEMS;
+    int s = 0;
+    for (int k = threadIdx.x; k < SCAN_ELEMS; k += blockDim.x)
+        if (base + k < n) s += in[base + k];
+    s = wave_sum_i(s);
+    __shared__ int sm[TPB / 64];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < TPB / 64; ++w) t += sm[w]; bsum[blockIdx.x] = t; }
+}
+
+__global__ void k_scan_sums_serial(int32_t* bsum, int64_t nb) {
+    // one wave; nb is small (ncells / 1024).  Chunked wave scan.
+    int carry = 0;
+    for (int64_t base = 0; base < nb; base += 64) {
+        const int64_t i = base + threadIdx.x;
+        int v = i < nb ? bsum[i] : 0;
+        int x = v;
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if ((int)threadIdx.x >= o) x += y; }
+        if (i < nb) bsum[i] = carry + x - v;
+        carry += __shfl(x, 63, 64);
+    }
+}
+
+__global__ void k_scan_apply(const int32_t* __restrict__ in, int64_t n, const int32_t* __restrict__ bsum,
+                             int32_t* __restrict__ out) {
+    // each thread owns 4 consecutive elements of the block's 1024
+    const int64_t base = (int64_t)blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
+    int v[4], t = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; t += v[k]; }
+    int x = t;
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if ((int)(threadIdx.x & 63) >= o) x += y; }
+    __shared__ int sm[TPB / 64];
+    if ((threadIdx.x & 63) == 63) sm[threadIdx.x >> 6] = x;
+    __syncthreads();
+    int off = bsum[blockIdx.x];
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += sm[w];
+    int run = off + x - t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (base + k <= n) out[base + k] = run; run += v[k]; }   // out has n+1 entries
+}
+
+__global__ void k_scatter(const double* __restrict__ pts, const double* __restrict__ nrm, int64_t P,
+                          const int32_t* __restrict__ cell_of_pt, const int32_t* __restrict__ cell_start,
+                          int32_t* __restrict__ cursor, float4* __restrict__ spos, double* __restrict__ tpos,
+                          double* __restrict__ tnrm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int c = cell_of_pt[i];
+    const int64_t d = (int64_t)cell_start[c] + atomicAdd(&cursor[c], 1);
+    const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    spos[d] = make_float4((float)x, (float)y, (float)z, __int_as_float((int)i));
+    tpos[3 * d] = x; tpos[3 * d + 1] = y; tpos[3 * d + 2] = z;
+    tnrm[3 * d] = nrm[3 * i]; tnrm[3 * d + 1] = nrm[3 * i + 1]; tnrm[3 * d + 2] = nrm[3 * i + 2];
+}
+
+}  // namespace
+
+// in: n+1 entries (in[n] ignored, treated as 0); out: n+1 entries, out[n] = total.  Syncs the stream.
+int scan_exclusive_i32(const int32_t* in, int64_t n, int32_t* out, hipStream_t s) {
+    const int64_t nb = (n + 1 + SCAN_ELEMS - 1) / SCAN_ELEMS;
+    int32_t* bsum = nullptr;
+    HIPCHK(hipMalloc(&bsum, sizeof(int32_t) * nb));
+    k_scan_block_sums<<<dim3((unsigned)nb), dim3(TPB), 0, s>>>(in, n, bsum);
+    k_scan_sums_serial<<<dim3(1), dim3(64), 0, s>>>(bsum, nb);
+    k_scan_apply<<<dim3((unsigned)nb), dim3(TPB), 0, s>>>(in, n, bsum, out);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(bsum));
+    return MVS_OK;
+}
+
+namespace {
+
+GridGeom make_geom(const float mn[3], const float mx[3], float h) {
+    GridGeom g;
+    g.minx = mn[0]; g.miny = mn[1]; g.minz = mn[2];
+    g.h = h; g.inv_h = 1.0f / h;
+    g.nx = std::max(1, (int)std::floor((mx[0] - mn[0]) * g.inv_h) + 1);
+    g.ny = std::max(1, (int)std::floor((mx[1] - mn[1]) * g.inv_h) + 1);
+    g.nz = std::max(1, (int)std::floor((mx[2] - mn[2]) * g.inv_h) + 1);
+    return g;
+}
+
+}  // namespace
+
+int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* nrm_dev, int64_t index_base) {
+    hipStream_t s = h->stream;
+    if (h->d_spos) { hipFree(h->d_spos); h->d_spos = nullptr; }
+    if (h->d_tpos) { hipFree(h->d_tpos); h->d_tpos = nullptr; }
+    if (h->d_tnrm) { hipFree(h->d_tnrm); h->d_tnrm = nullptr; }
+    if (h->d_cell_start) { hipFree(h->d_cell_start); h->d_cell_start = nullptr; }
+    h->P = P;
+    h->grid = GridDev{};
+    h->grid.P = P; h->grid.index_base = index_base;
+    h->grid.nx = h->grid.ny = h->grid.nz = 0;
+    if (P == 0) { h->has_target = true; return MVS_OK; }
+    if (P > 0x7fffffffLL) { mvs_set_error("target too large for int32 indices"); return MVS_E_INVALID_ARG; }
+
+    // 1. bounding box of the float32-rounded coordinates
+    const int nbb = (int)std::min<int64_t>(1024, (P + TPB - 1) / TPB);
+    float* d_part = nullptr;
+    HIPCHK(hipMalloc(&d_part, sizeof(float) * 6 * nbb));
+    k_bbox<<<dim3(nbb), dim3(TPB), 0, s>>>(pts_dev, P, d_part);
+    std::vector<float> part(6 * (size_t)nbb);
+    HIPCHK(hipMemcpyAsync(part.data(), d_part, sizeof(float) * 6 * nbb, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(d_part));
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int b = 0; b < nbb; ++b)
+        for (int c = 0; c < 3; ++c) { mn[c] = std::min(mn[c], part[6 * b + c]); mx[c] = std::max(mx[c], part[6 * b + 3 + c]); }
+    for (int c = 0; c < 3; ++c)
+        if (!(mn[c] <= mx[c])) { mn[c] = 0.f; mx[c] = 0.f; }   // all-NaN axis
+    float ext = std::max(mx[0] - mn[0], std::max(mx[1] - mn[1], mx[2] - mn[2]));
+    if (!(ext > 0.f)) ext = 1.f;
+
+    // 2. cell size: probe at ext/128, then aim at ~16 points per occupied cell
+    const int64_t MAX_CELLS = 1LL << 26;
+    float hh = ext / 128.f;
+    GridGeom g = make_geom(mn, mx, hh);
+    int32_t* d_counts = nullptr;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int64_t ncells = (int64_t)g.nx * g.ny * g.nz;
+        HIPCHK(hipMalloc(&d_counts, sizeof(int32_t) * (ncells + 1)));
+        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (ncells + 1), s));
+        if (pass == 1) break;
+        k_cell_count<<<dim3((unsigned)((P + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(pts_dev, P, g, d_counts, nullptr);
+        unsigned long long* d_nz = nullptr; unsigned long long nz = 0;
+        HIPCHK(hipMalloc(&d_nz, sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(d_nz, 0, sizeof(unsigned long long), s));
+        k_count_nonzero<<<dim3((unsigned)((ncells + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(d_counts, ncells, d_nz);
+        HIPCHK(hipMemcpyAsync(&nz, d_nz, sizeof nz, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipFree(d_nz));
+        HIPCHK(hipFree(d_counts)); d_counts = nullptr;
+        const double occ = (double)P / (double)std::max<unsigned long long>(1, nz);
+        // surface-like data: occupancy ~ h^2
+        float hn = hh * (float)std::sqrt(16.0 / occ);
+        hn = std::max(hn, ext / 1024.f);
+        hn = std::min(hn, ext / 4.f);
+        g = make_geom(mn, mx, hn);
+        while ((int64_t)g.nx * g.ny * g.nz > MAX_CELLS) { hn *= 1.26f; g = make_geom(mn, mx, hn); }
+        hh = hn;
+    }
+    const int64_t ncells = (int64_t)g.nx * g.ny * g.nz;
+
+    // 3. histogram, scan, scatter
+    int32_t* d_cell_of = nullptr;
+    HIPCHK(hipMalloc(&d_cell_of, sizeof(int32_t) * P));
+    k_cell_count<<<dim3((unsigned)((P + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(pts_dev, P, g, d_counts, d_cell_of);
+    HIPCHK(hipMalloc(&h->d_cell_start, sizeof(int32_t) * (ncells + 1)));
+    int rc = scan_exclusive_i32(d_counts, ncells, h->d_cell_start, s);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (ncells + 1), s));
+    HIPCHK(hipMalloc(&h->d_spos, sizeof(float4) * P));
+    HIPCHK(hipMalloc(&h->d_tpos, sizeof(double) * 3 * P));
+    HIPCHK(hipMalloc(&h->d_tnrm, sizeof(double) * 3 * P));
+    k_scatter<<<dim3((unsigned)((P + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(pts_dev, nrm_dev, P, d_cell_of, h->d_cell_start,
+                                                                    d_counts, h->d_spos, h->d_tpos, h->d_tnrm);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(d_counts));
+    HIPCHK(hipFree(d_cell_of));
+    h->grid.minx = g.minx; h->grid.miny = g.miny; h->grid.minz = g.minz;
+    h->grid.h = g.h; h->grid.inv_h = g.inv_h;
+    h->grid.nx = g.nx; h->grid.ny = g.ny; h->grid.nz = g.nz;
+    h->grid.spos = h->d_spos; h->grid.tpos = h->d_tpos; h->grid.tnrm = h->d_tnrm;
+    h->grid.cell_start = h->d_cell_start;
+    h->has_target = true;
+    return MVS_OK;
+}

@@ -1,0 +1,205 @@
+"""Host mirror of ``class Deformation`` (R/Deformation/Deformation.h:224-252).
+
+Same method names and argument meaning as the reference; every method calls
+the HIP engine through the C-ABI (include/mvs.h).  Differences a caller sees:
+
+* errors raise ``MvsError`` instead of ``exit(-1)`` (Deformation.cpp:41-45,393-397);
+* no files are written (``./Result/sample.obj``, Deformation.cpp:105);
+* ``Deform`` can run more than the reference's single pass (``counter = 1``,
+  Deformation.cpp:252) and the target may be a view shard of a larger set.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def default_params(**kw) -> L.CParams:
+    p = L.CParams()
+    L.lib().mvs_deform_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _stats(st: L.CStats) -> dict:
+    return dict(outer_done=st.outer_done, arap_iters_run=st.arap_iters_run, cg_iters=st.cg_iters,
+                n_valid=st.n_valid, energy=np.array(st.energy[:]), cg_rel_residual=st.cg_rel_residual)
+
+
+class Deformation:
+    """``Deformation(points, normals, facets)`` — Deformation.cpp:29-46."""
+
+    def __init__(self, points, normals, facets, device: int | None = None):
+        lib = L.lib()
+        if device is not None:
+            L.check(lib.mvs_set_device(int(device)))
+        pts = L.arr(points, np.float64).reshape(-1, 3)
+        nrm = L.arr(normals, np.float64).reshape(-1, 3)
+        fcs = L.arr(facets, np.int32).reshape(-1, 3)
+        if nrm.shape != pts.shape:
+            raise ValueError("normals must match points")
+        self._h = C.c_void_p()
+        L.check(lib.mvs_deform_create(len(pts), L.ptr(pts), L.ptr(nrm), len(fcs), L.ptr(fcs), C.byref(self._h)))
+        self.V, self.F = len(pts), len(fcs)
+        self._faces = fcs
+        self.params = default_params()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            L.lib().mvs_deform_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------- reference API --
+    def UniformSampling(self, knn: int = 16) -> int:
+        """Deformation.cpp:63-106; returns sampIdx.size()."""
+        K = C.c_int64()
+        L.check(L.lib().mvs_deform_sample_nodes(self._h, knn, C.byref(K)))
+        return K.value
+
+    def Deform(self, tpts, tnormals, projLenErr: float = 100.0, projDistErr: float = 100.0, n_outer: int = 1) -> dict:
+        """``Deform(tpts, tnormals, projLenErr, projDistErr)`` — Deformation.cpp:232-402
+        (call site R/Processor/Processor.cpp:1136 passes 100.0, 100.0)."""
+        self.set_target(tpts, tnormals)
+        if self.K == 0:
+            self.UniformSampling()                       # Deformation.cpp:248-250
+        self.params.proj_len_err = projLenErr
+        self.params.proj_dist_err = projDistErr
+        return self.iterate(n_outer)
+
+    def Polyhedron(self):
+        """Vertices and facets of the (deformed) mesh — what exportOBJ walks, Deformation.h:193-217."""
+        return self.vertices(), self._faces.copy()
+
+    # ----------------------------------------------------------------- engine --
+    @property
+    def K(self) -> int:
+        k = C.c_int64()
+        L.check(L.lib().mvs_deform_sizes(self._h, None, None, C.byref(k), None))
+        return k.value
+
+    @property
+    def P(self) -> int:
+        p = C.c_int64()
+        L.check(L.lib().mvs_deform_sizes(self._h, None, None, None, C.byref(p)))
+        return p.value
+
+    def set_nodes(self, idx):
+        idx = L.arr(idx, np.int32)
+        L.check(L.lib().mvs_deform_set_nodes(self._h, L.ptr(idx), len(idx)))
+
+    def nodes(self) -> np.ndarray:
+        out = np.empty(self.K, np.int32)
+        L.check(L.lib().mvs_deform_get_nodes(self._h, L.ptr(out)))
+        return out
+
+    def set_target(self, tpts, tnormals, index_base: int = 0):
+        tp = L.arr(tpts, np.float64).reshape(-1, 3)
+        tn = L.arr(tnormals, np.float64).reshape(-1, 3)
+        if tp.shape != tn.shape:
+            raise ValueError("tnormals must match tpts")
+        L.check(L.lib().mvs_deform_set_target(self._h, len(tp), L.ptr(tp), L.ptr(tn), index_base))
+
+    def set_target_dev(self, pts_dev: int, nrm_dev: int, P: int, index_base: int = 0):
+        """Target already in HBM (raw device addresses, e.g. torch ``tensor.data_ptr()``)."""
+        L.check(L.lib().mvs_deform_set_target_dev(self._h, P, L.ptr(int(pts_dev)), L.ptr(int(nrm_dev)), index_base))
+
+    def iterate(self, n_outer: int = 1) -> dict:
+        st = L.CStats()
+        L.check(L.lib().mvs_deform_iterate(self._h, C.byref(self.params), n_outer, C.byref(st)))
+        return _stats(st)
+
+    # sharded phases (mvs.h: mvs_deform_assoc_*), device addresses in / out
+    def assoc_dmin(self, d2min_dev: int):
+        L.check(L.lib().mvs_deform_assoc_dmin(self._h, C.byref(self.params), L.ptr(int(d2min_dev))))
+
+    def assoc_select(self, d2min_dev: int, records_dev: int, counts_dev: int):
+        L.check(L.lib().mvs_deform_assoc_select(self._h, C.byref(self.params), L.ptr(int(d2min_dev)),
+                                                L.ptr(int(records_dev)), L.ptr(int(counts_dev))))
+
+    def assoc_merge(self, records_all_dev: int, counts_all_dev: int, nranks: int):
+        L.check(L.lib().mvs_deform_assoc_merge(self._h, C.byref(self.params), L.ptr(int(records_all_dev)),
+                                               L.ptr(int(counts_all_dev)), nranks))
+
+    def solve(self) -> dict:
+        st = L.CStats()
+        L.check(L.lib().mvs_deform_solve(self._h, C.byref(self.params), C.byref(st)))
+        return _stats(st)
+
+    def sync(self):
+        L.check(L.lib().mvs_deform_sync(self._h))
+
+    def stream(self) -> int:
+        return int(L.lib().mvs_deform_stream(self._h) or 0)
+
+    def arap(self, ctrl_targets) -> dict:
+        """CGAL-equivalent ARAP with explicit targets for the handle's nodes (Deformation.cpp:383-400)."""
+        ct = L.arr(ctrl_targets, np.float64).reshape(-1, 3)
+        if len(ct) != self.K:
+            raise ValueError("one target per node")
+        st = L.CStats()
+        L.check(L.lib().mvs_deform_arap(self._h, C.byref(self.params), L.ptr(ct), C.byref(st)))
+        return _stats(st)
+
+    # ---------------------------------------------------------------- getters --
+    def vertices(self) -> np.ndarray:
+        out = np.empty((self.V, 3))
+        L.check(L.lib().mvs_deform_get_vertices(self._h, L.ptr(out)))
+        return out
+
+    def normals(self) -> np.ndarray:
+        out = np.empty((self.V, 3))
+        L.check(L.lib().mvs_deform_get_normals(self._h, L.ptr(out)))
+        return out
+
+    def rotations(self) -> np.ndarray:
+        out = np.empty((self.V, 3, 3))
+        L.check(L.lib().mvs_deform_get_rotations(self._h, L.ptr(out)))
+        return out
+
+    def compute_normals(self) -> np.ndarray:
+        """exportOBJ's vertex normals of the current geometry (Deformation.h:86-150)."""
+        out = np.empty((self.V, 3))
+        L.check(L.lib().mvs_deform_compute_normals(self._h, L.ptr(out)))
+        return out
+
+    def node_targets(self, smoothed: bool = False) -> dict:
+        K = self.K
+        ctrl, valid = np.empty((K, 3)), np.empty(K, np.uint8)
+        d2, cnt, top = np.empty(K, np.float32), np.empty((K, 2), np.int32), np.empty((K, 8), np.int64)
+        L.check(L.lib().mvs_deform_get_node_targets(self._h, int(smoothed), L.ptr(ctrl), L.ptr(valid), L.ptr(d2),
+                                                    L.ptr(cnt), L.ptr(top)))
+        return dict(controls=ctrl, valid=valid, d2min=d2, counts=cnt, top_idx=top)
+
+    def node_graph(self) -> np.ndarray:
+        out = np.empty((self.K, self.params.graph_k + 1), np.int32)
+        L.check(L.lib().mvs_deform_get_node_graph(self._h, L.ptr(out)))
+        return out
+
+    # ----------------------------------------------------------------- timing --
+    def enable_timing(self, on: bool = True):
+        L.check(L.lib().mvs_deform_enable_timing(self._h, int(on)))
+
+    def kernel_time(self, name: str):
+        ms, n = C.c_double(), C.c_int64()
+        L.check(L.lib().mvs_deform_kernel_time(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def knn_points(pts, k: int) -> np.ndarray:
+    """KNearestNeighbor on arbitrary points (Deformation.cpp:108-134): (n,k) indices, self included."""
+    pts = L.arr(pts, np.float64).reshape(-1, 3)
+    out = np.empty((len(pts), k), np.int32)
+    L.check(L.lib().mvs_knn_points(L.ptr(pts), len(pts), k, L.ptr(out)))
+    return out

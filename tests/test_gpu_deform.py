@@ -1,0 +1,166 @@
+"""Parity of the HIP deformation engine against the CPU oracle (through the C-ABI).
+
+Bars: index / integer outputs bit-exact; node targets <= 1e-9; vertices, rotations <= 1e-6 RMS
+(the north-star bound is 1e-4 RMS; scene units are O(1)).
+"""
+import numpy as np
+import pytest
+
+from multiviewstitch_amd import scene as S
+from tests.util import scene_and_target, rms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from multiviewstitch_amd import _lib
+    if _lib.device_count() == 0:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box")
+    from multiviewstitch_amd import deformation
+    return deformation
+
+
+def test_knn_matches_oracle(eng, oracle):
+    rng = np.random.default_rng(3)
+    pts = rng.normal(size=(3000, 3))
+    pts[10] = pts[11]                       # exact duplicate: tie broken on the lower index
+    for k in (1, 9, 16):
+        got = eng.knn_points(pts, k)
+        ref = oracle.knn_points(pts, k)
+        assert np.array_equal(got, ref)
+
+
+def test_knn_fewer_points_than_k(eng, oracle):
+    pts = np.random.default_rng(4).normal(size=(5, 3))
+    got = eng.knn_points(pts, 9)
+    ref = oracle.knn_points(pts, 9)
+    assert np.array_equal(got, ref)
+    assert (got[:, 5:] == -1).all()
+
+
+def test_uniform_sampling_matches_oracle(eng, oracle):
+    sc, tp, tn, _ = scene_and_target(1)
+    d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    K = d.UniformSampling(16)
+    ref = oracle.uniform_sampling(sc.verts, 16)
+    assert K == len(ref)
+    assert np.array_equal(d.nodes(), ref)
+
+
+@pytest.mark.parametrize("config", [0, 1])
+def test_association_matches_oracle(eng, oracle, config):
+    sc, tp, tn, _ = scene_and_target(config)
+    nodes = oracle.uniform_sampling(sc.verts, 16)
+    d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    d.set_nodes(nodes)
+    d.set_target(tp, tn)
+    d.iterate(1)
+    got = d.node_targets(smoothed=False)
+    ref = oracle.Target(tp, tn).associate(sc.verts[nodes], sc.normals[nodes], oracle.Params.default())
+    assert np.array_equal(got["d2min"], ref["d2min"])
+    assert np.array_equal(got["counts"], ref["counts"])
+    assert np.array_equal(got["top_idx"], ref["top_idx"])
+    assert np.array_equal(got["valid"], ref["valid"])
+    assert np.abs(got["controls"] - ref["controls"]).max() <= 1e-12
+    if config == 1:
+        assert ref["valid"].sum() > 0.5 * len(nodes)
+
+
+def test_iterate_matches_oracle(eng, oracle):
+    sc, tp, tn, _ = scene_and_target(1)
+    nodes = oracle.uniform_sampling(sc.verts, 16)
+    d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    d.set_nodes(nodes)
+    d.set_target(tp, tn)
+    o = oracle.Deform(sc.verts, sc.normals, sc.faces)
+    o.set_nodes(nodes)
+    o.set_target(tp, tn)
+    p = oracle.Params.default()
+    for it in range(3):
+        st = d.iterate(1)
+        so = o.iterate(p, 1)
+        assert st["arap_iters_run"] == so["arap_iters_run"]
+        assert st["n_valid"] == so["n_valid"]
+        assert np.allclose(st["energy"][:5], so["energy"][:5], rtol=1e-6, atol=1e-12)
+        assert st["cg_rel_residual"] <= 1e-9
+        gs = d.node_targets(smoothed=True)["controls"]
+        os_, _ = o.node_targets(smoothed=True)
+        assert np.abs(gs - os_).max() <= 1e-11
+        assert rms(d.vertices(), o.vertices()) <= 1e-6, f"outer {it}"
+        assert rms(d.rotations().reshape(-1, 9), o.rotations().reshape(-1, 9)) <= 1e-6
+
+
+def test_arap_matches_oracle_and_known_answers(eng, oracle):
+    sc, _, _, _ = scene_and_target(1)
+    nodes = oracle.uniform_sampling(sc.verts, 16)
+    d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    d.set_nodes(nodes)
+    # targets = rest pose: the rest pose comes back, R_i = I, energy 0
+    st = d.arap(sc.verts[nodes])
+    assert np.abs(d.vertices() - sc.verts).max() <= 1e-10
+    assert np.abs(d.rotations() - np.eye(3)).max() <= 1e-9
+    # rigid motion of the nodes: compare with the oracle iteration by iteration
+    ang = 0.3
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    tg = sc.verts[nodes] @ R.T + np.array([0.1, -0.2, 0.05])
+    d2 = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    d2.set_nodes(nodes)
+    st = d2.arap(tg)
+    ref = oracle.arap(sc.verts, sc.faces, nodes, tg, 5, 1e-4)
+    assert st["arap_iters_run"] == ref["iters"]
+    assert np.allclose(st["energy"][:5], ref["energies"][:5], rtol=1e-6)
+    assert all(np.diff(st["energy"][:st["arap_iters_run"]]) <= 1e-12)      # energy is non-increasing
+    assert rms(d2.vertices(), ref["pts"]) <= 1e-7
+    assert rms(d2.rotations().reshape(-1, 9), ref["rot"].reshape(-1, 9)) <= 1e-7
+
+
+def test_normals_match_oracle(eng, oracle):
+    sc, _, _, _ = scene_and_target(1)
+    d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    got = d.compute_normals()
+    ref = oracle.vertex_normals(sc.verts, sc.faces, "cgal")
+    assert np.abs(got - ref).max() <= 1e-14
+
+
+def test_empty_target_invalidates_every_node(eng, oracle):
+    sc, _, _, _ = scene_and_target(0)
+    d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    d.UniformSampling()
+    d.set_target(np.zeros((0, 3)), np.zeros((0, 3)))
+    st = d.iterate(1)
+    assert st["n_valid"] == 0
+    assert np.abs(d.vertices() - sc.verts).max() <= 1e-9      # every node pinned at its own position
+
+
+def test_far_and_nan_targets(eng, oracle):
+    """nodes far outside the grid, NaN normals and a single-point target follow the oracle."""
+    sc, tp, tn, _ = scene_and_target(0)
+    nodes = oracle.uniform_sampling(sc.verts, 16)
+    tp2 = tp[:1].copy()
+    tn2 = tn[:1].copy()
+    for (a, b) in ((tp2, tn2), (tp + 7.0, tn)):
+        d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+        d.set_nodes(nodes)
+        d.set_target(a, b)
+        d.iterate(1)
+        got = d.node_targets()
+        ref = oracle.Target(a, b).associate(sc.verts[nodes], sc.normals[nodes], oracle.Params.default())
+        assert np.array_equal(got["d2min"], ref["d2min"])
+        assert np.array_equal(got["top_idx"], ref["top_idx"])
+        assert np.array_equal(got["valid"], ref["valid"])
+
+
+def test_bad_mesh_is_rejected(eng):
+    from multiviewstitch_amd._lib import MvsError
+    sc, _, _, _ = scene_and_target(0)
+    bad = sc.faces.copy()
+    bad[0] = bad[0][::-1]                    # flipped facet -> a directed edge used twice
+    with pytest.raises(MvsError) as e:
+        eng.Deformation(sc.verts, sc.normals, bad)
+    assert e.value.code == -3
+    bad = sc.faces.copy()
+    bad[0, 0] = len(sc.verts)
+    with pytest.raises(MvsError) as e:
+        eng.Deformation(sc.verts, sc.normals, bad)
+    assert e.value.code == -2
