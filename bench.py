@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — outer non-rigid iterations per second of the MI355X deformation engine.
+
+One "step" = one pass of the reference's while(counter--) body
+(R/Deformation/Deformation.cpp:253-401): associate all K nodes against all P target
+points -> 9-NN node graph -> 2 smoothing sweeps -> ARAP(5 iterations, energy stop) ->
+overwrite geometry, on BASELINE.json's metric workload (config 3: 8 views of 1280x960
+inverse depth -> ~2 M target points, ~8 K nodes).  Inputs (depth rasters -> points ->
+SRT map -> spatial index, template mesh) are resident in HBM before the timed region.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): views are sharded over the
+ranks, the template is replicated; per step one all-reduce(MIN) + two all-gathers over
+RCCL (multiviewstitch_amd/dist.py).  The total work is fixed -> "scaling": "strong".
+
+Prints ONE JSON line on rank 0 (contract in the round prompt).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_target(torch, srt_mod, scene_mod, sc, views, device):
+    """depth rasters -> world-frame target points + normals in HBM (engine kernels only)."""
+    pts_l, nrm_l = [], []
+    for k in views:
+        d = torch.from_numpy(np.ascontiguousarray(sc.depth[k])).to(device)
+        cam = sc.cams[k]
+        npnt, _ = srt_mod.depth_to_model_dev(d.data_ptr(), cam, scene_mod.MIN_DSP, scene_mod.MAX_DSP, scene_mod.SMOOTH)
+        p = torch.empty((npnt, 3), dtype=torch.float64, device=device)
+        n = torch.empty((npnt, 3), dtype=torch.float64, device=device)
+        srt_mod.depth_to_model_dev(d.data_ptr(), cam, scene_mod.MIN_DSP, scene_mod.MAX_DSP, scene_mod.SMOOTH,
+                                   p.data_ptr(), n.data_ptr())
+        s, R, t = sc.srt[k]
+        pw, nw = torch.empty_like(p), torch.empty_like(n)
+        srt_mod.apply_dev(p.data_ptr(), n.data_ptr(), npnt, s, R, t, pw.data_ptr(), nw.data_ptr())
+        torch.cuda.synchronize(device)
+        pts_l.append(pw)
+        nrm_l.append(nw)
+    if not pts_l:
+        z = torch.zeros((0, 3), dtype=torch.float64, device=device)
+        return z, z.clone()
+    return torch.cat(pts_l).contiguous(), torch.cat(nrm_l).contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=3, help="scene config (multiviewstitch_amd/scene.py); 3 = metric workload")
+    ap.add_argument("--phases", action="store_true", help="extra instrumented pass: per-phase HIP-event times to stderr")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from multiviewstitch_amd import _lib, deformation, srt as srt_mod, scene as scene_mod
+    from multiviewstitch_amd import dist as mdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if not torch.cuda.is_available() or _lib.device_count() == 0:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    _lib.check(_lib.lib().mvs_set_device(local_rank))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    # ------------------------------------------------------------------ inputs ----
+    t0 = time.time()
+    cfg = scene_mod.CONFIGS[args.config]
+    shards = mdist.view_shards(cfg["n_views"], world)
+    my_views = shards[rank]
+    sc = scene_mod.make_scene(args.config, device=device, views=set(my_views))
+    log(f"[bench r{rank}] scene config {args.config}: V={len(sc.verts)} F={len(sc.faces)} views={my_views} ({time.time()-t0:.1f}s)")
+    d = deformation.Deformation(sc.verts, sc.normals, sc.faces, device=local_rank)
+    t1 = time.time()
+    K = d.UniformSampling(16)
+    tp, tn = build_target(torch, srt_mod, scene_mod, sc, my_views, device)
+    P_local = tp.shape[0]
+    offs, counts = mdist.exclusive_offsets(P_local, world, device)
+    P_total = int(counts.sum())
+    t2 = time.time()
+    d.set_target_dev(tp.data_ptr(), tn.data_ptr(), P_local, int(offs[rank]))
+    torch.cuda.synchronize(device)
+    log(f"[bench r{rank}] K={K} nodes ({t2-t1:.2f}s incl. depth->points), P_local={P_local} P_total={P_total}, "
+        f"grid build {time.time()-t2:.3f}s")
+
+    if world > 1:
+        shard = mdist.EngineShard(d, device)
+        bufs = shard.buffers(K, world)
+
+        def run(n):
+            st = None
+            for _ in range(n):
+                st = mdist.sharded_step(shard, bufs, world)
+            return st
+    else:
+        def run(n):
+            return d.iterate(n)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    # ------------------------------------------------------------ warmup + timed ----
+    st = run(max(args.warmup, 1))          # also calibrates the CG launch count
+    log(f"[bench r{rank}] warmup done: cg_iters/solve={st['cg_iters']} arap_iters_run={st['arap_iters_run']} "
+        f"n_valid={st['n_valid']} cg_rel_residual={st['cg_rel_residual']:.2e}")
+    d.enable_timing(2)                      # HIP events around the CG groups only (2 per solve)
+    fence()
+    tb = time.perf_counter()
+    st = run(args.steps)
+    fence()
+    te = time.perf_counter()
+    elapsed = te - tb
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    cg_ms, cg_launches = d.kernel_time("cg")
+    d.enable_timing(0)
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = args.steps / elapsed
+
+    # ---------------------------------------------------------------- roofline ----
+    # dominant kernel: k_cg_iter (one launch = one CG iteration over all V rows, 3 rhs fused).
+    # Algorithmic bytes per launch: every CG vector r,w,s,p,x read once and
+    # written once (fp64 AoS, 24 B) + diag 8 B + ctrl id 4 B per vertex row, + 12 B (col 4, w 8)
+    # per stored SELL-64 entry.
+    V = len(sc.verts)
+    deg = np.bincount(sc.faces.reshape(-1), minlength=V)          # closed manifold: degree == facet count
+    # ELL-8 by row group (arap.hip): a group of 8 rows stores ceil(max degree / 8) passes of 64 entries
+    n_entries = int(sum(-(-int(deg[i:i + 8].max()) // 8) * 64 for i in range(0, V, 8)))
+    cg_bytes = 252 * V + 12 * n_entries
+    roofline = None
+    if cg_launches > 0 and cg_ms > 0:
+        avg_s = 1e-3 * cg_ms / cg_launches
+        ach = cg_bytes / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_cg_iter", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(ach / 8000.0, 4), "traffic": None, "bytes_per_launch": cg_bytes,
+                    "avg_launch_us": round(1e6 * avg_s, 3), "launches": int(cg_launches),
+                    "share_of_step": round(cg_ms / (1e3 * elapsed), 3)}
+
+    if args.phases:
+        d.enable_timing(1)
+        run(args.steps)
+        fence()
+        tot = 0.0
+        for name in ("assoc", "graph", "smooth", "weights", "rhs", "cg", "local", "finalize"):
+            ms, n = d.kernel_time(name)
+            tot += ms
+            log(f"[phases r{rank}] {name:9s} {ms/args.steps:9.4f} ms/step  {n/args.steps:7.1f} launches/step")
+        log(f"[phases r{rank}] sum       {tot/args.steps:9.4f} ms/step")
+        d.enable_timing(0)
+
+    # ------------------------------------------------------------ CPU baseline ----
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import binding as O
+        tph, tnh = tp.cpu().numpy(), tn.cpu().numpy()
+        o = O.Deform(sc.verts, sc.normals, sc.faces)
+        o.set_nodes(d.nodes())
+        tk = time.perf_counter()
+        o.set_target(tph, tnh)                                   # kd-tree build: not part of an iteration
+        t_build = time.perf_counter() - tk
+        p = O.Params.default()
+        n_it, t_cpu = 0, 0.0
+        while n_it < 8 and t_cpu < 12.0:
+            ta = time.perf_counter()
+            o.iterate(p, 1)
+            t_cpu += time.perf_counter() - ta
+            n_it += 1
+        cpu_baseline = {"value": round(n_it / t_cpu, 4), "unit": "iter/s", "cores": 1, "kind": "port",
+                        "sample": f"{n_it} outer iterations of the full workload from the template pose "
+                                  f"(oracle/, single thread, kd-tree build {t_build:.2f}s excluded)"}
+        log(f"[bench] cpu_baseline: {n_it} it in {t_cpu:.2f}s ({os.cpu_count()} host cpus visible)")
+
+    if rank == 0:
+        out = {
+            "metric": "nonrigid_outer_iterations_per_sec", "value": round(value, 3), "unit": "iter/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"config{args.config}: {cfg['n_views']} views {cfg['w']}x{cfg['h']} inverse depth, "
+                                   f"P={P_total} target points, K={K} nodes, V={V} template vertices; step = associate + "
+                                   f"9-NN graph + 2 smoothing sweeps + ARAP(5, 1e-4) + geometry update",
+                       "points": P_total, "nodes": int(K), "vertices": V, "views_per_gpu": len(my_views),
+                       "cg_iters_per_solve": int(st["cg_iters"]), "parallelism": f"views sharded x{world}, template replicated"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -243,6 +243,10 @@ int mvs_deform_assoc_merge(mvs_deform_t h, const mvs_deform_params* p,
 int mvs_deform_solve(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stats* stats);
 int mvs_deform_sync(mvs_deform_t h);            /* wait for the handle's stream */
 void* mvs_deform_stream(mvs_deform_t h);        /* hipStream_t of the handle     */
+/* Run the handle's kernels on a caller-owned stream (e.g. torch's current
+ * stream, so RCCL collectives and engine kernels order without host syncs).
+ * NULL restores the handle's own stream.  The handle's stream is drained first. */
+int mvs_deform_set_stream(mvs_deform_t h, void* hip_stream);
 
 /* Read-back (host buffers). */
 int mvs_deform_get_vertices(mvs_deform_t h, double* pts /*V*3*/);
@@ -270,6 +274,7 @@ int mvs_deform_arap(mvs_deform_t h, const mvs_deform_params* p,
  * hipEvents on the handle's stream (bench.py's roofline object).  names:
  * "assoc", "graph", "smooth", "weights", "rhs", "cg", "local", "finalize". */
 int mvs_deform_kernel_time(mvs_deform_t h, const char* name, double* total_ms, int64_t* launches);
+/* on: 0 off, 1 every phase, 2 only the "cg" groups (two events per global solve). */
 int mvs_deform_enable_timing(mvs_deform_t h, int on);
 
 #ifdef __cplusplus

@@ -96,6 +96,7 @@ _SIGS = {
     "mvs_deform_solve": (C.c_int, [_VP, _VP, _VP]),
     "mvs_deform_sync": (C.c_int, [_VP]),
     "mvs_deform_stream": (C.c_void_p, [_VP]),
+    "mvs_deform_set_stream": (C.c_int, [_VP, _VP]),
     "mvs_deform_get_vertices": (C.c_int, [_VP, _VP]),
     "mvs_deform_get_normals": (C.c_int, [_VP, _VP]),
     "mvs_deform_get_rotations": (C.c_int, [_VP, _VP]),

@@ -93,13 +93,15 @@ hipEvent_t get_event(mvs_deform_s* h) {
     return e;
 }
 struct Tic { mvs_deform_s* h; const char* name; hipEvent_t a; };
+// timing: 0 off, 1 every phase, 2 only the CG iteration groups (cheap enough for a timed region)
+bool timed(const mvs_deform_s* h, const char* name) { return h->timing == 1 || (h->timing == 2 && std::strcmp(name, "cg") == 0); }
 Tic tic(mvs_deform_s* h, const char* name) {
     Tic t{h, name, nullptr};
-    if (h->timing) { t.a = get_event(h); (void)hipEventRecord(t.a, h->stream); }
+    if (timed(h, name)) { t.a = get_event(h); (void)hipEventRecord(t.a, h->stream); }
     return t;
 }
 void toc(Tic& t, int launches) {
-    if (!t.h->timing) return;
+    if (!t.a) return;
     hipEvent_t b = get_event(t.h);
     (void)hipEventRecord(b, t.h->stream);
     t.h->pending.push_back({t.name, {t.a, b}});
@@ -173,31 +175,28 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     if (rc) return rc;
     {
         Tic t = tic(h, "weights");
-        HIPCHK(hipMemsetAsync(h->d_slots, 0, sizeof(double) * (size_t)p.arap_iters * (cg + 2) * MVS_CG_SLOT, s));
-        HIPCHK(hipMemsetAsync(h->d_energy, 0, sizeof(double) * 16, s));
-        launch_cot_weights(h->sell, h->d_pts, s);                                                 // preprocess(), :393
-        launch_arap_prepare(h->sell, h->d_pts, h->d_nodes, ctrl, K, h->d_sol, h->d_rot, s);      // :383-392
-        toc(t, 2);
+        launch_cot_weights(h->sell, h->d_pts, h->d_coef, s);                                      // preprocess(), :393
+        launch_arap_prepare(h->sell, h->d_pts, ctrl, h->d_sol, h->d_rot, s);                     // :383-392
+        toc(t, 3);
     }
     for (int it = 0; it < p.arap_iters; ++it) {                                                   // deform(5, 1e-4), :398
         double* slots = h->d_slots + (size_t)it * (cg + 2) * MVS_CG_SLOT;
         {
             Tic t = tic(h, "rhs");
-            launch_arap_rhs(h->sell, h->d_pts, h->d_sol, h->d_rot, it, p.arap_tol, h->d_energy, h->d_r[0], h->d_p, h->d_s[0], slots, s);
-            launch_cg_w0(h->sell, it, p.arap_tol, h->d_energy, h->d_r[0], h->d_wv[0], slots, s);
+            launch_arap_rhs(h->sell, h->d_pts, h->d_sol, h->d_rot, it, p.arap_tol, h->d_energy, h->d_rws[0], h->d_p, s);
+            launch_cg_w0(h->sell, h->d_coef, it, p.arap_tol, h->d_energy, h->d_rws[0], slots, s);
             toc(t, 2);
         }
         {
             Tic t = tic(h, "cg");
             for (int i = 0; i < cg; ++i) {
                 const int a = i & 1, b = a ^ 1;
-                launch_cg_iter(h->sell, it, p.arap_tol, h->d_energy, i, p.cg_tol, slots, slots + (size_t)i * MVS_CG_SLOT,
-                               slots + (size_t)(i + 1) * MVS_CG_SLOT, h->d_r[a], h->d_wv[a], h->d_s[a], h->d_r[b],
-                               h->d_wv[b], h->d_s[b], h->d_p, h->d_sol, s);
+                launch_cg_iter(h->sell, h->d_coef, it, p.arap_tol, h->d_energy, i, p.cg_tol, slots, slots + (size_t)i * MVS_CG_SLOT,
+                               slots + (size_t)(i + 1) * MVS_CG_SLOT, h->d_rws[a], h->d_rws[b], h->d_p, h->d_sol, s);
             }
             toc(t, cg);
         }
-        { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, h->d_sol, it, p.arap_tol, h->d_energy, h->d_rot, s); toc(t, 1); }
+        { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, h->d_sol, it, p.arap_tol, h->d_energy, h->d_cov, h->d_rot, s); toc(t, 3); }
     }
     Tic t = tic(h, "finalize");
     launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, h->d_sol, h->d_pts, h->d_info, s);   // :400
@@ -213,25 +212,32 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
 int harvest(mvs_deform_s* h, const mvs_deform_params& p, int cg, mvs_deform_stats* st, bool* converged) {
     const size_t n = (size_t)p.arap_iters * (cg + 2) * MVS_CG_SLOT;
     std::vector<double> slots(n);
-    double energy[16];
+    std::vector<double> ered(MVS_ERED_SIZE);
     int32_t info[8];
     HIPCHK(hipMemcpyAsync(slots.data(), h->d_slots, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(energy, h->d_energy, sizeof energy, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(ered.data(), h->d_energy, sizeof(double) * MVS_ERED_SIZE, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(info, h->d_info, sizeof info, hipMemcpyDeviceToHost, h->stream));
     std::vector<uint8_t> valid(h->K);
     if (h->K) HIPCHK(hipMemcpyAsync(valid.data(), h->d_valid, (size_t)h->K, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     const int run = info[0];
+    const int nb = arap_grid_blocks(h->sell);
     int need = 0;
     double worst = 0.0;
     bool all_conv = true;
     for (int it = 0; it < run; ++it) {
         const double* S = slots.data() + (size_t)it * (cg + 2) * MVS_CG_SLOT;
         int first = -1;
+        auto gamma_of = [&](int i, int c) {           // reduced by the consumer kernel for i < cg, folded here for i == cg
+            if (i < cg) return S[(size_t)i * MVS_CG_SLOT + MVS_CG_FIN + 3 + c];
+            double g = 0.0;
+            for (int b = 0; b < nb; ++b) g += S[(size_t)i * MVS_CG_SLOT + c * MVS_NBMAX + b];
+            return g;
+        };
         for (int i = 0; i <= cg; ++i) {
             bool frozen = true;
             for (int c = 0; c < 3; ++c) {
-                const double gam = S[(size_t)i * MVS_CG_SLOT + c], bn = S[9 + c];
+                const double gam = gamma_of(i, c), bn = S[MVS_CG_FIN + 6 + c];
                 if (gam > 0.0 && gam > p.cg_tol * p.cg_tol * bn) frozen = false;
             }
             if (frozen) { first = i; break; }
@@ -239,7 +245,7 @@ int harvest(mvs_deform_s* h, const mvs_deform_params& p, int cg, mvs_deform_stat
         if (first < 0) { all_conv = false; first = cg; }
         need = std::max(need, first);
         for (int c = 0; c < 3; ++c) {
-            const double gam = S[(size_t)cg * MVS_CG_SLOT + c], bn = S[9 + c];
+            const double gam = gamma_of(cg, c), bn = S[MVS_CG_FIN + 6 + c];
             if (bn > 0) worst = std::max(worst, std::sqrt(std::max(0.0, gam) / bn));
         }
     }
@@ -248,7 +254,7 @@ int harvest(mvs_deform_s* h, const mvs_deform_params& p, int cg, mvs_deform_stat
     mvs_deform_stats out{};
     out.arap_iters_run = run;
     out.cg_iters = cg;
-    for (int i = 0; i < 8; ++i) out.energy[i] = i < p.arap_iters ? energy[i] : 0.0;
+    for (int i = 0; i < 8; ++i) out.energy[i] = i < p.arap_iters ? ered[MVS_ERED_FIN + i] : 0.0;
     out.cg_rel_residual = worst;
     int nv = 0;
     for (uint8_t v : valid) nv += v;
@@ -319,26 +325,28 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals, in
             rowptr[i + 1] = (int32_t)col.size();
         }
     }
-    // SELL-64
-    const int nslices = (int)((V + 63) / 64);
+    // ELL-8 by row group: group = 8 rows = one wave; entry (row r of group, pass t, lane l) at goff + (8 t + r) * 8 + l
+    const int nslices = (int)((V + 7) / 8);
     std::vector<int32_t> slice_off(nslices + 1, 0);
-    for (int sl = 0; sl < nslices; ++sl) {
-        int wmax = 0;
-        for (int64_t i = (int64_t)sl * 64; i < std::min<int64_t>(V, (int64_t)sl * 64 + 64); ++i) wmax = std::max(wmax, rowptr[i + 1] - rowptr[i]);
-        slice_off[sl + 1] = slice_off[sl] + wmax * 64;
+    for (int g = 0; g < nslices; ++g) {
+        int dmax = 0;
+        for (int64_t i = (int64_t)g * 8; i < std::min<int64_t>(V, (int64_t)g * 8 + 8); ++i) dmax = std::max(dmax, rowptr[i + 1] - rowptr[i]);
+        slice_off[g + 1] = slice_off[g] + ((dmax + 7) / 8) * 64;
     }
     const int64_t ne = slice_off[nslices];
     std::vector<int32_t> scol(ne), sopp0(ne, -1), sopp1(ne, -1);
-    for (int sl = 0; sl < nslices; ++sl) {
-        const int wdt = (slice_off[sl + 1] - slice_off[sl]) / 64;
-        for (int l = 0; l < 64; ++l) {
-            const int64_t i = (int64_t)sl * 64 + l;
-            for (int k = 0; k < wdt; ++k) {
-                const int64_t e = slice_off[sl] + 64 * k + l;
-                if (i < V && k < rowptr[i + 1] - rowptr[i]) {
-                    scol[e] = col[rowptr[i] + k]; sopp0[e] = o0[rowptr[i] + k]; sopp1[e] = o1[rowptr[i] + k];
-                } else scol[e] = (int32_t)std::min<int64_t>(i, V - 1);
-            }
+    for (int g = 0; g < nslices; ++g) {
+        const int passes = (slice_off[g + 1] - slice_off[g]) / 64;
+        for (int r = 0; r < 8; ++r) {
+            const int64_t i = (int64_t)g * 8 + r;
+            for (int t = 0; t < passes; ++t)
+                for (int l = 0; l < 8; ++l) {
+                    const int64_t e = slice_off[g] + (8 * t + r) * 8 + l;
+                    const int k = 8 * t + l;
+                    if (i < V && k < rowptr[i + 1] - rowptr[i]) {
+                        scol[e] = col[rowptr[i] + k]; sopp0[e] = o0[rowptr[i] + k]; sopp1[e] = o1[rowptr[i] + k];
+                    } else scol[e] = (int32_t)std::min<int64_t>(i, V - 1);
+                }
         }
     }
     // vertex -> facet CSR (ascending facet index)
@@ -353,15 +361,16 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals, in
     mvs_deform_s* h = new mvs_deform_s;
     h->device = g_device; h->V = V; h->F = F; h->n_entries = ne;
 #define TRY(x) do { rc = (x); if (rc) { mvs_deform_destroy(h); return rc; } } while (0)
-    TRY(mvs_check_hip(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate"));
+    TRY(mvs_check_hip(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking), "hipStreamCreate"));
+    h->stream = h->own_stream;
     TRY(dmalloc(&h->d_pts, (size_t)V * 3)); TRY(dmalloc(&h->d_nrm, (size_t)V * 3)); TRY(dmalloc(&h->d_sol, (size_t)V * 3));
     TRY(dmalloc(&h->d_rot, (size_t)V * 9)); TRY(dmalloc(&h->d_faces, (size_t)F * 3));
     TRY(dmalloc(&h->d_vf_ptr, (size_t)V + 1)); TRY(dmalloc(&h->d_vf, (size_t)F * 3));
     TRY(dmalloc(&h->d_slice_off, (size_t)nslices + 1)); TRY(dmalloc(&h->d_col, (size_t)ne)); TRY(dmalloc(&h->d_opp0, (size_t)ne));
     TRY(dmalloc(&h->d_opp1, (size_t)ne)); TRY(dmalloc(&h->d_w, (size_t)ne)); TRY(dmalloc(&h->d_diag, (size_t)V));
     TRY(dmalloc(&h->d_is_ctrl, (size_t)V));
-    for (int k = 0; k < 2; ++k) { TRY(dmalloc(&h->d_r[k], (size_t)V * 3)); TRY(dmalloc(&h->d_wv[k], (size_t)V * 3)); TRY(dmalloc(&h->d_s[k], (size_t)V * 3)); }
-    TRY(dmalloc(&h->d_p, (size_t)V * 3)); TRY(dmalloc(&h->d_energy, 16)); TRY(dmalloc(&h->d_info, 8));
+    for (int k = 0; k < 2; ++k) TRY(dmalloc(&h->d_rws[k], (size_t)V * 9));
+    TRY(dmalloc(&h->d_p, (size_t)V * 3)); TRY(dmalloc(&h->d_coef, (size_t)ne)); TRY(dmalloc(&h->d_cov, (size_t)V * 9)); TRY(dmalloc(&h->d_energy, MVS_ERED_SIZE)); TRY(dmalloc(&h->d_info, 8));
     auto up = [&](void* d, const void* s, size_t n) { return mvs_check_hip(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, h->stream), "upload"); };
     TRY(up(h->d_pts, points, sizeof(double) * V * 3)); TRY(up(h->d_nrm, normals, sizeof(double) * V * 3));
     TRY(up(h->d_sol, points, sizeof(double) * V * 3));
@@ -388,11 +397,11 @@ int mvs_deform_destroy(mvs_deform_t h) {
     dfree(h->d_pts); dfree(h->d_nrm); dfree(h->d_sol); dfree(h->d_rot); dfree(h->d_faces); dfree(h->d_vf_ptr); dfree(h->d_vf);
     dfree(h->d_slice_off); dfree(h->d_col); dfree(h->d_opp0); dfree(h->d_opp1); dfree(h->d_is_ctrl); dfree(h->d_w); dfree(h->d_diag);
     dfree(h->d_spos); dfree(h->d_tpos); dfree(h->d_tnrm); dfree(h->d_cell_start);
-    for (int k = 0; k < 2; ++k) { dfree(h->d_r[k]); dfree(h->d_wv[k]); dfree(h->d_s[k]); }
-    dfree(h->d_p); dfree(h->d_slots); dfree(h->d_energy); dfree(h->d_info);
+    for (int k = 0; k < 2; ++k) dfree(h->d_rws[k]);
+    dfree(h->d_p); dfree(h->d_coef); dfree(h->d_cov); dfree(h->d_slots); dfree(h->d_energy); dfree(h->d_info);
     for (auto& pr : h->pending) { (void)hipEventDestroy(pr.second.first); (void)hipEventDestroy(pr.second.second); }
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return MVS_OK;
 }
@@ -583,6 +592,13 @@ int mvs_deform_sync(mvs_deform_t h) {
     return mvs_check_hip(hipStreamSynchronize(h->stream), "sync");
 }
 void* mvs_deform_stream(mvs_deform_t h) { return h ? (void*)h->stream : nullptr; }
+int mvs_deform_set_stream(mvs_deform_t h, void* hip_stream) {
+    if (!h) return MVS_E_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return MVS_OK;
+}
 
 // ---------------------------------------------------------------- read-back ----
 static int download(mvs_deform_t h, void* dst, const void* src, size_t n) {
@@ -638,7 +654,7 @@ int mvs_knn_points(const double* pts, int64_t n, int k, int32_t* out_idx) {
 
 int mvs_deform_enable_timing(mvs_deform_t h, int on) {
     if (!h) return MVS_E_INVALID_ARG;
-    h->timing = on != 0;
+    h->timing = on;
     h->timers.clear();
     return MVS_OK;
 }

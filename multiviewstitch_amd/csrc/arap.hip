@@ -3,55 +3,132 @@
 // (call sites R/Deformation/Deformation.cpp:256-260,359-400; algorithm as
 // recalled in SURVEY.md Appendix A.6 and restated in oracle/orc_deform.cpp).
 //
-// Mesh adjacency is SELL-64: slice = 64 consecutive vertices, entry (row r,
-// k-th neighbour) at slice_off[slice] + 64*k + (r & 63) -> every per-row loop
-// is a coalesced 64-wide access.  Padded entries have col == row, opp == -1,
-// w == 0.  Vertex vectors are AoS double[3] (24 B) so a neighbour gather
-// touches one or two cache lines.
+// Layout.  The template has only ~5e4..3e5 vertices, so these kernels are
+// latency- and launch-bound, not bandwidth-bound (measured on MI355X,
+// tools/microbench.hip: launch floor 1.55 us, 3 K same-line fp64 atomics +2..5 us,
+// 9 fp64 divisions in every wave's preamble +1.2 us).  Hence:
+//  * EIGHT lanes share one vertex row.  Adjacency is "ELL-8 by row group": a
+//    group = 8 consecutive rows = one wave64; entry (row r of the group, pass t,
+//    lane l) sits at goff[g] + (8 t + r) * 8 + l, so every pass is one coalesced
+//    64-entry access and each lane issues ONE neighbour gather.  Row sums are 3
+//    DPP steps.  Lanes 0..2 of a row own the x,y,z component of the row's vectors.
+//    Padded entries have col == row, opp == -1, w == coef == 0.
+//  * One 1024-thread workgroup per CU (<= 256 workgroups); waves stride over the
+//    row groups.
+//  * No atomics: every workgroup STORES its partial sums (dot products, energy)
+//    into part[component][workgroup]; the consumer kernel folds the <= 256
+//    partials in a fixed order (one wave per component, then LDS broadcast) and
+//    only those waves evaluate the CG step scalars.  Sums are therefore
+//    bit-reproducible run to run.
 //
 // Global step: instead of CGAL's SparseLU the Dirichlet-reduced cotangent
 // system is solved by Jacobi-preconditioned CG in the Chronopoulos–Gear form:
 // ONE kernel per CG iteration (fused p/s/x/r updates + SpMV + both dot
-// products, neighbours' u = M^-1 r recomputed from the previous iterate so no
-// grid-wide barrier is needed inside an iteration).  x,y,z right-hand sides
-// share every memory access.  All control flow (ARAP energy stop rule, CG
-// freeze on convergence) is evaluated on the device so the whole outer
-// iteration is a fixed launch sequence.
+// products; a neighbour's u = M^-1 r of the NEW iterate is recomputed from the
+// previous iterate's packed {r,w,s} record (72 B, one gather), so no grid-wide
+// barrier is needed inside an iteration).  x,y,z right-hand sides share every
+// memory access.  All control flow (ARAP energy stop rule, CG freeze on
+// convergence) is evaluated on the device: an outer iteration is a fixed
+// launch sequence.
 #include "engine.h"
 #include "dev_common.h"
 #include "svd3_dev.h"
+#include <algorithm>
 
 namespace {
 
-constexpr int TPB = 256;
-constexpr int SLOT = 12;   // doubles per CG slot: gamma[3], delta[3], alpha[3], bnorm[3]
+constexpr int TPB = 1024;           // row kernels: 16 waves per workgroup
+constexpr int NW = TPB / 64;
+constexpr int NBMAX = MVS_NBMAX;    // max workgroups of a row kernel (= partials per sum)
+constexpr int SLOT = MVS_CG_SLOT;   // part[6][NBMAX] (gamma, delta) | alpha[3] gamma[3] bnorm[3] pad
+constexpr int FIN = MVS_CG_FIN;     // offset of the reduced scalars inside a slot
+constexpr int EIT = MVS_ERED_IT;    // per ARAP iteration: e_part[NBMAX] | bn_part[3][NBMAX]
+constexpr int EFIN = MVS_ERED_FIN;  // reduced energies e_fin[8]
 
-struct Row {
-    int i, lane, off, width;
+// ------------------------------------------------------------- lane helpers --
+template <int CTRL>
+__device__ inline double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// sum over the 8 lanes of a row (result in all 8); every lane of the wave must be active
+__device__ inline double red8(double v) {
+    v += dpp_d<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_d<0x141>(v);    // row_half_mirror: lane i <-> 7-i of each 8-lane half row
+    return v;
+}
+// sum over the 8 row groups of a wave for values already uniform within each 8-lane group
+__device__ inline double red_rows(double v) {
+    v += dpp_d<0x140>(v);    // row_mirror: lane i <-> 15-i (adds the other 8-lane group of the 16-lane row)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ inline double wave_total(double v) { return red_rows(red8(v)); }
+// fixed-order fold of nb partial sums by ONE wave (every lane gets the total)
+__device__ inline double fold_partials(const double* __restrict__ part, int nb) {
+    const int lane = threadIdx.x & 63;
+    double v = 0.0;
+    for (int k = lane; k < nb; k += 64) v += part[k];
+    return wave_total(v);
+}
+
+struct RowCtx {
+    int row, l, off, passes;
     bool live;
 };
-__device__ inline Row sell_row(const SellDev& m) {
-    Row r;
-    r.i = blockIdx.x * blockDim.x + threadIdx.x;
-    r.lane = r.i & 63;
-    const int slice = r.i >> 6;
-    r.live = r.i < m.V;
-    if (slice < m.nslices) {
-        r.off = m.slice_off[slice];
-        r.width = (m.slice_off[slice + 1] - r.off) >> 6;
-    } else { r.off = 0; r.width = 0; }
+// row context of row group g (wave-uniform g) for this lane
+__device__ inline RowCtx row_ctx(const SellDev& m, int g) {
+    RowCtx r;
+    const int lane = threadIdx.x & 63;
+    r.row = g * 8 + (lane >> 3);
+    r.l = lane & 7;
+    r.live = r.row < m.V;
+    r.off = m.slice_off[g] + lane;                                   // + 64 * pass
+    r.passes = (m.slice_off[g + 1] - m.slice_off[g]) >> 6;
     return r;
+}
+#define FOR_ROW_GROUPS(m, g) \
+    for (int g = blockIdx.x * NW + (threadIdx.x >> 6); g < (m).nslices; g += gridDim.x * NW)
+
+// store this workgroup's NV sums (each wave holds its own in v[], every lane) to part[k][blockIdx.x]
+template <int NV>
+__device__ inline void block_store_partials(const double* v, double* __restrict__ part) {
+    __shared__ double sm[NW][NV];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sm[w][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) s += sm[ww][threadIdx.x];
+        part[threadIdx.x * NBMAX + blockIdx.x] = s;
+    }
 }
 
 // has the reference's energy stop rule fired after some ARAP iteration t < it ?
 // deform(): checked after iteration t when t+1 < iters and t != 0 (Appendix A.6).
-__device__ inline bool arap_done_before(const double* __restrict__ energy, int it, double tol) {
+// efin[t] holds the reduced energies of the iterations t < it.
+__device__ inline bool arap_done_before(const double* __restrict__ efin, int it, double tol) {
     if (!(tol > 0.0)) return false;
     for (int t = 1; t < it; ++t) {
-        const double dif = fabs((energy[t - 1] - energy[t]) / energy[t]);
+        const double dif = fabs((efin[t - 1] - efin[t]) / efin[t]);
         if (dif < tol) return true;
     }
     return false;
+}
+
+// one thread evaluates the stop rule (it costs fp64 divisions), the workgroup shares the answer
+__device__ inline bool block_done(const double* __restrict__ efin, int it, double tol) {
+    __shared__ int s_flag;
+    if (threadIdx.x == 0) s_flag = arap_done_before(efin, it, tol) ? 1 : 0;
+    __syncthreads();
+    return s_flag != 0;
 }
 
 // ------------------------------------------------------------ small kernels --
@@ -89,29 +166,44 @@ __device__ inline double cot_clamped(d3 a, d3 b, d3 o) {
     return c > 0 ? c : 0.0;
 }
 
+// per entry: w_ij = (cot a + cot b) / 2 clamped per angle; per row: diag = sum_j (wij + wji)
 __global__ __launch_bounds__(TPB) void k_cot_weights(SellDev m, const double* __restrict__ pts) {
-    const Row r = sell_row(m);
-    if (!r.live) return;
-    const d3 pi = ld3(pts + 3 * r.i);
-    double diag = 0.0;
-    for (int k = 0; k < r.width; ++k) {
-        const int e = r.off + 64 * k + r.lane;
-        const int o0 = m.opp0[e], o1 = m.opp1[e];
-        double s = 0.0;
-        if (o0 >= 0) {
-            const d3 pj = ld3(pts + 3 * m.col[e]);
-            s = cot_clamped(pi, pj, ld3(pts + 3 * o0)) / 2.0;
-            if (o1 >= 0) s = s + cot_clamped(pi, pj, ld3(pts + 3 * o1)) / 2.0;
+    FOR_ROW_GROUPS(m, g) {
+        const RowCtx r = row_ctx(m, g);
+        const d3 pi = r.live ? ld3(pts + 3 * r.row) : mk3(0, 0, 0);
+        double diag = 0.0;
+        for (int t = 0; t < r.passes; ++t) {
+            const int e = r.off + 64 * t;
+            const int o0 = m.opp0[e], o1 = m.opp1[e];
+            double s = 0.0;
+            if (o0 >= 0) {
+                const d3 pj = ld3(pts + 3 * m.col[e]);
+                s = cot_clamped(pi, pj, ld3(pts + 3 * o0)) / 2.0;
+                if (o1 >= 0) s = s + cot_clamped(pi, pj, ld3(pts + 3 * o1)) / 2.0;
+            }
+            m.w[e] = s;
+            diag += s + s;                       // wij + wji
         }
-        m.w[e] = s;
-        diag += s + s;                       // wij + wji
+        diag = red8(diag);
+        if (r.live && r.l == 0) m.diag[r.row] = diag;
     }
-    m.diag[r.i] = diag;
 }
 
-__global__ __launch_bounds__(TPB) void k_arap_prepare(SellDev m, const double* __restrict__ pts,
-                                                      const double* __restrict__ ctrl, double* __restrict__ sol,
-                                                      double* __restrict__ rot) {
+// per entry: coef_ij = 2 w_ij / diag_j for free j, 0 for control vertices / padding
+__global__ __launch_bounds__(TPB) void k_cg_coef(SellDev m, double* __restrict__ coef) {
+    FOR_ROW_GROUPS(m, g) {
+        const RowCtx r = row_ctx(m, g);
+        for (int t = 0; t < r.passes; ++t) {
+            const int e = r.off + 64 * t;
+            const double w = m.w[e];
+            const int j = m.col[e];
+            coef[e] = (w == 0.0 || m.is_ctrl[j]) ? 0.0 : (2.0 * w) / m.diag[j];
+        }
+    }
+}
+
+__global__ void k_arap_prepare(SellDev m, const double* __restrict__ pts, const double* __restrict__ ctrl,
+                               double* __restrict__ sol, double* __restrict__ rot) {
     // set_target_position for every node (Deformation.cpp:383-392); rotations start at identity
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m.V) return;
@@ -123,98 +215,121 @@ __global__ __launch_bounds__(TPB) void k_arap_prepare(SellDev m, const double* _
 
 // --------------------------------------------------------------- global step --
 // r0 = b - A x0 on free rows;  b_i = sum_j (wij R_i + wji R_j)(p_i - p_j) (+ Dirichlet columns)
+// state record per vertex: rws[9] = {r.xyz, w.xyz, s.xyz}.
+// Also closes the previous ARAP iteration: folds its energy partials into ered[EFIN + it - 1].
 __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __restrict__ pts,
                                                   const double* __restrict__ sol, const double* __restrict__ rot,
-                                                  int it, double tol, const double* __restrict__ energy,
-                                                  double* __restrict__ r_out, double* __restrict__ p,
-                                                  double* __restrict__ s_prev, double* __restrict__ slot0) {
-    if (arap_done_before(energy, it, tol)) return;
-    const Row r = sell_row(m);
-    __shared__ double sm[16];
-    d3 res = mk3(0, 0, 0), bb = mk3(0, 0, 0);
-    double minv = 0.0;
-    if (r.live && !m.is_ctrl[r.i]) {
-        const d3 pi = ld3(pts + 3 * r.i), xi = ld3(sol + 3 * r.i);
-        const double* Ri = rot + 9 * (int64_t)r.i;
-        d3 ax = mk3(0, 0, 0);
-        for (int k = 0; k < r.width; ++k) {
-            const int e = r.off + 64 * k + r.lane;
-            const double w = m.w[e];
-            const int j = m.col[e];
-            const double* Rj = rot + 9 * (int64_t)j;
-            double M[9];
-#pragma unroll
-            for (int c = 0; c < 9; ++c) M[c] = w * Ri[c] + w * Rj[c];
-            const d3 xj = ld3(sol + 3 * j);
-            bb = bb + mulMv(M, pi - ld3(pts + 3 * j));
-            if (m.is_ctrl[j]) bb = bb + (2.0 * w) * xj;      // Dirichlet column moved to the rhs
-            else ax = ax - (2.0 * w) * xj;
+                                                  int it, double tol, double* __restrict__ ered,
+                                                  double* __restrict__ rws, double* __restrict__ p) {
+    double* efin = ered + EFIN;
+    __shared__ int s_done;
+    if (threadIdx.x < 64) {                      // wave 0 decides
+        bool done = arap_done_before(efin, it - 1, tol);
+        if (it >= 1) {
+            // iteration it-1 did not run if the rule had fired before it: its partials are stale
+            const double e_prev = done ? 0.0 : fold_partials(ered + (it - 1) * EIT, gridDim.x);
+            if (blockIdx.x == 0 && threadIdx.x == 0) efin[it - 1] = e_prev;
+            if (!done && tol > 0.0 && it >= 2 && fabs((efin[it - 2] - e_prev) / e_prev) < tol) done = true;
         }
-        ax = ax + m.diag[r.i] * xi;
-        res = bb - ax;
-        minv = 1.0 / m.diag[r.i];
+        if (threadIdx.x == 0) s_done = done ? 1 : 0;
     }
-    if (r.live) {
-        st3(r_out + 3 * r.i, res);
-        st3(p + 3 * r.i, mk3(0, 0, 0));
-        st3(s_prev + 3 * r.i, mk3(0, 0, 0));
-    }
-    // ||b||^2 in the M^-1 norm: reference scale of the CG stop test
-    const double bx = block_sum_d(minv * bb.x * bb.x, sm), by = block_sum_d(minv * bb.y * bb.y, sm),
-                 bz = block_sum_d(minv * bb.z * bb.z, sm);
-    if (threadIdx.x == 0) { atomicAdd(slot0 + 9, bx); atomicAdd(slot0 + 10, by); atomicAdd(slot0 + 11, bz); }
-}
-
-// w0 = A u0, gamma0 = (r0,u0), delta0 = (w0,u0)
-__global__ __launch_bounds__(TPB) void k_cg_w0(SellDev m, int it, double tol, const double* __restrict__ energy,
-                                               const double* __restrict__ rv, double* __restrict__ wv,
-                                               double* __restrict__ slot0) {
-    if (arap_done_before(energy, it, tol)) return;
-    const Row r = sell_row(m);
-    __shared__ double sm[16];
-    d3 g = mk3(0, 0, 0), dl = mk3(0, 0, 0);
-    if (r.live) {
-        d3 wnew = mk3(0, 0, 0);
-        if (!m.is_ctrl[r.i]) {
-            const double di = m.diag[r.i];
-            const d3 ri = ld3(rv + 3 * r.i);
-            const d3 ui = (1.0 / di) * ri;
-            d3 acc = di * ui;
-            for (int k = 0; k < r.width; ++k) {
-                const int e = r.off + 64 * k + r.lane;
-                const int j = m.col[e];
-                if (m.is_ctrl[j]) continue;
+    __syncthreads();
+    if (s_done) return;
+    double bn_acc = 0.0;
+    FOR_ROW_GROUPS(m, g) {
+        const RowCtx r = row_ctx(m, g);
+        const bool freerow = r.live && !m.is_ctrl[r.row];
+        d3 bb = mk3(0, 0, 0), ax = mk3(0, 0, 0);
+        if (freerow) {
+            const d3 pi = ld3(pts + 3 * r.row);
+            const double* Ri = rot + 9 * (int64_t)r.row;
+            for (int t = 0; t < r.passes; ++t) {
+                const int e = r.off + 64 * t;
                 const double w = m.w[e];
                 if (w == 0.0) continue;
-                acc = acc - (2.0 * w / m.diag[j]) * ld3(rv + 3 * j);
+                const int j = m.col[e];
+                const double* Rj = rot + 9 * (int64_t)j;
+                double M[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) M[c] = w * Ri[c] + w * Rj[c];
+                const d3 xj = ld3(sol + 3 * j);
+                bb = bb + mulMv(M, pi - ld3(pts + 3 * j));
+                if (m.is_ctrl[j]) bb = bb + (2.0 * w) * xj;      // Dirichlet column moved to the rhs
+                else ax = ax - (2.0 * w) * xj;
             }
-            wnew = acc;
-            g = mk3(ri.x * ui.x, ri.y * ui.y, ri.z * ui.z);
-            dl = mk3(wnew.x * ui.x, wnew.y * ui.y, wnew.z * ui.z);
         }
-        st3(wv + 3 * r.i, wnew);
+        bb = mk3(red8(bb.x), red8(bb.y), red8(bb.z));
+        ax = mk3(red8(ax.x), red8(ax.y), red8(ax.z));
+        if (r.live && r.l < 3) {
+            double res = 0.0;
+            if (freerow) {
+                const double di = m.diag[r.row];
+                const double b_c = r.l == 0 ? bb.x : (r.l == 1 ? bb.y : bb.z);
+                const double a_c = (r.l == 0 ? ax.x : (r.l == 1 ? ax.y : ax.z)) + di * sol[3 * r.row + r.l];
+                res = b_c - a_c;
+                bn_acc += b_c * b_c / di;                        // ||b||^2 in the M^-1 norm: scale of the CG stop test
+            }
+            double* o = rws + 9 * (int64_t)r.row;
+            o[r.l] = res; o[3 + r.l] = 0.0; o[6 + r.l] = 0.0;
+            p[3 * r.row + r.l] = 0.0;
+        }
     }
-    const double v0 = block_sum_d(g.x, sm), v1 = block_sum_d(g.y, sm), v2 = block_sum_d(g.z, sm);
-    const double v3 = block_sum_d(dl.x, sm), v4 = block_sum_d(dl.y, sm), v5 = block_sum_d(dl.z, sm);
-    if (threadIdx.x == 0) {
-        atomicAdd(slot0 + 0, v0); atomicAdd(slot0 + 1, v1); atomicAdd(slot0 + 2, v2);
-        atomicAdd(slot0 + 3, v3); atomicAdd(slot0 + 4, v4); atomicAdd(slot0 + 5, v5);
-    }
+    const int l = threadIdx.x & 7;
+    double v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = wave_total(l == c ? bn_acc : 0.0);
+    block_store_partials<3>(v, ered + it * EIT + NBMAX);
 }
 
-// step scalars of CG iteration i for one right-hand side
-__device__ inline void cg_scalars(const double* __restrict__ slot_prev, const double* __restrict__ slot_i,
-                                  const double* __restrict__ slot0, int i, int c, double cg_tol,
-                                  double* alpha, double* beta) {
-    const double gam = slot_i[c], del = slot_i[3 + c], bn = slot0[9 + c];
+// w0 = A u0, gamma0 = (r0,u0), delta0 = (w0,u0); folds the bnorm partials into slot0
+__global__ __launch_bounds__(TPB) void k_cg_w0(SellDev m, const double* __restrict__ coef, int it, double tol,
+                                               const double* __restrict__ ered, double* __restrict__ rws,
+                                               double* __restrict__ slot0) {
+    if (block_done(ered + EFIN, it, tol)) return;
+    if (blockIdx.x == 0 && threadIdx.x < 3 * 64) {
+        const int c = threadIdx.x >> 6;
+        const double b = fold_partials(ered + it * EIT + (1 + c) * NBMAX, gridDim.x);
+        if ((threadIdx.x & 63) == 0) slot0[FIN + 6 + c] = b;
+    }
+    double g_acc = 0.0, d_acc = 0.0;
+    FOR_ROW_GROUPS(m, g) {
+        const RowCtx r = row_ctx(m, g);
+        const bool freerow = r.live && !m.is_ctrl[r.row];
+        d3 acc = mk3(0, 0, 0);
+        if (freerow)
+            for (int t = 0; t < r.passes; ++t) {
+                const int e = r.off + 64 * t;
+                const double c = coef[e];
+                if (c == 0.0) continue;
+                acc = acc - c * ld3(rws + 9 * (int64_t)m.col[e]);      // u_j = r_j / diag_j folded into coef
+            }
+        acc = mk3(red8(acc.x), red8(acc.y), red8(acc.z));
+        if (freerow && r.l < 3) {
+            const double di = m.diag[r.row];
+            double* o = rws + 9 * (int64_t)r.row;
+            const double ri = o[r.l], ui = ri / di;
+            const double wn = di * ui + (r.l == 0 ? acc.x : (r.l == 1 ? acc.y : acc.z));
+            o[3 + r.l] = wn;
+            g_acc += ri * ui; d_acc += wn * ui;
+        }
+    }
+    const int l = threadIdx.x & 7;
+    double v[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { v[c] = wave_total(l == c ? g_acc : 0.0); v[3 + c] = wave_total(l == c ? d_acc : 0.0); }
+    block_store_partials<6>(v, slot0);
+}
+
+// step scalars of CG iteration i for one right-hand side (gam, del already folded)
+__device__ inline void cg_scalars(double gam, double del, double bn, double gam_prev, double alpha_prev, int i,
+                                  double cg_tol, double* alpha, double* beta) {
     double a = 0.0, b = 0.0;
     bool live = gam > 0.0 && gam > cg_tol * cg_tol * bn;
     if (live) {
         double denom = del;
         if (i > 0) {
-            const double gp = slot_prev[c], ap = slot_prev[6 + c];
-            b = gam / gp;
-            denom = del - b * gam / ap;
+            b = gam / gam_prev;
+            denom = del - b * gam / alpha_prev;
         }
         live = denom > 0.0 && denom < INFINITY && b == b;
         if (live) a = gam / denom; else b = 0.0;
@@ -222,117 +337,168 @@ __device__ inline void cg_scalars(const double* __restrict__ slot_prev, const do
     *alpha = a; *beta = b;
 }
 
-__global__ __launch_bounds__(TPB) void k_cg_iter(SellDev m, int it, double tol, const double* __restrict__ energy,
-                                                 int i, double cg_tol, const double* __restrict__ slot0,
-                                                 const double* __restrict__ slot_prev, double* __restrict__ slot_i,
-                                                 double* __restrict__ slot_next, const double* __restrict__ r_in,
-                                                 const double* __restrict__ w_in, const double* __restrict__ s_in,
-                                                 double* __restrict__ r_out, double* __restrict__ w_out,
-                                                 double* __restrict__ s_out, double* __restrict__ p,
-                                                 double* __restrict__ x) {
-    if (arap_done_before(energy, it, tol)) return;
-    double al[3], be[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) cg_scalars(slot_prev, slot_i, slot0, i, c, cg_tol, &al[c], &be[c]);
-    if (blockIdx.x == 0 && threadIdx.x < 3) slot_i[6 + threadIdx.x] = al[threadIdx.x];
-    const Row r = sell_row(m);
-    __shared__ double sm[16];
-    d3 g = mk3(0, 0, 0), dl = mk3(0, 0, 0);
-    if (r.live) {
-        d3 rn = mk3(0, 0, 0), wn = mk3(0, 0, 0), sn = mk3(0, 0, 0);
-        if (!m.is_ctrl[r.i]) {
-            const double di = m.diag[r.i], mi = 1.0 / di;
-            const d3 ri = ld3(r_in + 3 * r.i), wi = ld3(w_in + 3 * r.i), si = ld3(s_in + 3 * r.i);
-            d3 pi = ld3(p + 3 * r.i), xi = ld3(x + 3 * r.i);
-            const d3 ui = mi * ri;
-            pi = mk3(ui.x + be[0] * pi.x, ui.y + be[1] * pi.y, ui.z + be[2] * pi.z);
-            sn = mk3(wi.x + be[0] * si.x, wi.y + be[1] * si.y, wi.z + be[2] * si.z);
-            xi = mk3(xi.x + al[0] * pi.x, xi.y + al[1] * pi.y, xi.z + al[2] * pi.z);
-            rn = mk3(ri.x - al[0] * sn.x, ri.y - al[1] * sn.y, ri.z - al[2] * sn.z);
-            st3(p + 3 * r.i, pi);
-            st3(x + 3 * r.i, xi);
-            const d3 un = mi * rn;
-            d3 acc = di * un;
-            for (int k = 0; k < r.width; ++k) {
-                const int e = r.off + 64 * k + r.lane;
-                const int j = m.col[e];
-                if (m.is_ctrl[j]) continue;
-                const double w = m.w[e];
-                if (w == 0.0) continue;
-                const d3 rj = ld3(r_in + 3 * j), wj = ld3(w_in + 3 * j), sj = ld3(s_in + 3 * j);
-                // u_{i+1}[j] = M^-1_j (r_j - alpha (w_j + beta s_j)), recomputed from the previous iterate
-                const d3 uj = mk3(rj.x - al[0] * (wj.x + be[0] * sj.x), rj.y - al[1] * (wj.y + be[1] * sj.y),
-                                  rj.z - al[2] * (wj.z + be[2] * sj.z));
-                acc = acc - (2.0 * w / m.diag[j]) * uj;
-            }
-            wn = acc;
-            g = mk3(rn.x * un.x, rn.y * un.y, rn.z * un.z);
-            dl = mk3(wn.x * un.x, wn.y * un.y, wn.z * un.z);
+__global__ __launch_bounds__(TPB) void k_cg_iter(SellDev m, const double* __restrict__ coef, int it, double tol,
+                                                 const double* __restrict__ ered, int i, double cg_tol,
+                                                 const double* __restrict__ slot0, const double* __restrict__ slot_prev,
+                                                 double* __restrict__ slot_i, double* __restrict__ slot_next,
+                                                 const double* __restrict__ rws_in, double* __restrict__ rws_out,
+                                                 double* __restrict__ p, double* __restrict__ x) {
+    __shared__ double s_ab[6];
+    __shared__ int s_done;
+    if (threadIdx.x == 3 * 64) s_done = arap_done_before(ered + EFIN, it, tol) ? 1 : 0;      // wave 3
+    if (threadIdx.x < 3 * 64) {                  // waves 0..2: one right-hand side each
+        const int c = threadIdx.x >> 6;
+        const double gam = fold_partials(slot_i + c * NBMAX, gridDim.x), del = fold_partials(slot_i + (3 + c) * NBMAX, gridDim.x);
+        double a, b;
+        cg_scalars(gam, del, slot0[FIN + 6 + c], slot_prev[FIN + 3 + c], slot_prev[FIN + c], i, cg_tol, &a, &b);
+        if ((threadIdx.x & 63) == 0) {
+            s_ab[c] = a; s_ab[3 + c] = b;
+            if (blockIdx.x == 0) { slot_i[FIN + c] = a; slot_i[FIN + 3 + c] = gam; }
         }
-        st3(r_out + 3 * r.i, rn);
-        st3(w_out + 3 * r.i, wn);
-        st3(s_out + 3 * r.i, sn);
     }
-    const double v0 = block_sum_d(g.x, sm), v1 = block_sum_d(g.y, sm), v2 = block_sum_d(g.z, sm);
-    const double v3 = block_sum_d(dl.x, sm), v4 = block_sum_d(dl.y, sm), v5 = block_sum_d(dl.z, sm);
-    if (threadIdx.x == 0) {
-        atomicAdd(slot_next + 0, v0); atomicAdd(slot_next + 1, v1); atomicAdd(slot_next + 2, v2);
-        atomicAdd(slot_next + 3, v3); atomicAdd(slot_next + 4, v4); atomicAdd(slot_next + 5, v5);
-        if (blockIdx.x == 0) { slot_next[9] = slot0[9]; slot_next[10] = slot0[10]; slot_next[11] = slot0[11]; }
+    __syncthreads();
+    if (s_done) return;
+    const double al[3] = {s_ab[0], s_ab[1], s_ab[2]}, be[3] = {s_ab[3], s_ab[4], s_ab[5]};
+    double g_acc = 0.0, d_acc = 0.0;
+    FOR_ROW_GROUPS(m, g) {
+        const RowCtx r = row_ctx(m, g);
+        const bool freerow = r.live && !m.is_ctrl[r.row];
+        d3 acc = mk3(0, 0, 0);
+        if (freerow)
+            for (int t = 0; t < r.passes; ++t) {
+                const int e = r.off + 64 * t;
+                const double c = coef[e];
+                if (c == 0.0) continue;
+                const double* q = rws_in + 9 * (int64_t)m.col[e];
+                // u_{i+1}[j] * diag_j = r_j - alpha (w_j + beta s_j), recomputed from the previous iterate
+                const d3 uj = mk3(q[0] - al[0] * (q[3] + be[0] * q[6]), q[1] - al[1] * (q[4] + be[1] * q[7]),
+                                  q[2] - al[2] * (q[5] + be[2] * q[8]));
+                acc = acc - c * uj;
+            }
+        acc = mk3(red8(acc.x), red8(acc.y), red8(acc.z));
+        if (r.live && r.l < 3) {
+            double rn = 0.0, wn = 0.0, sn = 0.0;
+            if (freerow) {
+                const int c = r.l;
+                const double a_c = c == 0 ? al[0] : (c == 1 ? al[1] : al[2]), b_c = c == 0 ? be[0] : (c == 1 ? be[1] : be[2]);
+                const double di = m.diag[r.row], mi = 1.0 / di;
+                const double* q = rws_in + 9 * (int64_t)r.row;
+                const double ri = q[c], wi = q[3 + c], si = q[6 + c];
+                const double pn = mi * ri + b_c * p[3 * r.row + c];
+                sn = wi + b_c * si;
+                p[3 * r.row + c] = pn;
+                x[3 * r.row + c] = x[3 * r.row + c] + a_c * pn;
+                rn = ri - a_c * sn;
+                const double un = mi * rn;
+                wn = di * un + (c == 0 ? acc.x : (c == 1 ? acc.y : acc.z));
+                g_acc += rn * un; d_acc += wn * un;
+            }
+            double* o = rws_out + 9 * (int64_t)r.row;
+            o[r.l] = rn; o[3 + r.l] = wn; o[6 + r.l] = sn;
+        }
     }
+    const int l = threadIdx.x & 7;
+    double v[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { v[c] = wave_total(l == c ? g_acc : 0.0); v[3 + c] = wave_total(l == c ? d_acc : 0.0); }
+    block_store_partials<6>(v, slot_next);
 }
 
 // ---------------------------------------------------------------- local step --
-// R_i = closest rotation of sum_j wij p_ij q_ij^T ; E += sum_j wij |q_ij - R_i p_ij|^2
-__global__ __launch_bounds__(TPB) void k_arap_local(SellDev m, const double* __restrict__ pts,
-                                                    const double* __restrict__ sol, int it, double tol,
-                                                    double* __restrict__ energy, double* __restrict__ rot) {
-    if (arap_done_before(energy, it, tol)) return;
-    const Row r = sell_row(m);
-    __shared__ double sm[16];
-    double e_row = 0.0;
-    if (r.live) {
-        const d3 pi = ld3(pts + 3 * r.i), qi = ld3(sol + 3 * r.i);
-        double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k = 0; k < r.width; ++k) {
-            const int e = r.off + 64 * k + r.lane;
-            const double w = m.w[e];
-            const int j = m.col[e];
-            const d3 pp = pi - ld3(pts + 3 * j), qq = qi - ld3(sol + 3 * j);
-            cov[0] += w * (pp.x * qq.x); cov[1] += w * (pp.x * qq.y); cov[2] += w * (pp.x * qq.z);
-            cov[3] += w * (pp.y * qq.x); cov[4] += w * (pp.y * qq.y); cov[5] += w * (pp.y * qq.z);
-            cov[6] += w * (pp.z * qq.x); cov[7] += w * (pp.z * qq.y); cov[8] += w * (pp.z * qq.z);
+// cov_i = sum_j wij p_ij q_ij^T  (8 lanes per row)
+__global__ __launch_bounds__(TPB) void k_arap_cov(SellDev m, const double* __restrict__ pts,
+                                                  const double* __restrict__ sol, int it, double tol,
+                                                  const double* __restrict__ ered, double* __restrict__ cov) {
+    if (block_done(ered + EFIN, it, tol)) return;
+    FOR_ROW_GROUPS(m, g) {
+        const RowCtx r = row_ctx(m, g);
+        double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (r.live) {
+            const d3 pi = ld3(pts + 3 * r.row), qi = ld3(sol + 3 * r.row);
+            for (int t = 0; t < r.passes; ++t) {
+                const int e = r.off + 64 * t;
+                const double w = m.w[e];
+                if (w == 0.0) continue;
+                const int j = m.col[e];
+                const d3 pp = pi - ld3(pts + 3 * j), qq = qi - ld3(sol + 3 * j);
+                c[0] += w * (pp.x * qq.x); c[1] += w * (pp.x * qq.y); c[2] += w * (pp.x * qq.z);
+                c[3] += w * (pp.y * qq.x); c[4] += w * (pp.y * qq.y); c[5] += w * (pp.y * qq.z);
+                c[6] += w * (pp.z * qq.x); c[7] += w * (pp.z * qq.y); c[8] += w * (pp.z * qq.z);
+            }
         }
-        double R[9];
-        closest_rotation(cov, R);
-        double* Ro = rot + 9 * (int64_t)r.i;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) Ro[c] = R[c];
-        for (int k = 0; k < r.width; ++k) {
-            const int e = r.off + 64 * k + r.lane;
-            const double w = m.w[e];
-            const int j = m.col[e];
-            const d3 pp = pi - ld3(pts + 3 * j), qq = qi - ld3(sol + 3 * j);
-            e_row += w * sqn3(qq - mulMv(R, pp));
+        for (int k = 0; k < 9; ++k) c[k] = red8(c[k]);
+        if (r.live) {
+            double* o = cov + 9 * (int64_t)r.row;
+            // lane l writes element l (lane 0 also element 8): static selects keep c[] in registers
+            double val = c[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) val = r.l == k ? c[k] : val;
+            o[r.l] = val;
+            if (r.l == 0) o[8] = c[8];
         }
     }
-    const double eb = block_sum_d(e_row, sm);
-    if (threadIdx.x == 0) atomicAdd(energy + it, eb);
 }
 
-__global__ void k_arap_finalize(SellDev m, int iters, double tol, const double* __restrict__ energy,
+// R_i = closest rotation of cov_i (one thread per vertex: the Jacobi SVD is a serial chain)
+__global__ __launch_bounds__(256) void k_arap_svd(int V, int it, double tol, const double* __restrict__ ered,
+                                                  const double* __restrict__ cov, double* __restrict__ rot) {
+    if (block_done(ered + EFIN, it, tol)) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    double c[9], R[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) c[k] = cov[9 * (int64_t)i + k];
+    closest_rotation(c, R);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rot[9 * (int64_t)i + k] = R[k];
+}
+
+// E = sum_i sum_j wij |q_ij - R_i p_ij|^2  -> partials ered[it*EIT + workgroup]
+__global__ __launch_bounds__(TPB) void k_arap_energy(SellDev m, const double* __restrict__ pts,
+                                                     const double* __restrict__ sol, const double* __restrict__ rot,
+                                                     int it, double tol, double* __restrict__ ered) {
+    if (block_done(ered + EFIN, it, tol)) return;
+    double e_acc = 0.0;
+    FOR_ROW_GROUPS(m, g) {
+        const RowCtx r = row_ctx(m, g);
+        if (r.live) {
+            const d3 pi = ld3(pts + 3 * r.row), qi = ld3(sol + 3 * r.row);
+            const double* Ri = rot + 9 * (int64_t)r.row;
+            for (int t = 0; t < r.passes; ++t) {
+                const int e = r.off + 64 * t;
+                const double w = m.w[e];
+                if (w == 0.0) continue;
+                const int j = m.col[e];
+                const d3 pp = pi - ld3(pts + 3 * j), qq = qi - ld3(sol + 3 * j);
+                e_acc += w * sqn3(qq - mulMv(Ri, pp));
+            }
+        }
+    }
+    double v[1] = {wave_total(e_acc)};
+    block_store_partials<1>(v, ered + it * EIT);
+}
+
+__global__ void k_arap_finalize(SellDev m, int iters, double tol, int nb, double* __restrict__ ered,
                                 const double* __restrict__ sol, double* __restrict__ pts, int32_t* __restrict__ info) {
     // assign_solution + overwrite_initial_geometry (Deformation.cpp:398-400)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) {
-        int run = iters;
-        if (tol > 0.0)
-            for (int t = 1; t + 1 < iters; ++t) {
-                const double dif = fabs((energy[t - 1] - energy[t]) / energy[t]);
-                if (dif < tol) { run = t + 1; break; }
-            }
-        info[0] = run;
+    double* efin = ered + EFIN;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        // the last iteration's energy is only meaningful if that iteration ran (its kernels exit once the rule fired)
+        const bool done = arap_done_before(efin, iters - 1, tol);
+        const double e_last = fold_partials(ered + (iters - 1) * EIT, nb);
+        if (threadIdx.x == 0) {
+            efin[iters - 1] = done ? 0.0 : e_last;
+            int run = iters;
+            if (tol > 0.0)
+                for (int t = 1; t + 1 < iters; ++t) {
+                    const double dif = fabs((efin[t - 1] - efin[t]) / efin[t]);
+                    if (dif < tol) { run = t + 1; break; }
+                }
+            info[0] = run;
+        }
     }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m.V) st3(pts + 3 * i, ld3(sol + 3 * i));
 }
 
@@ -353,9 +519,10 @@ __global__ void k_vertex_normals(const double* __restrict__ pts, const int32_t* 
     st3(out + 3 * i, sum / sqrt(dot3(sum, sum)));
 }
 
-inline dim3 rows_grid(int V) { return dim3((unsigned)(((V + 63) / 64 * 64 + TPB - 1) / TPB)); }
-
 }  // namespace
+
+// one 1024-thread workgroup per CU at most; every row kernel of a handle uses this same grid
+int arap_grid_blocks(const SellDev& m) { return std::max(1, std::min((m.nslices + NW - 1) / NW, NBMAX)); }
 
 void launch_gather_nodes(const double* pts, const double* nrm, const int32_t* nodes, int K, double* node_pts,
                          double* node_nrm, hipStream_t s) {
@@ -364,36 +531,39 @@ void launch_gather_nodes(const double* pts, const double* nrm, const int32_t* no
 void launch_smooth(const double* orig, const double* cur, const int32_t* nbr, int nn, int K, double* out, hipStream_t s) {
     if (K > 0) k_smooth<<<dim3((K + 255) / 256), dim3(256), 0, s>>>(orig, cur, nbr, nn, K, out);
 }
-void launch_cot_weights(const SellDev& m, const double* pts, hipStream_t s) {
-    k_cot_weights<<<rows_grid(m.V), dim3(TPB), 0, s>>>(m, pts);
+void launch_cot_weights(const SellDev& m, const double* pts, double* coef, hipStream_t s) {
+    const dim3 g(arap_grid_blocks(m));
+    k_cot_weights<<<g, dim3(TPB), 0, s>>>(m, pts);
+    k_cg_coef<<<g, dim3(TPB), 0, s>>>(m, coef);
 }
-void launch_arap_prepare(const SellDev& m, const double* pts, const int32_t*, const double* ctrl, int,
-                         double* sol, double* rot, hipStream_t s) {
-    k_arap_prepare<<<rows_grid(m.V), dim3(TPB), 0, s>>>(m, pts, ctrl, sol, rot);
+void launch_arap_prepare(const SellDev& m, const double* pts, const double* ctrl, double* sol, double* rot, hipStream_t s) {
+    k_arap_prepare<<<dim3((m.V + 255) / 256), dim3(256), 0, s>>>(m, pts, ctrl, sol, rot);
 }
 void launch_arap_rhs(const SellDev& m, const double* pts, const double* sol, const double* rot, int it, double tol,
-                     const double* energy, double* r, double* p, double* sprev, double* slot0, hipStream_t s) {
-    k_arap_rhs<<<rows_grid(m.V), dim3(TPB), 0, s>>>(m, pts, sol, rot, it, tol, energy, r, p, sprev, slot0);
+                     double* ered, double* rws, double* p, hipStream_t s) {
+    k_arap_rhs<<<dim3(arap_grid_blocks(m)), dim3(TPB), 0, s>>>(m, pts, sol, rot, it, tol, ered, rws, p);
 }
-void launch_cg_w0(const SellDev& m, int it, double tol, const double* energy, const double* r, double* w,
+void launch_cg_w0(const SellDev& m, const double* coef, int it, double tol, const double* ered, double* rws,
                   double* slot0, hipStream_t s) {
-    k_cg_w0<<<rows_grid(m.V), dim3(TPB), 0, s>>>(m, it, tol, energy, r, w, slot0);
+    k_cg_w0<<<dim3(arap_grid_blocks(m)), dim3(TPB), 0, s>>>(m, coef, it, tol, ered, rws, slot0);
 }
-void launch_cg_iter(const SellDev& m, int it, double tol, const double* energy, int i, double cg_tol,
-                    const double* slot0, double* slot_i, double* slot_next, const double* r_in, const double* w_in,
-                    const double* s_in, double* r_out, double* w_out, double* s_out, double* p, double* x,
-                    hipStream_t s) {
+void launch_cg_iter(const SellDev& m, const double* coef, int it, double tol, const double* ered, int i, double cg_tol,
+                    const double* slot0, double* slot_i, double* slot_next, const double* rws_in, double* rws_out,
+                    double* p, double* x, hipStream_t s) {
     const double* slot_prev = i > 0 ? slot_i - SLOT : slot_i;
-    k_cg_iter<<<rows_grid(m.V), dim3(TPB), 0, s>>>(m, it, tol, energy, i, cg_tol, slot0, slot_prev, slot_i, slot_next,
-                                                   r_in, w_in, s_in, r_out, w_out, s_out, p, x);
+    k_cg_iter<<<dim3(arap_grid_blocks(m)), dim3(TPB), 0, s>>>(m, coef, it, tol, ered, i, cg_tol, slot0, slot_prev, slot_i,
+                                                             slot_next, rws_in, rws_out, p, x);
 }
-void launch_arap_local(const SellDev& m, const double* pts, const double* sol, int it, double tol, double* energy,
-                       double* rot, hipStream_t s) {
-    k_arap_local<<<rows_grid(m.V), dim3(TPB), 0, s>>>(m, pts, sol, it, tol, energy, rot);
+void launch_arap_local(const SellDev& m, const double* pts, const double* sol, int it, double tol, double* ered,
+                       double* cov, double* rot, hipStream_t s) {
+    const dim3 g(arap_grid_blocks(m));
+    k_arap_cov<<<g, dim3(TPB), 0, s>>>(m, pts, sol, it, tol, ered, cov);
+    k_arap_svd<<<dim3((m.V + 255) / 256), dim3(256), 0, s>>>(m.V, it, tol, ered, cov, rot);
+    k_arap_energy<<<g, dim3(TPB), 0, s>>>(m, pts, sol, rot, it, tol, ered);
 }
-void launch_arap_finalize(const SellDev& m, int iters, double tol, const double* energy, const double* sol,
+void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered, const double* sol,
                           double* pts, int32_t* info, hipStream_t s) {
-    k_arap_finalize<<<dim3((m.V + 255) / 256), dim3(256), 0, s>>>(m, iters, tol, energy, sol, pts, info);
+    k_arap_finalize<<<dim3((m.V + 255) / 256), dim3(256), 0, s>>>(m, iters, tol, arap_grid_blocks(m), ered, sol, pts, info);
 }
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf, int V,
                            double* out, hipStream_t s) {

@@ -28,9 +28,9 @@ struct GridDev {
     const int32_t* cell_start;  // nx*ny*nz + 1
 };
 
-struct SellDev {               // SELL-64 adjacency of the template mesh
-    int32_t  V, nslices;
-    const int32_t* slice_off;  // nslices+1, in entries
+struct SellDev {               // "ELL-8 by row group" adjacency of the template mesh (see arap.hip)
+    int32_t  V, nslices;       // nslices = number of 8-row groups
+    const int32_t* slice_off;  // nslices+1, in entries (64 per pass)
     const int32_t* col;
     const int32_t* opp0;
     const int32_t* opp1;
@@ -39,7 +39,12 @@ struct SellDev {               // SELL-64 adjacency of the template mesh
     const int32_t* is_ctrl;    // V
 };
 
-#define MVS_CG_SLOT 12   /* doubles per CG slot: gamma[3], delta[3], alpha[3], bnorm[3] */
+#define MVS_NBMAX 256                      /* max workgroups of a row kernel = partial sums per global sum (arap.hip) */
+#define MVS_CG_FIN (6 * MVS_NBMAX)
+#define MVS_CG_SLOT (MVS_CG_FIN + 16)      /* doubles per CG slot: part[6][NBMAX] (gamma, delta) | alpha[3] gamma[3] bnorm[3] pad */
+#define MVS_ERED_IT (4 * MVS_NBMAX)        /* per ARAP iteration: e_part[NBMAX] | bn_part[3][NBMAX] */
+#define MVS_ERED_FIN (8 * MVS_ERED_IT)     /* then e_fin[8] */
+#define MVS_ERED_SIZE (MVS_ERED_FIN + 8)
 
 struct PhaseTimer {
     double total_ms = 0; int64_t launches = 0;
@@ -47,7 +52,8 @@ struct PhaseTimer {
 
 struct mvs_deform_s {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // stream in use
+    hipStream_t own_stream = nullptr;   // created with the handle
     int64_t V = 0, F = 0, K = 0, P = 0;
     // mesh
     double *d_pts = nullptr, *d_nrm = nullptr, *d_sol = nullptr, *d_rot = nullptr;
@@ -73,15 +79,15 @@ struct mvs_deform_s {
     double *d_tpos = nullptr, *d_tnrm = nullptr;
     int32_t *d_cell_start = nullptr;
     bool has_target = false;
-    // CG work: ping-pong {r,w,s}, p
-    double *d_r[2] = {nullptr, nullptr}, *d_wv[2] = {nullptr, nullptr}, *d_s[2] = {nullptr, nullptr}, *d_p = nullptr;
+    // CG work: ping-pong packed {r,w,s} records (V*9), p (V*3), per-entry 2w/diag_j, per-vertex covariance
+    double *d_rws[2] = {nullptr, nullptr}, *d_p = nullptr, *d_coef = nullptr, *d_cov = nullptr;
     double *d_slots = nullptr;      // [arap_iters][cg_iters+2][9] : gamma[3], delta[3], alpha[3]
-    double *d_energy = nullptr;     // [16]
+    double *d_energy = nullptr;     // [MVS_ERED_SIZE] replicated energy / bnorm accumulators + reduced energies
     int32_t *d_info = nullptr;      // [8] : arap iterations run, ...
     int64_t slots_cap = 0;
     int cg_iters = 0;               // calibrated launches per global solve (0 = not yet)
     // timing
-    bool timing = false;
+    int timing = 0;                 // 0 off, 1 all phases, 2 "cg" groups only
     std::map<std::string, PhaseTimer> timers;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
     std::vector<hipEvent_t> event_pool;
@@ -106,22 +112,21 @@ void launch_knn(const double* pts, int n, int k, int32_t* out, hipStream_t s);
 void launch_gather_nodes(const double* pts, const double* nrm, const int32_t* nodes, int K,
                          double* node_pts, double* node_nrm, hipStream_t s);
 void launch_smooth(const double* orig, const double* cur, const int32_t* nbr, int nn, int K, double* out, hipStream_t s);
-void launch_cot_weights(const SellDev& m, const double* pts, hipStream_t s);
-void launch_arap_prepare(const SellDev& m, const double* pts, const int32_t* nodes, const double* ctrl, int K,
-                         double* sol, double* rot, hipStream_t s);
+void launch_cot_weights(const SellDev& m, const double* pts, double* coef, hipStream_t s);     // 2 launches
+void launch_arap_prepare(const SellDev& m, const double* pts, const double* ctrl, double* sol, double* rot, hipStream_t s);
 void launch_arap_rhs(const SellDev& m, const double* pts, const double* sol, const double* rot, int it, double tol,
-                     const double* energy, double* r, double* p, double* sprev, double* slot0, hipStream_t s);
-void launch_cg_w0(const SellDev& m, int it, double tol, const double* energy, const double* r, double* w,
+                     double* ered, double* rws, double* p, hipStream_t s);
+void launch_cg_w0(const SellDev& m, const double* coef, int it, double tol, const double* ered, double* rws,
                   double* slot0, hipStream_t s);
-// slot_i = slot of CG iteration i of this solve (slot0 + i*MVS_CG_SLOT); alpha_i is written into it
-void launch_cg_iter(const SellDev& m, int it, double tol, const double* energy, int i, double cg_tol,
-                    const double* slot0, double* slot_i, double* slot_next, const double* r_in, const double* w_in,
-                    const double* s_in, double* r_out, double* w_out, double* s_out, double* p, double* x,
-                    hipStream_t s);
-void launch_arap_local(const SellDev& m, const double* pts, const double* sol, int it, double tol, double* energy,
-                       double* rot, hipStream_t s);
-void launch_arap_finalize(const SellDev& m, int iters, double tol, const double* energy, const double* sol,
+// slot_i = slot of CG iteration i of this solve (slot0 + i*MVS_CG_SLOT); alpha_i / gamma_i are written into it
+void launch_cg_iter(const SellDev& m, const double* coef, int it, double tol, const double* ered, int i, double cg_tol,
+                    const double* slot0, double* slot_i, double* slot_next, const double* rws_in, double* rws_out,
+                    double* p, double* x, hipStream_t s);
+void launch_arap_local(const SellDev& m, const double* pts, const double* sol, int it, double tol, double* ered,
+                       double* cov, double* rot, hipStream_t s);                                  // 3 launches
+void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered, const double* sol,
                           double* pts, int32_t* info, hipStream_t s);
+int  arap_grid_blocks(const SellDev& m);
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf,
                            int V, double* out, hipStream_t s);
 

@@ -11,7 +11,7 @@
 // reflection fix (det < 0 -> flip the smallest singular direction).
 __device__ inline void jacobi_pair(d3& bp, d3& bq, d3& vp, d3& vq, bool& rotated) {
     const double al = sqn3(bp), be = sqn3(bq), ga = dot3(bp, bq);
-    if (ga == 0.0 || fabs(ga) <= 1e-17 * sqrt(al * be)) return;
+    if (ga == 0.0 || fabs(ga) <= 1e-15 * sqrt(al * be)) return;   // columns orthogonal to rounding
     rotated = true;
     const double zeta = (be - al) / (2.0 * ga);
     const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));

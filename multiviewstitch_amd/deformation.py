@@ -143,6 +143,10 @@ class Deformation:
     def stream(self) -> int:
         return int(L.lib().mvs_deform_stream(self._h) or 0)
 
+    def set_stream(self, hip_stream: int | None):
+        """Enqueue on a caller-owned stream (torch.cuda.current_stream().cuda_stream); None restores the own one."""
+        L.check(L.lib().mvs_deform_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
     def arap(self, ctrl_targets) -> dict:
         """CGAL-equivalent ARAP with explicit targets for the handle's nodes (Deformation.cpp:383-400)."""
         ct = L.arr(ctrl_targets, np.float64).reshape(-1, 3)
@@ -188,7 +192,8 @@ class Deformation:
         return out
 
     # ----------------------------------------------------------------- timing --
-    def enable_timing(self, on: bool = True):
+    def enable_timing(self, on: int = 1):
+        """0 off, 1 every phase, 2 only the "cg" groups (mvs_deform_enable_timing)."""
         L.check(L.lib().mvs_deform_enable_timing(self._h, int(on)))
 
     def kernel_time(self, name: str):

@@ -1,0 +1,95 @@
+"""View-sharded outer iteration: one process per GPU, target points sharded by
+view, template mesh / node graph replicated.
+
+Per outer iteration the ranks exchange, over ``torch.distributed`` (backend
+"nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests):
+
+  1. all-reduce(MIN)  of d2min[K]           float32   (32 KB at K = 8 K)
+  2. all-gather       of counts[K,2] int32 and the local best-8 records[K,8] (48 B each)
+  3. every rank merges the N record sets with the same total order -> identical
+     node targets everywhere; smoothing + ARAP run replicated, so the meshes
+     never diverge and nothing else is communicated.
+
+The exchange is written against a small "shard" protocol so the same code
+drives the HIP engine (``EngineShard``) and, in the CPU tests, a checker shard
+built on the oracle (tests/test_dist_gloo.py).  A shard provides
+``buffers(K)``, ``dmin(buf)``, ``select(d2min, rec, cnt)``,
+``merge(rec_all, cnt_all, nranks)``, ``solve()``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ._lib import CAND_DTYPE
+
+REC_BYTES = CAND_DTYPE.itemsize          # 48
+
+
+class EngineShard:
+    """Adapter of ``Deformation`` (HIP engine) to the shard protocol; buffers are torch CUDA tensors
+    whose addresses go straight into the C-ABI (mvs_deform_assoc_*)."""
+
+    def __init__(self, deform, device):
+        self.d = deform
+        self.device = device
+        # engine kernels and RCCL collectives share torch's current stream: ordering without host syncs
+        self.d.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+    def buffers(self, K, world):
+        dev = self.device
+        return dict(d2min=torch.empty(K, dtype=torch.float32, device=dev),
+                    rec=torch.empty(K * 8 * REC_BYTES, dtype=torch.uint8, device=dev),
+                    cnt=torch.empty(K * 2, dtype=torch.int32, device=dev),
+                    rec_all=torch.empty(world * K * 8 * REC_BYTES, dtype=torch.uint8, device=dev),
+                    cnt_all=torch.empty(world * K * 2, dtype=torch.int32, device=dev))
+
+    def dmin(self, b):
+        self.d.assoc_dmin(b["d2min"].data_ptr())
+
+    def select(self, b):
+        self.d.assoc_select(b["d2min"].data_ptr(), b["rec"].data_ptr(), b["cnt"].data_ptr())
+
+    def merge(self, b, world):
+        self.d.assoc_merge(b["rec_all"].data_ptr(), b["cnt_all"].data_ptr(), world)
+
+    def solve(self):
+        return self.d.solve()
+
+
+def sharded_step(shard, bufs, world: int, group=None):
+    """One outer iteration of Deformation::Deform's body over view-sharded targets."""
+    shard.dmin(bufs)
+    if world > 1:
+        dist.all_reduce(bufs["d2min"], op=dist.ReduceOp.MIN, group=group)
+    shard.select(bufs)
+    if world > 1:
+        dist.all_gather_into_tensor(bufs["rec_all"], bufs["rec"], group=group)
+        dist.all_gather_into_tensor(bufs["cnt_all"], bufs["cnt"], group=group)
+        shard.merge(bufs, world)
+    else:
+        shard.merge(dict(bufs, rec_all=bufs["rec"], cnt_all=bufs["cnt"]), 1)
+    return shard.solve()
+
+
+def view_shards(n_views: int, world: int):
+    """views of rank r: contiguous blocks, so global point indices follow view order."""
+    per = [n_views // world + (1 if r < n_views % world else 0) for r in range(world)]
+    out, s = [], 0
+    for r in range(world):
+        out.append(list(range(s, s + per[r])))
+        s += per[r]
+    return out
+
+
+def exclusive_offsets(local_count: int, world: int, device, group=None):
+    """global index base of this rank's points = sum of the counts of the lower ranks."""
+    t = torch.zeros(world, dtype=torch.int64, device=device)
+    mine = torch.tensor([local_count], dtype=torch.int64, device=device)
+    if world > 1:
+        dist.all_gather_into_tensor(t, mine, group=group)
+    else:
+        t[0] = local_count
+    counts = t.cpu().numpy()
+    return np.concatenate([[0], np.cumsum(counts)])[:-1], counts

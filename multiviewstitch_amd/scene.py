@@ -221,7 +221,70 @@ def render_inverse_depth(cam_R, cam_t, fx, fy, cx, cy, w, h, radius_fn, r_max, s
     return out.reshape(h, w).astype(np.float32)
 
 
-def make_scene(config: int = 1, seed: int | None = None, **override) -> Scene:
+def render_inverse_depth_torch(cam_R, cam_t, fx, fy, cx, cy, w, h, a, c, A, r_max, device, steps=64, bisect=44):
+    """Same ray caster on torch tensors (float64), for large rasters on the GPU box.  Input
+    generation only; last-bit differences from the numpy path are irrelevant because oracle
+    and engine always consume the same rasters."""
+    import torch
+    dd = dict(dtype=torch.float64, device=device)
+    R = torch.tensor(cam_R, **dd)
+    o = -(R.T @ torch.tensor(cam_t, **dd))
+    a_t, c_t, A_t = torch.tensor(a, **dd), torch.tensor(c, **dd), torch.tensor(A, **dd)
+
+    def radius(d):
+        x, y, z = d[:, 0], d[:, 1], d[:, 2]
+        s = a_t[0] * x + a_t[1] * y + a_t[2] * z + a_t[3] * 2.0 * x * y + a_t[4] * 2.0 * y * z + a_t[5] * (x * x - y * y)
+        r = 1.0 + 0.15 * s / 3.0
+        diff = d[:, None, :] - c_t[None, :, :]
+        ws = (A_t[None, :] * torch.exp(-(diff * diff).sum(-1) / (2.0 * 0.5 * 0.5))).sum(-1)
+        return r * (1.0 + ws)
+
+    vv, uu = torch.meshgrid(torch.arange(h, **dd), torch.arange(w, **dd), indexing="ij")
+    dc = torch.stack([(uu - cx) / fx, (vv - cy) / fy, torch.ones_like(uu)], -1).reshape(-1, 3)
+    dw = dc @ R
+    qa = (dw * dw).sum(-1)
+    qb = 2.0 * (dw @ o)
+    qc = float(o @ o) - r_max * r_max
+    disc = qb * qb - 4 * qa * qc
+    hit = torch.nonzero(disc > 0)[:, 0]
+    out = torch.zeros(w * h, **dd)
+    if hit.numel():
+        sq = torch.sqrt(disc[hit])
+        z0 = (-qb[hit] - sq) / (2 * qa[hit])
+        z1 = (-qb[hit] + sq) / (2 * qa[hit])
+        d = dw[hit]
+
+        def f(z, dsel=d):
+            p = o[None, :] + z[:, None] * dsel
+            r = torch.linalg.norm(p, dim=1)
+            return r - radius(p / r[:, None])
+
+        lo, hi = z0.clone(), z0.clone()
+        flo = f(lo)
+        found = torch.zeros(hit.numel(), dtype=torch.bool, device=device)
+        for s in range(1, steps + 1):
+            z = z0 + (z1 - z0) * (s / steps)
+            fz = f(z)
+            newly = (~found) & (flo > 0) & (fz <= 0)
+            hi = torch.where(newly, z, hi)
+            found |= newly
+            adv = ~found
+            lo = torch.where(adv, z, lo)
+            flo = torch.where(adv, fz, flo)
+        idx = torch.nonzero(found)[:, 0]
+        lo, hi, dsel = lo[idx], hi[idx], d[idx]
+        for _ in range(bisect):
+            mid = 0.5 * (lo + hi)
+            pos = f(mid, dsel) > 0
+            lo = torch.where(pos, mid, lo)
+            hi = torch.where(pos, hi, mid)
+        out[hit[idx]] = 1.0 / (0.5 * (lo + hi))
+    return out.reshape(h, w).to(torch.float32).cpu().numpy()
+
+
+def make_scene(config: int = 1, seed: int | None = None, device=None, views=None, **override) -> Scene:
+    """device: None -> numpy ray caster; a torch device -> torch ray caster.
+    views: optional iterable of view ids to render (others get depth None) — a rank renders its shard."""
     cfg = dict(CONFIGS[config])
     cfg.update(override)
     seed = 1000 + config if seed is None else seed
@@ -244,8 +307,12 @@ def make_scene(config: int = 1, seed: int | None = None, **override) -> Scene:
         Rc, tc = _look_at(eye)
         fx = fy = f * w
         cx, cy = w / 2 - 0.5, h / 2 - 0.5
-        d = render_inverse_depth(Rc, tc, fx, fy, cx, cy, w, h,
-                                 lambda q: _r_target(q, a, c, A), r_max)
+        if views is not None and k not in views:
+            d = None
+        elif device is not None:
+            d = render_inverse_depth_torch(Rc, tc, fx, fy, cx, cy, w, h, a, c, A, r_max, device)
+        else:
+            d = render_inverse_depth(Rc, tc, fx, fy, cx, cy, w, h, lambda q: _r_target(q, a, c, A), r_max)
         # ground-truth similarity of this view's sequence frame: world = s R local + t
         s = float(rng.uniform(0.9, 1.1))
         tilt = _rot_axis(rng.normal(size=3), math.radians(float(rng.uniform(0, 5))))
@@ -254,7 +321,7 @@ def make_scene(config: int = 1, seed: int | None = None, **override) -> Scene:
         # local-frame camera: Xc_local = (Rc R) p_l + (Rc t + tc)/s ; depth_local = depth / s
         cams.append(Camera(fx, fy, cx, cy, (Rc @ R).copy(), ((Rc @ t + tc) / s).copy(), w, h))
         srt.append((s, R.copy(), t.copy()))
-        depth.append((d.astype(np.float64) * s).astype(np.float32))
+        depth.append(None if d is None else (d.astype(np.float64) * s).astype(np.float32))
     return Scene(config, seed, verts, normals, faces, cams, srt, depth, a, c, A)
 
 

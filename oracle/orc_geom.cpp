@@ -23,7 +23,7 @@ void svd3(const double* A, double* U, double* S, double* Vm) {
                 be += B[3 * r + q] * B[3 * r + q];
                 ga += B[3 * r + p] * B[3 * r + q];
             }
-            if (ga == 0.0 || std::fabs(ga) <= 1e-17 * std::sqrt(al * be)) continue;
+            if (ga == 0.0 || std::fabs(ga) <= 1e-15 * std::sqrt(al * be)) continue;   // columns orthogonal to rounding
             rotated = true;
             const double zeta = (be - al) / (2.0 * ga);
             const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
