@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <tuple>
 
 // ------------------------------------------------------------------ errors ----
@@ -126,8 +127,15 @@ void free_nodes(mvs_deform_s* h) {
     h->d_ctrl_final = nullptr; h->K = 0; h->nbr_k = 0; h->h_nodes.clear();
 }
 
-int ensure_slots(mvs_deform_s* h, int arap_iters, int cg) {
-    const int64_t need = (int64_t)arap_iters * (cg + 2) * MVS_CG_SLOT;
+struct CgPlan {                      // CG launches per ARAP iteration and where each solve's slots start
+    int n[8];
+    int64_t total_slots(int iters) const { int64_t t = 0; for (int i = 0; i < iters; ++i) t += n[i] + 2; return t; }
+    int64_t offset(int it) const { return total_slots(it) * MVS_CG_SLOT; }
+    int max(int iters) const { int m = 0; for (int i = 0; i < iters; ++i) m = std::max(m, n[i]); return m; }
+};
+
+int ensure_slots(mvs_deform_s* h, int arap_iters, const CgPlan& cg) {
+    const int64_t need = cg.total_slots(arap_iters) * MVS_CG_SLOT;
     if (need > h->slots_cap) {
         dfree(h->d_slots);
         int rc = dmalloc(&h->d_slots, (size_t)need);
@@ -149,7 +157,7 @@ void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
 }
 
 // graph smoothing (optional) + ARAP + geometry update.  ctrl_src: K*3 node targets.
-int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctrl_src, bool graph_smooth, int cg) {
+int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctrl_src, bool graph_smooth, const CgPlan& plan) {
     hipStream_t s = h->stream;
     const int K = (int)h->K, V = (int)h->V;
     const double* ctrl = ctrl_src;
@@ -171,7 +179,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
         toc(t, p.smooth_sweeps);
     }
     h->d_ctrl_final = const_cast<double*>(ctrl);
-    int rc = ensure_slots(h, p.arap_iters, cg);
+    int rc = ensure_slots(h, p.arap_iters, plan);
     if (rc) return rc;
     {
         Tic t = tic(h, "weights");
@@ -180,7 +188,8 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
         toc(t, 3);
     }
     for (int it = 0; it < p.arap_iters; ++it) {                                                   // deform(5, 1e-4), :398
-        double* slots = h->d_slots + (size_t)it * (cg + 2) * MVS_CG_SLOT;
+        double* slots = h->d_slots + plan.offset(it);
+        const int cg = plan.n[it];
         {
             Tic t = tic(h, "rhs");
             launch_arap_rhs(h->sell, h->d_pts, h->d_sol, h->d_rot, it, p.arap_tol, h->d_energy, h->d_rws[0], h->d_p, s);
@@ -209,8 +218,8 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
 }
 
 // after a sync: read the CG slots of the last solve, fill stats, re-calibrate cg_iters
-int harvest(mvs_deform_s* h, const mvs_deform_params& p, int cg, mvs_deform_stats* st, bool* converged) {
-    const size_t n = (size_t)p.arap_iters * (cg + 2) * MVS_CG_SLOT;
+int harvest(mvs_deform_s* h, const mvs_deform_params& p, const CgPlan& plan, mvs_deform_stats* st, bool* converged) {
+    const size_t n = (size_t)plan.total_slots(p.arap_iters) * MVS_CG_SLOT;
     std::vector<double> slots(n);
     std::vector<double> ered(MVS_ERED_SIZE);
     int32_t info[8];
@@ -226,7 +235,8 @@ int harvest(mvs_deform_s* h, const mvs_deform_params& p, int cg, mvs_deform_stat
     double worst = 0.0;
     bool all_conv = true;
     for (int it = 0; it < run; ++it) {
-        const double* S = slots.data() + (size_t)it * (cg + 2) * MVS_CG_SLOT;
+        const double* S = slots.data() + plan.offset(it);
+        const int cg = plan.n[it];
         int first = -1;
         auto gamma_of = [&](int i, int c) {           // reduced by the consumer kernel for i < cg, folded here for i == cg
             if (i < cg) return S[(size_t)i * MVS_CG_SLOT + MVS_CG_FIN + 3 + c];
@@ -242,15 +252,21 @@ int harvest(mvs_deform_s* h, const mvs_deform_params& p, int cg, mvs_deform_stat
             }
             if (frozen) { first = i; break; }
         }
-        if (first < 0) { all_conv = false; first = cg; }
+        if (first < 0) { all_conv = false; h->cg_plan[it] = std::min(p.cg_max_iters, 2 * cg); first = cg; }
+        else h->cg_plan[it] = std::min(p.cg_max_iters, first + first / 8 + 2);
         need = std::max(need, first);
+        if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] arap it %d: CG frozen at %d of %d (gamma0 %.3e bn %.3e)\n", it, first, cg, gamma_of(0, 0), S[MVS_CG_FIN + 6]);
         for (int c = 0; c < 3; ++c) {
             const double gam = gamma_of(cg, c), bn = S[MVS_CG_FIN + 6 + c];
             if (bn > 0) worst = std::max(worst, std::sqrt(std::max(0.0, gam) / bn));
         }
     }
     if (converged) *converged = all_conv;
-    h->cg_iters = all_conv ? std::min(p.cg_max_iters, need + need / 4 + 4) : std::min(p.cg_max_iters, 2 * cg);
+    for (int it = run; it < p.arap_iters; ++it)            // solves skipped by the energy stop rule keep a safe count
+        if (h->cg_plan[it] == 0 || h->cg_iters == 0) h->cg_plan[it] = h->cg_plan[std::max(0, run - 1)];
+    h->cg_iters = 1;
+    const int cg = plan.max(p.arap_iters);
+    (void)need;
     mvs_deform_stats out{};
     out.arap_iters_run = run;
     out.cg_iters = cg;
@@ -269,8 +285,11 @@ int harvest(mvs_deform_s* h, const mvs_deform_params& p, int cg, mvs_deform_stat
     return MVS_OK;
 }
 
-int probe_cg(const mvs_deform_s* h, const mvs_deform_params& p) {
-    return h->cg_iters > 0 ? std::min(h->cg_iters, p.cg_max_iters) : std::min(p.cg_max_iters, 192);
+CgPlan probe_cg(const mvs_deform_s* h, const mvs_deform_params& p) {
+    CgPlan c;
+    for (int i = 0; i < 8; ++i)
+        c.n[i] = (h->cg_iters > 0 && h->cg_plan[i] > 0) ? std::min(h->cg_plan[i], p.cg_max_iters) : std::min(p.cg_max_iters, 192);
+    return c;
 }
 
 }  // namespace
@@ -396,7 +415,7 @@ int mvs_deform_destroy(mvs_deform_t h) {
     free_nodes(h);
     dfree(h->d_pts); dfree(h->d_nrm); dfree(h->d_sol); dfree(h->d_rot); dfree(h->d_faces); dfree(h->d_vf_ptr); dfree(h->d_vf);
     dfree(h->d_slice_off); dfree(h->d_col); dfree(h->d_opp0); dfree(h->d_opp1); dfree(h->d_is_ctrl); dfree(h->d_w); dfree(h->d_diag);
-    dfree(h->d_spos); dfree(h->d_tpos); dfree(h->d_tnrm); dfree(h->d_cell_start);
+    dfree(h->d_spos); dfree(h->d_tpos); dfree(h->d_tnrm); dfree(h->d_cell_start); dfree(h->d_coarse_cnt);
     for (int k = 0; k < 2; ++k) dfree(h->d_rws[k]);
     dfree(h->d_p); dfree(h->d_coef); dfree(h->d_cov); dfree(h->d_slots); dfree(h->d_energy); dfree(h->d_info);
     for (auto& pr : h->pending) { (void)hipEventDestroy(pr.second.first); (void)hipEventDestroy(pr.second.second); }
@@ -521,7 +540,7 @@ int mvs_deform_iterate(mvs_deform_t h, const mvs_deform_params* p, int n_outer, 
     while (done < n_outer) {
         // enqueue as many outer iterations as the current calibration allows, then harvest once
         const bool calibrated = h->cg_iters > 0;
-        const int cg = probe_cg(h, *p);
+        const CgPlan cg = probe_cg(h, *p);
         const int batch = calibrated ? (n_outer - done) : 1;
         for (int o = 0; o < batch; ++o) {
             enqueue_assoc_local(h, *p);
@@ -572,7 +591,7 @@ int mvs_deform_assoc_merge(mvs_deform_t h, const mvs_deform_params* p, const mvs
 int mvs_deform_solve(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stats* stats) {
     int rc = ready(h, p, false);
     if (rc) return rc;
-    const int cg = probe_cg(h, *p);
+    const CgPlan cg = probe_cg(h, *p);
     rc = enqueue_solve(h, *p, h->d_ctrl_raw, true, cg);
     if (rc) return rc;
     return harvest(h, *p, cg, stats, nullptr);
@@ -582,7 +601,7 @@ int mvs_deform_arap(mvs_deform_t h, const mvs_deform_params* p, const double* ct
     if (rc) return rc;
     if (!ctrl_targets) return MVS_E_INVALID_ARG;
     HIPCHK(hipMemcpyAsync(h->d_ctrl_a, ctrl_targets, sizeof(double) * h->K * 3, hipMemcpyHostToDevice, h->stream));
-    const int cg = probe_cg(h, *p);
+    const CgPlan cg = probe_cg(h, *p);
     rc = enqueue_solve(h, *p, h->d_ctrl_a, false, cg);
     if (rc) return rc;
     return harvest(h, *p, cg, stats, nullptr);

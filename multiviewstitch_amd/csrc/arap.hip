@@ -359,6 +359,12 @@ __global__ __launch_bounds__(TPB) void k_cg_iter(SellDev m, const double* __rest
     __syncthreads();
     if (s_done) return;
     const double al[3] = {s_ab[0], s_ab[1], s_ab[2]}, be[3] = {s_ab[3], s_ab[4], s_ab[5]};
+    if (al[0] == 0.0 && al[1] == 0.0 && al[2] == 0.0) {
+        // all three right-hand sides have converged (frozen): x, r, w, s would be rewritten unchanged.
+        // Carry this workgroup's partial sums forward so the following launches stay frozen, touch nothing else.
+        if (threadIdx.x < 6) slot_next[threadIdx.x * NBMAX + blockIdx.x] = slot_i[threadIdx.x * NBMAX + blockIdx.x];
+        return;
+    }
     double g_acc = 0.0, d_acc = 0.0;
     FOR_ROW_GROUPS(m, g) {
         const RowCtx r = row_ctx(m, g);

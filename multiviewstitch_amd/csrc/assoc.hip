@@ -9,9 +9,14 @@
 //   k_assoc_merge  : merge rank lists, means (:338-349), rejection tests (:350-353)
 //
 // One wave64 per node.  The dense grid is x-fastest, so every (y,z) row of a
-// search box is one contiguous, coalesced run of float4 points.  The running
-// top-k lives across lanes 0..top_k-1 of the wave (one element per lane) and is
-// updated by ballot/readlane/shfl_up — no LDS, no atomics, deterministic.
+// search box is one contiguous, coalesced run of float4 points.  Nodes close to
+// the target (the common case) touch the 3x3x3 fine cells around them; nodes far
+// from it (uncovered regions: the tail that would otherwise set the kernel's
+// duration) walk a COARSE occupancy grid (8x8x8 fine cells per coarse cell) in
+// expanding shells and only descend into occupied coarse cells that can still
+// beat the current best.  The running top-k lives across lanes 0..top_k-1 of the
+// wave (one element per lane) and is updated by ballot/readlane/shfl_up — no LDS,
+// no atomics, deterministic.
 #include "engine.h"
 #include "dev_common.h"
 #include "grid_dev.h"
@@ -43,14 +48,41 @@ __device__ inline bool key_less(double pd_a, double apl_a, long long i_a, double
 }
 
 struct QCell {
-    float fx, fy, fz;
-    int cx, cy, cz;
+    float fx, fy, fz;      // query in fine-cell units
+    int cx, cy, cz;        // clamped fine cell
 };
 __device__ inline QCell query_cell(const GridDev& g, float qx, float qy, float qz) {
     QCell c;
     c.fx = grid_cellf(qx, g.minx, g.inv_h); c.fy = grid_cellf(qy, g.miny, g.inv_h); c.fz = grid_cellf(qz, g.minz, g.inv_h);
     c.cx = grid_axis(qx, g.minx, g.inv_h, g.nx); c.cy = grid_axis(qy, g.miny, g.inv_h, g.ny); c.cz = grid_axis(qz, g.minz, g.inv_h, g.nz);
     return c;
+}
+
+// distance (fine-cell units) from coordinate f to the interval [lo, hi], shrunk by a slack that
+// covers the float32 rounding of the cell assignment (a point may sit ~1e-4 cells outside its cell)
+__device__ inline float axis_gap(float f, float lo, float hi) {
+    const float e = fmaxf(fmaxf(lo - f, f - hi), 0.0f);
+    return fmaxf(e - 0.002f, 0.0f);
+}
+__device__ inline float box_lb2(const QCell& c, float x0, float x1, float y0, float y1, float z0, float z1) {
+    const float ex = axis_gap(c.fx, x0, x1), ey = axis_gap(c.fy, y0, y1), ez = axis_gap(c.fz, z0, z1);
+    return (ex * ex + ey * ey) + ez * ez;
+}
+
+// decode the t-th cell of the cubic shell of radius S >= 1 (n = 2S+1): two z faces, two y faces, two x faces
+__device__ inline void shell_cell(int t, int S, int* dx, int* dy, int* dz) {
+    const int n = 2 * S + 1, m = n - 2;
+    const int nzf = n * n, nyf = n * m;
+    if (t < 2 * nzf) {
+        const int f = t / nzf, r = t - f * nzf;
+        *dz = f ? S : -S; *dy = r / n - S; *dx = r % n - S;
+    } else if (t < 2 * nzf + 2 * nyf) {
+        const int t1 = t - 2 * nzf, f = t1 / nyf, r = t1 - f * nyf;
+        *dy = f ? S : -S; *dz = r / n - (S - 1); *dx = r % n - S;
+    } else {
+        const int t2 = t - 2 * nzf - 2 * nyf, f = t2 / (m * m), r = t2 - f * m * m;
+        *dx = f ? S : -S; *dz = r / m - (S - 1); *dy = r % m - (S - 1);
+    }
 }
 
 // ------------------------------------------------------------------ dmin ----
@@ -61,50 +93,103 @@ __global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __r
     const int lane = threadIdx.x & 63;
     const float qx = (float)node_pts[3 * node], qy = (float)node_pts[3 * node + 1], qz = (float)node_pts[3 * node + 2];
     float best = INFINITY;
-    if (g.P > 0) {
+    const bool finite_q = (qx - qx == 0.0f) && (qy - qy == 0.0f) && (qz - qz == 0.0f);
+    if (g.P > 0 && finite_q) {
         const QCell c = query_cell(g, qx, qy, qz);
+        const int32_t* __restrict__ cs = g.cell_start;
+        auto scan = [&](int A, int B) {
+            for (int i = A + lane; i < B; i += 64) {
+                const float4 p = g.spos[i];
+                best = fminf(best, d2f(qx, qy, qz, p.x, p.y, p.z));
+            }
+        };
+        // ---- stage A: the fine cells around the query (shells s = 0, 1)
         float m = fminf(fminf(fminf(c.fx - c.cx, c.cx + 1 - c.fx), fminf(c.fy - c.cy, c.cy + 1 - c.fy)),
                         fminf(c.fz - c.cz, c.cz + 1 - c.fz));
-        m = fmaxf(m, 0.0f);                      // query outside the grid (or NaN): no credit
-        const int smax = max(g.nx, max(g.ny, g.nz));
-        const int32_t* __restrict__ cs = g.cell_start;
-        for (int s = 0; s <= smax; ++s) {        // bounded: at s == smax every cell has been visited
-            const int side = 2 * s + 1, nrows = side * side;
-            for (int base = 0; base < nrows; base += 64) {
-                int a0 = 0, b0 = 0, a1 = 0, b1 = 0;
-                const int ridx = base + lane;
-                if (ridx < nrows) {
-                    const int dy = ridx / side - s, dz = ridx % side - s;
-                    const int y = c.cy + dy, z = c.cz + dz;
-                    if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
-                        const int64_t rb = ((int64_t)z * g.ny + y) * g.nx;
-                        if (abs(dy) == s || abs(dz) == s) {          // face rows of the shell: whole x run
-                            const int x0 = max(c.cx - s, 0), x1 = min(c.cx + s, g.nx - 1);
-                            if (x0 <= x1) { a0 = cs[rb + x0]; b0 = cs[rb + x1 + 1]; }
-                        } else {                                      // interior rows: the two end cells
-                            if (c.cx - s >= 0) { a0 = cs[rb + c.cx - s]; b0 = cs[rb + c.cx - s + 1]; }
-                            if (c.cx + s < g.nx) { a1 = cs[rb + c.cx + s]; b1 = cs[rb + c.cx + s + 1]; }
-                        }
-                    }
-                }
-                unsigned long long mask = __ballot(b0 > a0 || b1 > a1);
-                while (mask) {
-                    const int l = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const int A0 = rl_i(a0, l), B0 = rl_i(b0, l), A1 = rl_i(a1, l), B1 = rl_i(b1, l);
-                    for (int i = A0 + lane; i < B0; i += 64) {
-                        const float4 p = g.spos[i];
-                        best = fminf(best, d2f(qx, qy, qz, p.x, p.y, p.z));
-                    }
-                    for (int i = A1 + lane; i < B1; i += 64) {
-                        const float4 p = g.spos[i];
-                        best = fminf(best, d2f(qx, qy, qz, p.x, p.y, p.z));
+        m = fmaxf(m, 0.0f);                      // query outside the grid: no credit
+        bool found = false;
+        for (int s = 0; s <= 1 && !found; ++s) {
+            const int side = 2 * s + 1, nrows = side * side;     // <= 9 rows: one pass
+            int a0 = 0, b0 = 0, a1 = 0, b1 = 0;
+            if (lane < nrows) {
+                const int dy = lane / side - s, dz = lane % side - s;
+                const int y = c.cy + dy, z = c.cz + dz;
+                if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+                    const int64_t rb = ((int64_t)z * g.ny + y) * g.nx;
+                    if (abs(dy) == s || abs(dz) == s) {          // face rows of the shell: whole x run
+                        const int x0 = max(c.cx - s, 0), x1 = min(c.cx + s, g.nx - 1);
+                        if (x0 <= x1) { a0 = cs[rb + x0]; b0 = cs[rb + x1 + 1]; }
+                    } else {                                      // interior row: the two end cells
+                        if (c.cx - s >= 0) { a0 = cs[rb + c.cx - s]; b0 = cs[rb + c.cx - s + 1]; }
+                        if (c.cx + s < g.nx) { a1 = cs[rb + c.cx + s]; b1 = cs[rb + c.cx + s + 1]; }
                     }
                 }
             }
-            const float wb = wave_min_f(best);
-            const float bound = ((float)s + m - 0.01f) * g.h;        // everything within `bound` has been seen
-            if (bound > 0.0f && wb <= bound * bound) break;
+            unsigned long long mask = __ballot(b0 > a0 || b1 > a1);
+            while (mask) {
+                const int l = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                scan(rl_i(a0, l), rl_i(b0, l));
+                scan(rl_i(a1, l), rl_i(b1, l));
+            }
+            best = wave_min_f(best);
+            const float bound = ((float)s + m - 0.01f) * g.h;    // everything within `bound` has been seen
+            found = bound > 0.0f && best <= bound * bound;
+        }
+        // ---- stage B: coarse occupancy grid, expanding shells with pruning
+        if (!found) {
+            const int CX = c.cx >> 3, CY = c.cy >> 3, CZ = c.cz >> 3;
+            const float ih2 = g.inv_h * g.inv_h;
+            float Mc = fminf(fminf(fminf(c.fx - 8.f * CX, 8.f * CX + 8.f - c.fx), fminf(c.fy - 8.f * CY, 8.f * CY + 8.f - c.fy)),
+                             fminf(c.fz - 8.f * CZ, 8.f * CZ + 8.f - c.fz));
+            Mc = fmaxf(Mc, 0.0f);                                // fine-cell units
+            const int SmaxC = max(g.NX, max(g.NY, g.NZ));
+            for (int S = 0; S <= SmaxC; ++S) {                   // bounded: at S == SmaxC every coarse cell was visited
+                const int n = 2 * S + 1;
+                const int total = S == 0 ? 1 : 6 * n * n - 12 * n + 8;
+                for (int base = 0; base < total; base += 64) {
+                    const int t = base + lane;
+                    int X = 0, Y = 0, Z = 0;
+                    bool cand = false;
+                    if (t < total) {
+                        int dx = 0, dy = 0, dz = 0;
+                        if (S > 0) shell_cell(t, S, &dx, &dy, &dz);
+                        X = CX + dx; Y = CY + dy; Z = CZ + dz;
+                        if (X >= 0 && X < g.NX && Y >= 0 && Y < g.NY && Z >= 0 && Z < g.NZ &&
+                            g.coarse_cnt[((int64_t)Z * g.NY + Y) * g.NX + X] > 0) {
+                            const float lb2 = box_lb2(c, 8.f * X, 8.f * X + 8.f, 8.f * Y, 8.f * Y + 8.f, 8.f * Z, 8.f * Z + 8.f);
+                            cand = lb2 <= best * ih2;             // best == inf -> true
+                        }
+                    }
+                    unsigned long long cmask = __ballot(cand);
+                    while (cmask) {
+                        const int l = __ffsll((long long)cmask) - 1;
+                        cmask &= cmask - 1;
+                        const int Xc = rl_i(X, l), Yc = rl_i(Y, l), Zc = rl_i(Z, l);
+                        const float lim = best * ih2;
+                        // the 64 (y,z) rows of this coarse cell, one per lane
+                        const int y = 8 * Yc + (lane & 7), z = 8 * Zc + (lane >> 3);
+                        int a = 0, b = 0;
+                        if (y < g.ny && z < g.nz) {
+                            const float ey = axis_gap(c.fy, (float)y, (float)y + 1.f), ez = axis_gap(c.fz, (float)z, (float)z + 1.f);
+                            const float ex = axis_gap(c.fx, 8.f * Xc, 8.f * Xc + 8.f);
+                            if ((ex * ex + ey * ey) + ez * ez <= lim) {
+                                const int64_t rb = ((int64_t)z * g.ny + y) * g.nx;
+                                a = cs[rb + 8 * Xc]; b = cs[rb + min(8 * Xc + 8, g.nx)];
+                            }
+                        }
+                        unsigned long long rmask = __ballot(b > a);
+                        while (rmask) {
+                            const int lr = __ffsll((long long)rmask) - 1;
+                            rmask &= rmask - 1;
+                            scan(rl_i(a, lr), rl_i(b, lr));
+                        }
+                        best = wave_min_f(best);
+                    }
+                }
+                const float bound = (((float)S) * 8.f + Mc - 0.08f) * g.h;
+                if (bound > 0.0f && best <= bound * bound) break;
+            }
         }
     }
     best = wave_min_f(best);
@@ -134,7 +219,59 @@ __global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* _
         const float r2 = dm * 2.0f;                          // radiusSearch(..., minDist * 2.0f, ...)  :288
         const double nlen = norm3(nn);
         const QCell c = query_cell(g, qx, qy, qz);
-        const float rc = sqrtf(r2) * g.inv_h + 0.01f;
+        const int32_t* __restrict__ cs = g.cell_start;
+
+        // all points of the sorted range [A, B): ball test, normal filter, keys, top-k insertion
+        auto scan = [&](int A, int B) {
+            for (int cb = A; cb < B; cb += 64) {             // wave-uniform trip count
+                const int i = cb + lane;
+                bool has = false;
+                double pd = 0, pl = 0; d3 tp = mk3(0, 0, 0); long long gi = 0;
+                if (i < B) {
+                    const float4 p = g.spos[i];
+                    if (d2f(qx, qy, qz, p.x, p.y, p.z) <= r2) {
+                        ++n_ball;
+                        const d3 tn = ld3(g.tnrm + 3 * (int64_t)i);
+                        if (dot3(nn, tn) > 0) {                       // :307
+                            ++n_pass;
+                            tp = ld3(g.tpos + 3 * (int64_t)i);
+                            const d3 dir = tp - orig;                 // :331
+                            pl = dot3(dir, nn) / nlen;                // :332
+                            const double x = sqn3(dir) - pl * pl;
+                            pd = sqrt((0.0 < x) ? x : 0.0);           // :334, clamped (Appendix A.2)
+                            gi = g.index_base + (long long)__float_as_int(p.w);
+                            has = true;
+                        }
+                    }
+                }
+                const double apl = fabs(pl);
+                unsigned long long pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
+                while (pend) {
+                    const int src = __ffsll((long long)pend) - 1;
+                    const double c_pd = rl_d(pd, src), c_pl = rl_d(pl, src);
+                    const double c_x = rl_d(tp.x, src), c_y = rl_d(tp.y, src), c_z = rl_d(tp.z, src);
+                    const long long c_i = rl_ll(gi, src);
+                    const bool less = lane < len && key_less(L_pd, fabs(L_pl), L_idx, c_pd, fabs(c_pl), c_i);
+                    const int pos = __popcll(__ballot(less));
+                    const double u_pd = __shfl_up(L_pd, 1, 64), u_pl = __shfl_up(L_pl, 1, 64);
+                    const double u_x = __shfl_up(L_x, 1, 64), u_y = __shfl_up(L_y, 1, 64), u_z = __shfl_up(L_z, 1, 64);
+                    const long long u_i = shfl_up_ll(L_idx);
+                    if (lane > pos && lane <= len && lane < top_k) {
+                        L_pd = u_pd; L_pl = u_pl; L_x = u_x; L_y = u_y; L_z = u_z; L_idx = u_i;
+                    } else if (lane == pos) {
+                        L_pd = c_pd; L_pl = c_pl; L_x = c_x; L_y = c_y; L_z = c_z; L_idx = c_i;
+                    }
+                    len = min(len + 1, top_k);
+                    if (len == top_k) {
+                        t_pd = rl_d(L_pd, top_k - 1); t_apl = fabs(rl_d(L_pl, top_k - 1)); t_idx = rl_ll(L_idx, top_k - 1);
+                    }
+                    if (lane == src) has = false;
+                    pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
+                }
+            }
+        };
+
+        const float rc = sqrtf(r2) * g.inv_h + 0.01f;       // ball radius in fine cells (+ rounding guard)
         const float lx = floorf(c.fx - rc), hx = floorf(c.fx + rc);
         const float ly = floorf(c.fy - rc), hy = floorf(c.fy + rc);
         const float lz = floorf(c.fz - rc), hz = floorf(c.fz + rc);
@@ -145,12 +282,11 @@ __global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* _
             const int y0 = (int)fmaxf(ly, 0.f), y1 = (int)fminf(hy, (float)(g.ny - 1));
             const int z0 = (int)fmaxf(lz, 0.f), z1 = (int)fminf(hz, (float)(g.nz - 1));
             const int ny_ = y1 - y0 + 1, nrows = ny_ * (z1 - z0 + 1);
-            const int32_t* __restrict__ cs = g.cell_start;
-            for (int base = 0; base < nrows; base += 64) {
+            if (nrows <= 64) {
+                // small ball: every (y,z) row of its bounding box, one per lane
                 int a = 0, b = 0;
-                const int ridx = base + lane;
-                if (ridx < nrows) {
-                    const int y = y0 + ridx % ny_, z = z0 + ridx / ny_;
+                if (lane < nrows) {
+                    const int y = y0 + lane % ny_, z = z0 + lane / ny_;
                     const int64_t rb = ((int64_t)z * g.ny + y) * g.nx;
                     a = cs[rb + x0]; b = cs[rb + x1 + 1];
                 }
@@ -158,51 +294,42 @@ __global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* _
                 while (mask) {
                     const int l = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
-                    const int A = rl_i(a, l), B = rl_i(b, l);
-                    for (int cb = A; cb < B; cb += 64) {     // wave-uniform trip count
-                        const int i = cb + lane;
-                        bool has = false;
-                        double pd = 0, pl = 0; d3 tp = mk3(0, 0, 0); long long gi = 0;
-                        if (i < B) {
-                            const float4 p = g.spos[i];
-                            if (d2f(qx, qy, qz, p.x, p.y, p.z) <= r2) {
-                                ++n_ball;
-                                const d3 tn = ld3(g.tnrm + 3 * (int64_t)i);
-                                if (dot3(nn, tn) > 0) {                       // :307
-                                    ++n_pass;
-                                    tp = ld3(g.tpos + 3 * (int64_t)i);
-                                    const d3 dir = tp - orig;                 // :331
-                                    pl = dot3(dir, nn) / nlen;                // :332
-                                    const double x = sqn3(dir) - pl * pl;
-                                    pd = sqrt((0.0 < x) ? x : 0.0);           // :334, clamped (Appendix A.2)
-                                    gi = g.index_base + (long long)__float_as_int(p.w);
-                                    has = true;
-                                }
+                    scan(rl_i(a, l), rl_i(b, l));
+                }
+            } else {
+                // large ball (node far from the target): occupied coarse cells that intersect the ball
+                const float lim = rc * rc;
+                const int X0 = x0 >> 3, X1 = x1 >> 3, Y0 = y0 >> 3, Y1 = y1 >> 3, Z0 = z0 >> 3, Z1 = z1 >> 3;
+                const int nX = X1 - X0 + 1, nY = Y1 - Y0 + 1, ncc = nX * nY * (Z1 - Z0 + 1);
+                for (int base = 0; base < ncc; base += 64) {
+                    const int t = base + lane;
+                    int X = 0, Y = 0, Z = 0;
+                    bool cand = false;
+                    if (t < ncc) {
+                        X = X0 + t % nX; Y = Y0 + (t / nX) % nY; Z = Z0 + t / (nX * nY);
+                        if (g.coarse_cnt[((int64_t)Z * g.NY + Y) * g.NX + X] > 0)
+                            cand = box_lb2(c, 8.f * X, 8.f * X + 8.f, 8.f * Y, 8.f * Y + 8.f, 8.f * Z, 8.f * Z + 8.f) <= lim;
+                    }
+                    unsigned long long cmask = __ballot(cand);
+                    while (cmask) {
+                        const int l = __ffsll((long long)cmask) - 1;
+                        cmask &= cmask - 1;
+                        const int Xc = rl_i(X, l), Yc = rl_i(Y, l), Zc = rl_i(Z, l);
+                        const int y = 8 * Yc + (lane & 7), z = 8 * Zc + (lane >> 3);
+                        const int xa = max(8 * Xc, x0), xb = min(8 * Xc + 7, x1);
+                        int a = 0, b = 0;
+                        if (y >= y0 && y <= y1 && z >= z0 && z <= z1 && xa <= xb) {
+                            const float ey = axis_gap(c.fy, (float)y, (float)y + 1.f), ez = axis_gap(c.fz, (float)z, (float)z + 1.f);
+                            if (ey * ey + ez * ez <= lim) {
+                                const int64_t rb = ((int64_t)z * g.ny + y) * g.nx;
+                                a = cs[rb + xa]; b = cs[rb + xb + 1];
                             }
                         }
-                        const double apl = fabs(pl);
-                        unsigned long long pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
-                        while (pend) {
-                            const int src = __ffsll((long long)pend) - 1;
-                            const double c_pd = rl_d(pd, src), c_pl = rl_d(pl, src);
-                            const double c_x = rl_d(tp.x, src), c_y = rl_d(tp.y, src), c_z = rl_d(tp.z, src);
-                            const long long c_i = rl_ll(gi, src);
-                            const bool less = lane < len && key_less(L_pd, fabs(L_pl), L_idx, c_pd, fabs(c_pl), c_i);
-                            const int pos = __popcll(__ballot(less));
-                            const double u_pd = __shfl_up(L_pd, 1, 64), u_pl = __shfl_up(L_pl, 1, 64);
-                            const double u_x = __shfl_up(L_x, 1, 64), u_y = __shfl_up(L_y, 1, 64), u_z = __shfl_up(L_z, 1, 64);
-                            const long long u_i = shfl_up_ll(L_idx);
-                            if (lane > pos && lane <= len && lane < top_k) {
-                                L_pd = u_pd; L_pl = u_pl; L_x = u_x; L_y = u_y; L_z = u_z; L_idx = u_i;
-                            } else if (lane == pos) {
-                                L_pd = c_pd; L_pl = c_pl; L_x = c_x; L_y = c_y; L_z = c_z; L_idx = c_i;
-                            }
-                            len = min(len + 1, top_k);
-                            if (len == top_k) {
-                                t_pd = rl_d(L_pd, top_k - 1); t_apl = fabs(rl_d(L_pl, top_k - 1)); t_idx = rl_ll(L_idx, top_k - 1);
-                            }
-                            if (lane == src) has = false;
-                            pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
+                        unsigned long long rmask = __ballot(b > a);
+                        while (rmask) {
+                            const int lr = __ffsll((long long)rmask) - 1;
+                            rmask &= rmask - 1;
+                            scan(rl_i(a, lr), rl_i(b, lr));
                         }
                     }
                 }

@@ -26,6 +26,8 @@ struct GridDev {
     const double*  tpos;        // P*3 cell-sorted double positions
     const double*  tnrm;        // P*3 cell-sorted double normals
     const int32_t* cell_start;  // nx*ny*nz + 1
+    int32_t  NX, NY, NZ;        // coarse occupancy grid: 8x8x8 fine cells per coarse cell
+    const int32_t* coarse_cnt;  // NX*NY*NZ point counts
 };
 
 struct SellDev {               // "ELL-8 by row group" adjacency of the template mesh (see arap.hip)
@@ -77,15 +79,16 @@ struct mvs_deform_s {
     GridDev grid{};
     float4 *d_spos = nullptr;
     double *d_tpos = nullptr, *d_tnrm = nullptr;
-    int32_t *d_cell_start = nullptr;
+    int32_t *d_cell_start = nullptr, *d_coarse_cnt = nullptr;
     bool has_target = false;
     // CG work: ping-pong packed {r,w,s} records (V*9), p (V*3), per-entry 2w/diag_j, per-vertex covariance
     double *d_rws[2] = {nullptr, nullptr}, *d_p = nullptr, *d_coef = nullptr, *d_cov = nullptr;
-    double *d_slots = nullptr;      // [arap_iters][cg_iters+2][9] : gamma[3], delta[3], alpha[3]
+    double *d_slots = nullptr;      // per ARAP iteration: (cg_plan[it] + 2) slots of MVS_CG_SLOT doubles
     double *d_energy = nullptr;     // [MVS_ERED_SIZE] replicated energy / bnorm accumulators + reduced energies
     int32_t *d_info = nullptr;      // [8] : arap iterations run, ...
     int64_t slots_cap = 0;
-    int cg_iters = 0;               // calibrated launches per global solve (0 = not yet)
+    int cg_iters = 0;               // 0 = not calibrated yet, else max over cg_plan
+    int cg_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // calibrated CG launches of each ARAP iteration's global solve
     // timing
     int timing = 0;                 // 0 off, 1 all phases, 2 "cg" groups only
     std::map<std::string, PhaseTimer> timers;

@@ -114,6 +114,22 @@ __global__ void k_scatter(const double* __restrict__ pts, const double* __restri
     tnrm[3 * d] = nrm[3 * i]; tnrm[3 * d + 1] = nrm[3 * i + 1]; tnrm[3 * d + 2] = nrm[3 * i + 2];
 }
 
+// points per coarse cell (8x8x8 fine cells): sum over its 64 (y,z) rows of the x-run lengths
+__global__ void k_coarse_count(const int32_t* __restrict__ cs, int nx, int ny, int nz, int NX, int NY, int NZ,
+                               int32_t* __restrict__ cnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)NX * NY * NZ) return;
+    const int X = (int)(i % NX), Y = (int)((i / NX) % NY), Z = (int)(i / ((int64_t)NX * NY));
+    const int xa = 8 * X, xb = min(8 * X + 8, nx);
+    int s = 0;
+    for (int z = 8 * Z; z < min(8 * Z + 8, nz); ++z)
+        for (int y = 8 * Y; y < min(8 * Y + 8, ny); ++y) {
+            const int64_t rb = ((int64_t)z * ny + y) * nx;
+            s += cs[rb + xb] - cs[rb + xa];
+        }
+    cnt[i] = s;
+}
+
 }  // namespace
 
 // in: n+1 entries (in[n] ignored, treated as 0); out: n+1 entries, out[n] = total.  Syncs the stream.
@@ -149,6 +165,7 @@ int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* 
     if (h->d_tpos) { hipFree(h->d_tpos); h->d_tpos = nullptr; }
     if (h->d_tnrm) { hipFree(h->d_tnrm); h->d_tnrm = nullptr; }
     if (h->d_cell_start) { hipFree(h->d_cell_start); h->d_cell_start = nullptr; }
+    if (h->d_coarse_cnt) { hipFree(h->d_coarse_cnt); h->d_coarse_cnt = nullptr; }
     h->P = P;
     h->grid = GridDev{};
     h->grid.P = P; h->grid.index_base = index_base;
@@ -224,6 +241,13 @@ int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* 
     h->grid.nx = g.nx; h->grid.ny = g.ny; h->grid.nz = g.nz;
     h->grid.spos = h->d_spos; h->grid.tpos = h->d_tpos; h->grid.tnrm = h->d_tnrm;
     h->grid.cell_start = h->d_cell_start;
+    h->grid.NX = (g.nx + 7) / 8; h->grid.NY = (g.ny + 7) / 8; h->grid.NZ = (g.nz + 7) / 8;
+    const int64_t ncoarse = (int64_t)h->grid.NX * h->grid.NY * h->grid.NZ;
+    HIPCHK(hipMalloc(&h->d_coarse_cnt, sizeof(int32_t) * ncoarse));
+    k_coarse_count<<<dim3((unsigned)((ncoarse + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(h->d_cell_start, g.nx, g.ny, g.nz, h->grid.NX,
+                                                                                   h->grid.NY, h->grid.NZ, h->d_coarse_cnt);
+    HIPCHK(hipStreamSynchronize(s));
+    h->grid.coarse_cnt = h->d_coarse_cnt;
     h->has_target = true;
     return MVS_OK;
 }
