@@ -103,6 +103,18 @@ __global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __r
                 best = fminf(best, d2f(qx, qy, qz, p.x, p.y, p.z));
             }
         };
+        // (start,end) of the x-run [xlo, xhi] (length <= 8) of row (y,z): at most two tiled pieces
+        auto run2 = [&](int y, int z, int xlo, int xhi, int& a0, int& b0, int& a1, int& b1) {
+            const int X0 = xlo >> 3, X1 = xhi >> 3;
+            const int64_t r0 = grid_rowbase(g.NX, g.NY, X0, y, z);
+            a0 = cs[r0 + (xlo & 7)];
+            if (X0 == X1) { b0 = cs[r0 + (xhi & 7) + 1]; }
+            else {
+                b0 = cs[r0 + 8];
+                const int64_t r1 = grid_rowbase(g.NX, g.NY, X1, y, z);
+                a1 = cs[r1]; b1 = cs[r1 + (xhi & 7) + 1];
+            }
+        };
         // ---- stage A: the fine cells around the query (shells s = 0, 1)
         float m = fminf(fminf(fminf(c.fx - c.cx, c.cx + 1 - c.fx), fminf(c.fy - c.cy, c.cy + 1 - c.fy)),
                         fminf(c.fz - c.cz, c.cz + 1 - c.fz));
@@ -115,13 +127,12 @@ __global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __r
                 const int dy = lane / side - s, dz = lane % side - s;
                 const int y = c.cy + dy, z = c.cz + dz;
                 if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
-                    const int64_t rb = ((int64_t)z * g.ny + y) * g.nx;
                     if (abs(dy) == s || abs(dz) == s) {          // face rows of the shell: whole x run
                         const int x0 = max(c.cx - s, 0), x1 = min(c.cx + s, g.nx - 1);
-                        if (x0 <= x1) { a0 = cs[rb + x0]; b0 = cs[rb + x1 + 1]; }
+                        if (x0 <= x1) run2(y, z, x0, x1, a0, b0, a1, b1);
                     } else {                                      // interior row: the two end cells
-                        if (c.cx - s >= 0) { a0 = cs[rb + c.cx - s]; b0 = cs[rb + c.cx - s + 1]; }
-                        if (c.cx + s < g.nx) { a1 = cs[rb + c.cx + s]; b1 = cs[rb + c.cx + s + 1]; }
+                        if (c.cx - s >= 0) { const int64_t i0 = grid_index(g.NX, g.NY, c.cx - s, y, z); a0 = cs[i0]; b0 = cs[i0 + 1]; }
+                        if (c.cx + s < g.nx) { const int64_t i1 = grid_index(g.NX, g.NY, c.cx + s, y, z); a1 = cs[i1]; b1 = cs[i1 + 1]; }
                     }
                 }
             }
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __r
             const float bound = ((float)s + m - 0.01f) * g.h;    // everything within `bound` has been seen
             found = bound > 0.0f && best <= bound * bound;
         }
-        // ---- stage B: coarse occupancy grid, expanding shells with pruning
+        // ---- stage B: coarse occupancy grid, expanding shells with pruning; a coarse cell is ONE range
         if (!found) {
             const int CX = c.cx >> 3, CY = c.cy >> 3, CZ = c.cz >> 3;
             const float ih2 = g.inv_h * g.inv_h;
@@ -149,41 +160,26 @@ __global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __r
                 const int total = S == 0 ? 1 : 6 * n * n - 12 * n + 8;
                 for (int base = 0; base < total; base += 64) {
                     const int t = base + lane;
-                    int X = 0, Y = 0, Z = 0;
-                    bool cand = false;
+                    int a = 0, b = 0;
+                    float lb2 = INFINITY;
                     if (t < total) {
                         int dx = 0, dy = 0, dz = 0;
                         if (S > 0) shell_cell(t, S, &dx, &dy, &dz);
-                        X = CX + dx; Y = CY + dy; Z = CZ + dz;
-                        if (X >= 0 && X < g.NX && Y >= 0 && Y < g.NY && Z >= 0 && Z < g.NZ &&
-                            g.coarse_cnt[((int64_t)Z * g.NY + Y) * g.NX + X] > 0) {
-                            const float lb2 = box_lb2(c, 8.f * X, 8.f * X + 8.f, 8.f * Y, 8.f * Y + 8.f, 8.f * Z, 8.f * Z + 8.f);
-                            cand = lb2 <= best * ih2;             // best == inf -> true
+                        const int X = CX + dx, Y = CY + dy, Z = CZ + dz;
+                        if (X >= 0 && X < g.NX && Y >= 0 && Y < g.NY && Z >= 0 && Z < g.NZ) {
+                            const int64_t C = grid_coarse(g.NX, g.NY, X, Y, Z);
+                            if (g.coarse_cnt[C] > 0) {
+                                lb2 = box_lb2(c, 8.f * X, 8.f * X + 8.f, 8.f * Y, 8.f * Y + 8.f, 8.f * Z, 8.f * Z + 8.f);
+                                if (lb2 <= best * ih2) { a = cs[C * 512]; b = cs[(C + 1) * 512]; }   // best == inf -> true
+                            }
                         }
                     }
-                    unsigned long long cmask = __ballot(cand);
+                    unsigned long long cmask = __ballot(b > a);
                     while (cmask) {
                         const int l = __ffsll((long long)cmask) - 1;
                         cmask &= cmask - 1;
-                        const int Xc = rl_i(X, l), Yc = rl_i(Y, l), Zc = rl_i(Z, l);
-                        const float lim = best * ih2;
-                        // the 64 (y,z) rows of this coarse cell, one per lane
-                        const int y = 8 * Yc + (lane & 7), z = 8 * Zc + (lane >> 3);
-                        int a = 0, b = 0;
-                        if (y < g.ny && z < g.nz) {
-                            const float ey = axis_gap(c.fy, (float)y, (float)y + 1.f), ez = axis_gap(c.fz, (float)z, (float)z + 1.f);
-                            const float ex = axis_gap(c.fx, 8.f * Xc, 8.f * Xc + 8.f);
-                            if ((ex * ex + ey * ey) + ez * ez <= lim) {
-                                const int64_t rb = ((int64_t)z * g.ny + y) * g.nx;
-                                a = cs[rb + 8 * Xc]; b = cs[rb + min(8 * Xc + 8, g.nx)];
-                            }
-                        }
-                        unsigned long long rmask = __ballot(b > a);
-                        while (rmask) {
-                            const int lr = __ffsll((long long)rmask) - 1;
-                            rmask &= rmask - 1;
-                            scan(rl_i(a, lr), rl_i(b, lr));
-                        }
+                        if (__int_as_float(rl_i(__float_as_int(lb2), l)) > best * ih2) continue;   // a closer point turned up meanwhile
+                        scan(rl_i(a, l), rl_i(b, l));
                         best = wave_min_f(best);
                     }
                 }
@@ -283,54 +279,43 @@ __global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* _
             const int z0 = (int)fmaxf(lz, 0.f), z1 = (int)fminf(hz, (float)(g.nz - 1));
             const int ny_ = y1 - y0 + 1, nrows = ny_ * (z1 - z0 + 1);
             if (nrows <= 64) {
-                // small ball: every (y,z) row of its bounding box, one per lane
-                int a = 0, b = 0;
-                if (lane < nrows) {
-                    const int y = y0 + lane % ny_, z = z0 + lane / ny_;
-                    const int64_t rb = ((int64_t)z * g.ny + y) * g.nx;
-                    a = cs[rb + x0]; b = cs[rb + x1 + 1];
-                }
-                unsigned long long mask = __ballot(b > a);
-                while (mask) {
-                    const int l = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    scan(rl_i(a, l), rl_i(b, l));
+                // small ball: every (y,z) row of its bounding box, one per lane; the x run is cut at coarse columns
+                for (int X = x0 >> 3; X <= (x1 >> 3); ++X) {
+                    int a = 0, b = 0;
+                    if (lane < nrows) {
+                        const int y = y0 + lane % ny_, z = z0 + lane / ny_;
+                        const int64_t rb = grid_rowbase(g.NX, g.NY, X, y, z);
+                        a = cs[rb + (max(x0, 8 * X) & 7)]; b = cs[rb + (min(x1, 8 * X + 7) & 7) + 1];
+                    }
+                    unsigned long long mask = __ballot(b > a);
+                    while (mask) {
+                        const int l = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        scan(rl_i(a, l), rl_i(b, l));
+                    }
                 }
             } else {
-                // large ball (node far from the target): occupied coarse cells that intersect the ball
+                // large ball (node far from the target): every occupied coarse cell that intersects the ball
+                // is ONE contiguous range; 64 of them are looked up per pass
                 const float lim = rc * rc;
                 const int X0 = x0 >> 3, X1 = x1 >> 3, Y0 = y0 >> 3, Y1 = y1 >> 3, Z0 = z0 >> 3, Z1 = z1 >> 3;
                 const int nX = X1 - X0 + 1, nY = Y1 - Y0 + 1, ncc = nX * nY * (Z1 - Z0 + 1);
                 for (int base = 0; base < ncc; base += 64) {
                     const int t = base + lane;
-                    int X = 0, Y = 0, Z = 0;
-                    bool cand = false;
+                    int a = 0, b = 0;
                     if (t < ncc) {
-                        X = X0 + t % nX; Y = Y0 + (t / nX) % nY; Z = Z0 + t / (nX * nY);
-                        if (g.coarse_cnt[((int64_t)Z * g.NY + Y) * g.NX + X] > 0)
-                            cand = box_lb2(c, 8.f * X, 8.f * X + 8.f, 8.f * Y, 8.f * Y + 8.f, 8.f * Z, 8.f * Z + 8.f) <= lim;
+                        const int X = X0 + t % nX, Y = Y0 + (t / nX) % nY, Z = Z0 + t / (nX * nY);
+                        const int64_t C = grid_coarse(g.NX, g.NY, X, Y, Z);
+                        if (g.coarse_cnt[C] > 0 &&
+                            box_lb2(c, 8.f * X, 8.f * X + 8.f, 8.f * Y, 8.f * Y + 8.f, 8.f * Z, 8.f * Z + 8.f) <= lim) {
+                            a = cs[C * 512]; b = cs[(C + 1) * 512];
+                        }
                     }
-                    unsigned long long cmask = __ballot(cand);
+                    unsigned long long cmask = __ballot(b > a);
                     while (cmask) {
                         const int l = __ffsll((long long)cmask) - 1;
                         cmask &= cmask - 1;
-                        const int Xc = rl_i(X, l), Yc = rl_i(Y, l), Zc = rl_i(Z, l);
-                        const int y = 8 * Yc + (lane & 7), z = 8 * Zc + (lane >> 3);
-                        const int xa = max(8 * Xc, x0), xb = min(8 * Xc + 7, x1);
-                        int a = 0, b = 0;
-                        if (y >= y0 && y <= y1 && z >= z0 && z <= z1 && xa <= xb) {
-                            const float ey = axis_gap(c.fy, (float)y, (float)y + 1.f), ez = axis_gap(c.fz, (float)z, (float)z + 1.f);
-                            if (ey * ey + ez * ez <= lim) {
-                                const int64_t rb = ((int64_t)z * g.ny + y) * g.nx;
-                                a = cs[rb + xa]; b = cs[rb + xb + 1];
-                            }
-                        }
-                        unsigned long long rmask = __ballot(b > a);
-                        while (rmask) {
-                            const int lr = __ffsll((long long)rmask) - 1;
-                            rmask &= rmask - 1;
-                            scan(rl_i(a, lr), rl_i(b, lr));
-                        }
+                        scan(rl_i(a, l), rl_i(b, l));
                     }
                 }
             }

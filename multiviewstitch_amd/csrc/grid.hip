@@ -41,7 +41,7 @@ __global__ void k_cell_count(const double* __restrict__ pts, int64_t P, GridGeom
                              int32_t* __restrict__ cell_of_pt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    const int c = grid_cell(g, (float)pts[3 * i], (float)pts[3 * i + 1], (float)pts[3 * i + 2]);
+    const int c = (int)grid_cell(g, (float)pts[3 * i], (float)pts[3 * i + 1], (float)pts[3 * i + 2]);
     if (cell_of_pt) cell_of_pt[i] = c;
     atomicAdd(&counts[c], 1);
 }
@@ -114,20 +114,10 @@ __global__ void k_scatter(const double* __restrict__ pts, const double* __restri
     tnrm[3 * d] = nrm[3 * i]; tnrm[3 * d + 1] = nrm[3 * i + 1]; tnrm[3 * d + 2] = nrm[3 * i + 2];
 }
 
-// points per coarse cell (8x8x8 fine cells): sum over its 64 (y,z) rows of the x-run lengths
-__global__ void k_coarse_count(const int32_t* __restrict__ cs, int nx, int ny, int nz, int NX, int NY, int NZ,
-                               int32_t* __restrict__ cnt) {
+// points per coarse cell: a coarse cell is one contiguous run of 512 tiled fine cells
+__global__ void k_coarse_count(const int32_t* __restrict__ cs, int64_t ncoarse, int32_t* __restrict__ cnt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)NX * NY * NZ) return;
-    const int X = (int)(i % NX), Y = (int)((i / NX) % NY), Z = (int)(i / ((int64_t)NX * NY));
-    const int xa = 8 * X, xb = min(8 * X + 8, nx);
-    int s = 0;
-    for (int z = 8 * Z; z < min(8 * Z + 8, nz); ++z)
-        for (int y = 8 * Y; y < min(8 * Y + 8, ny); ++y) {
-            const int64_t rb = ((int64_t)z * ny + y) * nx;
-            s += cs[rb + xb] - cs[rb + xa];
-        }
-    cnt[i] = s;
+    if (i < ncoarse) cnt[i] = cs[(i + 1) * 512] - cs[i * 512];
 }
 
 }  // namespace
@@ -154,6 +144,7 @@ GridGeom make_geom(const float mn[3], const float mx[3], float h) {
     g.nx = std::max(1, (int)std::floor((mx[0] - mn[0]) * g.inv_h) + 1);
     g.ny = std::max(1, (int)std::floor((mx[1] - mn[1]) * g.inv_h) + 1);
     g.nz = std::max(1, (int)std::floor((mx[2] - mn[2]) * g.inv_h) + 1);
+    g.NX = (g.nx + 7) / 8; g.NY = (g.ny + 7) / 8; g.NZ = (g.nz + 7) / 8;
     return g;
 }
 
@@ -196,7 +187,7 @@ int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* 
     GridGeom g = make_geom(mn, mx, hh);
     int32_t* d_counts = nullptr;
     for (int pass = 0; pass < 2; ++pass) {
-        const int64_t ncells = (int64_t)g.nx * g.ny * g.nz;
+        const int64_t ncells = (int64_t)g.NX * g.NY * g.NZ * 512;       // tiled order: padded to whole coarse cells
         HIPCHK(hipMalloc(&d_counts, sizeof(int32_t) * (ncells + 1)));
         HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (ncells + 1), s));
         if (pass == 1) break;
@@ -215,10 +206,10 @@ int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* 
         hn = std::max(hn, ext / 1024.f);
         hn = std::min(hn, ext / 4.f);
         g = make_geom(mn, mx, hn);
-        while ((int64_t)g.nx * g.ny * g.nz > MAX_CELLS) { hn *= 1.26f; g = make_geom(mn, mx, hn); }
+        while ((int64_t)g.NX * g.NY * g.NZ * 512 > MAX_CELLS) { hn *= 1.26f; g = make_geom(mn, mx, hn); }
         hh = hn;
     }
-    const int64_t ncells = (int64_t)g.nx * g.ny * g.nz;
+    const int64_t ncells = (int64_t)g.NX * g.NY * g.NZ * 512;
 
     // 3. histogram, scan, scatter
     int32_t* d_cell_of = nullptr;
@@ -241,11 +232,10 @@ int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* 
     h->grid.nx = g.nx; h->grid.ny = g.ny; h->grid.nz = g.nz;
     h->grid.spos = h->d_spos; h->grid.tpos = h->d_tpos; h->grid.tnrm = h->d_tnrm;
     h->grid.cell_start = h->d_cell_start;
-    h->grid.NX = (g.nx + 7) / 8; h->grid.NY = (g.ny + 7) / 8; h->grid.NZ = (g.nz + 7) / 8;
-    const int64_t ncoarse = (int64_t)h->grid.NX * h->grid.NY * h->grid.NZ;
+    h->grid.NX = g.NX; h->grid.NY = g.NY; h->grid.NZ = g.NZ;
+    const int64_t ncoarse = (int64_t)g.NX * g.NY * g.NZ;
     HIPCHK(hipMalloc(&h->d_coarse_cnt, sizeof(int32_t) * ncoarse));
-    k_coarse_count<<<dim3((unsigned)((ncoarse + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(h->d_cell_start, g.nx, g.ny, g.nz, h->grid.NX,
-                                                                                   h->grid.NY, h->grid.NZ, h->d_coarse_cnt);
+    k_coarse_count<<<dim3((unsigned)((ncoarse + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(h->d_cell_start, ncoarse, h->d_coarse_cnt);
     HIPCHK(hipStreamSynchronize(s));
     h->grid.coarse_cnt = h->d_coarse_cnt;
     h->has_target = true;

@@ -1,0 +1,102 @@
+"""World-size-2 run (gloo, CPU) of the view-sharded outer iteration protocol
+(multiviewstitch_amd/dist.py): all-reduce(MIN) of d2min, all-gather of the per-rank best-8
+records, identical merge on every rank.  The shard behind the protocol is a CHECKER shard
+built on the oracle (the product shard needs a GPU); the exchange code under test is the one
+bench.py runs over RCCL."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class OracleShard:
+    """Shard protocol (dist.py) on top of oracle/ — CPU tensors, gloo."""
+
+    def __init__(self, O, g, lo, hi):
+        self.O, self.p = O, O.Params.default()
+        self.nodes = g["nodes"]
+        self.pts, self.nrm, self.faces = g["verts"].copy(), g["normals"], g["faces"]
+        self.tgt = O.Target(g["tp"][lo:hi], g["tn"][lo:hi], lo)
+        self.result = None
+
+    def buffers(self, K, world):
+        return dict(d2min=torch.empty(K, dtype=torch.float32), rec=torch.empty(K * 8 * 48, dtype=torch.uint8),
+                    cnt=torch.empty(K * 2, dtype=torch.int32), rec_all=torch.empty(world * K * 8 * 48, dtype=torch.uint8),
+                    cnt_all=torch.empty(world * K * 2, dtype=torch.int32))
+
+    def dmin(self, b):
+        b["d2min"].copy_(torch.from_numpy(self.tgt.dmin(self.pts[self.nodes])))
+
+    def select(self, b):
+        rec, cnt = self.tgt.select(self.pts[self.nodes], self.nrm[self.nodes], self.p, b["d2min"].numpy())
+        b["rec"].copy_(torch.from_numpy(rec.view(np.uint8).reshape(-1)))
+        b["cnt"].copy_(torch.from_numpy(cnt.reshape(-1)))
+
+    def merge(self, b, world):
+        K = len(self.nodes)
+        rec = b["rec_all"].numpy().view(self.O.CAND_DTYPE).reshape(world, K, 8)
+        self.merged = self.O.assoc_merge(self.pts[self.nodes], self.nrm[self.nodes], self.p, rec, b["cnt_all"].numpy().reshape(world, K, 2))
+
+    def solve(self):
+        O = self.O
+        npts = self.pts[self.nodes]
+        ctrl = O.smooth(npts, self.merged["controls"], O.knn_points(npts, 9), 2)
+        r = O.arap(self.pts, self.faces, self.nodes, ctrl, 5, 1e-4)
+        self.pts = r["pts"]
+        return r
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import binding as O
+    from multiviewstitch_amd import dist as mdist
+    g = np.load(os.path.join(GOLD, "deform_cfg0.npz"))
+    P = len(g["tp"])
+    # uneven split, one rank may even be empty of useful points
+    cuts = [0, P // 3, P]
+    offs, counts = mdist.exclusive_offsets(cuts[rank + 1] - cuts[rank], world, torch.device("cpu"))
+    assert offs[rank] == cuts[rank] and counts.sum() == P
+    shard = OracleShard(O, g, cuts[rank], cuts[rank + 1])
+    bufs = shard.buffers(len(g["nodes"]), world)
+    for _ in range(2):
+        mdist.sharded_step(shard, bufs, world)
+    q.put((rank, shard.pts, shard.merged["valid"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_step_world2_matches_single_rank():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, pts, valid = q.get(timeout=120)
+        res[r] = (pts, valid)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g = np.load(os.path.join(GOLD, "deform_cfg0.npz"))
+    # every rank ends with the same mesh, and it is the unsharded answer (fixture: 2 outer iterations)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.sqrt(np.mean(np.sum((res[0][0] - g["it2_pts"]) ** 2, axis=1))) < 1e-9
+
+
+def test_view_shards_cover_every_view_once():
+    from multiviewstitch_amd import dist as mdist
+    for n, w in ((8, 1), (8, 2), (8, 4), (8, 8), (16, 8), (4, 8), (5, 3)):
+        sh = mdist.view_shards(n, w)
+        assert len(sh) == w and sorted(v for s in sh for v in s) == list(range(n))
+        assert max(len(s) for s in sh) - min(len(s) for s in sh) <= 1
