@@ -182,10 +182,12 @@ void mvs_deform_default_params(mvs_deform_params* p);
 typedef struct mvs_deform_stats {
     int32_t outer_done;
     int32_t arap_iters_run;   /* of the last outer iteration           */
-    int32_t cg_iters;         /* per global solve (fixed per handle)   */
+    int32_t cg_iters;         /* largest per-solve CG launch count      */
     int32_t n_valid;          /* nodes with isValid (Deformation.cpp:355) */
     double  energy[8];        /* ARAP energy after each iteration      */
     double  cg_rel_residual;  /* worst over the solves of the last outer iteration */
+    int32_t cg_launches;      /* CG-iteration kernels launched in the last outer iteration   */
+    int32_t cg_active;        /* ... of which did work (the rest exited early: converged)    */
 } mvs_deform_stats;
 
 /* Deformation(points,normals,facets)  R/Deformation/Deformation.cpp:29-46.

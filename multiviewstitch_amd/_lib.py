@@ -54,7 +54,8 @@ class CParams(C.Structure):
 class CStats(C.Structure):
     """struct mvs_deform_stats."""
     _fields_ = [("outer_done", C.c_int32), ("arap_iters_run", C.c_int32), ("cg_iters", C.c_int32),
-                ("n_valid", C.c_int32), ("energy", C.c_double * 8), ("cg_rel_residual", C.c_double)]
+                ("n_valid", C.c_int32), ("energy", C.c_double * 8), ("cg_rel_residual", C.c_double),
+                ("cg_launches", C.c_int32), ("cg_active", C.c_int32)]
 
 
 CAND_DTYPE = np.dtype([("proj_dist", "<f8"), ("proj_len", "<f8"), ("pos", "<f8", (3,)), ("index", "<i8")])

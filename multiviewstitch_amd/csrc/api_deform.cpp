@@ -231,7 +231,7 @@ int harvest(mvs_deform_s* h, const mvs_deform_params& p, const CgPlan& plan, mvs
     HIPCHK(hipStreamSynchronize(h->stream));
     const int run = info[0];
     const int nb = arap_grid_blocks(h->sell);
-    int need = 0;
+    int need = 0, launches = 0, active = 0;
     double worst = 0.0;
     bool all_conv = true;
     for (int it = 0; it < run; ++it) {
@@ -255,6 +255,7 @@ int harvest(mvs_deform_s* h, const mvs_deform_params& p, const CgPlan& plan, mvs
         if (first < 0) { all_conv = false; h->cg_plan[it] = std::min(p.cg_max_iters, 2 * cg); first = cg; }
         else h->cg_plan[it] = std::min(p.cg_max_iters, first + first / 8 + 2);
         need = std::max(need, first);
+        launches += cg; active += first;
         if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] arap it %d: CG frozen at %d of %d (gamma0 %.3e bn %.3e)\n", it, first, cg, gamma_of(0, 0), S[MVS_CG_FIN + 6]);
         for (int c = 0; c < 3; ++c) {
             const double gam = gamma_of(cg, c), bn = S[MVS_CG_FIN + 6 + c];
@@ -272,6 +273,7 @@ int harvest(mvs_deform_s* h, const mvs_deform_params& p, const CgPlan& plan, mvs
     out.cg_iters = cg;
     for (int i = 0; i < 8; ++i) out.energy[i] = i < p.arap_iters ? ered[MVS_ERED_FIN + i] : 0.0;
     out.cg_rel_residual = worst;
+    out.cg_launches = launches; out.cg_active = active;
     int nv = 0;
     for (uint8_t v : valid) nv += v;
     out.n_valid = nv;

@@ -29,7 +29,8 @@ def default_params(**kw) -> L.CParams:
 
 def _stats(st: L.CStats) -> dict:
     return dict(outer_done=st.outer_done, arap_iters_run=st.arap_iters_run, cg_iters=st.cg_iters,
-                n_valid=st.n_valid, energy=np.array(st.energy[:]), cg_rel_residual=st.cg_rel_residual)
+                n_valid=st.n_valid, energy=np.array(st.energy[:]), cg_rel_residual=st.cg_rel_residual,
+                cg_launches=st.cg_launches, cg_active=st.cg_active)
 
 
 class Deformation:

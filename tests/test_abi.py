@@ -30,7 +30,7 @@ def test_struct_layouts_match_the_header():
     from multiviewstitch_amd import _lib
     assert C.sizeof(_lib.CCamera) == 4 * 8 + 9 * 8 + 3 * 8 + 2 * 4
     assert C.sizeof(_lib.CParams) == 72
-    assert C.sizeof(_lib.CStats) == 4 * 4 + 8 * 8 + 8
+    assert C.sizeof(_lib.CStats) == 4 * 4 + 8 * 8 + 8 + 2 * 4
     assert _lib.CAND_DTYPE.itemsize == 48
     from oracle import binding as O
     assert C.sizeof(O.Params) == C.sizeof(_lib.CParams) and C.sizeof(O.Camera) == C.sizeof(_lib.CCamera)
