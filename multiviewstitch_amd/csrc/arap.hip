@@ -45,6 +45,19 @@ constexpr int FIN = MVS_CG_FIN;     // offset of the reduced scalars inside a sl
 constexpr int EIT = MVS_ERED_IT;    // per ARAP iteration: e_part[NBMAX] | bn_part[3][NBMAX]
 constexpr int EFIN = MVS_ERED_FIN;  // reduced energies e_fin[8]
 
+// ---- diagnostic build only (-DMVS_STAMPS): per-wave s_memtime stamps of k_cg_iter, read back by
+// mvs_debug_stamps(); never compiled into the product library (cdna_hip_programming.md §7, in-kernel stamps)
+#ifdef MVS_STAMPS
+__device__ unsigned long long g_stamps[8192 * 8];
+#define STAMP_(k, pre) do { unsigned long long t_; asm volatile(pre "s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        if ((threadIdx.x & 63) == 0 && i == 5 && it == 0) g_stamps[(blockIdx.x * NW + (threadIdx.x >> 6)) * 8 + (k)] = t_; } while (0)
+#define STAMP(k) STAMP_(k, "")
+#define STAMPW(k) STAMP_(k, "s_waitcnt vmcnt(0)\n\t")
+#else
+#define STAMP(k)
+#define STAMPW(k)
+#endif
+
 // ------------------------------------------------------------- lane helpers --
 template <int CTRL>
 __device__ inline double dpp_d(double v) {
@@ -69,11 +82,35 @@ __device__ inline double red_rows(double v) {
 }
 __device__ inline double wave_total(double v) { return red_rows(red8(v)); }
 // fixed-order fold of nb partial sums by ONE wave (every lane gets the total)
+// (all loads are issued before the first add: a runtime-trip-count loop would serialise the memory latencies —
+//  measured with the stamps build: 7.6 K cycles of preamble per launch, scripts/cg_stamps.py)
 __device__ inline double fold_partials(const double* __restrict__ part, int nb) {
     const int lane = threadIdx.x & 63;
+    double t[NBMAX / 64];
+#pragma unroll
+    for (int u = 0; u < NBMAX / 64; ++u) { const int k = lane + 64 * u; t[u] = k < nb ? part[k] : 0.0; }
     double v = 0.0;
-    for (int k = lane; k < nb; k += 64) v += part[k];
+#pragma unroll
+    for (int u = 0; u < NBMAX / 64; ++u) v += t[u];
     return wave_total(v);
+}
+// two folds with every load of both in flight together
+__device__ inline void fold_partials2(const double* __restrict__ pa, const double* __restrict__ pb, int nb, double* a, double* b) {
+    const int lane = threadIdx.x & 63;
+    double t[NBMAX / 64], u_[NBMAX / 64];
+#pragma unroll
+    for (int u = 0; u < NBMAX / 64; ++u) { const int k = lane + 64 * u; t[u] = k < nb ? pa[k] : 0.0; u_[u] = k < nb ? pb[k] : 0.0; }
+    double va = 0.0, vb = 0.0;
+#pragma unroll
+    for (int u = 0; u < NBMAX / 64; ++u) { va += t[u]; vb += u_[u]; }
+    *a = wave_total(va); *b = wave_total(vb);
+}
+// sum over the 8 row groups of a wave of a value held by the lanes with the same (lane & 7); lanes 0..7 get the totals
+__device__ inline double sum_over_rows(double v) {
+    v += dpp_d<0x128>(v);    // row_ror:8 -> lane i += lane (i+8) mod 16 of its 16-lane row
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
 }
 
 struct RowCtx {
@@ -93,6 +130,21 @@ __device__ inline RowCtx row_ctx(const SellDev& m, int g) {
 }
 #define FOR_ROW_GROUPS(m, g) \
     for (int g = blockIdx.x * NW + (threadIdx.x >> 6); g < (m).nslices; g += gridDim.x * NW)
+
+// store this workgroup's per-component sums to part[k][blockIdx.x]: wave w passes its sums of components 0..2 in
+// lanes 0..2 (va -> part[0..2], vb -> part[3..5]); 96 threads then add the 16 waves' values with DPP row ops
+__device__ inline void block_store_partials_gd(double va, double vb, double* __restrict__ part) {
+    __shared__ double sm[6][NW];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 3) { sm[lane][w] = va; sm[3 + lane][w] = vb; }
+    __syncthreads();
+    if (threadIdx.x < 128) {                     // two full waves so the DPP steps see active lanes
+        const int c = threadIdx.x >> 4, k = threadIdx.x & 15;
+        double s = c < 6 ? sm[c][k] : 0.0;
+        s += dpp_d<0xB1>(s); s += dpp_d<0x4E>(s); s += dpp_d<0x141>(s); s += dpp_d<0x140>(s);   // 16-lane row sum
+        if (c < 6 && k == 0) part[c * NBMAX + blockIdx.x] = s;
+    }
+}
 
 // store this workgroup's NV sums (each wave holds its own in v[], every lane) to part[k][blockIdx.x]
 template <int NV>
@@ -313,11 +365,7 @@ __global__ __launch_bounds__(TPB) void k_cg_w0(SellDev m, const double* __restri
             g_acc += ri * ui; d_acc += wn * ui;
         }
     }
-    const int l = threadIdx.x & 7;
-    double v[6];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { v[c] = wave_total(l == c ? g_acc : 0.0); v[3 + c] = wave_total(l == c ? d_acc : 0.0); }
-    block_store_partials<6>(v, slot0);
+    block_store_partials_gd(sum_over_rows(g_acc), sum_over_rows(d_acc), slot0);
 }
 
 // step scalars of CG iteration i for one right-hand side (gam, del already folded)
@@ -345,18 +393,22 @@ __global__ __launch_bounds__(TPB) void k_cg_iter(SellDev m, const double* __rest
                                                  double* __restrict__ p, double* __restrict__ x) {
     __shared__ double s_ab[6];
     __shared__ int s_done;
+    STAMP(0);
     if (threadIdx.x == 3 * 64) s_done = arap_done_before(ered + EFIN, it, tol) ? 1 : 0;      // wave 3
     if (threadIdx.x < 3 * 64) {                  // waves 0..2: one right-hand side each
         const int c = threadIdx.x >> 6;
-        const double gam = fold_partials(slot_i + c * NBMAX, gridDim.x), del = fold_partials(slot_i + (3 + c) * NBMAX, gridDim.x);
-        double a, b;
-        cg_scalars(gam, del, slot0[FIN + 6 + c], slot_prev[FIN + 3 + c], slot_prev[FIN + c], i, cg_tol, &a, &b);
+        const double bn = slot0[FIN + 6 + c], gam_prev = slot_prev[FIN + 3 + c], alpha_prev = slot_prev[FIN + c];
+        double gam, del, a, b;
+        fold_partials2(slot_i + c * NBMAX, slot_i + (3 + c) * NBMAX, gridDim.x, &gam, &del);
+        cg_scalars(gam, del, bn, gam_prev, alpha_prev, i, cg_tol, &a, &b);
         if ((threadIdx.x & 63) == 0) {
             s_ab[c] = a; s_ab[3 + c] = b;
             if (blockIdx.x == 0) { slot_i[FIN + c] = a; slot_i[FIN + 3 + c] = gam; }
         }
     }
+    STAMPW(1);
     __syncthreads();
+    STAMP(2);
     if (s_done) return;
     const double al[3] = {s_ab[0], s_ab[1], s_ab[2]}, be[3] = {s_ab[3], s_ab[4], s_ab[5]};
     if (al[0] == 0.0 && al[1] == 0.0 && al[2] == 0.0) {
@@ -381,6 +433,7 @@ __global__ __launch_bounds__(TPB) void k_cg_iter(SellDev m, const double* __rest
                                   q[2] - al[2] * (q[5] + be[2] * q[8]));
                 acc = acc - c * uj;
             }
+        STAMPW(3);
         acc = mk3(red8(acc.x), red8(acc.y), red8(acc.z));
         if (r.live && r.l < 3) {
             double rn = 0.0, wn = 0.0, sn = 0.0;
@@ -403,11 +456,9 @@ __global__ __launch_bounds__(TPB) void k_cg_iter(SellDev m, const double* __rest
             o[r.l] = rn; o[3 + r.l] = wn; o[6 + r.l] = sn;
         }
     }
-    const int l = threadIdx.x & 7;
-    double v[6];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { v[c] = wave_total(l == c ? g_acc : 0.0); v[3 + c] = wave_total(l == c ? d_acc : 0.0); }
-    block_store_partials<6>(v, slot_next);
+    STAMPW(4);
+    block_store_partials_gd(sum_over_rows(g_acc), sum_over_rows(d_acc), slot_next);   // lanes 0..2 hold components x,y,z
+    STAMPW(5);
 }
 
 // ---------------------------------------------------------------- local step --
@@ -526,6 +577,12 @@ __global__ void k_vertex_normals(const double* __restrict__ pts, const int32_t* 
 }
 
 }  // namespace
+
+#ifdef MVS_STAMPS
+extern "C" int mvs_debug_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 // one 1024-thread workgroup per CU at most; every row kernel of a handle uses this same grid
 int arap_grid_blocks(const SellDev& m) { return std::max(1, std::min((m.nslices + NW - 1) / NW, NBMAX)); }
