@@ -169,8 +169,10 @@ typedef struct mvs_deform_params {
     int32_t smooth_sweeps;   /* 2       Deformation.cpp:362                               */
     int32_t arap_iters;      /* 5       Deformation.cpp:398                               */
     double  arap_tol;        /* 1e-4    Deformation.cpp:398                               */
-    double  cg_tol;          /* relative residual of the global solve (build's own; the
-                                reference factorises with SparseLU inside CGAL)          */
+    double  cg_tol;          /* 1e-8: relative residual (M^-1 norm of the rhs) at which the
+                                CG global solve stops; build's own — the reference
+                                factorises with SparseLU inside CGAL.  Measured: vertex
+                                RMS vs a direct solve ~ 0.6 * cg_tol per outer iteration  */
     int32_t cg_max_iters;    /* safety cap                                                */
     int32_t update_normals;  /* 0: keep ctor normals for every outer iteration as the
                                 reference does (Deformation.cpp:34,304); 1: recompute

@@ -55,7 +55,7 @@ void mvs_deform_default_params(mvs_deform_params* p) {
     if (!p) return;
     p->proj_len_err = 100.0; p->proj_dist_err = 100.0; p->min_cos = 0.1;
     p->max_result = 10000; p->top_k = 8; p->graph_k = 8; p->smooth_sweeps = 2;
-    p->arap_iters = 5; p->arap_tol = 1e-4; p->cg_tol = 1e-10; p->cg_max_iters = 2000;
+    p->arap_iters = 5; p->arap_tol = 1e-4; p->cg_tol = 1e-8; p->cg_max_iters = 2000;
     p->update_normals = 0;
 }
 

@@ -40,7 +40,7 @@ namespace {
 constexpr int TPB = 1024;           // row kernels: 16 waves per workgroup
 constexpr int NW = TPB / 64;
 constexpr int NBMAX = MVS_NBMAX;    // max workgroups of a row kernel (= partials per sum)
-constexpr int SLOT = MVS_CG_SLOT;   // part[6][NBMAX] (gamma, delta) | alpha[3] gamma[3] bnorm[3] pad
+constexpr int SLOT = MVS_CG_SLOT;   // part[6][NBMAX] (gamma, delta) | alpha[3] gamma[3] bnorm[3] 1/gamma[3] 1/(gamma alpha)[3] pad
 constexpr int FIN = MVS_CG_FIN;     // offset of the reduced scalars inside a slot
 constexpr int EIT = MVS_ERED_IT;    // per ARAP iteration: e_part[NBMAX] | bn_part[3][NBMAX]
 constexpr int EFIN = MVS_ERED_FIN;  // reduced energies e_fin[8]
@@ -368,21 +368,72 @@ __global__ __launch_bounds__(TPB) void k_cg_w0(SellDev m, const double* __restri
     block_store_partials_gd(sum_over_rows(g_acc), sum_over_rows(d_acc), slot0);
 }
 
-// step scalars of CG iteration i for one right-hand side (gam, del already folded)
-__device__ inline void cg_scalars(double gam, double del, double bn, double gam_prev, double alpha_prev, int i,
+// step scalars of CG iteration i for one right-hand side (gam, del already folded).  ONE division on the critical
+// path: 1/gamma_{i-1} and 1/(gamma_{i-1} alpha_{i-1}) were stored by the previous launch after its barrier.
+//   beta = gam / gam_prev,  alpha = gam / (del - beta * gam / alpha_prev)
+__device__ inline void cg_scalars(double gam, double del, double bn, double inv_gam_prev, double cinv_prev, int i,
                                   double cg_tol, double* alpha, double* beta) {
     double a = 0.0, b = 0.0;
     bool live = gam > 0.0 && gam > cg_tol * cg_tol * bn;
     if (live) {
         double denom = del;
         if (i > 0) {
-            b = gam / gam_prev;
-            denom = del - b * gam / alpha_prev;
+            b = gam * inv_gam_prev;
+            denom = del - gam * gam * cinv_prev;
         }
-        live = denom > 0.0 && denom < INFINITY && b == b;
+        live = denom > 0.0 && denom < INFINITY && b == b && b < INFINITY;
         if (live) a = gam / denom; else b = 0.0;
     }
     *alpha = a; *beta = b;
+}
+
+// one row group of a CG iteration; c0/j0 = coefficient and column of its pass-0 entry, own = the row's own operands
+struct CgOwn { double ri, wi, si, pi, xi, di; };
+__device__ inline CgOwn cg_load_own(const SellDev& m, const RowCtx& r, bool freerow, const double* __restrict__ rws_in,
+                                    const double* __restrict__ p, const double* __restrict__ x) {
+    CgOwn o = {0.0, 0.0, 0.0, 0.0, 0.0, 1.0};
+    if (freerow && r.l < 3) {
+        const double* q = rws_in + 9 * (int64_t)r.row;
+        o.ri = q[r.l]; o.wi = q[3 + r.l]; o.si = q[6 + r.l];
+        o.pi = p[3 * r.row + r.l]; o.xi = x[3 * r.row + r.l]; o.di = m.diag[r.row];
+    }
+    return o;
+}
+__device__ inline void cg_group(const SellDev& m, const RowCtx& r, bool freerow, double c0, int j0, const CgOwn& o,
+                                const double* __restrict__ coef, const double* al, const double* be,
+                                const double* __restrict__ rws_in, double* __restrict__ rws_out, double* __restrict__ p,
+                                double* __restrict__ x, double& g_acc, double& d_acc) {
+    d3 acc = mk3(0, 0, 0);
+    if (freerow)
+        for (int t = 0; t < r.passes; ++t) {
+            const double c = t == 0 ? c0 : coef[r.off + 64 * t];
+            if (c == 0.0) continue;
+            const double* q = rws_in + 9 * (int64_t)(t == 0 ? j0 : m.col[r.off + 64 * t]);
+            // u_{i+1}[j] * diag_j = r_j - alpha (w_j + beta s_j), recomputed from the previous iterate
+            const d3 uj = mk3(q[0] - al[0] * (q[3] + be[0] * q[6]), q[1] - al[1] * (q[4] + be[1] * q[7]),
+                              q[2] - al[2] * (q[5] + be[2] * q[8]));
+            acc = acc - c * uj;
+        }
+    STAMPW(3);
+    acc = mk3(red8(acc.x), red8(acc.y), red8(acc.z));
+    if (r.live && r.l < 3) {
+        double rn = 0.0, wn = 0.0, sn = 0.0;
+        if (freerow) {
+            const int c = r.l;
+            const double a_c = c == 0 ? al[0] : (c == 1 ? al[1] : al[2]), b_c = c == 0 ? be[0] : (c == 1 ? be[1] : be[2]);
+            const double mi = 1.0 / o.di;
+            const double pn = mi * o.ri + b_c * o.pi;
+            sn = o.wi + b_c * o.si;
+            p[3 * r.row + c] = pn;
+            x[3 * r.row + c] = o.xi + a_c * pn;
+            rn = o.ri - a_c * sn;
+            const double un = mi * rn;
+            wn = o.di * un + (c == 0 ? acc.x : (c == 1 ? acc.y : acc.z));
+            g_acc += rn * un; d_acc += wn * un;
+        }
+        double* out = rws_out + 9 * (int64_t)r.row;
+        out[r.l] = rn; out[3 + r.l] = wn; out[6 + r.l] = sn;
+    }
 }
 
 __global__ __launch_bounds__(TPB) void k_cg_iter(SellDev m, const double* __restrict__ coef, int it, double tol,
@@ -394,21 +445,39 @@ __global__ __launch_bounds__(TPB) void k_cg_iter(SellDev m, const double* __rest
     __shared__ double s_ab[6];
     __shared__ int s_done;
     STAMP(0);
-    if (threadIdx.x == 3 * 64) s_done = arap_done_before(ered + EFIN, it, tol) ? 1 : 0;      // wave 3
-    if (threadIdx.x < 3 * 64) {                  // waves 0..2: one right-hand side each
+    // phase A: every wave issues the loads of its first row group that do not depend on the step scalars
+    const int g0 = blockIdx.x * NW + (threadIdx.x >> 6), gstride = gridDim.x * NW;
+    const bool have0 = g0 < m.nslices;
+    RowCtx r0 = {0, 0, 0, 0, false};
+    bool free0 = false;
+    double c0 = 0.0;
+    int j0 = 0;
+    CgOwn own0 = {0.0, 0.0, 0.0, 0.0, 0.0, 1.0};
+    if (have0) {
+        r0 = row_ctx(m, g0);
+        free0 = r0.live && !m.is_ctrl[r0.row];
+        if (free0 && r0.passes > 0) { c0 = coef[r0.off]; j0 = m.col[r0.off]; }
+        own0 = cg_load_own(m, r0, free0, rws_in, p, x);
+    }
+    // phase B: waves 0..2 fold the partial dot products of one right-hand side each, wave 3 checks the stop rule
+    if (threadIdx.x == 3 * 64) s_done = arap_done_before(ered + EFIN, it, tol) ? 1 : 0;
+    double gam = 0.0, a = 0.0;
+    if (threadIdx.x < 3 * 64) {
         const int c = threadIdx.x >> 6;
-        const double bn = slot0[FIN + 6 + c], gam_prev = slot_prev[FIN + 3 + c], alpha_prev = slot_prev[FIN + c];
-        double gam, del, a, b;
+        const double bn = slot0[FIN + 6 + c], inv_gam_prev = slot_prev[FIN + 9 + c], cinv_prev = slot_prev[FIN + 12 + c];
+        double del, b;
         fold_partials2(slot_i + c * NBMAX, slot_i + (3 + c) * NBMAX, gridDim.x, &gam, &del);
-        cg_scalars(gam, del, bn, gam_prev, alpha_prev, i, cg_tol, &a, &b);
-        if ((threadIdx.x & 63) == 0) {
-            s_ab[c] = a; s_ab[3 + c] = b;
-            if (blockIdx.x == 0) { slot_i[FIN + c] = a; slot_i[FIN + 3 + c] = gam; }
-        }
+        cg_scalars(gam, del, bn, inv_gam_prev, cinv_prev, i, cg_tol, &a, &b);
+        if ((threadIdx.x & 63) == 0) { s_ab[c] = a; s_ab[3 + c] = b; }
     }
     STAMPW(1);
     __syncthreads();
     STAMP(2);
+    if (blockIdx.x == 0 && threadIdx.x < 3 * 64 && (threadIdx.x & 63) == 0) {   // off the critical path of the barrier
+        const int c = threadIdx.x >> 6;
+        slot_i[FIN + c] = a; slot_i[FIN + 3 + c] = gam;
+        slot_i[FIN + 9 + c] = 1.0 / gam; slot_i[FIN + 12 + c] = 1.0 / (gam * a);
+    }
     if (s_done) return;
     const double al[3] = {s_ab[0], s_ab[1], s_ab[2]}, be[3] = {s_ab[3], s_ab[4], s_ab[5]};
     if (al[0] == 0.0 && al[1] == 0.0 && al[2] == 0.0) {
@@ -417,44 +486,17 @@ __global__ __launch_bounds__(TPB) void k_cg_iter(SellDev m, const double* __rest
         if (threadIdx.x < 6) slot_next[threadIdx.x * NBMAX + blockIdx.x] = slot_i[threadIdx.x * NBMAX + blockIdx.x];
         return;
     }
+    // phase C
     double g_acc = 0.0, d_acc = 0.0;
-    FOR_ROW_GROUPS(m, g) {
+    if (have0) cg_group(m, r0, free0, c0, j0, own0, coef, al, be, rws_in, rws_out, p, x, g_acc, d_acc);
+    for (int g = g0 + gstride; g < m.nslices; g += gstride) {
         const RowCtx r = row_ctx(m, g);
         const bool freerow = r.live && !m.is_ctrl[r.row];
-        d3 acc = mk3(0, 0, 0);
-        if (freerow)
-            for (int t = 0; t < r.passes; ++t) {
-                const int e = r.off + 64 * t;
-                const double c = coef[e];
-                if (c == 0.0) continue;
-                const double* q = rws_in + 9 * (int64_t)m.col[e];
-                // u_{i+1}[j] * diag_j = r_j - alpha (w_j + beta s_j), recomputed from the previous iterate
-                const d3 uj = mk3(q[0] - al[0] * (q[3] + be[0] * q[6]), q[1] - al[1] * (q[4] + be[1] * q[7]),
-                                  q[2] - al[2] * (q[5] + be[2] * q[8]));
-                acc = acc - c * uj;
-            }
-        STAMPW(3);
-        acc = mk3(red8(acc.x), red8(acc.y), red8(acc.z));
-        if (r.live && r.l < 3) {
-            double rn = 0.0, wn = 0.0, sn = 0.0;
-            if (freerow) {
-                const int c = r.l;
-                const double a_c = c == 0 ? al[0] : (c == 1 ? al[1] : al[2]), b_c = c == 0 ? be[0] : (c == 1 ? be[1] : be[2]);
-                const double di = m.diag[r.row], mi = 1.0 / di;
-                const double* q = rws_in + 9 * (int64_t)r.row;
-                const double ri = q[c], wi = q[3 + c], si = q[6 + c];
-                const double pn = mi * ri + b_c * p[3 * r.row + c];
-                sn = wi + b_c * si;
-                p[3 * r.row + c] = pn;
-                x[3 * r.row + c] = x[3 * r.row + c] + a_c * pn;
-                rn = ri - a_c * sn;
-                const double un = mi * rn;
-                wn = di * un + (c == 0 ? acc.x : (c == 1 ? acc.y : acc.z));
-                g_acc += rn * un; d_acc += wn * un;
-            }
-            double* o = rws_out + 9 * (int64_t)r.row;
-            o[r.l] = rn; o[3 + r.l] = wn; o[6 + r.l] = sn;
-        }
+        double c1 = 0.0;
+        int j1 = 0;
+        if (freerow && r.passes > 0) { c1 = coef[r.off]; j1 = m.col[r.off]; }
+        const CgOwn own = cg_load_own(m, r, freerow, rws_in, p, x);
+        cg_group(m, r, freerow, c1, j1, own, coef, al, be, rws_in, rws_out, p, x, g_acc, d_acc);
     }
     STAMPW(4);
     block_store_partials_gd(sum_over_rows(g_acc), sum_over_rows(d_acc), slot_next);   // lanes 0..2 hold components x,y,z

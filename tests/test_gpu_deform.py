@@ -83,7 +83,7 @@ def test_iterate_matches_oracle(eng, oracle):
         assert st["arap_iters_run"] == so["arap_iters_run"]
         assert st["n_valid"] == so["n_valid"]
         assert np.allclose(st["energy"][:5], so["energy"][:5], rtol=1e-6, atol=1e-12)
-        assert st["cg_rel_residual"] <= 1e-9
+        assert st["cg_rel_residual"] <= 1.5 * d.params.cg_tol
         gs = d.node_targets(smoothed=True)["controls"]
         os_, _ = o.node_targets(smoothed=True)
         assert np.abs(gs - os_).max() <= 1e-11
@@ -106,6 +106,7 @@ def test_arap_matches_oracle_and_known_answers(eng, oracle):
     tg = sc.verts[nodes] @ R.T + np.array([0.1, -0.2, 0.05])
     d2 = eng.Deformation(sc.verts, sc.normals, sc.faces)
     d2.set_nodes(nodes)
+    d2.params.cg_tol = 1e-10                 # tight solve: compare with the oracle's exact global step at 1e-7
     st = d2.arap(tg)
     ref = oracle.arap(sc.verts, sc.faces, nodes, tg, 5, 1e-4)
     assert st["arap_iters_run"] == ref["iters"]

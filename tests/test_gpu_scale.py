@@ -52,7 +52,7 @@ def test_full_size_iteration_properties(big, oracle):
     verts0 = d.vertices()
     nodes = d.nodes()
     st = d.iterate(1)
-    assert st["cg_rel_residual"] <= 1e-9 and st["arap_iters_run"] >= 2
+    assert st["cg_rel_residual"] <= 1.5 * d.params.cg_tol and st["arap_iters_run"] >= 2
     e = st["energy"][:st["arap_iters_run"]]
     assert (np.diff(e) <= 1e-12 * e[0]).all()                                    # local/global ARAP is monotone
     # sampled association check against the oracle (kd-tree on the full 2 M-point set)
