@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="scene config (multiviewstitch_amd/scene.py); 3 = metric workload")
     ap.add_argument("--phases", action="store_true", help="extra instrumented pass: per-phase HIP-event times to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                                                      "the N > 1 code path with several ranks sharing one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -77,12 +79,16 @@ def main():
         log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available() or _lib.device_count() == 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    _lib.check(_lib.lib().mvs_set_device(local_rank))
+    dev_id = local_rank % torch.cuda.device_count()          # == local_rank on a full node
+    torch.cuda.set_device(dev_id)
+    device = torch.device("cuda", dev_id)
+    _lib.check(_lib.lib().mvs_set_device(dev_id))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     # ------------------------------------------------------------------ inputs ----
     t0 = time.time()
@@ -91,7 +97,7 @@ def main():
     my_views = shards[rank]
     sc = scene_mod.make_scene(args.config, device=device, views=set(my_views))
     log(f"[bench r{rank}] scene config {args.config}: V={len(sc.verts)} F={len(sc.faces)} views={my_views} ({time.time()-t0:.1f}s)")
-    d = deformation.Deformation(sc.verts, sc.normals, sc.faces, device=local_rank)
+    d = deformation.Deformation(sc.verts, sc.normals, sc.faces, device=dev_id)
     t1 = time.time()
     K = d.UniformSampling(16)
     tp, tn = build_target(torch, srt_mod, scene_mod, sc, my_views, device)
@@ -110,8 +116,8 @@ def main():
 
         def run(n):
             st = None
-            for _ in range(n):
-                st = mdist.sharded_step(shard, bufs, world)
+            for k in range(n):                    # only the last step of a batch synchronises with the host
+                st = mdist.sharded_step(shard, bufs, world, sync=(k == n - 1))
             return st
     else:
         def run(n):

@@ -244,6 +244,7 @@ int mvs_deform_assoc_select(mvs_deform_t h, const mvs_deform_params* p,
 int mvs_deform_assoc_merge(mvs_deform_t h, const mvs_deform_params* p,
                            const mvs_cand* records_all_dev, const int32_t* counts_all_dev,
                            int nranks);
+/* stats == NULL (after the first, calibrating call): enqueue only, no host synchronisation. */
 int mvs_deform_solve(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stats* stats);
 int mvs_deform_sync(mvs_deform_t h);            /* wait for the handle's stream */
 void* mvs_deform_stream(mvs_deform_t h);        /* hipStream_t of the handle     */

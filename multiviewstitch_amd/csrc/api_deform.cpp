@@ -596,6 +596,8 @@ int mvs_deform_solve(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stat
     const CgPlan cg = probe_cg(h, *p);
     rc = enqueue_solve(h, *p, h->d_ctrl_raw, true, cg);
     if (rc) return rc;
+    // stats == NULL on a calibrated handle: enqueue only (no host sync); the next call with stats harvests
+    if (!stats && h->cg_iters > 0) return MVS_OK;
     return harvest(h, *p, cg, stats, nullptr);
 }
 int mvs_deform_arap(mvs_deform_t h, const mvs_deform_params* p, const double* ctrl_targets, mvs_deform_stats* stats) {

@@ -133,7 +133,11 @@ class Deformation:
         L.check(L.lib().mvs_deform_assoc_merge(self._h, C.byref(self.params), L.ptr(int(records_all_dev)),
                                                L.ptr(int(counts_all_dev)), nranks))
 
-    def solve(self) -> dict:
+    def solve(self, sync: bool = True):
+        """sync=False: enqueue only (no host synchronisation, no stats) — for back-to-back sharded steps."""
+        if not sync:
+            L.check(L.lib().mvs_deform_solve(self._h, C.byref(self.params), None))
+            return None
         st = L.CStats()
         L.check(L.lib().mvs_deform_solve(self._h, C.byref(self.params), C.byref(st)))
         return _stats(st)

@@ -54,12 +54,13 @@ class EngineShard:
     def merge(self, b, world):
         self.d.assoc_merge(b["rec_all"].data_ptr(), b["cnt_all"].data_ptr(), world)
 
-    def solve(self):
-        return self.d.solve()
+    def solve(self, sync=True):
+        return self.d.solve(sync)
 
 
-def sharded_step(shard, bufs, world: int, group=None):
-    """One outer iteration of Deformation::Deform's body over view-sharded targets."""
+def sharded_step(shard, bufs, world: int, group=None, sync: bool = True):
+    """One outer iteration of Deformation::Deform's body over view-sharded targets.
+    sync=False leaves the step enqueued (no host synchronisation, returns None)."""
     shard.dmin(bufs)
     if world > 1:
         dist.all_reduce(bufs["d2min"], op=dist.ReduceOp.MIN, group=group)
@@ -70,7 +71,7 @@ def sharded_step(shard, bufs, world: int, group=None):
         shard.merge(bufs, world)
     else:
         shard.merge(dict(bufs, rec_all=bufs["rec"], cnt_all=bufs["cnt"]), 1)
-    return shard.solve()
+    return shard.solve(sync) if not sync else shard.solve()
 
 
 def view_shards(n_views: int, world: int):

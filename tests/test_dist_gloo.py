@@ -42,7 +42,7 @@ class OracleShard:
         rec = b["rec_all"].numpy().view(self.O.CAND_DTYPE).reshape(world, K, 8)
         self.merged = self.O.assoc_merge(self.pts[self.nodes], self.nrm[self.nodes], self.p, rec, b["cnt_all"].numpy().reshape(world, K, 2))
 
-    def solve(self):
+    def solve(self, sync=True):
         O = self.O
         npts = self.pts[self.nodes]
         ctrl = O.smooth(npts, self.merged["controls"], O.knn_points(npts, 9), 2)
