@@ -124,6 +124,7 @@ void free_nodes(mvs_deform_s* h) {
     dfree(h->d_nodes); dfree(h->d_nbr); dfree(h->d_node_pts); dfree(h->d_node_nrm); dfree(h->d_ctrl_raw);
     dfree(h->d_ctrl_a); dfree(h->d_ctrl_b); dfree(h->d_valid); dfree(h->d_d2min); dfree(h->d_counts);
     dfree(h->d_records); dfree(h->d_top_idx);
+    if (h->d_knn_ws) { (void)hipFree(h->d_knn_ws); h->d_knn_ws = nullptr; }
     h->d_ctrl_final = nullptr; h->K = 0; h->nbr_k = 0; h->h_nodes.clear();
 }
 
@@ -169,7 +170,11 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
             if (rc) return rc;
             h->nbr_k = nn;
         }
-        { Tic t = tic(h, "graph"); launch_knn(h->d_node_pts, K, nn, h->d_nbr, s); toc(t, 1); }   // Deformation.cpp:359
+        {                                                                                       // Deformation.cpp:359
+            Tic t = tic(h, "graph");
+            if (h->d_knn_ws) { launch_knn_grid(h->d_node_pts, K, nn, h->d_nbr, h->d_knn_ws, s); toc(t, 5); }
+            else { launch_knn(h->d_node_pts, K, nn, h->d_nbr, s); toc(t, 1); }
+        }
         Tic t = tic(h, "smooth");
         double* bufs[2] = {h->d_ctrl_a, h->d_ctrl_b};
         for (int sw = 0; sw < p.smooth_sweeps; ++sw) {                                            // :362-381
@@ -448,6 +453,7 @@ int mvs_deform_set_nodes(mvs_deform_t h, const int32_t* vertex_idx, int64_t K) {
     TRY(dmalloc(&h->d_ctrl_raw, (size_t)K * 3)); TRY(dmalloc(&h->d_ctrl_a, (size_t)K * 3)); TRY(dmalloc(&h->d_ctrl_b, (size_t)K * 3));
     TRY(dmalloc(&h->d_valid, (size_t)K)); TRY(dmalloc(&h->d_d2min, (size_t)K)); TRY(dmalloc(&h->d_counts, (size_t)K * 2));
     TRY(dmalloc(&h->d_records, (size_t)K * 8)); TRY(dmalloc(&h->d_top_idx, (size_t)K * 8));
+    if (K >= 1024) TRY(mvs_check_hip(hipMalloc(&h->d_knn_ws, knn_grid_ws_bytes((int)K)), "hipMalloc"));   // small graphs: brute force
 #undef TRY
     HIPCHK(hipMemcpyAsync(h->d_is_ctrl, ctrl_id.data(), sizeof(int32_t) * h->V, hipMemcpyHostToDevice, h->stream));
     if (K) HIPCHK(hipMemcpyAsync(h->d_nodes, vertex_idx, sizeof(int32_t) * K, hipMemcpyHostToDevice, h->stream));
@@ -469,11 +475,14 @@ int mvs_deform_sample_nodes(mvs_deform_t h, int knn, int64_t* K) {
     int32_t* d_tab = nullptr;
     int rc = dmalloc(&d_tab, (size_t)V * knn);
     if (rc) return rc;
-    launch_knn(h->d_pts, (int)V, knn, d_tab, h->stream);
+    void* ws = nullptr;
+    if (V >= 1024 && hipMalloc(&ws, knn_grid_ws_bytes((int)V)) == hipSuccess) launch_knn_grid(h->d_pts, (int)V, knn, d_tab, ws, h->stream);
+    else launch_knn(h->d_pts, (int)V, knn, d_tab, h->stream);
     std::vector<int32_t> tab((size_t)V * knn);
     rc = mvs_check_hip(hipMemcpyAsync(tab.data(), d_tab, sizeof(int32_t) * V * knn, hipMemcpyDeviceToHost, h->stream), "download");
     if (!rc) rc = mvs_check_hip(hipStreamSynchronize(h->stream), "sync");
     (void)hipFree(d_tab);
+    if (ws) (void)hipFree(ws);
     if (rc) return rc;
     std::vector<char> removed(V, 0);
     std::vector<int32_t> samp;
@@ -669,7 +678,13 @@ int mvs_knn_points(const double* pts, int64_t n, int k, int32_t* out_idx) {
     rc = dmalloc(&d, (size_t)n * 3);
     if (!rc) rc = dmalloc(&o, (size_t)n * k);
     if (!rc) rc = mvs_check_hip(hipMemcpy(d, pts, sizeof(double) * n * 3, hipMemcpyHostToDevice), "upload");
-    if (!rc) { launch_knn(d, (int)n, k, o, nullptr); rc = mvs_check_hip(hipDeviceSynchronize(), "knn"); }
+    void* ws = nullptr;
+    if (!rc && n >= 1024) rc = mvs_check_hip(hipMalloc(&ws, knn_grid_ws_bytes((int)n)), "hipMalloc");
+    if (!rc) {
+        if (ws) launch_knn_grid(d, (int)n, k, o, ws, nullptr); else launch_knn(d, (int)n, k, o, nullptr);
+        rc = mvs_check_hip(hipDeviceSynchronize(), "knn");
+    }
+    if (ws) (void)hipFree(ws);
     if (!rc) rc = mvs_check_hip(hipMemcpy(out_idx, o, sizeof(int32_t) * n * k, hipMemcpyDeviceToHost), "download");
     (void)hipFree(d); (void)hipFree(o);
     return rc;

@@ -67,6 +67,7 @@ struct mvs_deform_s {
     // nodes
     std::vector<int32_t> h_nodes;
     int32_t *d_nodes = nullptr, *d_nbr = nullptr;
+    void *d_knn_ws = nullptr;           // workspace of the node-graph grid kNN
     int nbr_k = 0;
     double *d_node_pts = nullptr, *d_node_nrm = nullptr, *d_ctrl_raw = nullptr, *d_ctrl_a = nullptr, *d_ctrl_b = nullptr;
     double *d_ctrl_final = nullptr;   // points at d_ctrl_a or _b after smoothing
@@ -110,7 +111,9 @@ void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, c
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks,
                         double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s);
 // knn.hip
-void launch_knn(const double* pts, int n, int k, int32_t* out, hipStream_t s);
+void launch_knn(const double* pts, int n, int k, int32_t* out, hipStream_t s);                 // brute force, LDS tiles
+size_t knn_grid_ws_bytes(int n);
+void launch_knn_grid(const double* pts, int n, int k, int32_t* out, void* ws, hipStream_t s);  // 1 memset + 5 launches
 // arap.hip
 void launch_gather_nodes(const double* pts, const double* nrm, const int32_t* nodes, int K,
                          double* node_pts, double* node_nrm, hipStream_t s);

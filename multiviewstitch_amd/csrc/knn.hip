@@ -72,3 +72,202 @@ void launch_knn(const double* pts, int n, int k, int32_t* out, hipStream_t s) {
     if (n <= 0) return;
     k_knn<<<dim3((n + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, s>>>(pts, n, k, out);
 }
+
+// ===================================================================================================
+// Grid variant: same results, ~n*k work instead of n^2.  A small x-fastest uniform grid (<= NC^3 cells) is rebuilt
+// on the device for the current points (no host synchronisation: the geometry lives in device memory), then one
+// wave per query walks cubic shells of cells until its k-th best is inside the searched radius.
+// ===================================================================================================
+namespace {
+
+struct NgGeom { float minx, miny, minz, h, inv_h; int nx, ny, nz; };
+
+__global__ __launch_bounds__(1024) void k_ng_bbox(const double* __restrict__ pts, int n, int NC, NgGeom* __restrict__ geo) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = threadIdx.x; i < n; i += 1024)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float v = (float)pts[3 * i + c]; mn[c] = fminf(mn[c], v); mx[c] = fmaxf(mx[c], v); }
+    __shared__ float sm[6][16];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float a = mn[c], b = mx[c];
+        for (int o = 32; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o, 64)); b = fmaxf(b, __shfl_xor(b, o, 64)); }
+        if ((threadIdx.x & 63) == 0) { sm[c][threadIdx.x >> 6] = a; sm[3 + c][threadIdx.x >> 6] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float lo[3], hi[3];
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = sm[c][0]; hi[c] = sm[3 + c][0];
+            for (int w = 1; w < 16; ++w) { lo[c] = fminf(lo[c], sm[c][w]); hi[c] = fmaxf(hi[c], sm[3 + c][w]); }
+            if (!(lo[c] <= hi[c])) { lo[c] = 0.f; hi[c] = 0.f; }
+        }
+        float ext = fmaxf(hi[0] - lo[0], fmaxf(hi[1] - lo[1], hi[2] - lo[2]));
+        if (!(ext > 0.f)) ext = 1.f;
+        NgGeom g;
+        g.h = ext / (float)NC * 1.0001f; g.inv_h = 1.0f / g.h;
+        g.minx = lo[0]; g.miny = lo[1]; g.minz = lo[2];
+        g.nx = min(NC, (int)floorf((hi[0] - lo[0]) * g.inv_h) + 1);
+        g.ny = min(NC, (int)floorf((hi[1] - lo[1]) * g.inv_h) + 1);
+        g.nz = min(NC, (int)floorf((hi[2] - lo[2]) * g.inv_h) + 1);
+        *geo = g;
+    }
+}
+
+__device__ inline int ng_axis(float x, float mn, float inv_h, int n) {
+    float f = floorf((x - mn) * inv_h);
+    f = fminf(fmaxf(f, 0.0f), (float)(n - 1));
+    return (int)f;
+}
+
+__global__ void k_ng_count(const double* __restrict__ pts, int n, const NgGeom* __restrict__ geo, int* __restrict__ counts,
+                           int* __restrict__ cell_of) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const NgGeom g = *geo;
+    const int cx = ng_axis((float)pts[3 * i], g.minx, g.inv_h, g.nx), cy = ng_axis((float)pts[3 * i + 1], g.miny, g.inv_h, g.ny),
+              cz = ng_axis((float)pts[3 * i + 2], g.minz, g.inv_h, g.nz);
+    const int c = (cz * g.ny + cy) * g.nx + cx;
+    cell_of[i] = c;
+    atomicAdd(&counts[c], 1);
+}
+
+// single-workgroup exclusive scan of ncell counts into start[0..ncell]; also clears the counts for reuse as cursors
+__global__ __launch_bounds__(1024) void k_ng_scan(int* __restrict__ counts, int ncell, int* __restrict__ start) {
+    const int per = (ncell + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(lo + per, ncell);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += counts[i];
+    int x = s;
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if ((int)(threadIdx.x & 63) >= o) x += y; }
+    __shared__ int sm[16];
+    if ((threadIdx.x & 63) == 63) sm[threadIdx.x >> 6] = x;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += sm[w];
+    int run = off + x - s;
+    for (int i = lo; i < hi; ++i) { start[i] = run; run += counts[i]; counts[i] = 0; }
+    if (threadIdx.x == 1023) start[ncell] = off + x;
+}
+
+__global__ void k_ng_scatter(const double* __restrict__ pts, int n, const int* __restrict__ cell_of, const int* __restrict__ start,
+                             int* __restrict__ cursor, float4* __restrict__ sorted) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = cell_of[i];
+    const int d = start[c] + atomicAdd(&cursor[c], 1);
+    sorted[d] = make_float4((float)pts[3 * i], (float)pts[3 * i + 1], (float)pts[3 * i + 2], __int_as_float(i));
+}
+
+__global__ __launch_bounds__(256) void k_ng_knn(const double* __restrict__ pts, int n, int k, const NgGeom* __restrict__ geo,
+                                                const int* __restrict__ cs, const float4* __restrict__ sorted,
+                                                int32_t* __restrict__ out) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= n) return;
+    const int lane = threadIdx.x & 63;
+    const NgGeom g = *geo;
+    const float qx = (float)pts[3 * q], qy = (float)pts[3 * q + 1], qz = (float)pts[3 * q + 2];
+    float L_d = INFINITY; int L_i = -1; int len = 0;
+    float t_d = INFINITY; int t_i = 0x7fffffff;
+    const bool finite_q = (qx - qx == 0.0f) && (qy - qy == 0.0f) && (qz - qz == 0.0f);
+    if (finite_q) {
+        const float fx = (qx - g.minx) * g.inv_h, fy = (qy - g.miny) * g.inv_h, fz = (qz - g.minz) * g.inv_h;
+        const int cx = ng_axis(qx, g.minx, g.inv_h, g.nx), cy = ng_axis(qy, g.miny, g.inv_h, g.ny), cz = ng_axis(qz, g.minz, g.inv_h, g.nz);
+        float m = fminf(fminf(fminf(fx - cx, cx + 1 - fx), fminf(fy - cy, cy + 1 - fy)), fminf(fz - cz, cz + 1 - fz));
+        m = fmaxf(m, 0.0f);
+        auto scan = [&](int A, int B) {
+            for (int cb = A; cb < B; cb += 64) {
+                const int i = cb + lane;
+                float d = INFINITY; int j = -1;
+                bool has = false;
+                if (i < B) {
+                    const float4 p = sorted[i];
+                    d = d2f(qx, qy, qz, p.x, p.y, p.z);
+                    j = __float_as_int(p.w);
+                    has = !(d != d);
+                }
+                unsigned long long pend = __ballot(has && (len < k || dl_less(d, j, t_d, t_i)));
+                while (pend) {
+                    const int src = __ffsll((long long)pend) - 1;
+                    const float c_d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), src));
+                    const int c_i = __builtin_amdgcn_readlane(j, src);
+                    const bool less = lane < len && dl_less(L_d, L_i, c_d, c_i);
+                    const int pos = __popcll(__ballot(less));
+                    const float u_d = __shfl_up(L_d, 1, 64);
+                    const int u_i = __shfl_up(L_i, 1, 64);
+                    if (lane > pos && lane <= len && lane < k) { L_d = u_d; L_i = u_i; }
+                    else if (lane == pos) { L_d = c_d; L_i = c_i; }
+                    len = min(len + 1, k);
+                    if (len == k) {
+                        t_d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L_d), k - 1));
+                        t_i = __builtin_amdgcn_readlane(L_i, k - 1);
+                    }
+                    if (lane == src) has = false;
+                    pend = __ballot(has && (len < k || dl_less(d, j, t_d, t_i)));
+                }
+            }
+        };
+        const int smax = max(g.nx, max(g.ny, g.nz));
+        for (int s = 0; s <= smax; ++s) {                    // bounded: every cell has been visited at s == smax
+            const int side = 2 * s + 1, nrows = side * side;
+            for (int base = 0; base < nrows; base += 64) {
+                int a0 = 0, b0 = 0, a1 = 0, b1 = 0;
+                const int ridx = base + lane;
+                if (ridx < nrows) {
+                    const int dy = ridx / side - s, dz = ridx % side - s;
+                    const int y = cy + dy, z = cz + dz;
+                    if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+                        const int rb = (z * g.ny + y) * g.nx;
+                        if (abs(dy) == s || abs(dz) == s) {
+                            const int x0 = max(cx - s, 0), x1 = min(cx + s, g.nx - 1);
+                            if (x0 <= x1) { a0 = cs[rb + x0]; b0 = cs[rb + x1 + 1]; }
+                        } else {
+                            if (cx - s >= 0) { a0 = cs[rb + cx - s]; b0 = cs[rb + cx - s + 1]; }
+                            if (cx + s < g.nx) { a1 = cs[rb + cx + s]; b1 = cs[rb + cx + s + 1]; }
+                        }
+                    }
+                }
+                unsigned long long mask = __ballot(b0 > a0 || b1 > a1);
+                while (mask) {
+                    const int l = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    scan(__builtin_amdgcn_readlane(a0, l), __builtin_amdgcn_readlane(b0, l));
+                    scan(__builtin_amdgcn_readlane(a1, l), __builtin_amdgcn_readlane(b1, l));
+                }
+            }
+            const float bound = ((float)s + m - 0.01f) * g.h;
+            if (len == k && bound > 0.0f && t_d <= bound * bound) break;
+        }
+    }
+    if (lane < k) out[(int64_t)q * k + lane] = lane < len ? L_i : -1;
+}
+
+}  // namespace
+
+int knn_grid_cap(int n) {                                   // cells per axis: ~1.3 surface points per occupied cell
+    int nc = (int)(sqrtf((float)n / 8.0f) + 0.5f);
+    return nc < 4 ? 4 : (nc > 128 ? 128 : nc);
+}
+size_t knn_grid_ws_bytes(int n) {
+    const size_t nc = (size_t)knn_grid_cap(n), ncell = nc * nc * nc;
+    return 64 + sizeof(int) * (ncell + 1) * 2 + sizeof(int) * (size_t)n + sizeof(float4) * (size_t)n + 64;
+}
+// ws: device workspace of knn_grid_ws_bytes(n) bytes
+void launch_knn_grid(const double* pts, int n, int k, int32_t* out, void* ws, hipStream_t s) {
+    if (n <= 0) return;
+    const int NC = knn_grid_cap(n);
+    const size_t ncell = (size_t)NC * NC * NC;
+    char* p = (char*)ws;
+    NgGeom* geo = (NgGeom*)p; p += 64;
+    int* counts = (int*)p; p += sizeof(int) * (ncell + 1);
+    int* start = (int*)p; p += sizeof(int) * (ncell + 1);
+    int* cell_of = (int*)p; p += sizeof(int) * (size_t)n;
+    p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    float4* sorted = (float4*)p;
+    (void)hipMemsetAsync(counts, 0, sizeof(int) * (ncell + 1), s);
+    k_ng_bbox<<<dim3(1), dim3(1024), 0, s>>>(pts, n, NC, geo);
+    k_ng_count<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, geo, counts, cell_of);
+    k_ng_scan<<<dim3(1), dim3(1024), 0, s>>>(counts, (int)ncell, start);
+    k_ng_scatter<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, cell_of, start, counts, sorted);
+    k_ng_knn<<<dim3((n + 3) / 4), dim3(256), 0, s>>>(pts, n, k, geo, start, sorted, out);
+}
