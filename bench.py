@@ -161,6 +161,17 @@ def main():
     n_entries = int(sum(-(-int(deg[i:i + 8].max()) // 8) * 64 for i in range(0, V, 8)))
     cg_bytes = 252 * V + 12 * n_entries
     roofline = None
+    # HBM-side traffic of the same kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
+    # separate runs, gfx950 x2 fetch correction calibrated on k_srt_apply): profiles/rNN/pmc_traffic.json
+    traffic, traffic_src = None, None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json"))):
+        try:
+            t = json.load(open(f))
+            if t.get("kernel") == "k_cg_iter" and t.get("vertices") == V:
+                traffic, traffic_src = int(t["bytes_per_active_launch"]), os.path.relpath(f, ROOT)
+        except Exception:
+            pass
     if cg_launches > 0 and cg_ms > 0:
         # launches that found all three right-hand sides converged exit after the scalar preamble and move no
         # vertex data: only the active ones count as algorithmic traffic (stats of the last step; every step
@@ -169,7 +180,8 @@ def main():
         avg_s = 1e-3 * cg_ms / cg_launches
         ach = active_frac * cg_bytes / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": "k_cg_iter", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(ach / 8000.0, 4), "traffic": None, "bytes_per_launch": cg_bytes,
+                    "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "bytes_per_launch": cg_bytes,
                     "avg_launch_us": round(1e6 * avg_s, 3), "launches": int(cg_launches), "active_fraction": round(active_frac, 3),
                     "share_of_step": round(cg_ms / (1e3 * elapsed), 3)}
 
