@@ -156,6 +156,49 @@ int mvs_srt_apply_dev(const double* pts_dev, const double* normals_dev, int64_t 
                       double s, const double* R, const double* t, int inverse,
                       double* out_pts_dev, double* out_normals_dev, void* hip_stream);
 
+/* ---------------------------------------------------- Alignment (a10-a15) -- */
+/* Template -> scan coarse alignment, class Alignment (R/Alignment/Alignment.h:21-36) and its helpers.
+ * Labels are the 16 body parts of enum PART (R/PartRecognition/PartRecognition.h:13-30), 0..31 accepted;
+ * a `mask` selects points by label (bit l = label l), labels == NULL selects every point.
+ * Conventions for what the reference leaves open (PCA axis sign, component tie-break, the erased label of
+ * LocalAlignmentCore) are listed in DESIGN.md §3. */
+
+/* PointSetUtils::SetInput + CalcPivots (R/SetUtils/PointSetUtils.cpp:3-61): barycentre, bounding box
+ * {min xyz, max xyz}, the three pivots (row i of axes = i-th pivot, largest eigenvalue first), eigenvalues. */
+int mvs_pca(const double* pts, int64_t n, const int32_t* labels, uint32_t mask,
+            double* barycentre /*3*/, double* bbox /*6*/, double* axes /*9*/, double* eigenvalues /*3*/);
+
+/* Alignment::RetainConnectRegion (Alignment.cpp:618-654): keep the largest facet-connected component,
+ * compact points / normals (may be NULL) / facets IN PLACE; V, F in/out. */
+int mvs_retain_connect_region(int64_t* V, double* pts, double* normals, int64_t* F, int32_t* faces);
+
+/* Alignment::RemoveGround (Alignment.cpp:79-233): dist_thres = ParamParser::dist_thres (R/config.txt:37);
+ * in place like the reference; ground_ray[3] out. */
+int mvs_remove_ground(int64_t* V, double* pts, double* normals, int64_t* F, int32_t* faces,
+                      double dist_thres, double* ground_ray);
+
+/* Alignment::InitAlignment (Alignment.cpp:235-314): src -> tgt similarity from PCA axes and extents. */
+int mvs_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t nt,
+                       const double* ground_ray, const double* view_ray, double* R /*9*/, double* t /*3*/, double* scale);
+
+/* PartRecognition::PartRecog (R/PartRecognition/PartRecognition.cpp:50-77): label of the nearest template vertex. */
+int mvs_part_recog(const double* tmpl_pts, const int32_t* tmpl_labels, int64_t V,
+                   const double* pts, int64_t P, int32_t* out_labels);
+
+/* Alignment::LocalAlignmentCore (Alignment.cpp:423-546) for one limb group (slabel == tlabel == label). */
+int mvs_local_alignment_core(const double* src, const int32_t* s_labels, int64_t ns,
+                             const double* tgt, const int32_t* t_labels, int64_t nt,
+                             uint32_t group_mask, int label, double* R /*9*/, double* t /*3*/, double* scale);
+
+/* Alignment::Align (Alignment.cpp:11-76; call site R/Processor/Processor.cpp:1130-1131) without its file I/O:
+ * tgt / t_normals / t_faces are trimmed in place (ground removal + largest component; nt, nf in/out),
+ * src / s_normals are moved in place, t_labels (capacity: the input *nt) receives the scan's part labels
+ * (what PartRecog returns), ground_ray[3] (optional) the detected ground direction.  s_labels are the template's
+ * part labels (the contents of ./Template/part/parts, Alignment.cpp:38-41). */
+int mvs_align(double* src, double* s_normals, int64_t ns, const int32_t* s_labels,
+              double* tgt, double* t_normals, int64_t* nt, int32_t* t_faces, int64_t* nf,
+              const double* view_ray, double dist_thres, int32_t* t_labels, double* ground_ray);
+
 /* ----------------------------------------------------- Deformation (a16-a22) */
 typedef struct mvs_deform_s* mvs_deform_t;
 

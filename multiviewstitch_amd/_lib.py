@@ -81,6 +81,13 @@ _SIGS = {
     "mvs_srt_relative": (C.c_int, [_D, _VP, _VP, _D, _VP, _VP, _VP, _VP, _VP]),
     "mvs_srt_apply": (C.c_int, [_VP, _VP, _I64, _D, _VP, _VP, _I32, _VP, _VP]),
     "mvs_srt_apply_dev": (C.c_int, [_VP, _VP, _I64, _D, _VP, _VP, _I32, _VP, _VP, _VP]),
+    "mvs_pca": (C.c_int, [_VP, _I64, _VP, _U32, _VP, _VP, _VP, _VP]),
+    "mvs_retain_connect_region": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "mvs_remove_ground": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _D, _VP]),
+    "mvs_init_alignment": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _VP]),
+    "mvs_part_recog": (C.c_int, [_VP, _VP, _I64, _VP, _I64, _VP]),
+    "mvs_local_alignment_core": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _I64, _U32, _I32, _VP, _VP, _VP]),
+    "mvs_align": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _D, _VP, _VP]),
     "mvs_deform_default_params": (None, [_VP]),
     "mvs_deform_create": (C.c_int, [_I64, _VP, _VP, _I64, _VP, _VP]),
     "mvs_deform_destroy": (C.c_int, [_VP]),

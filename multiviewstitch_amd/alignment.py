@@ -1,0 +1,99 @@
+"""Host mirror of ``class Alignment`` (R/Alignment/Alignment.h:21-36), ``PointSetUtils``
+(R/SetUtils/PointSetUtils.h) and ``PartRecognition`` (R/PartRecognition/PartRecognition.h:33-60)
+over the C-ABI (include/mvs.h, mvs_align / mvs_remove_ground / ...).  Like the reference the
+methods mutate: they return the trimmed / moved arrays instead of resizing std::vectors in place.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+# enum PART, R/PartRecognition/PartRecognition.h:13-30
+PART = {"Head": 0, "Neck": 1, "LeftUpperArm": 2, "LeftLowerArm": 3, "LeftHand": 4, "RightUpperArm": 5,
+        "RightLowerArm": 6, "RightHand": 7, "LeftThigh": 8, "LeftShank": 9, "LeftFoot": 10, "RightThigh": 11,
+        "RightShank": 12, "RightFoot": 13, "Truncus": 14, "Hip": 15}
+DIST_THRESHOLD = 0.81          # R/config.txt:37
+
+
+def load_parts(path: str, n_vertices: int) -> np.ndarray:
+    """PartRecognition::LoadParts (PartRecognition.cpp:7-48): lines ``Name=i;j;k;...`` -> label per template vertex."""
+    labels = np.zeros(n_vertices, np.int32)
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if "=" not in line:
+                continue
+            name, ids = line.split("=", 1)
+            idx = np.array([int(x) for x in ids.split(";") if x.strip()], dtype=np.int64)
+            labels[idx] = PART[name]
+    return labels
+
+
+def pca(pts, labels=None, mask: int = 0):
+    """PointSetUtils::SetInput + CalcPivots: (barycentre, bbox(2,3), axes(3,3) rows = pivots, eigenvalues)."""
+    pts = L.arr(pts, np.float64).reshape(-1, 3)
+    lab = L.arr(labels, np.int32) if labels is not None else None
+    b, bb, ax, ev = np.empty(3), np.empty(6), np.empty((3, 3)), np.empty(3)
+    L.check(L.lib().mvs_pca(L.ptr(pts), len(pts), L.ptr(lab), mask, L.ptr(b), L.ptr(bb), L.ptr(ax), L.ptr(ev)))
+    return b, bb.reshape(2, 3), ax, ev
+
+
+def part_recog(tmpl_pts, tmpl_labels, pts) -> np.ndarray:
+    """PartRecognition::PartRecog: label of the nearest template vertex for every point."""
+    t, tl = L.arr(tmpl_pts, np.float64).reshape(-1, 3), L.arr(tmpl_labels, np.int32)
+    p = L.arr(pts, np.float64).reshape(-1, 3)
+    out = np.empty(len(p), np.int32)
+    L.check(L.lib().mvs_part_recog(L.ptr(t), L.ptr(tl), len(t), L.ptr(p), len(p), L.ptr(out)))
+    return out
+
+
+class Alignment:
+    def RetainConnectRegion(self, points, normals, facets):
+        p = L.arr(points, np.float64).reshape(-1, 3).copy()
+        n = L.arr(normals, np.float64).reshape(-1, 3).copy() if normals is not None and len(normals) else None
+        f = L.arr(facets, np.int32).reshape(-1, 3).copy()
+        V, F = C.c_int64(len(p)), C.c_int64(len(f))
+        L.check(L.lib().mvs_retain_connect_region(C.byref(V), L.ptr(p), L.ptr(n), C.byref(F), L.ptr(f)))
+        return p[:V.value], (n[:V.value] if n is not None else None), f[:F.value]
+
+    def RemoveGround(self, points, normals, facets, dist_thres: float = DIST_THRESHOLD):
+        """Alignment::RemoveGround -> (groundRay, points, normals, facets)."""
+        p = L.arr(points, np.float64).reshape(-1, 3).copy()
+        n = L.arr(normals, np.float64).reshape(-1, 3).copy() if normals is not None and len(normals) else None
+        f = L.arr(facets, np.int32).reshape(-1, 3).copy()
+        V, F, gr = C.c_int64(len(p)), C.c_int64(len(f)), np.empty(3)
+        L.check(L.lib().mvs_remove_ground(C.byref(V), L.ptr(p), L.ptr(n), C.byref(F), L.ptr(f), dist_thres, L.ptr(gr)))
+        return gr, p[:V.value], (n[:V.value] if n is not None else None), f[:F.value]
+
+    def InitAlignment(self, src, tgt, groundRay, viewRay):
+        s, t = L.arr(src, np.float64).reshape(-1, 3), L.arr(tgt, np.float64).reshape(-1, 3)
+        g, v = L.arr(groundRay, np.float64), L.arr(viewRay, np.float64)
+        R, tr, sc = np.empty((3, 3)), np.empty(3), C.c_double()
+        L.check(L.lib().mvs_init_alignment(L.ptr(s), len(s), L.ptr(t), len(t), L.ptr(g), L.ptr(v), L.ptr(R), L.ptr(tr), C.byref(sc)))
+        return R, tr, sc.value
+
+    def LocalAlignmentCore(self, src, s_labels, tgt, t_labels, group_mask: int, label: int):
+        s, t = L.arr(src, np.float64).reshape(-1, 3), L.arr(tgt, np.float64).reshape(-1, 3)
+        sl, tl = L.arr(s_labels, np.int32), L.arr(t_labels, np.int32)
+        R, tr, sc = np.empty((3, 3)), np.empty(3), C.c_double()
+        L.check(L.lib().mvs_local_alignment_core(L.ptr(s), L.ptr(sl), len(s), L.ptr(t), L.ptr(tl), len(t), group_mask, label,
+                                                 L.ptr(R), L.ptr(tr), C.byref(sc)))
+        return R, tr, sc.value
+
+    def Align(self, src, s_normals, s_labels, tgt, t_normals, t_facets, viewRay, dist_thres: float = DIST_THRESHOLD):
+        """Alignment::Align (s_facets are untouched by the reference, so they are not an argument).
+        Returns dict(src, s_normals, tgt, t_normals, t_facets, t_labels, ground_ray)."""
+        s, sn = L.arr(src, np.float64).reshape(-1, 3).copy(), L.arr(s_normals, np.float64).reshape(-1, 3).copy()
+        sl = L.arr(s_labels, np.int32)
+        t, tn = L.arr(tgt, np.float64).reshape(-1, 3).copy(), L.arr(t_normals, np.float64).reshape(-1, 3).copy()
+        tf = L.arr(t_facets, np.int32).reshape(-1, 3).copy()
+        v = L.arr(viewRay, np.float64)
+        nt, nf = C.c_int64(len(t)), C.c_int64(len(tf))
+        tl, gr = np.empty(len(t), np.int32), np.empty(3)
+        L.check(L.lib().mvs_align(L.ptr(s), L.ptr(sn), len(s), L.ptr(sl), L.ptr(t), L.ptr(tn), C.byref(nt), L.ptr(tf), C.byref(nf),
+                                  L.ptr(v), dist_thres, L.ptr(tl), L.ptr(gr)))
+        return dict(src=s, s_normals=sn, tgt=t[:nt.value], t_normals=tn[:nt.value], t_facets=tf[:nf.value],
+                    t_labels=tl[:nt.value], ground_ray=gr)

@@ -1,0 +1,716 @@
+// align.hip — template -> scan coarse alignment: Alignment::Align and its pieces
+// (R/Alignment/Alignment.cpp:11-546,618-654; R/SetUtils/PointSetUtils.cpp:3-61;
+//  R/SetUtils/UnionSetUtils.cpp:4-45; R/PartRecognition/PartRecognition.cpp:50-77).
+//
+// Everything that touches a point set is a kernel over points resident in HBM: masked moment /
+// min-max / range reductions with fixed-order block partials (fp64, reproducible), stream
+// compaction by exclusive scan, connected components by min-label hooking + pointer jumping,
+// exact 1-NN label transfer through the device-built point grid of knn.hip.  The host only does
+// 3x3 algebra (symmetric eigen-decomposition, plane fit inverse, Rodrigues rotation) and the
+// control flow between stages.  Conventions for the unpinned bits are those of
+// oracle/orc_align.cpp (PCA axis sign, component tie-break, erased label).
+#include "engine.h"
+#include "dev_common.h"
+#include "geom.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+int mvs_current_device();
+void knn_grid_build(const double* pts, int n, void* ws, hipStream_t s);
+size_t knn_grid_ws_bytes(int n);
+void launch_label_nn(const double* tmpl, int V, const int32_t* tmpl_labels, void* ws, const double* pts, int64_t P,
+                     int32_t* out, hipStream_t s);
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int NBLK = 512;             // fixed grid of every reduction kernel: partials are folded in block order
+
+__device__ inline bool sel(const int32_t* __restrict__ labels, uint32_t mask, int64_t i) {
+    return !labels || ((mask >> labels[i]) & 1u);
+}
+
+// block-wide sums of NV doubles (fixed order: lanes by shuffle tree, waves in index order) -> thread 0
+template <int NV>
+__device__ inline void block_sums(double* v, double* sm /* (TPB/64) * NV */) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum_d(v[k]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sm[(threadIdx.x >> 6) * NV + k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            double s = 0.0;
+            for (int w = 0; w < TPB / 64; ++w) s += sm[w * NV + k];
+            v[k] = s;
+        }
+}
+
+// pass 1: count, sum, bbox, set of labels present.  part[b] = {cnt, sx, sy, sz, lo[3], hi[3], present}
+__global__ __launch_bounds__(TPB) void k_moments1(const double* __restrict__ pts, int64_t n, const int32_t* __restrict__ labels,
+                                                  uint32_t mask, double* __restrict__ part) {
+    double v[4] = {0, 0, 0, 0};
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    uint32_t present = 0;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)NBLK * TPB) {
+        if (!sel(labels, mask, i)) continue;
+        const d3 p = ld3(pts + 3 * i);
+        v[0] += 1.0; v[1] += p.x; v[2] += p.y; v[3] += p.z;
+        lo[0] = fmin(lo[0], p.x); lo[1] = fmin(lo[1], p.y); lo[2] = fmin(lo[2], p.z);
+        hi[0] = fmax(hi[0], p.x); hi[1] = fmax(hi[1], p.y); hi[2] = fmax(hi[2], p.z);
+        if (labels) present |= 1u << labels[i];
+    }
+    __shared__ double sm[(TPB / 64) * 4];
+    __shared__ double smm[6][TPB / 64];
+    __shared__ uint32_t spr[TPB / 64];
+    block_sums<4>(v, sm);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double a = lo[c], b = hi[c];
+        for (int o = 32; o > 0; o >>= 1) { a = fmin(a, __shfl_xor(a, o, 64)); b = fmax(b, __shfl_xor(b, o, 64)); }
+        if ((threadIdx.x & 63) == 0) { smm[c][threadIdx.x >> 6] = a; smm[3 + c][threadIdx.x >> 6] = b; }
+    }
+    for (int o = 32; o > 0; o >>= 1) present |= __shfl_xor((int)present, o, 64);
+    if ((threadIdx.x & 63) == 0) spr[threadIdx.x >> 6] = present;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* o = part + 11 * (int64_t)blockIdx.x;
+        for (int k = 0; k < 4; ++k) o[k] = v[k];
+        uint32_t pr = 0;
+        for (int w = 0; w < TPB / 64; ++w) pr |= spr[w];
+        for (int c = 0; c < 3; ++c) {
+            double a = smm[c][0], b = smm[3 + c][0];
+            for (int w = 1; w < TPB / 64; ++w) { a = fmin(a, smm[c][w]); b = fmax(b, smm[3 + c][w]); }
+            o[4 + c] = a; o[7 + c] = b;
+        }
+        o[10] = (double)pr;
+    }
+}
+
+// pass 2: centred second moments  part[b] = {xx, xy, xz, yy, yz, zz}
+__global__ __launch_bounds__(TPB) void k_moments2(const double* __restrict__ pts, int64_t n, const int32_t* __restrict__ labels,
+                                                  uint32_t mask, double bx, double by, double bz, double* __restrict__ part) {
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)NBLK * TPB) {
+        if (!sel(labels, mask, i)) continue;
+        const double x = pts[3 * i] - bx, y = pts[3 * i + 1] - by, z = pts[3 * i + 2] - bz;
+        v[0] += x * x; v[1] += x * y; v[2] += x * z; v[3] += y * y; v[4] += y * z; v[5] += z * z;
+    }
+    __shared__ double sm[(TPB / 64) * 6];
+    block_sums<6>(v, sm);
+    if (threadIdx.x == 0) for (int k = 0; k < 6; ++k) part[6 * (int64_t)blockIdx.x + k] = v[k];
+}
+
+// t = pivot . (p - c) / den ; first index of the minimum and of the maximum.  part[b] = {lo, ilo, hi, ihi}
+__global__ __launch_bounds__(TPB) void k_range(const double* __restrict__ pts, int64_t n, const int32_t* __restrict__ labels,
+                                               uint32_t mask, d3 pivot, d3 c, double den, double* __restrict__ tout,
+                                               double* __restrict__ part) {
+    double lo = INFINITY, hi = -INFINITY;
+    long long ilo = -1, ihi = -1;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)NBLK * TPB) {
+        const double t = dot3(pivot, ld3(pts + 3 * i) - c) / den;
+        if (tout) tout[i] = t;
+        if (!sel(labels, mask, i)) continue;
+        if (t < lo || (t == lo && i < ilo)) { lo = t; ilo = i; }
+        if (t > hi || (t == hi && i < ihi)) { hi = t; ihi = i; }
+    }
+    __shared__ double s_v[2][TPB];
+    __shared__ long long s_i[2][TPB];
+    s_v[0][threadIdx.x] = lo; s_i[0][threadIdx.x] = ilo; s_v[1][threadIdx.x] = hi; s_i[1][threadIdx.x] = ihi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < TPB; ++k) {
+            if (s_i[0][k] >= 0 && (ilo < 0 || s_v[0][k] < lo || (s_v[0][k] == lo && s_i[0][k] < ilo))) { lo = s_v[0][k]; ilo = s_i[0][k]; }
+            if (s_i[1][k] >= 0 && (ihi < 0 || s_v[1][k] > hi || (s_v[1][k] == hi && s_i[1][k] < ihi))) { hi = s_v[1][k]; ihi = s_i[1][k]; }
+        }
+        double* o = part + 4 * (int64_t)blockIdx.x;
+        o[0] = lo; o[1] = (double)ilo; o[2] = hi; o[3] = (double)ihi;
+    }
+}
+
+// RemoveGround helpers -----------------------------------------------------------------------------
+// max of -t over t < 0 and of t over t >= 0 (Alignment.cpp:103-113); part[b] = {m1, m2}
+__global__ __launch_bounds__(TPB) void k_rg_tmax(const double* __restrict__ t, int64_t n, double* __restrict__ part) {
+    double m1 = DBL_MIN, m2 = DBL_MIN;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)NBLK * TPB) {
+        const double v = t[i];
+        if (v < 0) m1 = fmax(m1, -v); else m2 = fmax(m2, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) { m1 = fmax(m1, __shfl_xor(m1, o, 64)); m2 = fmax(m2, __shfl_xor(m2, o, 64)); }
+    __shared__ double sm[2][TPB / 64];
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = m1; sm[1][threadIdx.x >> 6] = m2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TPB / 64; ++w) { m1 = fmax(m1, sm[0][w]); m2 = fmax(m2, sm[1][w]); }
+        part[2 * blockIdx.x] = m1; part[2 * blockIdx.x + 1] = m2;
+    }
+}
+// side[i] = 1 / 2 for candidates of the negative / positive end (:115-126), 0 otherwise; counts per block
+__global__ __launch_bounds__(TPB) void k_rg_side(const double* __restrict__ t, int64_t n, double th1, double th2,
+                                                 uint8_t* __restrict__ side, double* __restrict__ part) {
+    double v[2] = {0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)NBLK * TPB) {
+        const double x = t[i];
+        uint8_t s = 0;
+        if (x < 0) { if (-x > th1) { s = 1; v[0] += 1.0; } }
+        else if (x > th2) { s = 2; v[1] += 1.0; }
+        side[i] = s;
+    }
+    __shared__ double sm[(TPB / 64) * 2];
+    block_sums<2>(v, sm);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = v[0]; part[2 * blockIdx.x + 1] = v[1]; }
+}
+// plane-fit sums over the candidates of one side (:148-153): A (6 unique) and b (3)
+__global__ __launch_bounds__(TPB) void k_rg_plane(const double* __restrict__ pts, const uint8_t* __restrict__ side, int64_t n,
+                                                  int which, double* __restrict__ part) {
+    double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)NBLK * TPB) {
+        if (side[i] != which) continue;
+        const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        v[0] += x * x; v[1] += x * y; v[2] += x * z; v[3] += y * y; v[4] += y * z; v[5] += z * z;
+        v[6] += x; v[7] += y; v[8] += z;
+    }
+    __shared__ double sm[(TPB / 64) * 9];
+    block_sums<9>(v, sm);
+    if (threadIdx.x == 0) for (int k = 0; k < 9; ++k) part[9 * (int64_t)blockIdx.x + k] = v[k];
+}
+// |ans . p + d| of the candidates (:182-186): dist[i] (others: -1), block max
+__global__ __launch_bounds__(TPB) void k_rg_dist(const double* __restrict__ pts, const uint8_t* __restrict__ side, int64_t n,
+                                                 int which, d3 ans, double d, double* __restrict__ dist, double* __restrict__ part) {
+    double m = DBL_MIN;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)NBLK * TPB) {
+        double v = -1.0;
+        if (side[i] == which) { v = fabs(dot3(ans, ld3(pts + 3 * i)) + d); m = fmax(m, v); }
+        dist[i] = v;
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    __shared__ double sm[TPB / 64];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int w = 1; w < TPB / 64; ++w) m = fmax(m, sm[w]); part[blockIdx.x] = m; }
+}
+__global__ void k_rg_keep(const double* __restrict__ dist, int64_t n, double threshold, int32_t* __restrict__ keep) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keep[i] = (dist[i] >= 0.0 && dist[i] < threshold) ? 0 : 1;        // :191-193
+}
+
+// stream compaction ---------------------------------------------------------------------------------
+__global__ void k_compact_points(const double* __restrict__ pts, const double* __restrict__ nrm, const int32_t* __restrict__ keep,
+                                 const int32_t* __restrict__ pos, int64_t n, double* __restrict__ opts, double* __restrict__ onrm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    const int64_t o = pos[i];
+    st3(opts + 3 * o, ld3(pts + 3 * i));
+    if (nrm) st3(onrm + 3 * o, ld3(nrm + 3 * i));
+}
+__global__ void k_face_keep(const int32_t* __restrict__ faces, int64_t F, const int32_t* __restrict__ keep, int32_t* __restrict__ fkeep) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < F) fkeep[f] = (keep[faces[3 * f]] && keep[faces[3 * f + 1]] && keep[faces[3 * f + 2]]) ? 1 : 0;
+}
+__global__ void k_compact_faces(const int32_t* __restrict__ faces, int64_t F, const int32_t* __restrict__ fkeep,
+                                const int32_t* __restrict__ fpos, const int32_t* __restrict__ vpos, int32_t* __restrict__ out) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F || !fkeep[f]) return;
+    const int64_t o = fpos[f];
+    out[3 * o] = vpos[faces[3 * f]]; out[3 * o + 1] = vpos[faces[3 * f + 1]]; out[3 * o + 2] = vpos[faces[3 * f + 2]];
+}
+
+// connected components: parent[v] -> lowest vertex index of v's component ---------------------------
+__global__ void k_cc_init(int32_t* __restrict__ parent, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) parent[i] = (int32_t)i;
+}
+__device__ inline int cc_find(const int32_t* parent, int x) {
+    int p = parent[x];
+    while (p != x) { x = p; p = parent[x]; }                 // parents only ever decrease: terminates
+    return x;
+}
+__global__ void k_cc_hook(const int32_t* __restrict__ faces, int64_t F, int32_t* parent, int32_t* __restrict__ changed) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const int a = faces[3 * f];
+    for (int k = 1; k < 3; ++k) {                            // Merge(f0, f1), Merge(f0, f2)  (Alignment.cpp:623-626)
+        int ra = cc_find(parent, a), rb = cc_find(parent, faces[3 * f + k]);
+        if (ra == rb) continue;
+        if (ra > rb) { const int t = ra; ra = rb; rb = t; }
+        atomicMin(&parent[rb], ra);
+        *changed = 1;
+    }
+}
+__global__ void k_cc_compress(int32_t* parent, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) parent[i] = cc_find(parent, (int)i);
+}
+__global__ void k_cc_sizes(const int32_t* __restrict__ parent, int64_t n, int32_t* __restrict__ size) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&size[parent[i]], 1);
+}
+// largest component, ties -> lowest root: part[b] = {size, root}
+__global__ __launch_bounds__(TPB) void k_cc_best(const int32_t* __restrict__ size, int64_t n, long long* __restrict__ part) {
+    long long bs = -1, br = -1;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)NBLK * TPB) {
+        const long long s = size[i];
+        if (s > bs || (s == bs && i < br)) { bs = s; br = i; }
+    }
+    __shared__ long long sm[2][TPB];
+    sm[0][threadIdx.x] = bs; sm[1][threadIdx.x] = br;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < TPB; ++k)
+            if (sm[0][k] > bs || (sm[0][k] == bs && sm[1][k] >= 0 && sm[1][k] < br)) { bs = sm[0][k]; br = sm[1][k]; }
+        part[2 * blockIdx.x] = bs; part[2 * blockIdx.x + 1] = br;
+    }
+}
+__global__ void k_cc_keep(const int32_t* __restrict__ parent, int64_t n, int root, int32_t* __restrict__ keep) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keep[i] = parent[i] == root ? 1 : 0;
+}
+
+// masked similarity map p <- M p + t, n <- Rn n (Alignment.cpp:31-34,381-419); identity on the other points
+__global__ void k_apply_masked(double* __restrict__ pts, double* __restrict__ nrm, int64_t n, const int32_t* __restrict__ labels,
+                               uint32_t mask, const double* __restrict__ Mt /* M[9], Rn[9], t[3] */) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !sel(labels, mask, i)) return;
+    const d3 t = mk3(Mt[18], Mt[19], Mt[20]);
+    st3(pts + 3 * i, mulMv(Mt, ld3(pts + 3 * i)) + t);
+    if (nrm) st3(nrm + 3 * i, mulMv(Mt + 9, ld3(nrm + 3 * i)));
+}
+
+// ------------------------------------------------------------------------------------ host side ----
+struct Dev {                 // RAII scratch
+    void* p = nullptr;
+    int alloc(size_t b) { return mvs_check_hip(hipMalloc(&p, b ? b : 1), "hipMalloc"); }
+    ~Dev() { if (p) (void)hipFree(p); }
+    template <class T> T* as() const { return (T*)p; }
+};
+inline dim3 blocks(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, (n + TPB - 1) / TPB)); }
+inline double nrm3(const double* a) { return std::sqrt((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]); }
+inline double dotp(const double* a, const double* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+// symmetric 3x3 eigen-decomposition (cyclic Jacobi), eigenvalues ascending, eigenvectors in columns
+void eig3(const double* C, double* val, double* vec) {
+    double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    std::memcpy(A, C, sizeof A);
+    static const int PQ[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5], dia = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+        if (off == 0.0 || off <= 1e-32 * dia) break;
+        for (int k = 0; k < 3; ++k) {
+            const int p = PQ[k][0], q = PQ[k][1];
+            const double apq = A[3 * p + q];
+            if (apq == 0.0) continue;
+            const double theta = (A[3 * q + q] - A[3 * p + p]) / (2.0 * apq);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+            const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+            for (int r = 0; r < 3; ++r) { const double x = A[3 * r + p], y = A[3 * r + q]; A[3 * r + p] = c * x - s * y; A[3 * r + q] = s * x + c * y; }
+            for (int r = 0; r < 3; ++r) { const double x = A[3 * p + r], y = A[3 * q + r]; A[3 * p + r] = c * x - s * y; A[3 * q + r] = s * x + c * y; }
+            for (int r = 0; r < 3; ++r) { const double x = V[3 * r + p], y = V[3 * r + q]; V[3 * r + p] = c * x - s * y; V[3 * r + q] = s * x + c * y; }
+        }
+    }
+    int ord[3] = {0, 1, 2};
+    const double d[3] = {A[0], A[4], A[8]};
+    std::sort(ord, ord + 3, [&](int a, int b) { return d[a] < d[b] || (d[a] == d[b] && a < b); });
+    for (int j = 0; j < 3; ++j) { val[j] = d[ord[j]]; for (int r = 0; r < 3; ++r) vec[3 * r + j] = V[3 * r + ord[j]]; }
+}
+void inv3(const double* M, double* I) {
+    const double d = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+    I[0] = (M[4] * M[8] - M[5] * M[7]) / d; I[1] = (M[2] * M[7] - M[1] * M[8]) / d; I[2] = (M[1] * M[5] - M[2] * M[4]) / d;
+    I[3] = (M[5] * M[6] - M[3] * M[8]) / d; I[4] = (M[0] * M[8] - M[2] * M[6]) / d; I[5] = (M[2] * M[3] - M[0] * M[5]) / d;
+    I[6] = (M[3] * M[7] - M[4] * M[6]) / d; I[7] = (M[1] * M[6] - M[0] * M[7]) / d; I[8] = (M[0] * M[4] - M[1] * M[3]) / d;
+}
+void mm3(const double* A, const double* B, double* C) {
+    double T[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[3 * i + j] = (A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j]) + A[3 * i + 2] * B[6 + j];
+    std::memcpy(C, T, sizeof T);
+}
+void mv3(const double* M, const double* v, double* o) {
+    const double x = (M[0] * v[0] + M[1] * v[1]) + M[2] * v[2], y = (M[3] * v[0] + M[4] * v[1]) + M[5] * v[2], z = (M[6] * v[0] + M[7] * v[1]) + M[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+
+struct Pca { double bary[3], lo[3], hi[3], axis[3][3], eval[3]; double cnt; uint32_t present; };
+struct Work {                 // per-call reduction scratch (device + pinned-size host mirror)
+    Dev part;
+    std::vector<double> h;
+    int init() { h.resize((size_t)NBLK * 11); return part.alloc(sizeof(double) * NBLK * 11); }
+    int fetch(size_t n) { return mvs_check_hip(hipMemcpy(h.data(), part.p, sizeof(double) * n, hipMemcpyDeviceToHost), "memcpy"); }
+};
+
+// PointSetUtils::SetInput + CalcPivots on the selected device points
+int pca_dev(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, Work& w, Pca* out) {
+    k_moments1<<<dim3(NBLK), dim3(TPB)>>>(pts, n, labels, mask, w.part.as<double>());
+    int rc = w.fetch((size_t)NBLK * 11);
+    if (rc) return rc;
+    double cnt = 0, s[3] = {0, 0, 0};
+    uint32_t present = 0;
+    for (int c = 0; c < 3; ++c) { out->lo[c] = INFINITY; out->hi[c] = -INFINITY; }
+    for (int b = 0; b < NBLK; ++b) {
+        const double* p = &w.h[(size_t)b * 11];
+        cnt += p[0]; s[0] += p[1]; s[1] += p[2]; s[2] += p[3];
+        for (int c = 0; c < 3; ++c) { out->lo[c] = std::min(out->lo[c], p[4 + c]); out->hi[c] = std::max(out->hi[c], p[7 + c]); }
+        present |= (uint32_t)p[10];
+    }
+    out->cnt = cnt; out->present = present;
+    if (cnt < 2) { mvs_set_error("PCA needs at least 2 points (got %.0f)", cnt); return MVS_E_DEGENERATE; }
+    for (int c = 0; c < 3; ++c) out->bary[c] = s[c] / cnt;                    // PointSetUtils.cpp:43-47
+    k_moments2<<<dim3(NBLK), dim3(TPB)>>>(pts, n, labels, mask, out->bary[0], out->bary[1], out->bary[2], w.part.as<double>());
+    if ((rc = w.fetch((size_t)NBLK * 6))) return rc;
+    double m[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < NBLK; ++b) for (int k = 0; k < 6; ++k) m[k] += w.h[(size_t)b * 6 + k];
+    double C[9] = {m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5]};
+    for (int k = 0; k < 9; ++k) C[k] /= (cnt - 1.0);                          // :26
+    double val[3], vec[9];
+    eig3(C, val, vec);
+    for (int i = 0; i < 3; ++i) {                                             // :36-39, sign convention Appendix A.5
+        double a[3] = {vec[2 - i], vec[3 + 2 - i], vec[6 + 2 - i]};
+        const double len = nrm3(a);
+        for (int c = 0; c < 3; ++c) a[c] /= len;
+        const double ax = std::fabs(a[0]), ay = std::fabs(a[1]), az = std::fabs(a[2]);
+        const double big = (ax >= ay && ax >= az) ? a[0] : ((ay >= az) ? a[1] : a[2]);
+        if (big < 0) for (int c = 0; c < 3; ++c) a[c] = -a[c];
+        std::memcpy(out->axis[i], a, sizeof a);
+        out->eval[i] = val[2 - i];
+    }
+    return MVS_OK;
+}
+
+struct Range { double lo = DBL_MAX, hi = DBL_MIN; int64_t ilo = -1, ihi = -1; };
+int range_dev(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, const double* pivot, const double* c,
+              double* tout, Work& w, Range* out) {
+    const double den = nrm3(pivot) * nrm3(pivot);
+    k_range<<<dim3(NBLK), dim3(TPB)>>>(pts, n, labels, mask, mk3(pivot[0], pivot[1], pivot[2]), mk3(c[0], c[1], c[2]), den, tout,
+                                       w.part.as<double>());
+    int rc = w.fetch((size_t)NBLK * 4);
+    if (rc) return rc;
+    Range r;                                                                   // the loops start from (DBL_MAX, DBL_MIN), Alignment.cpp:281-282
+    for (int b = 0; b < NBLK; ++b) {
+        const double* p = &w.h[(size_t)b * 4];
+        const int64_t il = (int64_t)p[1], ih = (int64_t)p[3];
+        if (il >= 0 && (p[0] < r.lo || (p[0] == r.lo && r.ilo >= 0 && il < r.ilo))) { r.lo = p[0]; r.ilo = il; }
+        if (ih >= 0 && (p[2] > r.hi || (p[2] == r.hi && r.ihi >= 0 && ih < r.ihi))) { r.hi = p[2]; r.ihi = ih; }
+    }
+    *out = r;
+    return MVS_OK;
+}
+
+// keep[] (int32 0/1 on the device) -> compact points / normals / faces in place; updates n, F
+int compact_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F, const int32_t* keep /* n+1 */) {
+    Dev vpos, fkeep, fpos, tp, tn, tf;
+    int rc;
+    if ((rc = vpos.alloc(sizeof(int32_t) * (*n + 1)))) return rc;
+    if ((rc = scan_exclusive_i32(keep, *n, vpos.as<int32_t>(), nullptr))) return rc;
+    int32_t m = 0, mf = 0;
+    HIPCHK(hipMemcpy(&m, vpos.as<int32_t>() + *n, sizeof m, hipMemcpyDeviceToHost));
+    if ((rc = tp.alloc(sizeof(double) * 3 * (size_t)std::max<int64_t>(m, 1)))) return rc;
+    if (nrm && (rc = tn.alloc(sizeof(double) * 3 * (size_t)std::max<int64_t>(m, 1)))) return rc;
+    k_compact_points<<<blocks(*n), dim3(TPB)>>>(pts, nrm, keep, vpos.as<int32_t>(), *n, tp.as<double>(), tn.as<double>());
+    if (*F > 0) {
+        if ((rc = fkeep.alloc(sizeof(int32_t) * (*F + 1))) || (rc = fpos.alloc(sizeof(int32_t) * (*F + 1)))) return rc;
+        HIPCHK(hipMemset(fkeep.p, 0, sizeof(int32_t) * (*F + 1)));
+        k_face_keep<<<blocks(*F), dim3(TPB)>>>(faces, *F, keep, fkeep.as<int32_t>());
+        if ((rc = scan_exclusive_i32(fkeep.as<int32_t>(), *F, fpos.as<int32_t>(), nullptr))) return rc;
+        HIPCHK(hipMemcpy(&mf, fpos.as<int32_t>() + *F, sizeof mf, hipMemcpyDeviceToHost));
+        if ((rc = tf.alloc(sizeof(int32_t) * 3 * (size_t)std::max<int32_t>(mf, 1)))) return rc;
+        k_compact_faces<<<blocks(*F), dim3(TPB)>>>(faces, *F, fkeep.as<int32_t>(), fpos.as<int32_t>(), vpos.as<int32_t>(), tf.as<int32_t>());
+        HIPCHK(hipMemcpy(faces, tf.p, sizeof(int32_t) * 3 * (size_t)mf, hipMemcpyDeviceToDevice));
+    }
+    HIPCHK(hipMemcpy(pts, tp.p, sizeof(double) * 3 * (size_t)m, hipMemcpyDeviceToDevice));
+    if (nrm) HIPCHK(hipMemcpy(nrm, tn.p, sizeof(double) * 3 * (size_t)m, hipMemcpyDeviceToDevice));
+    *n = m; *F = mf;
+    return MVS_OK;
+}
+
+// Alignment::RetainConnectRegion on device arrays
+int retain_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F) {
+    if (*n <= 0) return MVS_OK;
+    Dev parent, size, keep, flag, part;
+    int rc;
+    if ((rc = parent.alloc(sizeof(int32_t) * *n)) || (rc = size.alloc(sizeof(int32_t) * *n)) || (rc = keep.alloc(sizeof(int32_t) * (*n + 1))) ||
+        (rc = flag.alloc(sizeof(int32_t))) || (rc = part.alloc(sizeof(long long) * 2 * NBLK))) return rc;
+    k_cc_init<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n);
+    for (int round = 0; round < 64 && *F > 0; ++round) {             // O(log) rounds in practice; bounded
+        int32_t changed = 0;
+        HIPCHK(hipMemset(flag.p, 0, sizeof(int32_t)));
+        k_cc_hook<<<blocks(*F), dim3(TPB)>>>(faces, *F, parent.as<int32_t>(), flag.as<int32_t>());
+        k_cc_compress<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n);
+        HIPCHK(hipMemcpy(&changed, flag.p, sizeof changed, hipMemcpyDeviceToHost));
+        if (!changed) break;
+    }
+    HIPCHK(hipMemset(size.p, 0, sizeof(int32_t) * *n));
+    k_cc_sizes<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n, size.as<int32_t>());
+    k_cc_best<<<dim3(NBLK), dim3(TPB)>>>(size.as<int32_t>(), *n, part.as<long long>());
+    std::vector<long long> hp(2 * NBLK);
+    HIPCHK(hipMemcpy(hp.data(), part.p, sizeof(long long) * 2 * NBLK, hipMemcpyDeviceToHost));
+    long long bs = -1, br = -1;
+    for (int b = 0; b < NBLK; ++b)
+        if (hp[2 * b + 1] >= 0 && (hp[2 * b] > bs || (hp[2 * b] == bs && hp[2 * b + 1] < br))) { bs = hp[2 * b]; br = hp[2 * b + 1]; }
+    HIPCHK(hipMemset(keep.p, 0, sizeof(int32_t) * (*n + 1)));
+    k_cc_keep<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n, (int)br, keep.as<int32_t>());
+    return compact_dev(pts, nrm, n, faces, F, keep.as<int32_t>());
+}
+
+// Alignment::RemoveGround on device arrays
+int remove_ground_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F, double dist_thres, double* ground_ray, Work& w) {
+    Pca p;
+    int rc = pca_dev(pts, *n, nullptr, 0, w, &p);
+    if (rc) return rc;
+    const double* pivot = p.axis[0];
+    Dev t, side, dist, keep;
+    if ((rc = t.alloc(sizeof(double) * *n)) || (rc = side.alloc((size_t)*n)) || (rc = dist.alloc(sizeof(double) * *n)) ||
+        (rc = keep.alloc(sizeof(int32_t) * (*n + 1)))) return rc;
+    Range rr;
+    if ((rc = range_dev(pts, *n, nullptr, 0, pivot, p.bary, t.as<double>(), w, &rr))) return rc;   // t[i], Alignment.cpp:104
+    k_rg_tmax<<<dim3(NBLK), dim3(TPB)>>>(t.as<double>(), *n, w.part.as<double>());
+    if ((rc = w.fetch((size_t)NBLK * 2))) return rc;
+    double tMax1 = DBL_MIN, tMax2 = DBL_MIN;
+    for (int b = 0; b < NBLK; ++b) { tMax1 = std::max(tMax1, w.h[2 * b]); tMax2 = std::max(tMax2, w.h[2 * b + 1]); }
+    k_rg_side<<<dim3(NBLK), dim3(TPB)>>>(t.as<double>(), *n, tMax1 * dist_thres, tMax2 * dist_thres, side.as<uint8_t>(), w.part.as<double>());
+    if ((rc = w.fetch((size_t)NBLK * 2))) return rc;
+    double c1 = 0, c2 = 0;
+    for (int b = 0; b < NBLK; ++b) { c1 += w.h[2 * b]; c2 += w.h[2 * b + 1]; }
+    const int which = c1 > c2 ? 1 : 2;                                          // :129-138
+    for (int c = 0; c < 3; ++c) ground_ray[c] = which == 1 ? -pivot[c] : pivot[c];
+    k_rg_plane<<<dim3(NBLK), dim3(TPB)>>>(pts, side.as<uint8_t>(), *n, which, w.part.as<double>());
+    if ((rc = w.fetch((size_t)NBLK * 9))) return rc;
+    double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < NBLK; ++b) for (int k = 0; k < 9; ++k) m[k] += w.h[(size_t)b * 9 + k];
+    const double A[9] = {m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5]}, bb[3] = {m[6], m[7], m[8]};
+    double Ai[9], ans[3];
+    inv3(A, Ai);
+    mv3(Ai, bb, ans);
+    for (int c = 0; c < 3; ++c) ans[c] = -ans[c];                                // :154
+    double d = 1.0 / nrm3(ans);
+    const double len = nrm3(ans);
+    for (int c = 0; c < 3; ++c) ans[c] /= len;
+    if (dotp(ans, pivot) < 0) { for (int c = 0; c < 3; ++c) ans[c] = -ans[c]; d = -d; }   // :158-161
+    k_rg_dist<<<dim3(NBLK), dim3(TPB)>>>(pts, side.as<uint8_t>(), *n, which, mk3(ans[0], ans[1], ans[2]), d, dist.as<double>(), w.part.as<double>());
+    if ((rc = w.fetch((size_t)NBLK))) return rc;
+    double maxDist = DBL_MIN;
+    for (int b = 0; b < NBLK; ++b) maxDist = std::max(maxDist, w.h[b]);
+    HIPCHK(hipMemset(keep.p, 0, sizeof(int32_t) * (*n + 1)));
+    k_rg_keep<<<blocks(*n), dim3(TPB)>>>(dist.as<double>(), *n, maxDist * 0.28, keep.as<int32_t>());   // :187-193
+    if ((rc = compact_dev(pts, nrm, n, faces, F, keep.as<int32_t>()))) return rc;                      // :196-219
+    return retain_dev(pts, nrm, n, faces, F);                                                          // :227
+}
+
+int init_alignment_dev(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray, const double* view_ray,
+                       Work& w, double* R, double* t, double* scale) {
+    Pca ps, pt;
+    int rc;
+    if ((rc = pca_dev(src, ns, nullptr, 0, w, &ps)) || (rc = pca_dev(tgt, nt, nullptr, 0, w, &pt))) return rc;
+    if (dotp(ground_ray, pt.axis[0]) < 0) for (int c = 0; c < 3; ++c) pt.axis[0][c] = -pt.axis[0][c];   // :255
+    if (dotp(view_ray, pt.axis[2]) < 0) for (int c = 0; c < 3; ++c) pt.axis[2][c] = -pt.axis[2][c];     // :256
+    Range r1, r2;
+    if ((rc = range_dev(src, ns, nullptr, 0, ps.axis[0], ps.bary, nullptr, w, &r1)) ||
+        (rc = range_dev(tgt, nt, nullptr, 0, pt.axis[0], pt.bary, nullptr, w, &r2))) return rc;
+    *scale = (r2.hi - r2.lo) / (r1.hi - r1.lo);                                  // :297
+    double S[9], T[9], Si[9];
+    for (int i = 0; i < 3; ++i) for (int r = 0; r < 3; ++r) { S[3 * r + i] = ps.axis[i][r]; T[3 * r + i] = pt.axis[i][r]; }   // pivots as columns
+    inv3(S, Si);
+    mm3(T, Si, R);                                                               // :299
+    double sR[9], rb[3];
+    for (int k = 0; k < 9; ++k) sR[k] = *scale * R[k];
+    mv3(sR, ps.bary, rb);
+    const double f = r2.hi - r1.hi * *scale;
+    for (int c = 0; c < 3; ++c) t[c] = (f * pt.axis[0][c] + pt.bary[c]) - rb[c];  // :300
+    return MVS_OK;
+}
+
+void rotation_between(const double* before, const double* after, double* R) {    // Utils.h:124-149
+    double b[3], a[3];
+    const double lb = nrm3(before), la = nrm3(after);
+    for (int c = 0; c < 3; ++c) { b[c] = before[c] / lb; a[c] = after[c] / la; }
+    const double angle = std::acos(dotp(b, a));
+    double u[3] = {b[1] * a[2] - b[2] * a[1], b[2] * a[0] - b[0] * a[2], b[0] * a[1] - b[1] * a[0]};
+    const double lu = nrm3(u);
+    for (int c = 0; c < 3; ++c) u[c] /= lu;
+    const double c = std::cos(angle), s = std::sin(angle);
+    R[0] = c + u[0] * u[0] * (1 - c);         R[1] = u[0] * u[1] * (1 - c) - u[2] * s;  R[2] = u[1] * s + u[0] * u[2] * (1 - c);
+    R[3] = u[2] * s + u[0] * u[1] * (1 - c);  R[4] = c + u[1] * u[1] * (1 - c);         R[5] = -u[0] * s + u[1] * u[2] * (1 - c);
+    R[6] = -u[1] * s + u[0] * u[2] * (1 - c); R[7] = u[0] * s + u[1] * u[2] * (1 - c);  R[8] = c + u[2] * u[2] * (1 - c);
+}
+
+int local_core_dev(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels, int64_t nt,
+                   uint32_t group, int label, Work& w, double* R, double* t, double* scale) {
+    Pca ps, pt;
+    int rc;
+    if ((rc = pca_dev(src, ns, s_labels, group, w, &ps)) || (rc = pca_dev(tgt, nt, t_labels, group, w, &pt))) return rc;
+    if (dotp(ps.axis[0], pt.axis[0]) < 0) for (int c = 0; c < 3; ++c) pt.axis[0][c] = -pt.axis[0][c];   // :444-446
+    uint32_t sset = ps.present & group, tset = pt.present & group;
+    auto popc = [](uint32_t x) { int c = 0; while (x) { c += x & 1; x >>= 1; } return c; };
+    if (popc(sset) < popc(tset)) { const uint32_t e = tset & ~sset; tset &= ~(e & (~e + 1u)); }          // :479-488
+    else if (popc(sset) > popc(tset)) { const uint32_t e = sset & ~tset; sset &= ~(e & (~e + 1u)); }     // :489-498
+    Range r1, r2;
+    if ((rc = range_dev(src, ns, s_labels, sset, ps.axis[0], ps.bary, nullptr, w, &r1)) ||
+        (rc = range_dev(tgt, nt, t_labels, tset, pt.axis[0], pt.bary, nullptr, w, &r2))) return rc;
+    if (r1.ilo < 0 || r1.ihi < 0 || r2.ilo < 0 || r2.ihi < 0) { mvs_set_error("limb group 0x%x has no extent", group); return MVS_E_DEGENERATE; }
+    int32_t lab1 = 0, lab2 = 0;
+    double far[3];
+    HIPCHK(hipMemcpy(&lab1, s_labels + r1.ihi, sizeof lab1, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&lab2, t_labels + r2.ihi, sizeof lab2, hipMemcpyDeviceToHost));
+    if (lab1 != label) { std::swap(r1.lo, r1.hi); std::swap(r1.ilo, r1.ihi); }                          // :513-517
+    if (lab2 != label) { std::swap(r2.lo, r2.hi); std::swap(r2.ilo, r2.ihi); }                          // :525-528
+    *scale = (r2.hi - r2.lo) / (r1.hi - r1.lo);                                                         // :529
+    rotation_between(ps.axis[0], pt.axis[0], R);                                                        // :532
+    HIPCHK(hipMemcpy(far, src + 3 * r1.ilo, sizeof far, hipMemcpyDeviceToHost));                        // src_[fidx1] + baryCenter1
+    double sR[9], rf[3];
+    for (int k = 0; k < 9; ++k) sR[k] = *scale * R[k];
+    mv3(sR, far, rf);
+    for (int c = 0; c < 3; ++c) t[c] = far[c] - rf[c];                                                  // :535
+    return MVS_OK;
+}
+
+int apply_masked_dev(double* pts, double* nrm, int64_t n, const int32_t* labels, uint32_t mask, const double* M, const double* Rn, const double* t) {
+    double h[21];
+    std::memcpy(h, M, 72); std::memcpy(h + 9, Rn, 72); std::memcpy(h + 18, t, 24);
+    Dev d;
+    int rc = d.alloc(sizeof h);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(d.p, h, sizeof h, hipMemcpyHostToDevice));
+    k_apply_masked<<<blocks(n), dim3(TPB)>>>(pts, nrm, n, labels, mask, d.as<double>());
+    return mvs_check_hip(hipDeviceSynchronize(), "apply_masked");
+}
+
+int part_recog_dev(const double* tmpl, const int32_t* tmpl_labels, int64_t V, const double* pts, int64_t P, int32_t* out) {
+    Dev ws;
+    int rc = ws.alloc(knn_grid_ws_bytes((int)V));
+    if (rc) return rc;
+    knn_grid_build(tmpl, (int)V, ws.p, nullptr);
+    launch_label_nn(tmpl, (int)V, tmpl_labels, ws.p, pts, P, out, nullptr);
+    return mvs_check_hip(hipDeviceSynchronize(), "part_recog");
+}
+
+int need_device() {
+    if (mvs_device_count() == 0) { mvs_set_error("no HIP device: the MI355X engine has no CPU fallback"); return MVS_E_NO_DEVICE; }
+    return mvs_check_hip(hipSetDevice(mvs_current_device()), "hipSetDevice");
+}
+template <class T> int up(Dev& d, const T* h, size_t n, size_t cap = 0) {
+    int rc = d.alloc(sizeof(T) * std::max(n, cap));
+    if (rc || !n) return rc;
+    return mvs_check_hip(hipMemcpy(d.p, h, sizeof(T) * n, hipMemcpyHostToDevice), "upload");
+}
+template <class T> int down(T* h, const Dev& d, size_t n) {
+    return n ? mvs_check_hip(hipMemcpy(h, d.p, sizeof(T) * n, hipMemcpyDeviceToHost), "download") : MVS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvs_pca(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, double* bary, double* bbox, double* axes, double* evals) {
+    if (!pts || n < 2 || !bary || !bbox || !axes || !evals) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    Dev dp, dl; Work w; Pca p;
+    if ((rc = up(dp, pts, (size_t)n * 3)) || (labels && (rc = up(dl, labels, (size_t)n))) || (rc = w.init())) return rc;
+    if ((rc = pca_dev(dp.as<double>(), n, labels ? dl.as<int32_t>() : nullptr, mask, w, &p))) return rc;
+    std::memcpy(bary, p.bary, 24); std::memcpy(bbox, p.lo, 24); std::memcpy(bbox + 3, p.hi, 24);
+    for (int i = 0; i < 3; ++i) { std::memcpy(axes + 3 * i, p.axis[i], 24); evals[i] = p.eval[i]; }
+    return MVS_OK;
+}
+
+int mvs_retain_connect_region(int64_t* V, double* pts, double* normals, int64_t* F, int32_t* faces) {
+    if (!V || !F || !pts || *V < 0 || *F < 0 || (*F > 0 && !faces)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    Dev dp, dn, df;
+    if ((rc = up(dp, pts, (size_t)*V * 3)) || (normals && (rc = up(dn, normals, (size_t)*V * 3))) || (rc = up(df, faces, (size_t)*F * 3))) return rc;
+    int64_t n = *V, f = *F;
+    if ((rc = retain_dev(dp.as<double>(), normals ? dn.as<double>() : nullptr, &n, df.as<int32_t>(), &f))) return rc;
+    if ((rc = down(pts, dp, (size_t)n * 3)) || (normals && (rc = down(normals, dn, (size_t)n * 3))) || (rc = down(faces, df, (size_t)f * 3))) return rc;
+    *V = n; *F = f;
+    return MVS_OK;
+}
+
+int mvs_remove_ground(int64_t* V, double* pts, double* normals, int64_t* F, int32_t* faces, double dist_thres, double* ground_ray) {
+    if (!V || !F || !pts || !ground_ray || *V < 2 || *F < 0 || (*F > 0 && !faces)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    Dev dp, dn, df; Work w;
+    if ((rc = up(dp, pts, (size_t)*V * 3)) || (normals && (rc = up(dn, normals, (size_t)*V * 3))) || (rc = up(df, faces, (size_t)*F * 3)) || (rc = w.init())) return rc;
+    int64_t n = *V, f = *F;
+    if ((rc = remove_ground_dev(dp.as<double>(), normals ? dn.as<double>() : nullptr, &n, df.as<int32_t>(), &f, dist_thres, ground_ray, w))) return rc;
+    if ((rc = down(pts, dp, (size_t)n * 3)) || (normals && (rc = down(normals, dn, (size_t)n * 3))) || (rc = down(faces, df, (size_t)f * 3))) return rc;
+    *V = n; *F = f;
+    return MVS_OK;
+}
+
+int mvs_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray, const double* view_ray,
+                       double* R, double* t, double* scale) {
+    if (!src || !tgt || ns < 2 || nt < 2 || !ground_ray || !view_ray || !R || !t || !scale) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    Dev ds, dt; Work w;
+    if ((rc = up(ds, src, (size_t)ns * 3)) || (rc = up(dt, tgt, (size_t)nt * 3)) || (rc = w.init())) return rc;
+    return init_alignment_dev(ds.as<double>(), ns, dt.as<double>(), nt, ground_ray, view_ray, w, R, t, scale);
+}
+
+int mvs_part_recog(const double* tmpl_pts, const int32_t* tmpl_labels, int64_t V, const double* pts, int64_t P, int32_t* out_labels) {
+    if (!tmpl_pts || !tmpl_labels || V < 1 || P < 0 || (P > 0 && (!pts || !out_labels)) || V > 0x7ffffff0LL) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    if (P == 0) return MVS_OK;
+    Dev dt, dl, dp, dout;
+    if ((rc = up(dt, tmpl_pts, (size_t)V * 3)) || (rc = up(dl, tmpl_labels, (size_t)V)) || (rc = up(dp, pts, (size_t)P * 3)) || (rc = dout.alloc(sizeof(int32_t) * P))) return rc;
+    if ((rc = part_recog_dev(dt.as<double>(), dl.as<int32_t>(), V, dp.as<double>(), P, dout.as<int32_t>()))) return rc;
+    return down(out_labels, dout, (size_t)P);
+}
+
+int mvs_local_alignment_core(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels, int64_t nt,
+                             uint32_t group_mask, int label, double* R, double* t, double* scale) {
+    if (!src || !tgt || !s_labels || !t_labels || ns < 2 || nt < 2 || !R || !t || !scale) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    Dev ds, dsl, dt, dtl; Work w;
+    if ((rc = up(ds, src, (size_t)ns * 3)) || (rc = up(dsl, s_labels, (size_t)ns)) || (rc = up(dt, tgt, (size_t)nt * 3)) || (rc = up(dtl, t_labels, (size_t)nt)) || (rc = w.init())) return rc;
+    return local_core_dev(ds.as<double>(), dsl.as<int32_t>(), ns, dt.as<double>(), dtl.as<int32_t>(), nt, group_mask, label, w, R, t, scale);
+}
+
+int mvs_align(double* src, double* s_normals, int64_t ns, const int32_t* s_labels, double* tgt, double* t_normals, int64_t* nt,
+              int32_t* t_faces, int64_t* nf, const double* view_ray, double dist_thres, int32_t* t_labels, double* ground_ray) {
+    if (!src || !s_normals || !s_labels || !tgt || !t_normals || !nt || !nf || !view_ray || !t_labels || ns < 2 || *nt < 2 || *nf < 0 ||
+        (*nf > 0 && !t_faces)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    for (int64_t i = 0; i < ns; ++i) if (s_labels[i] < 0 || s_labels[i] > 31) { mvs_set_error("labels must be 0..31"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    enum { HEAD, NECK, LUA, LLA, LH, RUA, RLA, RH, LT, LS, LF, RT, RS, RF, TRUNCUS, HIP };   // PartRecognition.h:13-30
+    Dev ds, dsn, dsl, dt, dtn, dtf, dtl; Work w;
+    if ((rc = up(ds, src, (size_t)ns * 3)) || (rc = up(dsn, s_normals, (size_t)ns * 3)) || (rc = up(dsl, s_labels, (size_t)ns)) ||
+        (rc = up(dt, tgt, (size_t)*nt * 3)) || (rc = up(dtn, t_normals, (size_t)*nt * 3)) || (rc = up(dtf, t_faces, (size_t)*nf * 3)) ||
+        (rc = dtl.alloc(sizeof(int32_t) * *nt)) || (rc = w.init())) return rc;
+    int64_t n = *nt, f = *nf;
+    double gr[3], R[9], t[3], scale;
+    if ((rc = remove_ground_dev(dt.as<double>(), dtn.as<double>(), &n, dtf.as<int32_t>(), &f, dist_thres, gr, w))) return rc;          // Alignment.cpp:21
+    if (ground_ray) std::memcpy(ground_ray, gr, sizeof gr);
+    if ((rc = init_alignment_dev(ds.as<double>(), ns, dt.as<double>(), n, gr, view_ray, w, R, t, &scale))) return rc;                  // :27
+    double M[9];
+    for (int k = 0; k < 9; ++k) M[k] = scale * R[k];
+    if ((rc = apply_masked_dev(ds.as<double>(), dsn.as<double>(), ns, nullptr, 0, M, R, t))) return rc;                                // :31-34
+    if ((rc = part_recog_dev(ds.as<double>(), dsl.as<int32_t>(), ns, dt.as<double>(), n, dtl.as<int32_t>()))) return rc;               // :38-49
+    Pca p1, p2;                                                                                                                       // :56-64 neck centroids
+    if ((rc = pca_dev(ds.as<double>(), ns, dsl.as<int32_t>(), 1u << NECK, w, &p1)) || (rc = pca_dev(dt.as<double>(), n, dtl.as<int32_t>(), 1u << NECK, w, &p2))) return rc;
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, off[3] = {p2.bary[0] - p1.bary[0], p2.bary[1] - p1.bary[1], p2.bary[2] - p1.bary[2]};
+    if ((rc = apply_masked_dev(ds.as<double>(), nullptr, ns, nullptr, 0, I, I, off))) return rc;
+    struct G { uint32_t group, apply; int label; };                                                                                  // :378-419
+    const G groups[4] = {{1u << LUA | 1u << LLA | 1u << LH, 1u << LUA | 1u << LLA | 1u << LH, LH},
+                         {1u << RUA | 1u << RLA | 1u << RH, 1u << RUA | 1u << RLA | 1u << RH, RH},
+                         {1u << LT | 1u << LS, 1u << LT | 1u << LS | 1u << LF, LS},
+                         {1u << RT | 1u << RS, 1u << RT | 1u << RS | 1u << RF, RS}};
+    for (const G& g : groups) {
+        if ((rc = local_core_dev(ds.as<double>(), dsl.as<int32_t>(), ns, dt.as<double>(), dtl.as<int32_t>(), n, g.group, g.label, w, R, t, &scale))) return rc;
+        for (int k = 0; k < 9; ++k) M[k] = scale * R[k];
+        if ((rc = apply_masked_dev(ds.as<double>(), dsn.as<double>(), ns, dsl.as<int32_t>(), g.apply, M, R, t))) return rc;
+    }
+    if ((rc = down(src, ds, (size_t)ns * 3)) || (rc = down(s_normals, dsn, (size_t)ns * 3)) || (rc = down(tgt, dt, (size_t)n * 3)) ||
+        (rc = down(t_normals, dtn, (size_t)n * 3)) || (rc = down(t_faces, dtf, (size_t)f * 3)) || (rc = down(t_labels, dtl, (size_t)n))) return rc;
+    *nt = n; *nf = f;
+    return MVS_OK;
+}
+
+}  // extern "C"

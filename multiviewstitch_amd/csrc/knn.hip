@@ -252,22 +252,92 @@ size_t knn_grid_ws_bytes(int n) {
     const size_t nc = (size_t)knn_grid_cap(n), ncell = nc * nc * nc;
     return 64 + sizeof(int) * (ncell + 1) * 2 + sizeof(int) * (size_t)n + sizeof(float4) * (size_t)n + 64;
 }
-// ws: device workspace of knn_grid_ws_bytes(n) bytes
+struct NgWs { NgGeom* geo; int* counts; int* start; int* cell_of; float4* sorted; int NC; size_t ncell; };
+static NgWs ng_carve(void* ws, int n) {
+    NgWs w;
+    w.NC = knn_grid_cap(n);
+    w.ncell = (size_t)w.NC * w.NC * w.NC;
+    char* p = (char*)ws;
+    w.geo = (NgGeom*)p; p += 64;
+    w.counts = (int*)p; p += sizeof(int) * (w.ncell + 1);
+    w.start = (int*)p; p += sizeof(int) * (w.ncell + 1);
+    w.cell_of = (int*)p; p += sizeof(int) * (size_t)n;
+    p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    w.sorted = (float4*)p;
+    return w;
+}
+// build the point grid of `pts` in ws (device workspace of knn_grid_ws_bytes(n) bytes): 1 memset + 4 launches
+void knn_grid_build(const double* pts, int n, void* ws, hipStream_t s) {
+    const NgWs w = ng_carve(ws, n);
+    (void)hipMemsetAsync(w.counts, 0, sizeof(int) * (w.ncell + 1), s);
+    k_ng_bbox<<<dim3(1), dim3(1024), 0, s>>>(pts, n, w.NC, w.geo);
+    k_ng_count<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.geo, w.counts, w.cell_of);
+    k_ng_scan<<<dim3(1), dim3(1024), 0, s>>>(w.counts, (int)w.ncell, w.start);
+    k_ng_scatter<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.cell_of, w.start, w.counts, w.sorted);
+}
 void launch_knn_grid(const double* pts, int n, int k, int32_t* out, void* ws, hipStream_t s) {
     if (n <= 0) return;
-    const int NC = knn_grid_cap(n);
-    const size_t ncell = (size_t)NC * NC * NC;
-    char* p = (char*)ws;
-    NgGeom* geo = (NgGeom*)p; p += 64;
-    int* counts = (int*)p; p += sizeof(int) * (ncell + 1);
-    int* start = (int*)p; p += sizeof(int) * (ncell + 1);
-    int* cell_of = (int*)p; p += sizeof(int) * (size_t)n;
-    p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
-    float4* sorted = (float4*)p;
-    (void)hipMemsetAsync(counts, 0, sizeof(int) * (ncell + 1), s);
-    k_ng_bbox<<<dim3(1), dim3(1024), 0, s>>>(pts, n, NC, geo);
-    k_ng_count<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, geo, counts, cell_of);
-    k_ng_scan<<<dim3(1), dim3(1024), 0, s>>>(counts, (int)ncell, start);
-    k_ng_scatter<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, cell_of, start, counts, sorted);
-    k_ng_knn<<<dim3((n + 3) / 4), dim3(256), 0, s>>>(pts, n, k, geo, start, sorted, out);
+    knn_grid_build(pts, n, ws, s);
+    const NgWs w = ng_carve(ws, n);
+    k_ng_knn<<<dim3((n + 3) / 4), dim3(256), 0, s>>>(pts, n, k, w.geo, w.start, w.sorted, out);
+}
+
+// PartRecognition::PartRecog (R/PartRecognition/PartRecognition.cpp:50-77): label of the exact nearest template
+// vertex (float32 distances, ties -> lower vertex index) for every query point; one thread per query walking
+// cubic shells of the template's point grid.
+namespace {
+__global__ __launch_bounds__(256) void k_label_nn(const NgGeom* __restrict__ geo, const int* __restrict__ cs,
+                                                  const float4* __restrict__ sorted, const int32_t* __restrict__ labels,
+                                                  const double* __restrict__ pts, int64_t P, int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const NgGeom g = *geo;
+    const float qx = (float)pts[3 * i], qy = (float)pts[3 * i + 1], qz = (float)pts[3 * i + 2];
+    float best = INFINITY;
+    int arg = 0;
+    if ((qx - qx == 0.0f) && (qy - qy == 0.0f) && (qz - qz == 0.0f)) {
+        const float fx = (qx - g.minx) * g.inv_h, fy = (qy - g.miny) * g.inv_h, fz = (qz - g.minz) * g.inv_h;
+        const int cx = ng_axis(qx, g.minx, g.inv_h, g.nx), cy = ng_axis(qy, g.miny, g.inv_h, g.ny), cz = ng_axis(qz, g.minz, g.inv_h, g.nz);
+        float m = fminf(fminf(fminf(fx - cx, cx + 1 - fx), fminf(fy - cy, cy + 1 - fy)), fminf(fz - cz, cz + 1 - fz));
+        m = fmaxf(m, 0.0f);
+        auto scan = [&](int A, int B) {
+            for (int k = A; k < B; ++k) {
+                const float4 p = sorted[k];
+                const float d = d2f(qx, qy, qz, p.x, p.y, p.z);
+                const int j = __float_as_int(p.w);
+                if (d < best || (d == best && j < arg)) { best = d; arg = j; }
+            }
+        };
+        const int smax = max(g.nx, max(g.ny, g.nz));
+        for (int s = 0; s <= smax; ++s) {
+            for (int dz = -s; dz <= s; ++dz) {
+                const int z = cz + dz;
+                if (z < 0 || z >= g.nz) continue;
+                for (int dy = -s; dy <= s; ++dy) {
+                    const int y = cy + dy;
+                    if (y < 0 || y >= g.ny) continue;
+                    const int rb = (z * g.ny + y) * g.nx;
+                    if (abs(dy) == s || abs(dz) == s) {
+                        const int x0 = max(cx - s, 0), x1 = min(cx + s, g.nx - 1);
+                        if (x0 <= x1) scan(cs[rb + x0], cs[rb + x1 + 1]);
+                    } else {
+                        if (cx - s >= 0) scan(cs[rb + cx - s], cs[rb + cx - s + 1]);
+                        if (cx + s < g.nx) scan(cs[rb + cx + s], cs[rb + cx + s + 1]);
+                    }
+                }
+            }
+            const float bound = ((float)s + m - 0.01f) * g.h;
+            if (bound > 0.0f && best <= bound * bound) break;
+        }
+    }
+    out[i] = labels[arg];
+}
+}  // namespace
+
+void launch_label_nn(const double* tmpl, int V, const int32_t* tmpl_labels, void* ws, const double* pts, int64_t P,
+                     int32_t* out, hipStream_t s) {
+    if (P <= 0) return;
+    const NgWs w = ng_carve(ws, V);
+    (void)tmpl;
+    k_label_nn<<<dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s>>>(w.geo, w.start, w.sorted, tmpl_labels, pts, P, out);
 }

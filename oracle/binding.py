@@ -351,3 +351,74 @@ class Deform:
         c, v = np.empty((self.K, 3)), np.empty(self.K, np.uint8)
         lib().orc_deform_get_node_targets(self.h, C.c_int(int(smoothed)), _p(c), _p(v))
         return c, v
+
+
+# ---------------------------------------------------------------- alignment ----
+def pca(pts, labels=None, mask=0):
+    pts = _c(pts, np.float64)
+    lab = _c(labels, np.int32) if labels is not None else None
+    b, bb, ax, ev = np.empty(3), np.empty(6), np.empty((3, 3)), np.empty(3)
+    rc = lib().orc_pca(_p(pts), C.c_int64(len(pts)), _p(lab), C.c_uint32(mask), _p(b), _p(bb), _p(ax), _p(ev))
+    if rc:
+        raise RuntimeError(f"orc_pca -> {rc}")
+    return b, bb.reshape(2, 3), ax, ev
+
+
+def retain_connect_region(pts, nrm, faces):
+    p, f = _c(pts, np.float64).copy(), _c(faces, np.int32).copy()
+    n = _c(nrm, np.float64).copy() if nrm is not None else None
+    V, F = C.c_int64(len(p)), C.c_int64(len(f))
+    lib().orc_retain_connect_region(C.byref(V), _p(p), _p(n), C.byref(F), _p(f))
+    return p[:V.value], (n[:V.value] if n is not None else None), f[:F.value]
+
+
+def remove_ground(pts, nrm, faces, dist_thres=0.81):
+    p, f = _c(pts, np.float64).copy(), _c(faces, np.int32).copy()
+    n = _c(nrm, np.float64).copy() if nrm is not None else None
+    V, F, gr = C.c_int64(len(p)), C.c_int64(len(f)), np.empty(3)
+    rc = lib().orc_remove_ground(C.byref(V), _p(p), _p(n), C.byref(F), _p(f), C.c_double(dist_thres), _p(gr))
+    if rc:
+        raise RuntimeError(f"orc_remove_ground -> {rc}")
+    return gr, p[:V.value], (n[:V.value] if n is not None else None), f[:F.value]
+
+
+def init_alignment(src, tgt, ground_ray, view_ray):
+    s, t = _c(src, np.float64), _c(tgt, np.float64)
+    g, v = _c(ground_ray, np.float64), _c(view_ray, np.float64)
+    R, tr, sc = np.empty((3, 3)), np.empty(3), C.c_double()
+    rc = lib().orc_init_alignment(_p(s), C.c_int64(len(s)), _p(t), C.c_int64(len(t)), _p(g), _p(v), _p(R), _p(tr), C.byref(sc))
+    if rc:
+        raise RuntimeError(f"orc_init_alignment -> {rc}")
+    return R, tr, sc.value
+
+
+def part_recog(tmpl, tmpl_labels, pts):
+    t, tl, p = _c(tmpl, np.float64), _c(tmpl_labels, np.int32), _c(pts, np.float64)
+    out = np.empty(len(p), np.int32)
+    lib().orc_part_recog(_p(t), _p(tl), C.c_int64(len(t)), _p(p), C.c_int64(len(p)), _p(out))
+    return out
+
+
+def local_alignment_core(src, s_labels, tgt, t_labels, group_mask, label):
+    s, t = _c(src, np.float64), _c(tgt, np.float64)
+    sl, tl = _c(s_labels, np.int32), _c(t_labels, np.int32)
+    R, tr, sc = np.empty((3, 3)), np.empty(3), C.c_double()
+    rc = lib().orc_local_alignment_core(_p(s), _p(sl), C.c_int64(len(s)), _p(t), _p(tl), C.c_int64(len(t)), C.c_uint32(group_mask),
+                                        C.c_int(label), _p(R), _p(tr), C.byref(sc))
+    if rc:
+        raise RuntimeError(f"orc_local_alignment_core -> {rc}")
+    return R, tr, sc.value
+
+
+def align(src, s_nrm, s_labels, tgt, t_nrm, t_faces, view_ray, dist_thres=0.81):
+    s, sn, sl = _c(src, np.float64).copy(), _c(s_nrm, np.float64).copy(), _c(s_labels, np.int32)
+    t, tn, tf = _c(tgt, np.float64).copy(), _c(t_nrm, np.float64).copy(), _c(t_faces, np.int32).copy()
+    v = _c(view_ray, np.float64)
+    nt, nf = C.c_int64(len(t)), C.c_int64(len(tf))
+    tl, gr = np.empty(len(t), np.int32), np.empty(3)
+    rc = lib().orc_align(_p(s), _p(sn), C.c_int64(len(s)), _p(sl), _p(t), _p(tn), C.byref(nt), _p(tf), C.byref(nf), _p(v),
+                         C.c_double(dist_thres), _p(tl), _p(gr))
+    if rc:
+        raise RuntimeError(f"orc_align -> {rc}")
+    return dict(src=s, s_normals=sn, tgt=t[:nt.value], t_normals=tn[:nt.value], t_facets=tf[:nf.value], t_labels=tl[:nt.value],
+                ground_ray=gr)

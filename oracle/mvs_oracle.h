@@ -114,6 +114,19 @@ void    orc_deform_get_normals(orc_deform_t d, double* nrm);
 void    orc_deform_get_rotations(orc_deform_t d, double* R);
 void    orc_deform_get_node_targets(orc_deform_t d, int smoothed, double* controls, uint8_t* valid);
 
+/* ---- template -> scan coarse alignment (R/Alignment/Alignment.cpp, R/SetUtils, R/PartRecognition) ---- */
+int  orc_pca(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, double* bary, double* bbox /*6*/,
+             double* axes /*9: row i = i-th pivot*/, double* evals);
+void orc_retain_connect_region(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t* faces);
+int  orc_remove_ground(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t* faces, double dist_thres, double* ground_ray);
+int  orc_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray,
+                        const double* view_ray, double* R, double* t, double* scale);
+void orc_part_recog(const double* tmpl, const int32_t* tmpl_labels, int64_t V, const double* pts, int64_t P, int32_t* out);
+int  orc_local_alignment_core(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels,
+                              int64_t nt, uint32_t group_mask, int label, double* R, double* t, double* scale);
+int  orc_align(double* src, double* s_nrm, int64_t ns, const int32_t* s_labels, double* tgt, double* t_nrm, int64_t* nt,
+               int32_t* t_faces, int64_t* nf, const double* view_ray, double dist_thres, int32_t* t_labels, double* ground_ray_out);
+
 #ifdef __cplusplus
 }
 #endif

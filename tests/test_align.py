@@ -1,0 +1,166 @@
+"""Alignment rows: oracle checks against numpy / scipy restatements and known answers (CPU),
+then parity of the HIP path against the oracle through the C-ABI (GPU)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+from scipy.sparse.csgraph import connected_components
+
+from tests.util import body_scene
+
+ARM_L, ARM_R = (1 << 2 | 1 << 3 | 1 << 4), (1 << 5 | 1 << 6 | 1 << 7)
+LEG_L, LEG_R = (1 << 8 | 1 << 9), (1 << 11 | 1 << 12)
+
+
+# --------------------------------------------------------------------------------- oracle (CPU) ----
+def np_pca(p):
+    b = p.mean(0)
+    C = (p - b).T @ (p - b) / (len(p) - 1)
+    w, v = np.linalg.eigh(C)
+    ax = v[:, ::-1].T.copy()
+    for a in ax:                                        # sign convention of DESIGN.md §3: largest |component| positive
+        if a[np.argmax(np.abs(a))] < 0:
+            a *= -1
+    return b, ax, w[::-1]
+
+
+def test_oracle_pca_matches_numpy(oracle):
+    rng = np.random.default_rng(1)
+    p = rng.normal(size=(5000, 3)) * [5, 2, 0.7] @ np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    b, bb, ax, ev = oracle.pca(p)
+    nb, nax, nev = np_pca(p)
+    assert np.abs(b - nb).max() < 1e-12 and np.abs(ev - nev).max() < 1e-10 and np.abs(ax - nax).max() < 1e-9
+    assert np.array_equal(bb, np.stack([p.min(0), p.max(0)]))
+    lab = rng.integers(0, 16, len(p)).astype(np.int32)
+    b, bb, ax, ev = oracle.pca(p, lab, ARM_L)
+    sel = np.isin(lab, [2, 3, 4])
+    nb, nax, nev = np_pca(p[sel])
+    assert np.abs(b - nb).max() < 1e-12 and np.abs(ax - nax).max() < 1e-9
+
+
+def test_oracle_retain_connect_region_matches_scipy(oracle):
+    sc = body_scene()
+    p, n, f = oracle.retain_connect_region(sc["tgt"], sc["t_nrm"], sc["t_faces"])
+    V = len(sc["tgt"])
+    e = np.concatenate([sc["t_faces"][:, [0, 1]], sc["t_faces"][:, [0, 2]]])
+    ncomp, lab = connected_components(sp.coo_matrix((np.ones(len(e)), (e[:, 0], e[:, 1])), shape=(V, V)), directed=False)
+    big = np.argmax(np.bincount(lab))
+    keep = lab == big
+    assert ncomp == 2 and len(p) == keep.sum() == sc["n_body"]
+    assert np.array_equal(p, sc["tgt"][keep]) and np.array_equal(n, sc["t_nrm"][keep])
+    remap = np.cumsum(keep) - 1
+    assert np.array_equal(f, remap[sc["t_faces"][keep[sc["t_faces"][:, 0]]]])
+    # tie between two equal components -> the one holding the lowest vertex index; isolated vertices are dropped
+    tri = np.array([[0, 1, 2], [3, 4, 5]], np.int32)
+    pts = np.arange(21, dtype=float).reshape(7, 3)
+    p2, _, f2 = oracle.retain_connect_region(pts, None, tri)
+    assert np.array_equal(p2, pts[:3]) and np.array_equal(f2, [[0, 1, 2]])
+
+
+def test_oracle_part_recog_is_exact_nearest_vertex(oracle):
+    sc = body_scene()
+    rng = np.random.default_rng(2)
+    q = sc["src"][rng.integers(0, len(sc["src"]), 700)] + rng.normal(scale=0.05, size=(700, 3))
+    got = oracle.part_recog(sc["src"], sc["s_labels"], q)
+    d = ((q[:, None, :].astype(np.float32) - sc["src"][None].astype(np.float32)) ** 2)
+    d = (d[..., 0] + d[..., 1]) + d[..., 2]
+    assert np.array_equal(got, sc["s_labels"][np.argmin(d, 1)])
+
+
+def test_oracle_remove_ground_and_init_alignment_known_answers(oracle):
+    sc = body_scene()
+    gr, p, n, f = oracle.remove_ground(sc["tgt"], sc["t_nrm"], sc["t_faces"], 0.81)
+    assert len(p) == sc["n_body"] and len(f) == (sc["t_faces"] < sc["n_body"]).all(1).sum()     # exactly the ground patch goes
+    down = sc["R"] @ np.array([0, 0, -1.0])
+    assert gr @ down > 0.99                                                                       # ground ray points to the ground end
+    R, t, s = oracle.init_alignment(sc["src"], p, gr, sc["view_ray"])
+    assert abs(s / sc["s"] - 1) < 0.08                                                            # extent ratio of two discretisations
+    moved = s * sc["src"] @ R.T + t
+    # PCA alignment of a (near-)similar shape: every template vertex lands near the scan surface
+    from scipy.spatial import cKDTree
+    dist = cKDTree(p).query(moved)[0]
+    assert np.median(dist) < 0.08 * sc["s"]
+
+
+def test_oracle_local_alignment_core_recovers_a_limb_similarity(oracle):
+    """scan limb = similarity of the template limb about its far end -> that similarity (scale exactly, axis exactly)."""
+    sc = body_scene()
+    src, lab = sc["src"], sc["s_labels"]
+    sel = np.isin(lab, [2, 3, 4])
+    tgt = src.copy()
+    b, _, ax, _ = oracle.pca(src, lab, ARM_L)
+    tgt[sel] = (src[sel] - b) * 1.25 + b                      # pure scaling about the limb's barycentre
+    R, t, s = oracle.local_alignment_core(src, lab, tgt, lab, ARM_L, 4)
+    assert abs(s - 1.25) < 1e-12
+    assert np.isnan(R).all() or np.abs(R - np.eye(3)).max() < 1e-6   # parallel axes: the reference's acos/cross degenerates (Utils.h:145-147)
+
+
+def test_oracle_full_align_moves_template_onto_scan(oracle):
+    sc = body_scene()
+    out = oracle.align(sc["src"], sc["s_nrm"], sc["s_labels"], sc["tgt"], sc["t_nrm"], sc["t_faces"], sc["view_ray"], 0.81)
+    assert len(out["tgt"]) == sc["n_body"] and len(out["t_labels"]) == sc["n_body"]
+    assert set(np.unique(out["t_labels"])) <= set(range(16))
+    assert np.isfinite(out["src"]).all()
+
+
+# ------------------------------------------------------------------------------------ GPU parity ----
+@pytest.fixture(scope="module")
+def al():
+    from multiviewstitch_amd import _lib, alignment
+    if _lib.device_count() == 0:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box")
+    return alignment
+
+
+@pytest.mark.gpu
+def test_gpu_pca_and_part_recog_match_oracle(al, oracle):
+    sc = body_scene()
+    for lab, mask in ((None, 0), (sc["s_labels"], ARM_L), (sc["s_labels"], LEG_R)):
+        g, o = al.pca(sc["src"], lab, mask), oracle.pca(sc["src"], lab, mask)
+        assert np.abs(g[0] - o[0]).max() < 1e-13 and np.array_equal(g[1], o[1])
+        assert np.abs(g[2] - o[2]).max() < 1e-9 and np.abs(g[3] - o[3]).max() < 1e-11
+    rng = np.random.default_rng(3)
+    q = np.concatenate([sc["tgt"], sc["src"] * 3.0 + 5.0, rng.normal(size=(5000, 3)) * 4])      # near, far, scattered
+    assert np.array_equal(al.part_recog(sc["src"], sc["s_labels"], q), oracle.part_recog(sc["src"], sc["s_labels"], q))
+
+
+@pytest.mark.gpu
+def test_gpu_retain_and_remove_ground_match_oracle(al, oracle):
+    sc = body_scene()
+    A = al.Alignment()
+    gp, gn, gf = A.RetainConnectRegion(sc["tgt"], sc["t_nrm"], sc["t_faces"])
+    op, on, of = oracle.retain_connect_region(sc["tgt"], sc["t_nrm"], sc["t_faces"])
+    assert np.array_equal(gp, op) and np.array_equal(gn, on) and np.array_equal(gf, of)
+    tri = np.array([[0, 1, 2], [3, 4, 5]], np.int32)
+    pts = np.arange(21, dtype=float).reshape(7, 3)
+    gp, _, gf = A.RetainConnectRegion(pts, None, tri)
+    assert np.array_equal(gp, pts[:3]) and np.array_equal(gf, [[0, 1, 2]])
+    ggr, gp, gn, gf = A.RemoveGround(sc["tgt"], sc["t_nrm"], sc["t_faces"], 0.81)
+    ogr, op, on, of = oracle.remove_ground(sc["tgt"], sc["t_nrm"], sc["t_faces"], 0.81)
+    assert np.abs(ggr - ogr).max() < 1e-9 and np.array_equal(gp, op) and np.array_equal(gn, on) and np.array_equal(gf, of)
+
+
+@pytest.mark.gpu
+def test_gpu_init_and_local_alignment_match_oracle(al, oracle):
+    sc = body_scene()
+    A = al.Alignment()
+    gr, p, n, f = oracle.remove_ground(sc["tgt"], sc["t_nrm"], sc["t_faces"], 0.81)
+    g, o = A.InitAlignment(sc["src"], p, gr, sc["view_ray"]), oracle.init_alignment(sc["src"], p, gr, sc["view_ray"])
+    assert np.abs(g[0] - o[0]).max() < 1e-9 and np.abs(g[1] - o[1]).max() < 1e-9 and abs(g[2] - o[2]) < 1e-12
+    moved = o[2] * sc["src"] @ o[0].T + o[1]
+    tl = oracle.part_recog(moved, sc["s_labels"], p)
+    for mask, label in ((ARM_L, 4), (ARM_R, 7), (LEG_L, 9), (LEG_R, 12)):
+        g = A.LocalAlignmentCore(moved, sc["s_labels"], p, tl, mask, label)
+        o = oracle.local_alignment_core(moved, sc["s_labels"], p, tl, mask, label)
+        assert np.abs(g[0] - o[0]).max() < 1e-9 and np.abs(g[1] - o[1]).max() < 1e-9 and abs(g[2] - o[2]) < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes", [(8, 12), (30, 64)])
+def test_gpu_full_align_matches_oracle(al, oracle, sizes):
+    sc = body_scene(5, *sizes)
+    g = al.Alignment().Align(sc["src"], sc["s_nrm"], sc["s_labels"], sc["tgt"], sc["t_nrm"], sc["t_faces"], sc["view_ray"], 0.81)
+    o = oracle.align(sc["src"], sc["s_nrm"], sc["s_labels"], sc["tgt"], sc["t_nrm"], sc["t_faces"], sc["view_ray"], 0.81)
+    assert np.array_equal(g["tgt"], o["tgt"]) and np.array_equal(g["t_normals"], o["t_normals"])
+    assert np.array_equal(g["t_facets"], o["t_facets"]) and np.array_equal(g["t_labels"], o["t_labels"])
+    assert np.abs(g["ground_ray"] - o["ground_ray"]).max() < 1e-9
+    assert np.abs(g["src"] - o["src"]).max() < 1e-8 and np.abs(g["s_normals"] - o["s_normals"]).max() < 1e-8

@@ -23,3 +23,45 @@ def scene_and_target(config, smooth=S.SMOOTH, **kw):
 def rms(a, b):
     d = np.asarray(a) - np.asarray(b)
     return float(np.sqrt(np.mean(np.sum(d.reshape(-1, d.shape[-1]) ** 2, axis=1))))
+
+
+@functools.lru_cache(maxsize=4)
+def body_scene(seed=5, n_tmpl=8, n_scan=12):
+    """Synthetic stand-in for the template / scan pair of Processor::Deform (R/Processor/Processor.cpp:1119-1131):
+    an elongated closed template with 16 part labels (stripes of enum PART), a denser scan = similarity-moved,
+    slightly deformed copy with a disconnected ground patch under its far end."""
+    rng = np.random.default_rng(seed)
+    stretch = np.array([0.45, 0.6, 2.0])
+
+    def labels_of(d):                                  # 16 parts: 8 bands along the axis x 2 sides; limbs come out as bands
+        band = np.clip(((d[:, 2] + 1.0) * 4).astype(int), 0, 7)
+        return (band * 2 + (d[:, 0] > 0)).astype(np.int32)
+
+    dt, ft = S.geodesic_sphere(n_tmpl)
+    src = dt * stretch
+    src = src + 0.02 * np.sin(src @ np.array([[1.3, 0.7, -0.4], [-0.9, 1.1, 0.5], [0.3, -0.6, 1.7]]) + [0.1, 0.5, 0.9])   # break the mirror symmetries (no ties)
+    s_labels = labels_of(dt)
+    s_nrm = S.vertex_normals_plyobj(src, ft)
+    ds, fs = S.geodesic_sphere(n_scan)
+    body = ds * stretch * (1.0 + 0.03 * np.sin(3 * ds[:, 2:3]))
+    body[:, 0] += 0.10 * ds[:, 2] ** 2 + 0.05 * ds[:, 2] * ds[:, 1]      # bend + shear: limb axes differ from the template's
+    body[:, 1] += 0.06 * np.sin(2.0 * ds[:, 2]) * (1.0 + ds[:, 0])
+    ang = 0.5
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]]) @ \
+        np.array([[1, 0, 0], [0, np.cos(0.3), -np.sin(0.3)], [0, np.sin(0.3), np.cos(0.3)]])
+    s, t = 1.7, np.array([0.4, -0.2, 0.3])
+    # ground patch: regular grid just beyond the -z end, not connected to the body
+    g = np.linspace(-1.2, 1.2, 17)
+    gx, gy = np.meshgrid(g, g)
+    ground = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, -2.15)], 1) + rng.normal(scale=0.004, size=(gx.size, 3))
+    gf = []
+    for i in range(16):
+        for j in range(16):
+            a = i * 17 + j
+            gf += [(a, a + 17, a + 18), (a, a + 18, a + 1)]
+    tgt = np.concatenate([body, ground]) @ R.T * s + t
+    t_faces = np.concatenate([fs, np.array(gf, np.int32) + len(body)]).astype(np.int32)
+    t_nrm = S.vertex_normals_plyobj(tgt, t_faces)
+    view_ray = R @ np.array([0.0, 1.0, 0.0])
+    return dict(src=src, s_nrm=s_nrm, s_faces=ft, s_labels=s_labels, tgt=tgt, t_nrm=t_nrm, t_faces=t_faces,
+                view_ray=view_ray, n_body=len(body), s=s, R=R, t=t)
