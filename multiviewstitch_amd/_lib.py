@@ -127,6 +127,13 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `make -C multiviewstitch_amd/csrc` "
                 "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
                 "multiviewstitch_amd has no CPU fallback.")
+        # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64, and whichever copy is mapped
+        # first owns the devices (a later torch.cuda init on the other copy reports "No HIP GPUs are available"; the
+        # stream handles exchanged in set_stream() are only meaningful within one runtime anyway).  Map torch's first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)          # AttributeError if the ABI lost a symbol

@@ -30,6 +30,8 @@ names = ["entry", "scalars/loads done", "after barrier", "gathers back", "rows d
 # s_memtime counters differ per XCD: report every wave's stamps relative to ITS OWN entry stamp (cycles)
 for k in range(1, 6):
     v = (t[:, k] - t[:, 0])[t[:, k] > 0]
+    if len(v) == 0:
+        continue
     print(f"entry -> {names[k]:20s} min {v.min():7d} p10 {int(np.percentile(v, 10)):7d} p50 {int(np.median(v)):7d} "
           f"p90 {int(np.percentile(v, 90)):7d} max {v.max():7d}  (n={len(v)})")
 w = np.arange(len(t)) % 16
