@@ -51,7 +51,8 @@ enum mvs_status {
     MVS_E_OOM         = -6,
     MVS_E_SOLVER      = -7,  /* global solve failed (Deformation.cpp:393-397)   */
     MVS_E_STATE       = -8,  /* call order violated (e.g. no target set)        */
-    MVS_E_DEGENERATE  = -9   /* fewer than 3 matches etc.                       */
+    MVS_E_DEGENERATE  = -9,  /* fewer than 3 matches etc.                       */
+    MVS_E_IO          = -10  /* file cannot be opened / parsed (mvs_io.h)        */
 };
 
 const char* mvs_last_error(void);     /* thread-local message of the last failure */

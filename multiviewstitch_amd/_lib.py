@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmvs_hip.so")
 MVS_OK = 0
 STATUS = {0: "MVS_OK", -1: "MVS_E_INVALID_ARG", -2: "MVS_E_BAD_MESH", -3: "MVS_E_NONMANIFOLD",
           -4: "MVS_E_NO_DEVICE", -5: "MVS_E_HIP", -6: "MVS_E_OOM", -7: "MVS_E_SOLVER", -8: "MVS_E_STATE",
-          -9: "MVS_E_DEGENERATE"}
+          -9: "MVS_E_DEGENERATE", -10: "MVS_E_IO"}
 
 
 class MvsError(RuntimeError):
@@ -115,6 +115,17 @@ _SIGS = {
     "mvs_deform_arap": (C.c_int, [_VP, _VP, _VP, _VP]),
     "mvs_deform_kernel_time": (C.c_int, [_VP, C.c_char_p, _VP, _VP]),
     "mvs_deform_enable_timing": (C.c_int, [_VP, _I32]),
+    # include/mvs_io.h
+    "mvs_obj_read": (C.c_int, [C.c_char_p, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "mvs_obj_write": (C.c_int, [C.c_char_p, _I64, _VP, _VP, _I64, _VP]),
+    "mvs_npts_read": (C.c_int, [C.c_char_p, _VP, _VP, _VP]),
+    "mvs_npts_write": (C.c_int, [C.c_char_p, _I64, _VP, _VP]),
+    "mvs_srt_txt_read": (C.c_int, [C.c_char_p, _I64, _VP, _VP, _VP]),
+    "mvs_srt_txt_write": (C.c_int, [C.c_char_p, _I64, _VP, _VP, _VP]),
+    "mvs_depth_raw_read": (C.c_int, [C.c_char_p, _I32, _I32, _VP]),
+    "mvs_depth_raw_write": (C.c_int, [C.c_char_p, _I64, _VP]),
+    "mvs_parts_read": (C.c_int, [C.c_char_p, _I64, _VP]),
+    "mvs_processor_deform": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _VP, _D, _VP, C.c_char_p, _VP]),
 }
 EXPORTS = tuple(_SIGS)
 

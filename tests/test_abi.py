@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "mvs.h")).read()
+    import glob
+    src = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))))
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(mvs_[a-z0-9_]+)\s*\(", src)))
 
@@ -21,8 +22,8 @@ def test_every_declared_symbol_is_exported():
     decl = declared_symbols()
     assert len(decl) >= 40
     for name in decl:
-        assert hasattr(lib, name), f"{name} declared in include/mvs.h but not exported"
-    assert sorted(_lib.EXPORTS) == decl, "multiviewstitch_amd/_lib.py signature table out of sync with include/mvs.h"
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
+    assert sorted(_lib.EXPORTS) == decl, "multiviewstitch_amd/_lib.py signature table out of sync with include/*.h"
     assert lib.mvs_abi_version() == 1
 
 
