@@ -100,6 +100,25 @@ int mvs_depth_unproject(const float* inv_depth, const mvs_camera* cam,
                         double min_dsp, double max_dsp,
                         double* out_points /* w*h*3 */, uint8_t* out_valid /* w*h */);
 
+/* Processor::CheckConsistencyCore (R/Processor/Processor.cpp:72-126): depth-consistency filter of one frame against
+ * n_ref (<= 4) reference frames, applied in the given order.  A pixel keeps its inverse depth iff it is inside
+ * [min_dsp, max_dsp] and for every reference: its world point lands inside the reference image on a pixel with a valid
+ * inverse depth whose world point projects back inside the current image within reproj_err INTEGER pixels
+ * (`sqrt(int) > reproj_err`, ParamParser::reproj_err is an int); otherwise it becomes 0.  Rasters are the float32
+ * files of LoadDepth; `out` is what SaveDepth writes to DATA/CHECK (the values are float32 throughout).  All frames
+ * share one raster size (the reference indexes every raster with the current width, :93). */
+int mvs_check_consistency(const float* depth, const mvs_camera* cur, int32_t n_ref, const float* const* ref_depths,
+                          const mvs_camera* ref_cams, double min_dsp, double max_dsp, int32_t reproj_err,
+                          float* out /*w*h*/);
+
+/* Processor::CheckConsistency (R/Processor/Processor.cpp:29-70) for one sequence: frame i is checked against frames
+ * i-1 and i+1 (in that order, those that exist), always against the ORIGINAL rasters.  depths / out: n_frames*w*h. */
+int mvs_check_consistency_seq(int32_t n_frames, const float* depths, const mvs_camera* cams, double min_dsp,
+                              double max_dsp, int32_t reproj_err, float* out);
+/* same with both raster stacks in HBM (out_dev must not alias depths_dev); hip_stream may be NULL */
+int mvs_check_consistency_seq_dev(int32_t n_frames, const float* depths_dev, const mvs_camera* cams, double min_dsp,
+                                  double max_dsp, int32_t reproj_err, float* out_dev, void* hip_stream);
+
 /* ------------------------------------------------------------ SRT (a3-a9) -- */
 enum mvs_srt_mode {
     MVS_SRT_CLOSED_FORM = 0,  /* EstimateTransform(double&,Matrix3d&,Vector3d&)  SRTSolver.cpp:272-275 */

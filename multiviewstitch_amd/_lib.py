@@ -73,6 +73,9 @@ _SIGS = {
     "mvs_depth_to_model": (C.c_int, [_VP, _VP, _D, _D, _D, _VP, _VP, _VP, _VP, _VP, _VP]),
     "mvs_depth_to_model_dev": (C.c_int, [_VP, _VP, _D, _D, _D, _VP, _VP, _VP, _VP, _VP, _VP]),
     "mvs_depth_unproject": (C.c_int, [_VP, _VP, _D, _D, _VP, _VP]),
+    "mvs_check_consistency": (C.c_int, [_VP, _VP, _I32, _VP, _VP, _D, _D, _I32, _VP]),
+    "mvs_check_consistency_seq": (C.c_int, [_I32, _VP, _VP, _D, _D, _I32, _VP]),
+    "mvs_check_consistency_seq_dev": (C.c_int, [_I32, _VP, _VP, _D, _D, _I32, _VP, _VP]),
     "mvs_srt_fit": (C.c_int, [_VP, _I64, _VP, _VP, _I32, _VP, _I32, _U32, _VP, _VP, _VP, _VP]),
     "mvs_srt_residual": (C.c_int, [_VP, _I64, _VP, _VP, _D, _VP, _VP, _VP, _VP]),
     "mvs_srt_remove_outliers": (C.c_int, [_VP, _I64, _VP, _VP, _I32, _D, _D, _VP, _VP, _VP, _VP]),

@@ -10,18 +10,12 @@
 #include "engine.h"
 #include "dev_common.h"
 #include "geom.h"
+#include "camera_dev.h"
 #include <algorithm>
 
 namespace {
 
 constexpr int TPB = 256;
-
-__device__ inline d3 world_from_img(const CamDev& c, int u, int v, double d) {
-    // Camera.cpp:40-44 then :61-67
-    const d3 pc = mk3((u - c.cx) * d / c.fx, (v - c.cy) * d / c.fy, d);
-    const d3 tmp = mk3(pc.x - c.t[0], pc.y - c.t[1], pc.z - c.t[2]);
-    return mulMtv(c.R, tmp);
-}
 
 __device__ inline bool dsp_valid(double d, double mn, double mx) {    // Depth2Model.cpp:31-32
     return d > 0 && !(d > mx || d < mn);

@@ -13,26 +13,15 @@
 #include "dev_common.h"
 #include "svd3_dev.h"
 #include "geom.h"
+#include "camera_dev.h"
 
 namespace {
 
-__device__ inline int32_t cvt_i32(double x) {            // (int)double with x86 cvttsd2si's out-of-range value
-    return (x > -2147483649.0 && x < 2147483648.0) ? (int32_t)x : (int32_t)0x80000000;
-}
 __device__ inline double pix_dist(int32_t u1, int32_t v1, int32_t u2, int32_t v2) {
     const uint32_t du = (uint32_t)u1 - (uint32_t)u2, dv = (uint32_t)v1 - (uint32_t)v2;
     const int32_t s = (int32_t)(du * du + dv * dv);       // int arithmetic wraps as on MSVC/x64
     return sqrt((double)s);
 }
-__device__ inline void img_from_world(const CamDev& c, d3 pw, int32_t* u, int32_t* v) {
-    // Camera.cpp:68-72 then :45-48
-    const d3 p = mk3(((c.R[0] * pw.x + c.R[1] * pw.y) + c.R[2] * pw.z) + c.t[0],
-                     ((c.R[3] * pw.x + c.R[4] * pw.y) + c.R[5] * pw.z) + c.t[1],
-                     ((c.R[6] * pw.x + c.R[7] * pw.y) + c.R[8] * pw.z) + c.t[2]);
-    *u = cvt_i32(c.fx * p.x / p.z + c.cx + 0.5);
-    *v = cvt_i32(c.fy * p.y / p.z + c.cy + 0.5);
-}
-
 struct Xf { double sR[9], iRt[9], t[3]; };
 __device__ inline Xf make_xf(double scale, const double* R, const double* t) {
     Xf x;

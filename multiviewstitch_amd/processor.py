@@ -19,3 +19,30 @@ def Deform(model_obj, template_obj, parts_path, cam_R, dist_thres: float, out_ob
     L.check(L.lib().mvs_processor_deform(os.fsencode(model_obj), os.fsencode(template_obj), os.fsencode(parts_path), L.ptr(R),
                                          float(dist_thres), C.byref(prm), os.fsencode(out_obj), C.byref(st)))
     return _stats(st)
+
+
+def CheckConsistencyCore(curcam, refcams, depth, refdepths, min_dsp: float, max_dsp: float, reproj_err: int) -> np.ndarray:
+    """R/Processor/Processor.cpp:72-126 — float32 raster in, filtered float32 raster out (what SaveDepth writes to DATA/CHECK)."""
+    d = L.arr(depth, np.float32)
+    refs = [L.arr(r, np.float32) for r in refdepths]
+    ptrs = (C.c_void_p * max(1, len(refs)))(*[r.ctypes.data for r in refs])
+    cams = (L.CCamera * max(1, len(refs)))(*[L.CCamera.of(c) for c in refcams])
+    out = np.empty_like(d)
+    cc = L.CCamera.of(curcam)
+    L.check(L.lib().mvs_check_consistency(L.ptr(d), C.byref(cc), len(refs), ptrs, cams, float(min_dsp), float(max_dsp), int(reproj_err),
+                                          L.ptr(out)))
+    return out
+
+
+def CheckConsistency(cameras, depths, min_dsp: float, max_dsp: float, reproj_err: int, out_dev: int | None = None, stream: int | None = None):
+    """R/Processor/Processor.cpp:29-70 for one sequence: every frame against its two neighbours.
+    ``depths`` is a float32 array [n, h, w] — or a device address when ``out_dev`` (a device address) is given."""
+    cams = (L.CCamera * len(cameras))(*[L.CCamera.of(c) for c in cameras])
+    if out_dev is not None:
+        L.check(L.lib().mvs_check_consistency_seq_dev(len(cameras), L.ptr(int(depths)), cams, float(min_dsp), float(max_dsp), int(reproj_err),
+                                                      L.ptr(int(out_dev)), L.ptr(stream)))
+        return None
+    d = L.arr(depths, np.float32)
+    out = np.empty_like(d)
+    L.check(L.lib().mvs_check_consistency_seq(len(cameras), L.ptr(d), cams, float(min_dsp), float(max_dsp), int(reproj_err), L.ptr(out)))
+    return out

@@ -340,3 +340,31 @@ def make_matches(rng, cam1: Camera, cam2: Camera, s, R, t, n=64, outlier_frac=0.
         idx = rng.choice(n, n_out, replace=False)
         q[idx] += rng.normal(scale=0.5, size=(n_out, 3))
     return np.ascontiguousarray(np.concatenate([p, q], 1))
+
+
+def make_sequence(n_frames: int = 5, w: int = 320, h: int = 240, dyaw_deg: float = 3.0, seed: int = 77, f: float = 1.2,
+                  dist: float = 5.0, device=None):
+    """One key-frame sequence in ONE frame of reference (the input of Processor::CheckConsistency): the synthetic
+    surface seen from `n_frames` cameras `dyaw_deg` apart on the ring.  -> (cams, depths float32 [n, h, w])."""
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(-1, 1, 6)
+    c = rng.normal(size=(8, 3))
+    c /= np.linalg.norm(c, axis=1, keepdims=True)
+    A = rng.uniform(-0.05, 0.05, 8)
+    dirs, _ = geodesic_sphere(12)
+    r_max = 1.02 * float(_r_target(dirs, a, c, A).max())
+    fx = fy = f * w
+    cx, cy = w / 2 - 0.5, h / 2 - 0.5
+    cams, depths = [], []
+    for k in range(n_frames):
+        yaw = math.radians(dyaw_deg) * k
+        el = math.radians(10.0)
+        eye = dist * np.array([math.cos(el) * math.cos(yaw), math.cos(el) * math.sin(yaw), math.sin(el)])
+        Rc, tc = _look_at(eye)
+        if device is not None:
+            d = render_inverse_depth_torch(Rc, tc, fx, fy, cx, cy, w, h, a, c, A, r_max, device)
+        else:
+            d = render_inverse_depth(Rc, tc, fx, fy, cx, cy, w, h, lambda q: _r_target(q, a, c, A), r_max)
+        cams.append(Camera(fx, fy, cx, cy, Rc.copy(), tc.copy(), w, h))
+        depths.append(d)
+    return cams, np.stack(depths)

@@ -422,3 +422,24 @@ def align(src, s_nrm, s_labels, tgt, t_nrm, t_faces, view_ray, dist_thres=0.81):
         raise RuntimeError(f"orc_align -> {rc}")
     return dict(src=s, s_normals=sn, tgt=t[:nt.value], t_normals=tn[:nt.value], t_facets=tf[:nf.value], t_labels=tl[:nt.value],
                 ground_ray=gr)
+
+
+# --------------------------------------------------- depth consistency ----
+def check_consistency(depth, cur, ref_depths, ref_cams, min_dsp, max_dsp, reproj_err):
+    depth = _c(depth, np.float32)
+    refs = [_c(r, np.float32) for r in ref_depths]
+    ptrs = (C.c_void_p * max(1, len(refs)))(*[r.ctypes.data for r in refs])
+    cams = (Camera * max(1, len(refs)))(*[Camera.of(c) for c in ref_cams])
+    out = np.empty_like(depth)
+    cc = Camera.of(cur)
+    lib().orc_check_consistency(_p(depth), C.byref(cc), C.c_int(len(refs)), ptrs, cams, C.c_double(min_dsp), C.c_double(max_dsp),
+                                C.c_int(int(reproj_err)), _p(out))
+    return out
+
+
+def check_consistency_seq(depths, cams, min_dsp, max_dsp, reproj_err):
+    depths = _c(depths, np.float32)
+    cc = (Camera * len(cams))(*[Camera.of(c) for c in cams])
+    out = np.empty_like(depths)
+    lib().orc_check_consistency_seq(C.c_int(len(cams)), _p(depths), cc, C.c_double(min_dsp), C.c_double(max_dsp), C.c_int(int(reproj_err)), _p(out))
+    return out

@@ -145,6 +145,50 @@ void orc_cam_world_to_img(const orc_camera* c, const double* pw, int* u, int* v)
     img_from_world(c, v3(pw), u, v);
 }
 
+// -------------------------------------------------------- depth consistency ----
+// Processor::CheckConsistencyCore, R/Processor/Processor.cpp:72-126 (rasters float32 as loaded by LoadDepth)
+void orc_check_consistency(const float* depth, const orc_camera* cur, int n_ref, const float* const* ref_depths,
+                           const orc_camera* ref_cams, double min_dsp, double max_dsp, int reproj_err, float* out) {
+    const int w = cur->w, h = cur->h;
+    for (int j = 0; j < h; ++j)
+        for (int i = 0; i < w; ++i) {
+            double dp = (double)depth[j * w + i];
+            if (dp >= min_dsp && dp <= max_dsp) {
+                const V3 p3d = world_from_cam(cur, cam_from_img(cur, i, j, 1.0 / dp));
+                for (int k = 0; k < n_ref; ++k) {
+                    int u, v;
+                    img_from_world(ref_cams + k, p3d, &u, &v);
+                    if (!(u >= 0 && u < ref_cams[k].w && v >= 0 && v < ref_cams[k].h)) { dp = 0.0; break; }
+                    const double rd = (double)ref_depths[k][v * w + u];
+                    if (!(rd >= min_dsp && rd <= max_dsp)) { dp = 0.0; break; }
+                    const V3 q = world_from_cam(ref_cams + k, cam_from_img(ref_cams + k, u, v, 1.0 / rd));
+                    img_from_world(cur, q, &u, &v);
+                    if (!(u >= 0 && u < w && v >= 0 && v < h)) { dp = 0.0; break; }
+                    const double e = std::sqrt((double)((i - u) * (i - u) + (j - v) * (j - v)));
+                    if (e > reproj_err) { dp = 0.0; break; }
+                }
+            } else {
+                dp = 0.0;
+            }
+            out[j * w + i] = (float)dp;
+        }
+}
+// Processor::CheckConsistency for one sequence, :29-70
+void orc_check_consistency_seq(int n_frames, const float* depths, const orc_camera* cams, double min_dsp, double max_dsp,
+                               int reproj_err, float* out) {
+    const int64_t npx = (int64_t)cams[0].w * cams[0].h;
+    for (int i = 0; i < n_frames; ++i) {
+        const float* rd[2];
+        orc_camera rc[2];
+        int n = 0;
+        for (int j = 0; j < 3; ++j) {
+            const int idx = i - 1 + j;
+            if (idx >= 0 && idx < n_frames && idx != i) { rd[n] = depths + idx * npx; rc[n] = cams[idx]; ++n; }
+        }
+        orc_check_consistency(depths + i * npx, cams + i, n, rd, rc, min_dsp, max_dsp, reproj_err, out + i * npx);
+    }
+}
+
 // ---------------------------------------------------------------- depth ----
 void orc_depth_unproject(const float* dsp, const orc_camera* cam, double min_dsp, double max_dsp,
                          double* out_points, uint8_t* out_valid) {
