@@ -22,7 +22,7 @@ int mvs_current_device();
 void knn_grid_build(const double* pts, int n, void* ws, hipStream_t s);
 size_t knn_grid_ws_bytes(int n);
 void launch_label_nn(const double* tmpl, int V, const int32_t* tmpl_labels, void* ws, const double* pts, int64_t P,
-                     int32_t* out, hipStream_t s);
+                     int32_t* out, int32_t* far_list, hipStream_t s);
 
 namespace {
 
@@ -120,12 +120,21 @@ __global__ __launch_bounds__(TPB) void k_range(const double* __restrict__ pts, i
         if (t < lo || (t == lo && i < ilo)) { lo = t; ilo = i; }
         if (t > hi || (t == hi && i < ihi)) { hi = t; ihi = i; }
     }
-    __shared__ double s_v[2][TPB];
-    __shared__ long long s_i[2][TPB];
-    s_v[0][threadIdx.x] = lo; s_i[0][threadIdx.x] = ilo; s_v[1][threadIdx.x] = hi; s_i[1][threadIdx.x] = ihi;
+    for (int o = 32; o > 0; o >>= 1) {             // (value, first index) min / max over the wave
+        const double l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+        const long long il2 = __shfl_xor(ilo, o, 64), ih2 = __shfl_xor(ihi, o, 64);
+        if (il2 >= 0 && (ilo < 0 || l2 < lo || (l2 == lo && il2 < ilo))) { lo = l2; ilo = il2; }
+        if (ih2 >= 0 && (ihi < 0 || h2 > hi || (h2 == hi && ih2 < ihi))) { hi = h2; ihi = ih2; }
+    }
+    __shared__ double s_v[2][TPB / 64];
+    __shared__ long long s_i[2][TPB / 64];
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        s_v[0][w] = lo; s_i[0][w] = ilo; s_v[1][w] = hi; s_i[1][w] = ihi;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < TPB; ++k) {
+        for (int k = 1; k < TPB / 64; ++k) {
             if (s_i[0][k] >= 0 && (ilo < 0 || s_v[0][k] < lo || (s_v[0][k] == lo && s_i[0][k] < ilo))) { lo = s_v[0][k]; ilo = s_i[0][k]; }
             if (s_i[1][k] >= 0 && (ihi < 0 || s_v[1][k] > hi || (s_v[1][k] == hi && s_i[1][k] < ihi))) { hi = s_v[1][k]; ihi = s_i[1][k]; }
         }
@@ -249,7 +258,17 @@ __global__ void k_cc_compress(int32_t* parent, int64_t n) {
 }
 __global__ void k_cc_sizes(const int32_t* __restrict__ parent, int64_t n, int32_t* __restrict__ size) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&size[parent[i]], 1);
+    const int root = i < n ? parent[i] : -1;
+    // one atomic per distinct root of the wave (a mesh has few components: usually one per wave)
+    unsigned long long todo = __ballot(root >= 0);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int r = __shfl(root, leader, 64);
+        const unsigned long long same = __ballot(root == r);
+        if (lane == leader) atomicAdd(&size[r], __popcll(same));
+        todo &= ~same;
+    }
 }
 // largest component, ties -> lowest root: part[b] = {size, root}
 __global__ __launch_bounds__(TPB) void k_cc_best(const int32_t* __restrict__ size, int64_t n, long long* __restrict__ part) {
@@ -258,11 +277,15 @@ __global__ __launch_bounds__(TPB) void k_cc_best(const int32_t* __restrict__ siz
         const long long s = size[i];
         if (s > bs || (s == bs && i < br)) { bs = s; br = i; }
     }
-    __shared__ long long sm[2][TPB];
-    sm[0][threadIdx.x] = bs; sm[1][threadIdx.x] = br;
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long s2 = __shfl_xor(bs, o, 64), r2 = __shfl_xor(br, o, 64);
+        if (s2 > bs || (s2 == bs && r2 >= 0 && r2 < br)) { bs = s2; br = r2; }
+    }
+    __shared__ long long sm[2][TPB / 64];
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = bs; sm[1][threadIdx.x >> 6] = br; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < TPB; ++k)
+        for (int k = 1; k < TPB / 64; ++k)
             if (sm[0][k] > bs || (sm[0][k] == bs && sm[1][k] >= 0 && sm[1][k] < br)) { bs = sm[0][k]; br = sm[1][k]; }
         part[2 * blockIdx.x] = bs; part[2 * blockIdx.x + 1] = br;
     }
@@ -578,11 +601,10 @@ int apply_masked_dev(double* pts, double* nrm, int64_t n, const int32_t* labels,
 }
 
 int part_recog_dev(const double* tmpl, const int32_t* tmpl_labels, int64_t V, const double* pts, int64_t P, int32_t* out) {
-    Dev ws;
-    int rc = ws.alloc(knn_grid_ws_bytes((int)V));
-    if (rc) return rc;
-    knn_grid_build(tmpl, (int)V, ws.p, nullptr);
-    launch_label_nn(tmpl, (int)V, tmpl_labels, ws.p, pts, P, out, nullptr);
+    Dev ws, far;
+    int rc;
+    if ((rc = ws.alloc(knn_grid_ws_bytes((int)V))) || (rc = far.alloc(sizeof(int32_t) * (size_t)(P + 1)))) return rc;
+    launch_label_nn(tmpl, (int)V, tmpl_labels, ws.p, pts, P, out, far.as<int32_t>(), nullptr);
     return mvs_check_hip(hipDeviceSynchronize(), "part_recog");
 }
 

@@ -22,50 +22,58 @@ struct RefSet {
     int n;
 };
 
-// the reference indexes the reference rasters with the CURRENT width (`refdepth[k][v * w + u]`, :93): kept
-__device__ inline float check_pixel(const CamDev& cur, int i, int j, float dpf, const CamDev* rc, const float* const* rd, int n,
-                                    double mn, double mx, int reproj) {
-    const double dp = (double)dpf;
-    if (!(dp >= mn && dp <= mx)) return 0.0f;                                  // :84, :119-121
-    const int w = cur.w, h = cur.h;
-    const d3 p3d = world_from_img(cur, i, j, 1.0 / dp);                       // :86
-    for (int k = 0; k < n; ++k) {
-        int32_t u, v;
-        img_from_world(rc[k], p3d, &u, &v);                                   // :89
-        if (!(u >= 0 && u < rc[k].w && v >= 0 && v < rc[k].h)) return 0.0f;   // :90, :113-116
-        const double rdp = (double)rd[k][(int64_t)v * w + u];
-        if (!(rdp >= mn && rdp <= mx)) return 0.0f;                           // :91, :108-111
-        const d3 q = world_from_img(rc[k], u, v, 1.0 / rdp);                  // :93
-        img_from_world(cur, q, &u, &v);                                       // :94
-        if (!(u >= 0 && u < w && v >= 0 && v < h)) return 0.0f;               // :95-98
-        const int32_t du = i - u, dv = j - v;
-        if (sqrt((double)(du * du + dv * dv)) > (double)reproj) return 0.0f;  // :99-103
-    }
-    return dpf;
+// one reference frame of the chain (:88-117); the reference indexes the reference rasters with the CURRENT width
+// (`refdepth[k][v * w + u]`, :93): kept
+__device__ inline bool ref_agrees(const CamDev& cur, int i, int j, d3 p3d, const CamDev& rc, const float* __restrict__ rd,
+                                  double mn, double mx, int reproj) {
+    int32_t u, v;
+    img_from_world(rc, p3d, &u, &v);                                      // :89
+    if (!(u >= 0 && u < rc.w && v >= 0 && v < rc.h)) return false;        // :90, :113-116
+    const double rdp = (double)rd[(int64_t)v * cur.w + u];
+    if (!(rdp >= mn && rdp <= mx)) return false;                          // :91, :108-111
+    const d3 q = world_from_img(rc, u, v, 1.0 / rdp);                     // :93
+    img_from_world(cur, q, &u, &v);                                       // :94
+    if (!(u >= 0 && u < cur.w && v >= 0 && v < cur.h)) return false;      // :95-98
+    const int32_t du = i - u, dv = j - v;
+    return !(sqrt((double)(du * du + dv * dv)) > (double)reproj);         // :99-103
 }
 
 __global__ __launch_bounds__(TPB) void k_check_core(const float* __restrict__ dsp, CamDev cur, RefSet refs, double mn, double mx,
                                                     int reproj, float* __restrict__ out) {
     const int idx = blockIdx.x * TPB + threadIdx.x;
     if (idx >= cur.w * cur.h) return;
-    out[idx] = check_pixel(cur, idx % cur.w, idx / cur.w, dsp[idx], refs.cam, refs.dsp, refs.n, mn, mx, reproj);
+    const float dpf = dsp[idx];
+    const double dp = (double)dpf;
+    bool ok = dp >= mn && dp <= mx;                                       // :84, :119-121
+    if (ok) {
+        const int i = idx % cur.w, j = idx / cur.w;
+        const d3 p3d = world_from_img(cur, i, j, 1.0 / dp);              // :86
+#pragma unroll
+        for (int k = 0; k < MAXREF; ++k)                                  // unrolled: the camera structs stay in scalar registers
+            if (ok && k < refs.n) ok = ref_agrees(cur, i, j, p3d, refs.cam[k], refs.dsp[k], mn, mx, reproj);
+    }
+    out[idx] = ok ? dpf : 0.0f;
 }
 
 // whole sequence: frame f is checked against f-1 then f+1 (those that exist), always against the ORIGINAL rasters (:46-57)
 __global__ __launch_bounds__(TPB) void k_check_seq(const float* __restrict__ dsp, const CamDev* __restrict__ cams, int n_frames,
                                                    double mn, double mx, int reproj, float* __restrict__ out) {
     const int f = blockIdx.y;
-    const CamDev cur = cams[f];
+    const CamDev& cur = cams[f];
     const int npx = cur.w * cur.h;
     const int idx = blockIdx.x * TPB + threadIdx.x;
     if (idx >= npx) return;
-    CamDev rc[2];
-    const float* rd[2];
-    int n = 0;
-    if (f > 0) { rc[n] = cams[f - 1]; rd[n] = dsp + (int64_t)(f - 1) * npx; ++n; }
-    if (f + 1 < n_frames) { rc[n] = cams[f + 1]; rd[n] = dsp + (int64_t)(f + 1) * npx; ++n; }
     const int64_t o = (int64_t)f * npx + idx;
-    out[o] = check_pixel(cur, idx % cur.w, idx / cur.w, dsp[o], rc, rd, n, mn, mx, reproj);
+    const float dpf = dsp[o];
+    const double dp = (double)dpf;
+    bool ok = dp >= mn && dp <= mx;
+    if (ok) {
+        const int i = idx % cur.w, j = idx / cur.w;
+        const d3 p3d = world_from_img(cur, i, j, 1.0 / dp);
+        if (f > 0) ok = ref_agrees(cur, i, j, p3d, cams[f - 1], dsp + (int64_t)(f - 1) * npx, mn, mx, reproj);
+        if (ok && f + 1 < n_frames) ok = ref_agrees(cur, i, j, p3d, cams[f + 1], dsp + (int64_t)(f + 1) * npx, mn, mx, reproj);
+    }
+    out[o] = ok ? dpf : 0.0f;
 }
 
 struct Buf {

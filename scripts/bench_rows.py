@@ -1,0 +1,54 @@
+"""Secondary rows of the path (a2, a9, a10-a15, f2) at full size, to be run under
+`rocprofv3 --kernel-trace --stats` (scripts/profile_round.sh): each entry is called REPS times on inputs resident in
+HBM where the ABI allows it.  Prints the algorithmic bytes per call so the kernel durations of the trace turn into GB/s
+(scripts/rows_summary.py)."""
+import json
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import torch
+from multiviewstitch_amd import alignment, processor, scene as S, srt as srt_mod
+from tests.util import body_scene
+
+REPS = 10
+dev = torch.device("cuda", 0)
+rows = {}
+
+# f2: consistency filter, 8 frames of 1280x960
+cams, d = S.make_sequence(8, 1280, 960, 2.0, device=dev)
+din = torch.from_numpy(d).to(dev)
+dout = torch.empty_like(din)
+for _ in range(REPS):
+    processor.CheckConsistency(cams, din.data_ptr(), S.MIN_DSP, S.MAX_DSP, 4, out_dev=dout.data_ptr())
+npx = d.size
+valid = int(((d >= S.MIN_DSP) & (d <= S.MAX_DSP)).sum())
+rows["k_check_seq"] = {"bytes": 8 * npx + 8 * valid, "note": "4 B read + 4 B written per pixel, 2 x 4 B gathers per valid pixel", "pixels": npx}
+
+# a2: depth -> points/normals/triangles of one 1280x960 raster; a9: similarity map of its points
+raster = torch.from_numpy(np.ascontiguousarray(d[0])).to(dev)
+npnt, nfac = srt_mod.depth_to_model_dev(raster.data_ptr(), cams[0], S.MIN_DSP, S.MAX_DSP, S.SMOOTH)
+p = torch.empty((npnt, 3), dtype=torch.float64, device=dev)
+n = torch.empty_like(p)
+for _ in range(REPS):
+    srt_mod.depth_to_model_dev(raster.data_ptr(), cams[0], S.MIN_DSP, S.MAX_DSP, S.SMOOTH, p.data_ptr(), n.data_ptr())
+rows["k_depth_emit"] = {"bytes": 4 * d[0].size + 52 * npnt, "note": "4 B per pixel in, 48 + 4 B per valid pixel out", "points": npnt}
+R = np.linalg.qr(np.random.default_rng(0).normal(size=(3, 3)))[0]
+q, m = torch.empty_like(p), torch.empty_like(n)
+for _ in range(REPS):
+    srt_mod.apply_dev(p.data_ptr(), n.data_ptr(), npnt, 1.1, R, np.array([0.1, 0.2, 0.3]), q.data_ptr(), m.data_ptr())
+torch.cuda.synchronize()
+rows["k_srt_apply"] = {"bytes": 96 * npnt, "note": "48 B in + 48 B out per point", "points": npnt}
+
+# a10-a15: alignment of a 9 K-vertex labelled template to a 41 K-vertex scan mesh; a14 alone at 2 M scan points
+sc = body_scene(5, 30, 64)
+for _ in range(3):
+    alignment.Alignment().Align(sc["src"], sc["s_nrm"], sc["s_labels"], sc["tgt"], sc["t_nrm"], sc["t_faces"], sc["view_ray"], 0.81)
+base = p.cpu().numpy() * 0.5
+big = np.ascontiguousarray(np.concatenate([base + 1e-3 * k for k in range(7)])[:2_000_000])      # ~2 M scan points
+tm = sc["src"] / np.abs(sc["src"]).max() * np.abs(big).max()
+for _ in range(3):
+    alignment.part_recog(tm, sc["s_labels"], big)
+rows["k_label_nn"] = {"bytes": 28 * len(big), "note": "24 B query + 4 B label per scan point (template grid stays in L2)", "points": len(big)}
+print(json.dumps(rows))
