@@ -240,7 +240,13 @@ typedef struct mvs_deform_params {
     int32_t update_normals;  /* 0: keep ctor normals for every outer iteration as the
                                 reference does (Deformation.cpp:34,304); 1: recompute
                                 (Deformation.h:86-128) after each outer iteration        */
+    int32_t solver;          /* MVS_SOLVER_AUTO: overlapping-patch sweeps with LDS-resident local
+                                solves when the mesh fits (>= 2048 vertices, degree <= 16), else
+                                CG; MVS_SOLVER_CG: always the one-kernel-per-iteration CG.  Both
+                                stop at cg_tol                                               */
+    int32_t reserved0;
 } mvs_deform_params;
+enum { MVS_SOLVER_AUTO = 0, MVS_SOLVER_CG = 1 };
 
 void mvs_deform_default_params(mvs_deform_params* p);
 

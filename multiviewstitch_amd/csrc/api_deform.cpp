@@ -57,6 +57,7 @@ void mvs_deform_default_params(mvs_deform_params* p) {
     p->max_result = 10000; p->top_k = 8; p->graph_k = 8; p->smooth_sweeps = 2;
     p->arap_iters = 5; p->arap_tol = 1e-4; p->cg_tol = 1e-8; p->cg_max_iters = 2000;
     p->update_normals = 0;
+    p->solver = MVS_SOLVER_AUTO; p->reserved0 = 0;
 }
 
 }  // extern "C"
@@ -135,6 +136,32 @@ struct CgPlan {                      // CG launches per ARAP iteration and where
     int max(int iters) const { int m = 0; for (int i = 0; i < iters; ++i) m = std::max(m, n[i]); return m; }
 };
 
+struct RasPlan {                     // sweeps per ARAP iteration of the patch solver and where each solve's slots start
+    int n[8];
+    int64_t total(int iters) const { int64_t t = 0; for (int i = 0; i < iters; ++i) t += n[i]; return t; }
+};
+constexpr int RAS_FIRST_PLAN = 16;   // sweeps of an uncalibrated solve (5-7 are needed; the rest degenerate into copies)
+constexpr int RAS_MAX_SWEEPS = 64;
+
+RasPlan probe_ras(const mvs_deform_s* h) {
+    RasPlan r;
+    for (int i = 0; i < 8; ++i) r.n[i] = h->ras_plan[i] > 0 ? h->ras_plan[i] : RAS_FIRST_PLAN;
+    return r;
+}
+bool use_ras(const mvs_deform_s* h, const mvs_deform_params& p) { return h->has_ras && p.solver != MVS_SOLVER_CG; }
+
+int ensure_ras_slots(mvs_deform_s* h, int arap_iters, const RasPlan& rp) {
+    const int64_t need = rp.total(arap_iters);
+    if (need > h->ras_slots_cap) {
+        dfree(h->d_ras_slots); dfree(h->d_ras_iters);
+        int rc = dmalloc(&h->d_ras_slots, (size_t)need * ras_slot_size(h));
+        if (!rc) rc = dmalloc(&h->d_ras_iters, (size_t)need * h->ras.NP);
+        if (rc) return rc;
+        h->ras_slots_cap = need;
+    }
+    return MVS_OK;
+}
+
 int ensure_slots(mvs_deform_s* h, int arap_iters, const CgPlan& cg) {
     const int64_t need = cg.total_slots(arap_iters) * MVS_CG_SLOT;
     if (need > h->slots_cap) {
@@ -184,7 +211,9 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
         toc(t, p.smooth_sweeps);
     }
     h->d_ctrl_final = const_cast<double*>(ctrl);
-    int rc = ensure_slots(h, p.arap_iters, plan);
+    const bool ras = use_ras(h, p);
+    const RasPlan rp = probe_ras(h);
+    int rc = ras ? ensure_ras_slots(h, p.arap_iters, rp) : ensure_slots(h, p.arap_iters, plan);
     if (rc) return rc;
     {
         Tic t = tic(h, "weights");
@@ -192,12 +221,34 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
         launch_arap_prepare(h->sell, h->d_pts, ctrl, h->d_sol, h->d_rot, s);                     // :383-392
         toc(t, 3);
     }
-    for (int it = 0; it < p.arap_iters; ++it) {                                                   // deform(5, 1e-4), :398
+    double* x_cur = h->d_sol;            // the patch solver ping-pongs between d_sol and d_ras_x2
+    int64_t ras_slot = 0;
+    for (int it = 0; ras && it < p.arap_iters; ++it) {
+        {
+            Tic t = tic(h, "rhs");
+            launch_arap_rhs(h->sell, h->d_pts, x_cur, h->d_rot, it, p.arap_tol, h->d_energy, nullptr, nullptr, h->d_ras_b, s);
+            toc(t, 1);
+        }
+        {
+            Tic t = tic(h, "cg");
+            const int ss = ras_slot_size(h);
+            for (int i = 0; i < rp.n[it]; ++i, ++ras_slot) {
+                double* x_next = x_cur == h->d_sol ? h->d_ras_x2 : h->d_sol;
+                double* cur = h->d_ras_slots + (size_t)ras_slot * ss;
+                launch_ras_sweep(h, h->d_ras_b, x_cur, x_next, it, p.arap_tol, i, p.cg_tol, i > 0 ? cur - ss : nullptr, cur,
+                                 h->d_ras_iters + (size_t)ras_slot * h->ras.NP, s);
+                x_cur = x_next;
+            }
+            toc(t, rp.n[it]);
+        }
+        { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, x_cur, it, p.arap_tol, h->d_energy, h->d_cov, h->d_rot, s); toc(t, 3); }
+    }
+    for (int it = 0; !ras && it < p.arap_iters; ++it) {                                           // deform(5, 1e-4), :398
         double* slots = h->d_slots + plan.offset(it);
         const int cg = plan.n[it];
         {
             Tic t = tic(h, "rhs");
-            launch_arap_rhs(h->sell, h->d_pts, h->d_sol, h->d_rot, it, p.arap_tol, h->d_energy, h->d_rws[0], h->d_p, s);
+            launch_arap_rhs(h->sell, h->d_pts, h->d_sol, h->d_rot, it, p.arap_tol, h->d_energy, h->d_rws[0], h->d_p, nullptr, s);
             launch_cg_w0(h->sell, h->d_coef, it, p.arap_tol, h->d_energy, h->d_rws[0], slots, s);
             toc(t, 2);
         }
@@ -213,7 +264,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
         { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, h->d_sol, it, p.arap_tol, h->d_energy, h->d_cov, h->d_rot, s); toc(t, 3); }
     }
     Tic t = tic(h, "finalize");
-    launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, h->d_sol, h->d_pts, h->d_info, s);   // :400
+    launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, s);       // :400
     int n = 2;
     if (p.update_normals) { launch_vertex_normals(h->d_pts, h->d_faces, h->d_vf_ptr, h->d_vf, V, h->d_nrm, s); ++n; }
     launch_gather_nodes(h->d_pts, h->d_nrm, h->d_nodes, K, h->d_node_pts, h->d_node_nrm, s);
@@ -223,7 +274,10 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
 }
 
 // after a sync: read the CG slots of the last solve, fill stats, re-calibrate cg_iters
+int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* st, bool* converged);
+
 int harvest(mvs_deform_s* h, const mvs_deform_params& p, const CgPlan& plan, mvs_deform_stats* st, bool* converged) {
+    if (use_ras(h, p)) return harvest_ras(h, p, st, converged);
     const size_t n = (size_t)plan.total_slots(p.arap_iters) * MVS_CG_SLOT;
     std::vector<double> slots(n);
     std::vector<double> ered(MVS_ERED_SIZE);
@@ -289,6 +343,85 @@ int harvest(mvs_deform_s* h, const mvs_deform_params& p, const CgPlan& plan, mvs
         mvs_set_error("global solve did not reach cg_tol in cg_max_iters=%d (rel residual %.3e)", cg, worst);
         return MVS_E_SOLVER;
     }
+    return MVS_OK;
+}
+
+// patch solver: read the sweep slots of the last solve, fill stats, re-plan the sweep counts.
+// NOTE the plan used by the solve being harvested is probe_ras() of the state BEFORE this call.
+int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* st, bool* converged) {
+    const RasPlan rp = probe_ras(h);
+    const int ss = ras_slot_size(h), NP = h->ras.NP, NPpad = h->ras.NPpad;
+    const size_t nslots = (size_t)rp.total(p.arap_iters);
+    std::vector<double> slots(nslots * ss), ered(MVS_ERED_SIZE);
+    std::vector<int32_t> iters(nslots * NP);
+    int32_t info[8];
+    HIPCHK(hipMemcpyAsync(slots.data(), h->d_ras_slots, slots.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(iters.data(), h->d_ras_iters, iters.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(ered.data(), h->d_energy, sizeof(double) * MVS_ERED_SIZE, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(info, h->d_info, sizeof info, hipMemcpyDeviceToHost, h->stream));
+    std::vector<uint8_t> valid(h->K);
+    if (h->K) HIPCHK(hipMemcpyAsync(valid.data(), h->d_valid, (size_t)h->K, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int run = info[0];
+    int launches = 0, active = 0, max_local = 0, max_plan = 0;
+    double worst = 0.0;
+    bool all_conv = true;
+    size_t slot = 0;
+    for (int it = 0; it < p.arap_iters; ++it) {
+        const int n = rp.n[it];
+        max_plan = std::max(max_plan, n);
+        if (it >= run) { slot += n; continue; }
+        const double* last = slots.data() + (slot + n - 1) * ss;
+        const double bn[3] = {last[3 * NPpad + 3], last[3 * NPpad + 4], last[3 * NPpad + 5]};
+        // gamma of the INPUT of sweep i (folded here from the per-patch partials, patch order)
+        auto conv_at = [&](int i, double* rel) {
+            const double* S = slots.data() + (slot + i) * ss;
+            bool ok = true;
+            for (int c = 0; c < 3; ++c) {
+                double g = 0.0;
+                for (int q = 0; q < NP; ++q) g += S[c * NPpad + q];
+                if (g > 0.0 && g > p.cg_tol * p.cg_tol * bn[c]) ok = false;
+                if (rel && bn[c] > 0) *rel = std::max(*rel, std::sqrt(std::max(0.0, g) / bn[c]));
+            }
+            return ok;
+        };
+        int first = -1;
+        for (int i = 0; i < n; ++i) if (conv_at(i, nullptr)) { first = i; break; }
+        double rel = 0.0;
+        conv_at(n - 1, &rel);                              // what the last sweep started from (its output is better still)
+        worst = std::max(worst, rel);
+        for (int i = 0; i < n; ++i) {
+            int mx = 0;
+            for (int q = 0; q < NP; ++q) mx = std::max(mx, iters[(slot + i) * NP + q]);
+            max_local += mx;
+            if (mx > 0 || i == 0) ++active;
+        }
+        launches += n;
+        if (first < 0) { all_conv = false; h->ras_plan[it] = std::min(RAS_MAX_SWEEPS, 2 * n); }
+        else h->ras_plan[it] = std::min(RAS_MAX_SWEEPS, first + 2);           // sweep `first` confirms, one spare
+        if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] arap it %d: patch solver converged input at sweep %d of %d (rel %.3e)\n", it, first, n, rel);
+        slot += n;
+    }
+    for (int it = run; it < p.arap_iters; ++it)            // solves skipped by the energy stop rule keep a safe count
+        if (h->ras_plan[it] == 0) h->ras_plan[it] = h->ras_plan[std::max(0, run - 1)];
+    if (converged) *converged = all_conv;
+    mvs_deform_stats out{};
+    out.arap_iters_run = run;
+    out.cg_iters = max_local;                              // local PCG iterations on the critical path (max over patches, summed over sweeps)
+    for (int i = 0; i < 8; ++i) out.energy[i] = i < p.arap_iters ? ered[MVS_ERED_FIN + i] : 0.0;
+    out.cg_rel_residual = worst;
+    out.cg_launches = launches; out.cg_active = active;
+    int nv = 0;
+    for (uint8_t v : valid) nv += v;
+    out.n_valid = nv;
+    h->last = out;
+    if (st) *st = out;
+    collect_timers(h);
+    if (!all_conv && max_plan >= RAS_MAX_SWEEPS) {
+        mvs_set_error("patch solver did not reach cg_tol in %d sweeps (rel residual %.3e)", max_plan, worst);
+        return MVS_E_SOLVER;
+    }
+    h->cg_iters = std::max(h->cg_iters, 1);                // "calibrated": async solves allowed
     return MVS_OK;
 }
 
@@ -408,6 +541,7 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals, in
     TRY(mvs_check_hip(hipMemsetAsync(h->d_rot, 0, sizeof(double) * V * 9, h->stream), "memset"));
     TRY(mvs_check_hip(hipMemsetAsync(h->d_info, 0, sizeof(int32_t) * 8, h->stream), "memset"));
     TRY(mvs_check_hip(hipStreamSynchronize(h->stream), "sync"));
+    TRY(ras_build(h, points, rowptr, col, slice_off));
 #undef TRY
     h->sell.V = (int32_t)V; h->sell.nslices = nslices; h->sell.slice_off = h->d_slice_off; h->sell.col = h->d_col;
     h->sell.opp0 = h->d_opp0; h->sell.opp1 = h->d_opp1; h->sell.w = h->d_w; h->sell.diag = h->d_diag; h->sell.is_ctrl = h->d_is_ctrl;
@@ -425,6 +559,7 @@ int mvs_deform_destroy(mvs_deform_t h) {
     dfree(h->d_spos); dfree(h->d_tpos); dfree(h->d_tnrm); dfree(h->d_cell_start); dfree(h->d_coarse_cnt);
     for (int k = 0; k < 2; ++k) dfree(h->d_rws[k]);
     dfree(h->d_p); dfree(h->d_coef); dfree(h->d_cov); dfree(h->d_slots); dfree(h->d_energy); dfree(h->d_info);
+    ras_free(h);
     for (auto& pr : h->pending) { (void)hipEventDestroy(pr.second.first); (void)hipEventDestroy(pr.second.second); }
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

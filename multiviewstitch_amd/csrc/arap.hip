@@ -33,17 +33,15 @@
 #include "engine.h"
 #include "dev_common.h"
 #include "svd3_dev.h"
+#include "arap_dev.h"
 #include <algorithm>
 
 namespace {
 
 constexpr int TPB = 1024;           // row kernels: 16 waves per workgroup
 constexpr int NW = TPB / 64;
-constexpr int NBMAX = MVS_NBMAX;    // max workgroups of a row kernel (= partials per sum)
 constexpr int SLOT = MVS_CG_SLOT;   // part[6][NBMAX] (gamma, delta) | alpha[3] gamma[3] bnorm[3] 1/gamma[3] 1/(gamma alpha)[3] pad
 constexpr int FIN = MVS_CG_FIN;     // offset of the reduced scalars inside a slot
-constexpr int EIT = MVS_ERED_IT;    // per ARAP iteration: e_part[NBMAX] | bn_part[3][NBMAX]
-constexpr int EFIN = MVS_ERED_FIN;  // reduced energies e_fin[8]
 
 // ---- diagnostic build only (-DMVS_STAMPS): per-wave s_memtime stamps of k_cg_iter, read back by
 // mvs_debug_stamps(); never compiled into the product library (cdna_hip_programming.md §7, in-kernel stamps)
@@ -57,61 +55,6 @@ __device__ unsigned long long g_stamps[8192 * 8];
 #define STAMP(k)
 #define STAMPW(k)
 #endif
-
-// ------------------------------------------------------------- lane helpers --
-template <int CTRL>
-__device__ inline double dpp_d(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-// sum over the 8 lanes of a row (result in all 8); every lane of the wave must be active
-__device__ inline double red8(double v) {
-    v += dpp_d<0xB1>(v);     // quad_perm [1,0,3,2]
-    v += dpp_d<0x4E>(v);     // quad_perm [2,3,0,1]
-    v += dpp_d<0x141>(v);    // row_half_mirror: lane i <-> 7-i of each 8-lane half row
-    return v;
-}
-// sum over the 8 row groups of a wave for values already uniform within each 8-lane group
-__device__ inline double red_rows(double v) {
-    v += dpp_d<0x140>(v);    // row_mirror: lane i <-> 15-i (adds the other 8-lane group of the 16-lane row)
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
-__device__ inline double wave_total(double v) { return red_rows(red8(v)); }
-// fixed-order fold of nb partial sums by ONE wave (every lane gets the total)
-// (all loads are issued before the first add: a runtime-trip-count loop would serialise the memory latencies —
-//  measured with the stamps build: 7.6 K cycles of preamble per launch, scripts/cg_stamps.py)
-__device__ inline double fold_partials(const double* __restrict__ part, int nb) {
-    const int lane = threadIdx.x & 63;
-    double t[NBMAX / 64];
-#pragma unroll
-    for (int u = 0; u < NBMAX / 64; ++u) { const int k = lane + 64 * u; t[u] = k < nb ? part[k] : 0.0; }
-    double v = 0.0;
-#pragma unroll
-    for (int u = 0; u < NBMAX / 64; ++u) v += t[u];
-    return wave_total(v);
-}
-// two folds with every load of both in flight together
-__device__ inline void fold_partials2(const double* __restrict__ pa, const double* __restrict__ pb, int nb, double* a, double* b) {
-    const int lane = threadIdx.x & 63;
-    double t[NBMAX / 64], u_[NBMAX / 64];
-#pragma unroll
-    for (int u = 0; u < NBMAX / 64; ++u) { const int k = lane + 64 * u; t[u] = k < nb ? pa[k] : 0.0; u_[u] = k < nb ? pb[k] : 0.0; }
-    double va = 0.0, vb = 0.0;
-#pragma unroll
-    for (int u = 0; u < NBMAX / 64; ++u) { va += t[u]; vb += u_[u]; }
-    *a = wave_total(va); *b = wave_total(vb);
-}
-// sum over the 8 row groups of a wave of a value held by the lanes with the same (lane & 7); lanes 0..7 get the totals
-__device__ inline double sum_over_rows(double v) {
-    v += dpp_d<0x128>(v);    // row_ror:8 -> lane i += lane (i+8) mod 16 of its 16-lane row
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
 
 struct RowCtx {
     int row, l, off, passes;
@@ -161,18 +104,6 @@ __device__ inline void block_store_partials(const double* v, double* __restrict_
         for (int ww = 0; ww < NW; ++ww) s += sm[ww][threadIdx.x];
         part[threadIdx.x * NBMAX + blockIdx.x] = s;
     }
-}
-
-// has the reference's energy stop rule fired after some ARAP iteration t < it ?
-// deform(): checked after iteration t when t+1 < iters and t != 0 (Appendix A.6).
-// efin[t] holds the reduced energies of the iterations t < it.
-__device__ inline bool arap_done_before(const double* __restrict__ efin, int it, double tol) {
-    if (!(tol > 0.0)) return false;
-    for (int t = 1; t < it; ++t) {
-        const double dif = fabs((efin[t - 1] - efin[t]) / efin[t]);
-        if (dif < tol) return true;
-    }
-    return false;
 }
 
 // one thread evaluates the stop rule (it costs fp64 divisions), the workgroup shares the answer
@@ -272,7 +203,8 @@ __global__ void k_arap_prepare(SellDev m, const double* __restrict__ pts, const 
 __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __restrict__ pts,
                                                   const double* __restrict__ sol, const double* __restrict__ rot,
                                                   int it, double tol, double* __restrict__ ered,
-                                                  double* __restrict__ rws, double* __restrict__ p) {
+                                                  double* __restrict__ rws, double* __restrict__ p,
+                                                  double* __restrict__ bout) {
     double* efin = ered + EFIN;
     __shared__ int s_done;
     if (threadIdx.x < 64) {                      // wave 0 decides
@@ -321,9 +253,13 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
                 res = b_c - a_c;
                 bn_acc += b_c * b_c / di;                        // ||b||^2 in the M^-1 norm: scale of the CG stop test
             }
-            double* o = rws + 9 * (int64_t)r.row;
-            o[r.l] = res; o[3 + r.l] = 0.0; o[6 + r.l] = 0.0;
-            p[3 * r.row + r.l] = 0.0;
+            if (bout) {                                              // patch solver: it wants b itself
+                bout[3 * r.row + r.l] = freerow ? (r.l == 0 ? bb.x : (r.l == 1 ? bb.y : bb.z)) : 0.0;
+            } else {
+                double* o = rws + 9 * (int64_t)r.row;
+                o[r.l] = res; o[3 + r.l] = 0.0; o[6 + r.l] = 0.0;
+                p[3 * r.row + r.l] = 0.0;
+            }
         }
     }
     const int l = threadIdx.x & 7;
@@ -669,8 +605,8 @@ void launch_arap_prepare(const SellDev& m, const double* pts, const double* ctrl
     k_arap_prepare<<<dim3((m.V + 255) / 256), dim3(256), 0, s>>>(m, pts, ctrl, sol, rot);
 }
 void launch_arap_rhs(const SellDev& m, const double* pts, const double* sol, const double* rot, int it, double tol,
-                     double* ered, double* rws, double* p, hipStream_t s) {
-    k_arap_rhs<<<dim3(arap_grid_blocks(m)), dim3(TPB), 0, s>>>(m, pts, sol, rot, it, tol, ered, rws, p);
+                     double* ered, double* rws, double* p, double* bout, hipStream_t s) {
+    k_arap_rhs<<<dim3(arap_grid_blocks(m)), dim3(TPB), 0, s>>>(m, pts, sol, rot, it, tol, ered, rws, p, bout);
 }
 void launch_cg_w0(const SellDev& m, const double* coef, int it, double tol, const double* ered, double* rws,
                   double* slot0, hipStream_t s) {

@@ -1,0 +1,81 @@
+// arap_dev.h — wave / workgroup reduction idioms and the device-side ARAP stop rule shared by arap.hip and schwarz.hip.
+#ifndef MVS_ARAP_DEV_H_
+#define MVS_ARAP_DEV_H_
+#include "engine.h"
+#include "dev_common.h"
+
+namespace {
+
+constexpr int NBMAX = MVS_NBMAX;    // max workgroups of a row kernel (= partials per sum)
+constexpr int EIT = MVS_ERED_IT;    // per ARAP iteration: e_part[NBMAX] | bn_part[3][NBMAX]
+constexpr int EFIN = MVS_ERED_FIN;  // reduced energies e_fin[8]
+
+// ------------------------------------------------------------- lane helpers --
+template <int CTRL>
+__device__ inline double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// sum over the 8 lanes of a row (result in all 8); every lane of the wave must be active
+__device__ inline double red8(double v) {
+    v += dpp_d<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_d<0x141>(v);    // row_half_mirror: lane i <-> 7-i of each 8-lane half row
+    return v;
+}
+// sum over the 8 row groups of a wave for values already uniform within each 8-lane group
+__device__ inline double red_rows(double v) {
+    v += dpp_d<0x140>(v);    // row_mirror: lane i <-> 15-i (adds the other 8-lane group of the 16-lane row)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ inline double wave_total(double v) { return red_rows(red8(v)); }
+// fixed-order fold of nb partial sums by ONE wave (every lane gets the total)
+// (all loads are issued before the first add: a runtime-trip-count loop would serialise the memory latencies —
+//  measured with the stamps build: 7.6 K cycles of preamble per launch, scripts/cg_stamps.py)
+__device__ inline double fold_partials(const double* __restrict__ part, int nb) {
+    const int lane = threadIdx.x & 63;
+    double t[NBMAX / 64];
+#pragma unroll
+    for (int u = 0; u < NBMAX / 64; ++u) { const int k = lane + 64 * u; t[u] = k < nb ? part[k] : 0.0; }
+    double v = 0.0;
+#pragma unroll
+    for (int u = 0; u < NBMAX / 64; ++u) v += t[u];
+    return wave_total(v);
+}
+// two folds with every load of both in flight together
+__device__ inline void fold_partials2(const double* __restrict__ pa, const double* __restrict__ pb, int nb, double* a, double* b) {
+    const int lane = threadIdx.x & 63;
+    double t[NBMAX / 64], u_[NBMAX / 64];
+#pragma unroll
+    for (int u = 0; u < NBMAX / 64; ++u) { const int k = lane + 64 * u; t[u] = k < nb ? pa[k] : 0.0; u_[u] = k < nb ? pb[k] : 0.0; }
+    double va = 0.0, vb = 0.0;
+#pragma unroll
+    for (int u = 0; u < NBMAX / 64; ++u) { va += t[u]; vb += u_[u]; }
+    *a = wave_total(va); *b = wave_total(vb);
+}
+// sum over the 8 row groups of a wave of a value held by the lanes with the same (lane & 7); lanes 0..7 get the totals
+__device__ inline double sum_over_rows(double v) {
+    v += dpp_d<0x128>(v);    // row_ror:8 -> lane i += lane (i+8) mod 16 of its 16-lane row
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// has the reference's energy stop rule fired after some ARAP iteration t < it ?
+// deform(): checked after iteration t when t+1 < iters and t != 0 (Appendix A.6).
+// efin[t] holds the reduced energies of the iterations t < it.
+__device__ inline bool arap_done_before(const double* __restrict__ efin, int it, double tol) {
+    if (!(tol > 0.0)) return false;
+    for (int t = 1; t < it; ++t) {
+        const double dif = fabs((efin[t - 1] - efin[t]) / efin[t]);
+        if (dif < tol) return true;
+    }
+    return false;
+}
+
+}  // namespace
+#endif

@@ -41,6 +41,16 @@ struct SellDev {               // "ELL-8 by row group" adjacency of the template
     const int32_t* is_ctrl;    // V
 };
 
+struct RasDev {                // patches of the restricted additive Schwarz solver (schwarz.hip)
+    int32_t NP, NPpad, W;      // patches, NP rounded up to 64, entries per local row (8 / 12 / 16)
+    const int32_t* prow;       // NP+1: first local row of each patch in the row tables
+    const int32_t* pown;       // NP: owned rows (they come first in a patch)
+    const int32_t* l2g;        // local row -> vertex
+    const int16_t* lcol;       // per patch entry-major [W][nloc]: local column, -1 padding, -2 outside the patch
+    const int32_t* gent;       // same layout: entry id in the ELL-8 adjacency (addresses SellDev::w), -1 padding
+    const int32_t* gcol;       // same layout: vertex of the column, -1 padding
+};
+
 #define MVS_NBMAX 256                      /* max workgroups of a row kernel = partial sums per global sum (arap.hip) */
 #define MVS_CG_FIN (6 * MVS_NBMAX)
 #define MVS_CG_SLOT (MVS_CG_FIN + 16)      /* doubles per CG slot: part[6][NBMAX] (gamma, delta) | alpha[3] gamma[3] bnorm[3] pad */
@@ -90,6 +100,15 @@ struct mvs_deform_s {
     int64_t slots_cap = 0;
     int cg_iters = 0;               // 0 = not calibrated yet, else max over cg_plan
     int cg_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // calibrated CG launches of each ARAP iteration's global solve
+    // patch solver (schwarz.hip): tables, second solution buffer, right-hand side, per-sweep slots, local iteration counts
+    RasDev ras{};
+    bool has_ras = false;
+    int64_t ras_rows = 0;
+    int ras_block = 1024;           // workgroup size of the sweep kernel
+    double *d_ras_x2 = nullptr, *d_ras_b = nullptr, *d_ras_slots = nullptr;
+    int32_t *d_ras_iters = nullptr;
+    int64_t ras_slots_cap = 0;
+    int ras_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // calibrated sweeps per ARAP iteration (0 = not calibrated)
     // timing
     int timing = 0;                 // 0 off, 1 all phases, 2 "cg" groups only
     std::map<std::string, PhaseTimer> timers;
@@ -120,8 +139,9 @@ void launch_gather_nodes(const double* pts, const double* nrm, const int32_t* no
 void launch_smooth(const double* orig, const double* cur, const int32_t* nbr, int nn, int K, double* out, hipStream_t s);
 void launch_cot_weights(const SellDev& m, const double* pts, double* coef, hipStream_t s);     // 2 launches
 void launch_arap_prepare(const SellDev& m, const double* pts, const double* ctrl, double* sol, double* rot, hipStream_t s);
+// bout != NULL: patch-solver mode, writes the right-hand side b (V*3) instead of the CG state (rws, p)
 void launch_arap_rhs(const SellDev& m, const double* pts, const double* sol, const double* rot, int it, double tol,
-                     double* ered, double* rws, double* p, hipStream_t s);
+                     double* ered, double* rws, double* p, double* bout, hipStream_t s);
 void launch_cg_w0(const SellDev& m, const double* coef, int it, double tol, const double* ered, double* rws,
                   double* slot0, hipStream_t s);
 // slot_i = slot of CG iteration i of this solve (slot0 + i*MVS_CG_SLOT); alpha_i / gamma_i are written into it
@@ -133,6 +153,13 @@ void launch_arap_local(const SellDev& m, const double* pts, const double* sol, i
 void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered, const double* sol,
                           double* pts, int32_t* info, hipStream_t s);
 int  arap_grid_blocks(const SellDev& m);
+// schwarz.hip
+int  ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& rowptr, const std::vector<int32_t>& col,
+               const std::vector<int32_t>& slice_off);
+void ras_free(mvs_deform_s* h);
+int  ras_slot_size(const mvs_deform_s* h);       // doubles per sweep slot: part[3][NPpad] | gamma[3] bn[3] pad
+void launch_ras_sweep(const mvs_deform_s* h, const double* b, const double* xin, double* xout, int it, double arap_tol, int sweep,
+                      double cg_tol, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s);
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf,
                            int V, double* out, hipStream_t s);
 

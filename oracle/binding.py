@@ -39,7 +39,7 @@ class Params(C.Structure):
                 ("max_result", C.c_int32), ("top_k", C.c_int32), ("graph_k", C.c_int32),
                 ("smooth_sweeps", C.c_int32), ("arap_iters", C.c_int32),
                 ("arap_tol", C.c_double), ("cg_tol", C.c_double),
-                ("cg_max_iters", C.c_int32), ("update_normals", C.c_int32)]
+                ("cg_max_iters", C.c_int32), ("update_normals", C.c_int32), ("solver", C.c_int32), ("reserved0", C.c_int32)]
 
     @classmethod
     def default(cls, **kw):

@@ -36,6 +36,7 @@ typedef struct orc_params {          /* same layout as mvs_deform_params */
     int32_t max_result, top_k, graph_k, smooth_sweeps, arap_iters;
     double  arap_tol, cg_tol;
     int32_t cg_max_iters, update_normals;
+    int32_t solver, reserved0;      /* product-side solver choice; the oracle always solves directly */
 } orc_params;
 
 /* ---- small math (exposed for property tests) ---- */

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported():
 def test_struct_layouts_match_the_header():
     from multiviewstitch_amd import _lib
     assert C.sizeof(_lib.CCamera) == 4 * 8 + 9 * 8 + 3 * 8 + 2 * 4
-    assert C.sizeof(_lib.CParams) == 72
+    assert C.sizeof(_lib.CParams) == 80
     assert C.sizeof(_lib.CStats) == 4 * 4 + 8 * 8 + 8 + 2 * 4
     assert _lib.CAND_DTYPE.itemsize == 48
     from oracle import binding as O
