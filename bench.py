@@ -131,7 +131,7 @@ def main():
 
     # ------------------------------------------------------------ warmup + timed ----
     st = run(max(args.warmup, 1))          # also calibrates the CG launch count
-    log(f"[bench r{rank}] warmup done: cg_iters/solve={st['cg_iters']} arap_iters_run={st['arap_iters_run']} "
+    log(f"[bench r{rank}] warmup done: solver iterations={st['cg_iters']} arap_iters_run={st['arap_iters_run']} "
         f"n_valid={st['n_valid']} cg_rel_residual={st['cg_rel_residual']:.2e}")
     d.enable_timing(2)                      # HIP events around the CG groups only (2 per solve)
     fence()
@@ -151,39 +151,51 @@ def main():
     value = args.steps / elapsed
 
     # ---------------------------------------------------------------- roofline ----
-    # dominant kernel: k_cg_iter (one launch = one CG iteration over all V rows, 3 rhs fused).
-    # Algorithmic bytes per launch: every CG vector r,w,s,p,x read once and
-    # written once (fp64 AoS, 24 B) + diag 8 B + ctrl id 4 B per vertex row, + 12 B (col 4, w 8)
-    # per stored SELL-64 entry.
+    # Dominant kernel = the global-solve kernel (the "cg" phase timer brackets exactly its launches).
     V = len(sc.verts)
+    info = d.solver_info()
     deg = np.bincount(sc.faces.reshape(-1), minlength=V)          # closed manifold: degree == facet count
-    # ELL-8 by row group (arap.hip): a group of 8 rows stores ceil(max degree / 8) passes of 64 entries
-    n_entries = int(sum(-(-int(deg[i:i + 8].max()) // 8) * 64 for i in range(0, V, 8)))
-    cg_bytes = 252 * V + 12 * n_entries
+    if info["kind"] == "patch":
+        # k_ras_sweep (schwarz.hip): one launch = one overlapping-patch sweep over all V rows, 3 rhs fused.
+        # Algorithmic bytes per launch: the patch tables are distinct data per patch-local row
+        # (lcol 2 + gcol 4 + weight 8 per stored entry, l2g 4, diagonal 8), every vertex's x and b are needed once
+        # (24 + 24; re-reads by the overlap rows are not counted) and every vertex's x is written once (24).
+        kernel = "k_ras_sweep"
+        solve_bytes = (14 * info["width"] + 12) * info["local_rows"] + 72 * V
+    else:
+        # k_cg_iter (arap.hip): one launch = one CG iteration over all V rows: every CG vector r,w,s,p,x read once and
+        # written once (fp64 AoS, 24 B) + diag 8 B + ctrl id 4 B per vertex row, + 12 B (col 4, w 8) per stored entry
+        # of the ELL-8-by-row-group layout (a group of 8 rows stores ceil(max degree / 8) passes of 64 entries).
+        kernel = "k_cg_iter"
+        n_entries = int(sum(-(-int(deg[i:i + 8].max()) // 8) * 64 for i in range(0, V, 8)))
+        solve_bytes = 252 * V + 12 * n_entries
     roofline = None
     # HBM-side traffic of the same kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
-    # separate runs, gfx950 x2 fetch correction calibrated on k_srt_apply): profiles/rNN/pmc_traffic.json
+    # separate runs, gfx950 x2 fetch correction calibrated on k_srt_apply): profiles/rNN/pmc_traffic*.json
     traffic, traffic_src = None, None
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic*.json"))):
         try:
             t = json.load(open(f))
-            if t.get("kernel") == "k_cg_iter" and t.get("vertices") == V:
+            if t.get("kernel") == kernel and t.get("vertices") == V:
                 traffic, traffic_src = int(t["bytes_per_active_launch"]), os.path.relpath(f, ROOT)
         except Exception:
             pass
     if cg_launches > 0 and cg_ms > 0:
-        # launches that found all three right-hand sides converged exit after the scalar preamble and move no
-        # vertex data: only the active ones count as algorithmic traffic (stats of the last step; every step
-        # launches the same plan)
+        # launches that found all three right-hand sides converged degenerate into a copy of the owned rows (patch
+        # sweeps) or exit after the scalar preamble (CG): only the active ones count as algorithmic traffic (stats of
+        # the last step; every step launches the same plan)
         active_frac = st["cg_active"] / max(1, st["cg_launches"])
         avg_s = 1e-3 * cg_ms / cg_launches
-        ach = active_frac * cg_bytes / avg_s / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_cg_iter", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+        ach = active_frac * solve_bytes / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "bytes_per_launch": cg_bytes,
+                    "bytes_per_launch": solve_bytes,
                     "avg_launch_us": round(1e6 * avg_s, 3), "launches": int(cg_launches), "active_fraction": round(active_frac, 3),
                     "share_of_step": round(cg_ms / (1e3 * elapsed), 3)}
+        if info["kind"] == "patch":
+            roofline["note"] = ("LDS-resident local iterations: the launch is bound by its dependent load chain and workgroup "
+                                "barriers, not by HBM bytes; local Chebyshev steps per launch = 8")
 
     # the iteration with ONE global solve per outer pass, next to the reference's own schedule
     # (ARAP(5, 1e-4), the timed step above); and the box's device-to-device streaming-copy ceiling.
@@ -260,7 +272,8 @@ def main():
                                    f"P={P_total} target points, K={K} nodes, V={V} template vertices; step = associate + "
                                    f"9-NN graph + 2 smoothing sweeps + ARAP(5, 1e-4) + geometry update",
                        "points": P_total, "nodes": int(K), "vertices": V, "views_per_gpu": len(my_views),
-                       "cg_iters_per_solve": int(st["cg_iters"]), "parallelism": f"views sharded x{world}, template replicated"},
+                       "global_solver": info["kind"], "solver_launches_per_step": int(st["cg_launches"]),
+                       "local_iters_per_step": int(st["cg_iters"]), "parallelism": f"views sharded x{world}, template replicated"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         if single is not None:

@@ -336,6 +336,12 @@ int mvs_deform_get_node_graph(mvs_deform_t h, int32_t* nbr /*K*(graph_k+1)*/);
 /* exportOBJ's normals (Deformation.h:86-150,174-191) for the current geometry. */
 int mvs_deform_compute_normals(mvs_deform_t h, double* normals /*V*3*/);
 
+/* Which global solver mvs_deform_solve would use with `p` (NULL = defaults): kind 0 = CG (one launch per iteration),
+ * 1 = overlapping-patch sweeps; for kind 1 the number of patches, the total number of patch-local rows (owned +
+ * overlap) and the stored entries per row. */
+int mvs_deform_solver_info(mvs_deform_t h, const mvs_deform_params* p, int32_t* kind, int64_t* patches,
+                           int64_t* local_rows, int32_t* width);
+
 /* Stand-alone pieces of the body (parity tests / callers that only need one):
  * KNearestNeighbor on arbitrary points (Deformation.cpp:108-153) and the
  * CGAL-equivalent ARAP solve with explicit constraints (Deformation.cpp:383-400). */

@@ -114,6 +114,7 @@ _SIGS = {
     "mvs_deform_get_node_targets": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP]),
     "mvs_deform_get_node_graph": (C.c_int, [_VP, _VP]),
     "mvs_deform_compute_normals": (C.c_int, [_VP, _VP]),
+    "mvs_deform_solver_info": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "mvs_knn_points": (C.c_int, [_VP, _I64, _I32, _VP]),
     "mvs_deform_arap": (C.c_int, [_VP, _VP, _VP, _VP]),
     "mvs_deform_kernel_time": (C.c_int, [_VP, C.c_char_p, _VP, _VP]),

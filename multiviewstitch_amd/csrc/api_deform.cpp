@@ -217,8 +217,9 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     if (rc) return rc;
     {
         Tic t = tic(h, "weights");
-        launch_cot_weights(h->sell, h->d_pts, h->d_coef, s);                                      // preprocess(), :393
+        launch_cot_weights(h->sell, h->d_pts, ras ? nullptr : h->d_coef, s);                      // preprocess(), :393
         launch_arap_prepare(h->sell, h->d_pts, ctrl, h->d_sol, h->d_rot, s);                     // :383-392
+        if (ras) launch_ras_prepare(h, s);
         toc(t, 3);
     }
     double* x_cur = h->d_sol;            // the patch solver ping-pongs between d_sol and d_ras_x2
@@ -379,7 +380,7 @@ int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* s
             bool ok = true;
             for (int c = 0; c < 3; ++c) {
                 double g = 0.0;
-                for (int q = 0; q < NP; ++q) g += S[c * NPpad + q];
+                for (int q = 0; q < 4 * NP; ++q) g += S[c * NPpad + q];
                 if (g > 0.0 && g > p.cg_tol * p.cg_tol * bn[c]) ok = false;
                 if (rel && bn[c] > 0) *rel = std::max(*rel, std::sqrt(std::max(0.0, g) / bn[c]));
             }
@@ -753,6 +754,15 @@ int mvs_deform_arap(mvs_deform_t h, const mvs_deform_params* p, const double* ct
     rc = enqueue_solve(h, *p, h->d_ctrl_a, false, cg);
     if (rc) return rc;
     return harvest(h, *p, cg, stats, nullptr);
+}
+int mvs_deform_solver_info(mvs_deform_t h, const mvs_deform_params* p, int32_t* kind, int64_t* patches, int64_t* local_rows, int32_t* width) {
+    if (!h) { mvs_set_error("handle is NULL"); return MVS_E_INVALID_ARG; }
+    const bool ras = h->has_ras && (!p || p->solver != MVS_SOLVER_CG);
+    if (kind) *kind = ras ? 1 : 0;
+    if (patches) *patches = ras ? h->ras.NP : 0;
+    if (local_rows) *local_rows = ras ? h->ras_rows : 0;
+    if (width) *width = ras ? h->ras.W : 0;
+    return MVS_OK;
 }
 int mvs_deform_sync(mvs_deform_t h) {
     if (!h) return MVS_E_INVALID_ARG;

@@ -599,7 +599,7 @@ void launch_smooth(const double* orig, const double* cur, const int32_t* nbr, in
 void launch_cot_weights(const SellDev& m, const double* pts, double* coef, hipStream_t s) {
     const dim3 g(arap_grid_blocks(m));
     k_cot_weights<<<g, dim3(TPB), 0, s>>>(m, pts);
-    k_cg_coef<<<g, dim3(TPB), 0, s>>>(m, coef);
+    if (coef) k_cg_coef<<<g, dim3(TPB), 0, s>>>(m, coef);      // CG only (the patch solver builds its own matrix)
 }
 void launch_arap_prepare(const SellDev& m, const double* pts, const double* ctrl, double* sol, double* rot, hipStream_t s) {
     k_arap_prepare<<<dim3((m.V + 255) / 256), dim3(256), 0, s>>>(m, pts, ctrl, sol, rot);

@@ -42,7 +42,7 @@ struct SellDev {               // "ELL-8 by row group" adjacency of the template
 };
 
 struct RasDev {                // patches of the restricted additive Schwarz solver (schwarz.hip)
-    int32_t NP, NPpad, W;      // patches, NP rounded up to 64, entries per local row (8 / 12 / 16)
+    int32_t NP, NPpad, W;      // patches, 4*NP partial sums rounded up to 64, entries per local row (8 / 12 / 16)
     const int32_t* prow;       // NP+1: first local row of each patch in the row tables
     const int32_t* pown;       // NP: owned rows (they come first in a patch)
     const int32_t* l2g;        // local row -> vertex
@@ -105,7 +105,7 @@ struct mvs_deform_s {
     bool has_ras = false;
     int64_t ras_rows = 0;
     int ras_block = 1024;           // workgroup size of the sweep kernel
-    double *d_ras_x2 = nullptr, *d_ras_b = nullptr, *d_ras_slots = nullptr;
+    double *d_ras_x2 = nullptr, *d_ras_b = nullptr, *d_ras_slots = nullptr, *d_ras_pw = nullptr, *d_ras_pd = nullptr;
     int32_t *d_ras_iters = nullptr;
     int64_t ras_slots_cap = 0;
     int ras_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // calibrated sweeps per ARAP iteration (0 = not calibrated)
@@ -158,6 +158,7 @@ int  ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& r
                const std::vector<int32_t>& slice_off);
 void ras_free(mvs_deform_s* h);
 int  ras_slot_size(const mvs_deform_s* h);       // doubles per sweep slot: part[3][NPpad] | gamma[3] bn[3] pad
+void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s);
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, const double* xin, double* xout, int it, double arap_tol, int sweep,
                       double cg_tol, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s);
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf,

@@ -25,6 +25,7 @@
 #include "arap_dev.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 #include <vector>
@@ -39,7 +40,6 @@ __device__ unsigned long long g_ras_stamps[4096 * 8];
 #define RSTAMP(k)
 #endif
 constexpr int RTPB = 1024;          // threads per workgroup = max local rows of a patch
-constexpr int RNW = RTPB / 64;
 
 // uniform double from lane `l` of the wave (two v_readlane: no LDS crossbar as __shfl would use)
 __device__ inline double lane_bcast(double v, int l) {
@@ -81,7 +81,7 @@ __device__ inline double fast_inv(double x) {
     return y * (2.0 - x * y);
 }
 
-// fold n partial sums (n <= 4096) by one wave, every lane gets the total; loads of a chunk are issued together
+// fold n partial sums by one wave, every lane gets the total; loads of a chunk are issued together
 __device__ inline double fold_n(const double* __restrict__ part, int n) {
     const int lane = threadIdx.x & 63;
     double v = 0.0;
@@ -94,33 +94,85 @@ __device__ inline double fold_n(const double* __restrict__ part, int n) {
     return wave_total(v);
 }
 
-// slot of one sweep: part[3][NPpad] | gamma[3] bn[3] frozen pad
+// slot of one sweep: part[3][NPpad] | gamma[3] bn[3] pad.  Partials: one per (patch, wave 0..3) — the owned rows of a
+// patch (<= 256) sit in its first four waves, so no workgroup-level reduction is needed for the residual norm.
 __host__ __device__ inline int ras_slot_doubles(int NPpad) { return 3 * NPpad + 8; }
 
-template <int W>
-__global__ __launch_bounds__(RTPB) void k_ras_sweep(SellDev m, RasDev R, const double* __restrict__ bvec,
-                                                    const double* __restrict__ xin, double* __restrict__ xout, int it,
-                                                    double arap_tol, const double* __restrict__ ered, int nb_rhs, int sweep,
-                                                    double cg_tol, double cheb_a, int cheb_m, double* __restrict__ slot_prev,
-                                                    double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur) {
-    __shared__ float4 dbuf[2][RTPB];             // correction direction of the local rows, double-buffered.  float32: the
-                                                 // neighbours' directions only steer the inexact local solve; x, r, e stay fp64
-    __shared__ double red[2][RNW][8];
+struct ChebCoef { double c0, c1[16], c2[16]; };      // d_0 = c0 D^-1 r ;  d_{k+1} = c1[k] d_k + c2[k] D^-1 r_{k+1}
 
+// Once per outer iteration (after the cotangent weights and the control set are known): the patch-local matrix.
+//   pw[e][row] = 2 w_ij for a free row i and a free column j (inside OR outside the patch), else 0
+//   pd[row]    = diag_i for a free row, 0 for a control vertex
+template <int W>
+__global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, double* __restrict__ pw, double* __restrict__ pd) {
+    const int p = blockIdx.x, row = threadIdx.x;
+    const int base = R.prow[p], nloc = R.prow[p + 1] - base;
+    if (row >= nloc) return;
+    const int g = R.l2g[base + row];
+    const bool fixed = m.is_ctrl[g] != 0;
+    pd[base + row] = fixed ? 0.0 : m.diag[g];
+    const int32_t* gent = R.gent + (int64_t)base * W;
+    const int32_t* gcol = R.gcol + (int64_t)base * W;
+    double* o = pw + (int64_t)base * W;
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        const int ge = gent[e * nloc + row], gc = gcol[e * nloc + row];
+        o[e * nloc + row] = (ge >= 0 && !fixed && !m.is_ctrl[gc]) ? 2.0 * m.w[ge] : 0.0;
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __restrict__ pw, const double* __restrict__ pd,
+                                                    const double* __restrict__ bvec, const double* __restrict__ xin,
+                                                    double* __restrict__ xout, int it, double arap_tol,
+                                                    const double* __restrict__ ered, int nb_rhs, int sweep, double cg_tol,
+                                                    ChebCoef cc, int cheb_m, double* __restrict__ slot_prev,
+                                                    double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur) {
+    // LDS: fp64 x of the local rows while the residual is formed (24 KB), then the float32 correction directions,
+    // double-buffered (2 x 16 KB).  float32 there: the neighbours' directions only steer the inexact local solve; the
+    // residual, the accumulated correction and the solution stay fp64.
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * RTPB * sizeof(float4)];
     __shared__ double s_gam[3], s_bn[3];
     __shared__ int s_done;
+    double (*xs)[3] = reinterpret_cast<double (*)[3]>(smem);
+    float4* dbuf = reinterpret_cast<float4*>(smem);
     const int p = blockIdx.x, row = threadIdx.x, lane = row & 63, wv = row >> 6;
     const int base = R.prow[p], nloc = R.prow[p + 1] - base, nown = R.pown[p];
     const bool live = row < nloc;
-    const int g = live ? R.l2g[base + row] : 0;
     const int NPpad = R.NPpad;
     RSTAMP(0);
-    // ---- loads that do not depend on the convergence scalars
+    // ---- operand loads, issued before the convergence scalars are known (a frozen sweep wastes them, a planned one
+    //      overlaps them with the fold of the previous sweep's partials): tables, then this row's x, b, diagonal
+    const int g = live ? R.l2g[base + row] : 0;
+    int lc[W], gc[W];
+    double w2[W];
+    {
+        const int16_t* lcol = R.lcol + (int64_t)base * W;
+        const int32_t* gcol = R.gcol + (int64_t)base * W;
+        const double* pwp = pw + (int64_t)base * W;
+#pragma unroll
+        for (int e = 0; e < W; ++e) {                  // entry-major inside the patch: consecutive rows, consecutive addresses
+            lc[e] = live ? (int)lcol[e * nloc + row] : -1;
+            gc[e] = live ? gcol[e * nloc + row] : -1;
+            w2[e] = live ? pwp[e * nloc + row] : 0.0;
+        }
+    }
     const d3 xi = live ? ld3(xin + 3 * (int64_t)g) : mk3(0, 0, 0);
-    const bool fixed = !live || m.is_ctrl[g] != 0;
+    const double dd = live ? pd[base + row] : 0.0;
+    const bool fixed = dd == 0.0;
+    d3 rhs = live ? ld3(bvec + 3 * (int64_t)g) : mk3(0, 0, 0);      // (b is 0 on control rows)
+    // columns outside the patch: frozen at the previous sweep's value, moved to the right-hand side (branch-free gathers)
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        const bool outside = lc[e] == -2 && w2[e] != 0.0;
+        const d3 xo = ld3(xin + 3 * (int64_t)(outside ? gc[e] : g));
+        const double wo = outside ? w2[e] : 0.0;
+        rhs = mk3(__builtin_fma(wo, xo.x, rhs.x), __builtin_fma(wo, xo.y, rhs.y), __builtin_fma(wo, xo.z, rhs.z));
+        if (lc[e] < 0) { lc[e] = row; w2[e] = 0.0; }
+    }
     // ---- preamble: waves 0..2 fold the residual partials of the previous sweep, waves 3..5 the bnorm partials of the rhs kernel
     if (wv < 3) {
-        const double gam = sweep > 0 ? fold_n(slot_prev + wv * NPpad, R.NP) : INFINITY;
+        const double gam = sweep > 0 ? fold_n(slot_prev + wv * NPpad, R.NP * 4) : INFINITY;
         if (lane == 0) s_gam[wv] = gam;
     } else if (wv < 6) {
         const double bn = fold_partials(ered + it * EIT + (1 + (wv - 3)) * NBMAX, nb_rhs);
@@ -128,6 +180,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(SellDev m, RasDev R, const d
     } else if (row == 6 * 64) {
         s_done = arap_done_before(ered + EFIN, it, arap_tol) ? 1 : 0;
     }
+    xs[row][0] = xi.x; xs[row][1] = xi.y; xs[row][2] = xi.z;
     __syncthreads();
     RSTAMP(1);
     const double bn[3] = {s_bn[0], s_bn[1], s_bn[2]};
@@ -135,90 +188,63 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(SellDev m, RasDev R, const d
 #pragma unroll
     for (int c = 0; c < 3; ++c) if (s_gam[c] > 0.0 && s_gam[c] > cg_tol * cg_tol * bn[c]) frozen = false;
     if (p == 0 && row < 3 && sweep > 0) { slot_prev[3 * NPpad + row] = s_gam[row]; slot_prev[3 * NPpad + 3 + row] = bn[row]; }
+    if (p == 0 && row < 3) { slot_cur[3 * NPpad + row] = 0.0; slot_cur[3 * NPpad + 3 + row] = bn[row]; }
     if (s_done || frozen) {
         // nothing to solve: keep the ping-pong buffers consistent, carry the converged partials forward
         if (row < nown) st3(xout + 3 * (int64_t)g, xi);
-        if (row < 3) slot_cur[row * NPpad + p] = (frozen && !s_done) ? slot_prev[row * NPpad + p] : 0.0;
+        if (row < 12) slot_cur[(row >> 2) * NPpad + 4 * p + (row & 3)] = (frozen && !s_done) ? slot_prev[(row >> 2) * NPpad + 4 * p + (row & 3)] : 0.0;
         if (row == 0) iters_cur[p] = 0;
-        if (p == 0 && row < 3) { slot_cur[3 * NPpad + row] = 0.0; slot_cur[3 * NPpad + 3 + row] = bn[row]; }
         return;
     }
-    // ---- local system: row operands in registers.  Loads are arranged in three dependent hops only
-    // (tables -> operands of this row and of its entries), branch-free so that all of a hop's loads are in flight together.
-    const int16_t* lcol = R.lcol + (int64_t)base * W;
-    const int32_t* gent = R.gent + (int64_t)base * W;
-    const int32_t* gcol = R.gcol + (int64_t)base * W;
-    int lc[W], ge[W], gc[W];
-#pragma unroll
-    for (int e = 0; e < W; ++e) {                   // entry-major inside the patch: consecutive rows, consecutive addresses
-        lc[e] = live ? (int)lcol[e * nloc + row] : -1;
-        ge[e] = live ? gent[e * nloc + row] : -1;
-        gc[e] = live ? gcol[e * nloc + row] : -1;
-    }
-    const double di = fixed ? 1.0 : m.diag[g];
-    d3 rhs = (live && !fixed) ? ld3(bvec + 3 * (int64_t)g) : mk3(0, 0, 0);
-    double w2[W];
-    int jc[W];
-#pragma unroll
-    for (int e = 0; e < W; ++e) {
-        w2[e] = 2.0 * m.w[ge[e] >= 0 ? ge[e] : 0];
-        jc[e] = m.is_ctrl[gc[e] >= 0 ? gc[e] : g];
-    }
-    // residual of the input: r = b - (d x_i - sum_j 2 w_ij x_j) over the free columns (control columns are in b).
-    // Every column is read from the previous sweep's vector; columns outside the patch then leave the local matrix
-    // (frozen at that value), which is what makes the sweep a restricted additive Schwarz step.
+    // ---- residual of the input on the local rows: r = b + (outside columns) - (d x_i - sum_inside 2 w_ij x_j)
+    const double di = fixed ? 1.0 : dd;
     d3 r = mk3(0, 0, 0);
     {
         d3 acc = mk3(0, 0, 0);
 #pragma unroll
-        for (int e = 0; e < W; ++e) {
-            const bool use = ge[e] >= 0 && !fixed && !jc[e];
-            if (!use) w2[e] = 0.0;
-            const d3 xo = ld3(xin + 3 * (int64_t)(use ? gc[e] : g));
-            acc = acc + w2[e] * xo;
-            if (lc[e] < 0) { lc[e] = row; w2[e] = 0.0; }
-        }
+        for (int e = 0; e < W; ++e)
+            acc = mk3(__builtin_fma(w2[e], xs[lc[e]][0], acc.x), __builtin_fma(w2[e], xs[lc[e]][1], acc.y), __builtin_fma(w2[e], xs[lc[e]][2], acc.z));
         if (!fixed) r = rhs - (mk3(di * xi.x, di * xi.y, di * xi.z) - acc);
     }
     RSTAMP(2);
     const double inv_d = 1.0 / di;
     const int nw = (nloc + 63) >> 6;                                   // waves that hold rows
-    {   // owned rows only -> the global residual norm of the input (every vertex is owned by exactly one patch)
-        double o[3] = {row < nown ? r.x * r.x * inv_d : 0.0, row < nown ? r.y * r.y * inv_d : 0.0, row < nown ? r.z * r.z * inv_d : 0.0};
-        block_sum<3>(o, red[0], nw);
-        if (row < 3) slot_cur[row * NPpad + p] = row == 0 ? o[0] : (row == 1 ? o[1] : o[2]);
+    if (wv < 4) {   // owned rows only -> the global residual norm of the input (every vertex is owned by exactly one patch)
+        const bool own = row < nown;
+        const double o0 = wave_sum_u(own ? r.x * r.x * inv_d : 0.0), o1 = wave_sum_u(own ? r.y * r.y * inv_d : 0.0),
+                     o2 = wave_sum_u(own ? r.z * r.z * inv_d : 0.0);
+        if (lane < 3) slot_cur[lane * NPpad + 4 * p + wv] = lane == 0 ? o0 : (lane == 1 ? o1 : o2);
     }
     RSTAMP(3);
     // Local solve: `cheb_m` steps of the Chebyshev semi-iteration on D^-1 A_loc e = D^-1 r with the spectrum of the
-    // Jacobi-scaled patch matrix bracketed by [cheb_a, 2] (2 is the Gershgorin bound of a weakly diagonally dominant
+    // Jacobi-scaled patch matrix bracketed by [a, 2] (2 is the Gershgorin bound of a weakly diagonally dominant
     // M-matrix; the lower end is a parameter — measured 0.12..0.16 on the bench mesh — and an estimate above the true
-    // value only slows the smooth modes down, it cannot diverge).  No inner products: one workgroup barrier per step.
-    // The correction direction lives in LDS (neighbours read it), everything else in registers.
-    const double theta = 0.5 * (2.0 + cheb_a), delta = 0.5 * (2.0 - cheb_a), sigma1 = theta / delta;
-    double rho = 1.0 / sigma1;
+    // value only slows the smooth modes down, it cannot diverge).  No inner products: one workgroup barrier per step;
+    // the step coefficients come precomputed from the host.
     d3 e = mk3(0, 0, 0);
-    d3 dv = (1.0 / theta) * (inv_d * r);
+    d3 dv = cc.c0 * (inv_d * r);
+    __syncthreads();                                                   // xs has been read by everyone: the buffer turns into dbuf
     for (int k = 0; k < cheb_m; ++k) {
-        float4* buf = dbuf[k & 1];
+        float4* buf = dbuf + (k & 1) * RTPB;
         buf[row] = make_float4((float)dv.x, (float)dv.y, (float)dv.z, 0.0f);
         __syncthreads();
         if (wv < nw) {
             d3 adv = mk3(di * dv.x, di * dv.y, di * dv.z);
 #pragma unroll
-            for (int q = 0; q < W; ++q) { const float4 t = buf[lc[q]]; adv = adv - w2[q] * mk3((double)t.x, (double)t.y, (double)t.z); }
+            for (int q = 0; q < W; ++q) {
+                const float4 t = buf[lc[q]];
+                adv = mk3(__builtin_fma(-w2[q], (double)t.x, adv.x), __builtin_fma(-w2[q], (double)t.y, adv.y), __builtin_fma(-w2[q], (double)t.z, adv.z));
+            }
             if (fixed) adv = mk3(0, 0, 0);
             e = e + dv;
             r = r - adv;
-            const double rho_new = 1.0 / (2.0 * sigma1 - rho);
-            const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
-            dv = c1 * dv + c2 * (inv_d * r);
-            rho = rho_new;
+            const double c1 = cc.c1[k & 15], c2 = cc.c2[k & 15] * inv_d;
+            dv = mk3(__builtin_fma(c1, dv.x, c2 * r.x), __builtin_fma(c1, dv.y, c2 * r.y), __builtin_fma(c1, dv.z, c2 * r.z));
         }
     }
     RSTAMP(4);
     if (row < nown) st3(xout + 3 * (int64_t)g, xi + e);
     if (row == 0) iters_cur[p] = cheb_m;
-    if (p == 0 && row < 3) { slot_cur[3 * NPpad + row] = 0.0; slot_cur[3 * NPpad + 3 + row] = bn[row]; }
     RSTAMP(5);
 }
 
@@ -227,13 +253,6 @@ template <class T> int up(T** d, const std::vector<T>& h) {
     if (hipMalloc((void**)d, std::max<size_t>(1, h.size()) * sizeof(T)) != hipSuccess) { mvs_set_error("hipMalloc failed (patch tables)"); return MVS_E_OOM; }
     if (!h.empty() && hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { mvs_set_error("upload failed (patch tables)"); return MVS_E_HIP; }
     return MVS_OK;
-}
-
-inline uint64_t spread3(uint64_t v) {
-    v &= 0x1fffff;
-    v = (v | v << 32) & 0x1f00000000ffffULL; v = (v | v << 16) & 0x1f0000ff0000ffULL; v = (v | v << 8) & 0x100f00f00f00f00fULL;
-    v = (v | v << 4) & 0x10c30c30c30c30c3ULL; v = (v | v << 2) & 0x1249249249249249ULL;
-    return v;
 }
 
 }  // namespace
@@ -247,8 +266,8 @@ extern "C" int mvs_debug_ras_stamps(unsigned long long* out, int n) {
 void ras_free(mvs_deform_s* h) {
     auto fr = [](const void* p) { if (p) (void)hipFree(const_cast<void*>(p)); };
     fr(h->ras.prow); fr(h->ras.pown); fr(h->ras.l2g); fr(h->ras.lcol); fr(h->ras.gent); fr(h->ras.gcol);
-    fr(h->d_ras_x2); fr(h->d_ras_b); fr(h->d_ras_slots); fr(h->d_ras_iters);
-    h->ras = RasDev{}; h->d_ras_x2 = h->d_ras_b = h->d_ras_slots = nullptr; h->d_ras_iters = nullptr;
+    fr(h->d_ras_x2); fr(h->d_ras_b); fr(h->d_ras_pw); fr(h->d_ras_pd); fr(h->d_ras_slots); fr(h->d_ras_iters);
+    h->ras = RasDev{}; h->d_ras_x2 = h->d_ras_b = h->d_ras_slots = h->d_ras_pw = h->d_ras_pd = nullptr; h->d_ras_iters = nullptr;
     h->has_ras = false; h->ras_slots_cap = 0;
 }
 
@@ -264,38 +283,48 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
     for (int i = 0; i < V; ++i) maxdeg = std::max(maxdeg, rowptr[i + 1] - rowptr[i]);
     const int W = maxdeg <= 8 ? 8 : (maxdeg <= 12 ? 12 : 16);
     if (maxdeg > 16) return MVS_OK;
-    // Morton order of the rest positions
-    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = 0; i < V; ++i) for (int c = 0; c < 3; ++c) { lo[c] = std::min(lo[c], pts[3 * i + c]); hi[c] = std::max(hi[c], pts[3 * i + c]); }
-    const double ext = std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 1e-300});
-    std::vector<std::pair<uint64_t, int>> key(V);
-    for (int i = 0; i < V; ++i) {
-        uint64_t k = 0;
-        for (int c = 0; c < 3; ++c) {
-            const double f = (pts[3 * i + c] - lo[c]) / ext;
-            const uint64_t q = (uint64_t)std::min(2097151.0, std::max(0.0, f * 2097151.0));
-            k |= spread3(q) << c;
-        }
-        key[i] = {k, i};
-    }
-    std::sort(key.begin(), key.end());
     // patches: a whole number of "rounds" of one patch per CU (a 257th patch would cost a second round of the whole chip),
     // at most ~240 owned rows each so that three rings of overlap stay well inside the 1024-row limit
-    const int RINGS = 3;
+    const int RINGS = 3;                              // 2..5 rings measured within 10 % of each other on the bench mesh
     int cus = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
     const int rounds = std::max(1, (V + cus * 240 - 1) / (cus * 240));
     const int NP = std::min(V / 64, cus * rounds);
-    if (NP > 4096) return MVS_OK;                     // fold_n / slot layout limit (V > 850 K): keep CG
+    if (NP > 4096) return MVS_OK;                     // slot layout limit (V > 850 K): keep CG
+    // recursive coordinate bisection of the rest positions into NP parts of equal size: compact, box-like patches
+    // (a Z-curve cut left ragged patches whose three-ring halo was up to 832 rows; bisection keeps it near 450)
+    std::vector<int32_t> order(V), part_begin(NP + 1, 0);
+    std::iota(order.begin(), order.end(), 0);
+    {
+        struct Job { int lo, hi, p0, parts; };
+        std::vector<Job> stack{{0, V, 0, NP}};
+        while (!stack.empty()) {
+            const Job j = stack.back();
+            stack.pop_back();
+            if (j.parts == 1) { part_begin[j.p0] = j.lo; continue; }
+            double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int q = j.lo; q < j.hi; ++q) for (int c = 0; c < 3; ++c) { const double v = pts[3 * order[q] + c]; mn[c] = std::min(mn[c], v); mx[c] = std::max(mx[c], v); }
+            int ax = 0;
+            for (int c = 1; c < 3; ++c) if (mx[c] - mn[c] > mx[ax] - mn[ax]) ax = c;
+            const int pl = j.parts / 2, nl = (int)((int64_t)(j.hi - j.lo) * pl / j.parts);
+            std::nth_element(order.begin() + j.lo, order.begin() + j.lo + nl, order.begin() + j.hi, [&](int a, int b) {
+                const double va = pts[3 * a + ax], vb = pts[3 * b + ax];
+                return va < vb || (va == vb && a < b);
+            });
+            stack.push_back({j.lo, j.lo + nl, j.p0, pl});
+            stack.push_back({j.lo + nl, j.hi, j.p0 + pl, j.parts - pl});
+        }
+        part_begin[NP] = V;
+    }
     std::vector<int32_t> prow(NP + 1, 0), pown(NP), l2g;
     std::vector<int16_t> lcol;
     std::vector<int32_t> gent, gcolv;
     std::vector<int32_t> mark(V, -1), lidx(V, -1);
     l2g.reserve((size_t)V * 3);
     for (int p = 0; p < NP; ++p) {
-        const int a = (int)((int64_t)p * V / NP), b = (int)((int64_t)(p + 1) * V / NP);
-        std::vector<int32_t> rows;
-        for (int k = a; k < b; ++k) { rows.push_back(key[k].second); mark[key[k].second] = p; }
+        std::vector<int32_t> rows(order.begin() + part_begin[p], order.begin() + part_begin[p + 1]);
+        std::sort(rows.begin(), rows.end());            // owned rows in vertex order (gather locality)
+        for (int v : rows) mark[v] = p;
         const int nown = (int)rows.size();
         size_t level_begin = 0;
         for (int ring = 0; ring < RINGS; ++ring) {
@@ -333,7 +362,7 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
         for (int q = nown; q < nloc; ++q) mark[rows[q]] = -1;      // overlap rows may be owned by a later patch
     }
     RasDev R{};
-    R.NP = NP; R.NPpad = (NP + 63) / 64 * 64; R.W = W;
+    R.NP = NP; R.NPpad = (4 * NP + 63) / 64 * 64; R.W = W;
     int rc;
     int32_t *d_prow, *d_pown, *d_l2g, *d_gent, *d_gcol;
     int16_t* d_lcol;
@@ -343,25 +372,50 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
     if (hipMalloc((void**)&h->d_ras_x2, sizeof(double) * 3 * (size_t)V) != hipSuccess || hipMalloc((void**)&h->d_ras_b, sizeof(double) * 3 * (size_t)V) != hipSuccess) {
         mvs_set_error("hipMalloc failed (patch solver vectors)"); return MVS_E_OOM;
     }
+    if (hipMalloc((void**)&h->d_ras_pw, sizeof(double) * (size_t)W * l2g.size()) != hipSuccess || hipMalloc((void**)&h->d_ras_pd, sizeof(double) * l2g.size()) != hipSuccess) {
+        mvs_set_error("hipMalloc failed (patch matrix)"); return MVS_E_OOM;
+    }
     h->ras_rows = (int64_t)l2g.size();
     h->ras_block = 448;                                            // the preamble uses seven waves
     for (int p = 0; p < NP; ++p) h->ras_block = std::max(h->ras_block, (prow[p + 1] - prow[p] + 63) / 64 * 64);
     h->has_ras = true;
+    if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] patch solver: %d patches, %lld local rows for %d vertices, workgroup %d threads, %d entries per row\n", NP, (long long)h->ras_rows, V, h->ras_block, W);
     return MVS_OK;
 }
 
 int ras_slot_size(const mvs_deform_s* h) { return ras_slot_doubles(h->ras.NPpad); }
 
+// once per outer iteration, after launch_cot_weights and the control set: the patch-local matrix
+void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s) {
+    const RasDev& R = h->ras;
+    const dim3 grid(R.NP), blk(h->ras_block);
+    if (R.W == 8) k_ras_prepare<8><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd);
+    else if (R.W == 12) k_ras_prepare<12><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd);
+    else k_ras_prepare<16><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd);
+}
+
 // one sweep of ARAP iteration `it`: slot_prev / slot_cur are the slots of sweeps (sweep-1) / sweep
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, const double* xin, double* xout, int it, double arap_tol, int sweep,
                       double cg_tol, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s) {
-    const SellDev& m = h->sell;
     const RasDev& R = h->ras;
-    const int nb = arap_grid_blocks(m);
-    static const double frac = getenv("MVS_RAS_A") ? atof(getenv("MVS_RAS_A")) : 0.1;     // lower spectral bound of the Chebyshev steps
-    static const int itmax = getenv("MVS_RAS_M") ? std::min(64, std::max(1, atoi(getenv("MVS_RAS_M")))) : 8;    // steps per sweep
+    const int nb = arap_grid_blocks(h->sell);
+    const double cheb_a = 0.1;     // lower spectral bound of the Chebyshev steps (the patch matrices of the bench mesh have 0.12..0.16)
+    const int cheb_m = 8;          // steps per sweep (6..12 measured within 5 % of each other: fewer steps, more sweeps)
+    static ChebCoef cc;
+    static bool have = false;
+    if (!have) {                                   // Saad, Iterative Methods, Alg. 12.1 with [a, 2]
+        const double theta = 0.5 * (2.0 + cheb_a), delta = 0.5 * (2.0 - cheb_a), sigma1 = theta / delta;
+        double rho = 1.0 / sigma1;
+        cc.c0 = 1.0 / theta;
+        for (int k = 0; k < 16; ++k) {
+            const double rho_new = 1.0 / (2.0 * sigma1 - rho);
+            cc.c1[k] = rho_new * rho; cc.c2[k] = 2.0 * rho_new / delta;
+            rho = rho_new;
+        }
+        have = true;
+    }
     const dim3 grid(R.NP), blk(h->ras_block);     // as many waves as the largest patch has rows (idle waves only add barrier cost)
-    if (R.W == 8) k_ras_sweep<8><<<grid, blk, 0, s>>>(m, R, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, frac, itmax, slot_prev, slot_cur, iters_cur);
-    else if (R.W == 12) k_ras_sweep<12><<<grid, blk, 0, s>>>(m, R, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, frac, itmax, slot_prev, slot_cur, iters_cur);
-    else k_ras_sweep<16><<<grid, blk, 0, s>>>(m, R, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, frac, itmax, slot_prev, slot_cur, iters_cur);
+    if (R.W == 8) k_ras_sweep<8><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, cc, cheb_m, slot_prev, slot_cur, iters_cur);
+    else if (R.W == 12) k_ras_sweep<12><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, cc, cheb_m, slot_prev, slot_cur, iters_cur);
+    else k_ras_sweep<16><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, cc, cheb_m, slot_prev, slot_cur, iters_cur);
 }

@@ -197,6 +197,13 @@ class Deformation:
         return out
 
     # ----------------------------------------------------------------- timing --
+    def solver_info(self) -> dict:
+        """which global solver `self.params` selects: {'kind': 'cg' | 'patch', 'patches', 'local_rows', 'width'}"""
+        kind, width = C.c_int32(), C.c_int32()
+        patches, rows = C.c_int64(), C.c_int64()
+        L.check(L.lib().mvs_deform_solver_info(self._h, C.byref(self.params), C.byref(kind), C.byref(patches), C.byref(rows), C.byref(width)))
+        return {"kind": "patch" if kind.value else "cg", "patches": patches.value, "local_rows": rows.value, "width": width.value}
+
     def enable_timing(self, on: int = 1):
         """0 off, 1 every phase, 2 only the "cg" groups (mvs_deform_enable_timing)."""
         L.check(L.lib().mvs_deform_enable_timing(self._h, int(on)))

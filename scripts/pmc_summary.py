@@ -16,7 +16,7 @@ for r in csv.DictReader(open(f)):
 for k, cs in sorted(agg.items()):
     n = len(next(iter(cs.values())))
     print(k, "n=%d" % n, {c: round(sum(v) / len(v), 1) for c, v in sorted(cs.items())})
-    if k == "k_cg_iter":          # launches that exit early (converged) move no vertex data: report the active ones too
+    if k == "k_cg_iter" or k.startswith("k_ras_sweep"):   # launches that find the solve converged move little data: report the active ones too
         for c, v in sorted(cs.items()):
             act = [x for x in v if x > 0.5 * max(v)]
-            print("   k_cg_iter ACTIVE launches only:", c, "n=%d" % len(act), "mean", round(sum(act) / len(act), 1), "max", max(v))
+            print("   %s ACTIVE launches only:" % k, c, "n=%d" % len(act), "mean", round(sum(act) / len(act), 1), "max", max(v))

@@ -67,10 +67,13 @@ def test_association_matches_oracle(eng, oracle, config):
         assert ref["valid"].sum() > 0.5 * len(nodes)
 
 
-def test_iterate_matches_oracle(eng, oracle):
+@pytest.mark.parametrize("solver", [0, 1])          # MVS_SOLVER_AUTO (overlapping-patch sweeps at this size), MVS_SOLVER_CG
+def test_iterate_matches_oracle(eng, oracle, solver):
     sc, tp, tn, _ = scene_and_target(1)
     nodes = oracle.uniform_sampling(sc.verts, 16)
     d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    d.params.solver = solver
+    assert d.solver_info()["kind"] == ("cg" if solver else "patch")
     d.set_nodes(nodes)
     d.set_target(tp, tn)
     o = oracle.Deform(sc.verts, sc.normals, sc.faces)
@@ -91,10 +94,12 @@ def test_iterate_matches_oracle(eng, oracle):
         assert rms(d.rotations().reshape(-1, 9), o.rotations().reshape(-1, 9)) <= 1e-6
 
 
-def test_arap_matches_oracle_and_known_answers(eng, oracle):
+@pytest.mark.parametrize("solver", [0, 1])
+def test_arap_matches_oracle_and_known_answers(eng, oracle, solver):
     sc, _, _, _ = scene_and_target(1)
     nodes = oracle.uniform_sampling(sc.verts, 16)
     d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    d.params.solver = solver
     d.set_nodes(nodes)
     # targets = rest pose: the rest pose comes back, R_i = I, energy 0
     st = d.arap(sc.verts[nodes])
@@ -105,6 +110,7 @@ def test_arap_matches_oracle_and_known_answers(eng, oracle):
     R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
     tg = sc.verts[nodes] @ R.T + np.array([0.1, -0.2, 0.05])
     d2 = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    d2.params.solver = solver
     d2.set_nodes(nodes)
     d2.params.cg_tol = 1e-10                 # tight solve: compare with the oracle's exact global step at 1e-7
     st = d2.arap(tg)
