@@ -124,7 +124,7 @@ void collect_timers(mvs_deform_s* h) {
 void free_nodes(mvs_deform_s* h) {
     dfree(h->d_nodes); dfree(h->d_nbr); dfree(h->d_node_pts); dfree(h->d_node_nrm); dfree(h->d_ctrl_raw);
     dfree(h->d_ctrl_a); dfree(h->d_ctrl_b); dfree(h->d_valid); dfree(h->d_d2min); dfree(h->d_counts);
-    dfree(h->d_records); dfree(h->d_top_idx);
+    dfree(h->d_records); dfree(h->d_top_idx); dfree(h->d_heavy);
     if (h->d_knn_ws) { (void)hipFree(h->d_knn_ws); h->d_knn_ws = nullptr; }
     h->d_ctrl_final = nullptr; h->K = 0; h->nbr_k = 0; h->h_nodes.clear();
 }
@@ -178,7 +178,7 @@ void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
     Tic t = tic(h, "assoc");
     const int K = (int)h->K;
     launch_assoc_dmin(h->grid, h->d_node_pts, K, h->d_d2min, h->stream);
-    launch_assoc_select(h->grid, h->d_node_pts, h->d_node_nrm, K, p.top_k, h->d_d2min, h->d_records, h->d_counts, h->stream);
+    launch_assoc_select(h->grid, h->d_node_pts, h->d_node_nrm, K, p.top_k, h->d_d2min, h->d_records, h->d_counts, h->d_heavy, K, h->stream);
     launch_assoc_merge(h->d_node_pts, h->d_node_nrm, K, p, h->d_records, h->d_counts, 1, h->d_ctrl_raw, h->d_valid,
                        h->d_top_idx, h->stream);
     toc(t, 3);
@@ -588,7 +588,7 @@ int mvs_deform_set_nodes(mvs_deform_t h, const int32_t* vertex_idx, int64_t K) {
     TRY(dmalloc(&h->d_nodes, (size_t)K)); TRY(dmalloc(&h->d_node_pts, (size_t)K * 3)); TRY(dmalloc(&h->d_node_nrm, (size_t)K * 3));
     TRY(dmalloc(&h->d_ctrl_raw, (size_t)K * 3)); TRY(dmalloc(&h->d_ctrl_a, (size_t)K * 3)); TRY(dmalloc(&h->d_ctrl_b, (size_t)K * 3));
     TRY(dmalloc(&h->d_valid, (size_t)K)); TRY(dmalloc(&h->d_d2min, (size_t)K)); TRY(dmalloc(&h->d_counts, (size_t)K * 2));
-    TRY(dmalloc(&h->d_records, (size_t)K * 8)); TRY(dmalloc(&h->d_top_idx, (size_t)K * 8));
+    TRY(dmalloc(&h->d_records, (size_t)K * 8)); TRY(dmalloc(&h->d_top_idx, (size_t)K * 8)); TRY(dmalloc(&h->d_heavy, (size_t)K + 1));
     if (K >= 1024) TRY(mvs_check_hip(hipMalloc(&h->d_knn_ws, knn_grid_ws_bytes((int)K)), "hipMalloc"));   // small graphs: brute force
 #undef TRY
     HIPCHK(hipMemcpyAsync(h->d_is_ctrl, ctrl_id.data(), sizeof(int32_t) * h->V, hipMemcpyHostToDevice, h->stream));
@@ -720,7 +720,7 @@ int mvs_deform_assoc_select(mvs_deform_t h, const mvs_deform_params* p, const fl
     if (rc) return rc;
     if (!d2min_dev || !records_dev || !counts_dev) return MVS_E_INVALID_ARG;
     Tic t = tic(h, "assoc");
-    launch_assoc_select(h->grid, h->d_node_pts, h->d_node_nrm, (int)h->K, p->top_k, d2min_dev, records_dev, counts_dev, h->stream);
+    launch_assoc_select(h->grid, h->d_node_pts, h->d_node_nrm, (int)h->K, p->top_k, d2min_dev, records_dev, counts_dev, h->d_heavy, (int)h->K, h->stream);
     toc(t, 1);
     return mvs_check_hip(hipGetLastError(), "assoc_select");
 }

@@ -20,8 +20,19 @@
 #include "engine.h"
 #include "dev_common.h"
 #include "grid_dev.h"
+#include <algorithm>
 
 namespace {
+
+#ifdef MVS_STAMPS
+__device__ unsigned long long g_assoc_cycles[2 * 16384];      // per node: cycles of k_assoc_dmin, k_assoc_select
+#define ASTAMP_BEGIN unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory")
+#define ASTAMP_END(slot) do { unsigned long long t1_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory"); \
+        if ((threadIdx.x & 63) == 0 && node < 16384) g_assoc_cycles[2 * node + (slot)] = t1_ - t0_; } while (0)
+#else
+#define ASTAMP_BEGIN
+#define ASTAMP_END(slot)
+#endif
 
 __device__ inline int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ inline double rl_d(double v, int l) {
@@ -90,6 +101,7 @@ __global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __r
                                                     float* __restrict__ d2min) {
     const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (node >= K) return;                       // wave-uniform
+    ASTAMP_BEGIN;
     const int lane = threadIdx.x & 63;
     const float qx = (float)node_pts[3 * node], qy = (float)node_pts[3 * node + 1], qz = (float)node_pts[3 * node + 2];
     float best = INFINITY;
@@ -190,16 +202,27 @@ __global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __r
     }
     best = wave_min_f(best);
     if (lane == 0) d2min[node] = best;
+    ASTAMP_END(0);
 }
 
 // ---------------------------------------------------------------- select ----
-__global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* __restrict__ node_pts,
-                                                      const double* __restrict__ node_nrm, int K, int top_k,
-                                                      const float* __restrict__ d2min, mvs_cand* __restrict__ rec,
-                                                      int32_t* __restrict__ counts) {
-    const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (node >= K) return;
-    const int lane = threadIdx.x & 63;
+// One node by one wave (PARTS == 1) or by the PARTS waves of a workgroup (heavy nodes: each wave takes every
+// PARTS-th occupied coarse cell of the ball, the per-wave lists are merged through LDS by wave 0).
+// A PARTS == 1 caller that passes a `heavy` list defers nodes whose ball spans more than 64 grid rows to it.
+constexpr int HEAVY_WAVES = 16;
+constexpr int HEAVY_RANGES = 2048;
+constexpr int HEAVY_ROWS = 25;                              // rows of the ball's bounding box above which a node is deferred
+struct HeavyLds { double pd[HEAVY_WAVES][8], pl[HEAVY_WAVES][8], x[HEAVY_WAVES][8], y[HEAVY_WAVES][8], z[HEAVY_WAVES][8];
+                  long long idx[HEAVY_WAVES][8]; int nb[HEAVY_WAVES], np[HEAVY_WAVES];
+                  int nr, ra[HEAVY_RANGES], rb[HEAVY_RANGES]; };      // occupied coarse cells of the ball, found by all waves
+
+template <int PARTS>
+__device__ inline void select_node(const GridDev& g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm,
+                                   int node, int top_k, const float* __restrict__ d2min, mvs_cand* __restrict__ rec,
+                                   int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap, HeavyLds* lds) {
+    ASTAMP_BEGIN;
+    const int lane = threadIdx.x & 63, part = PARTS > 1 ? (int)(threadIdx.x >> 6) : 0;
+    int k_occ = 0;                                           // running index of the occupied rows (PARTS > 1)
     const d3 orig = ld3(node_pts + 3 * node), nn = ld3(node_nrm + 3 * node);
     const float qx = (float)orig.x, qy = (float)orig.y, qz = (float)orig.z;
     const float dm = d2min[node];
@@ -278,6 +301,13 @@ __global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* _
             const int y0 = (int)fmaxf(ly, 0.f), y1 = (int)fminf(hy, (float)(g.ny - 1));
             const int z0 = (int)fmaxf(lz, 0.f), z1 = (int)fminf(hz, (float)(g.nz - 1));
             const int ny_ = y1 - y0 + 1, nrows = ny_ * (z1 - z0 + 1);
+            // a ball wider than a few cells goes to the workgroup-per-node kernel (one wave would need > 100 K cycles)
+            if (PARTS == 1 && heavy && nrows > HEAVY_ROWS) {
+                int slot = 0;
+                if (lane == 0) slot = atomicAdd(&heavy[0], 1);
+                slot = rl_i(slot, 0);
+                if (slot < heavy_cap) { if (lane == 0) heavy[1 + slot] = node; return; }
+            }
             if (nrows <= 64) {
                 // small ball: every (y,z) row of its bounding box, one per lane; the x run is cut at coarse columns
                 for (int X = x0 >> 3; X <= (x1 >> 3); ++X) {
@@ -291,16 +321,20 @@ __global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* _
                     while (mask) {
                         const int l = __ffsll((long long)mask) - 1;
                         mask &= mask - 1;
-                        scan(rl_i(a, l), rl_i(b, l));
+                        if (PARTS == 1 || (k_occ++ % PARTS) == part) scan(rl_i(a, l), rl_i(b, l));
                     }
                 }
             } else {
                 // large ball (node far from the target): every occupied coarse cell that intersects the ball
                 // is ONE contiguous range; 64 of them are looked up per pass
+
                 const float lim = rc * rc;
                 const int X0 = x0 >> 3, X1 = x1 >> 3, Y0 = y0 >> 3, Y1 = y1 >> 3, Z0 = z0 >> 3, Z1 = z1 >> 3;
                 const int nX = X1 - X0 + 1, nY = Y1 - Y0 + 1, ncc = nX * nY * (Z1 - Z0 + 1);
-                for (int base = 0; base < ncc; base += 64) {
+                // (split mode: wave `part` looks up every PARTS-th group of 64 coarse cells and appends the occupied ones to
+                //  a workgroup list; the list is then scanned round-robin, so both the look-ups and the points are shared)
+                if (PARTS > 1) { if (threadIdx.x == 0) lds->nr = 0; __syncthreads(); }
+                for (int base = 64 * part; base < ncc; base += 64 * PARTS) {
                     const int t = base + lane;
                     int a = 0, b = 0;
                     if (t < ncc) {
@@ -311,18 +345,76 @@ __global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* _
                             a = cs[C * 512]; b = cs[(C + 1) * 512];
                         }
                     }
-                    unsigned long long cmask = __ballot(b > a);
+                    if (PARTS > 1) {
+                        int slot = HEAVY_RANGES;
+                        if (b > a) slot = atomicAdd(&lds->nr, 1);
+                        if (slot < HEAVY_RANGES) { lds->ra[slot] = a; lds->rb[slot] = b; b = a; }     // listed
+                    }
+                    unsigned long long cmask = __ballot(b > a);                                     // (overflow of the list: scanned here)
                     while (cmask) {
                         const int l = __ffsll((long long)cmask) - 1;
                         cmask &= cmask - 1;
                         scan(rl_i(a, l), rl_i(b, l));
                     }
                 }
+                if (PARTS > 1) {
+                    __syncthreads();
+                    const int nr = min(lds->nr, HEAVY_RANGES);
+                    for (int r = part; r < nr; r += PARTS) scan(lds->ra[r], lds->rb[r]);
+                }
             }
         }
     }
     n_ball = wave_sum_i(n_ball);
     n_pass = wave_sum_i(n_pass);
+    if (PARTS > 1) {
+        // merge the waves' lists: wave 0 re-inserts the <= PARTS * 8 survivors into a fresh list (same total order)
+        if (lane < 8) {
+            const bool live = lane < len;
+            lds->pd[part][lane] = L_pd; lds->pl[part][lane] = L_pl; lds->x[part][lane] = L_x; lds->y[part][lane] = L_y; lds->z[part][lane] = L_z;
+            lds->idx[part][lane] = live ? L_idx : -1;
+        }
+        if (lane == 0) { lds->nb[part] = n_ball; lds->np[part] = n_pass; }
+        __syncthreads();
+        if (part == 0) {
+            len = 0; L_idx = -1;
+            n_ball = 0; n_pass = 0;
+            for (int w = 0; w < PARTS; ++w) { n_ball += lds->nb[w]; n_pass += lds->np[w]; }
+            for (int base = 0; base < PARTS * 8; base += 64) {
+                const int q = base + lane, w = q >> 3, k = q & 7;
+                const bool has0 = q < PARTS * 8 && lds->idx[w][k] >= 0;
+                bool has = has0;
+                const double pd = has0 ? lds->pd[w][k] : 0.0, pl = has0 ? lds->pl[w][k] : 0.0;
+                const d3 tp = has0 ? mk3(lds->x[w][k], lds->y[w][k], lds->z[w][k]) : mk3(0, 0, 0);
+                const long long gi = has0 ? lds->idx[w][k] : 0;
+                const double apl = fabs(pl);
+                unsigned long long pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
+                while (pend) {
+                    const int src = __ffsll((long long)pend) - 1;
+                    const double c_pd = rl_d(pd, src), c_pl = rl_d(pl, src);
+                    const double c_x = rl_d(tp.x, src), c_y = rl_d(tp.y, src), c_z = rl_d(tp.z, src);
+                    const long long c_i = rl_ll(gi, src);
+                    const bool less = lane < len && key_less(L_pd, fabs(L_pl), L_idx, c_pd, fabs(c_pl), c_i);
+                    const int pos = __popcll(__ballot(less));
+                    const double u_pd = __shfl_up(L_pd, 1, 64), u_pl = __shfl_up(L_pl, 1, 64);
+                    const double u_x = __shfl_up(L_x, 1, 64), u_y = __shfl_up(L_y, 1, 64), u_z = __shfl_up(L_z, 1, 64);
+                    const long long u_i = shfl_up_ll(L_idx);
+                    if (lane > pos && lane <= len && lane < top_k) {
+                        L_pd = u_pd; L_pl = u_pl; L_x = u_x; L_y = u_y; L_z = u_z; L_idx = u_i;
+                    } else if (lane == pos) {
+                        L_pd = c_pd; L_pl = c_pl; L_x = c_x; L_y = c_y; L_z = c_z; L_idx = c_i;
+                    }
+                    len = min(len + 1, top_k);
+                    if (len == top_k) {
+                        t_pd = rl_d(L_pd, top_k - 1); t_apl = fabs(rl_d(L_pl, top_k - 1)); t_idx = rl_ll(L_idx, top_k - 1);
+                    }
+                    if (lane == src) has = false;
+                    pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
+                }
+            }
+        }
+        if (part != 0) return;
+    }
     if (lane < 8) {
         mvs_cand* o = rec + (int64_t)node * 8 + lane;
         const bool live = lane < len;
@@ -332,6 +424,31 @@ __global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* _
         o->index = live ? L_idx : -1;
     }
     if (lane == 0) { counts[2 * node] = n_ball; counts[2 * node + 1] = n_pass; }
+    ASTAMP_END(1);
+}
+
+__global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* __restrict__ node_pts,
+                                                      const double* __restrict__ node_nrm, int K, int top_k,
+                                                      const float* __restrict__ d2min, mvs_cand* __restrict__ rec,
+                                                      int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap) {
+    const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= K) return;
+    select_node<1>(g, node_pts, node_nrm, node, top_k, d2min, rec, counts, heavy, heavy_cap, nullptr);
+}
+
+// the deferred nodes: one 16-wave workgroup per node (a far node's ball covers thousands of points; left to one
+// wave, eight such nodes set the duration of the whole association: 300 K cycles against a median of 12 K)
+__global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_select_heavy(GridDev g, const double* __restrict__ node_pts,
+                                                                         const double* __restrict__ node_nrm, int top_k,
+                                                                         const float* __restrict__ d2min, mvs_cand* __restrict__ rec,
+                                                                         int32_t* __restrict__ counts, const int32_t* __restrict__ heavy,
+                                                                         int heavy_cap) {
+    __shared__ HeavyLds lds;
+    const int n = min(heavy[0], heavy_cap);
+    for (int h = blockIdx.x; h < n; h += gridDim.x) {
+        select_node<HEAVY_WAVES>(g, node_pts, node_nrm, heavy[1 + h], top_k, d2min, rec, counts, nullptr, 0, &lds);
+        __syncthreads();                                     // the LDS lists are reused by the next node
+    }
 }
 
 // ----------------------------------------------------------------- merge ----
@@ -389,14 +506,22 @@ __global__ void k_assoc_merge(const double* __restrict__ node_pts, const double*
 
 }  // namespace
 
+#ifdef MVS_STAMPS
+extern "C" int mvs_debug_assoc_cycles(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_assoc_cycles), sizeof(unsigned long long) * n);
+}
+#endif
+
 void launch_assoc_dmin(const GridDev& g, const double* node_pts, int K, float* d2min, hipStream_t s) {
     if (K <= 0) return;
     k_assoc_dmin<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, K, d2min);
 }
 void launch_assoc_select(const GridDev& g, const double* node_pts, const double* node_nrm, int K, int top_k,
-                         const float* d2min, mvs_cand* rec, int32_t* counts, hipStream_t s) {
+                         const float* d2min, mvs_cand* rec, int32_t* counts, int32_t* heavy, int heavy_cap, hipStream_t s) {
     if (K <= 0) return;
-    k_assoc_select<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, top_k, d2min, rec, counts);
+    if (heavy) (void)hipMemsetAsync(heavy, 0, sizeof(int32_t), s);
+    k_assoc_select<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, top_k, d2min, rec, counts, heavy, heavy_cap);
+    if (heavy) k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, top_k, d2min, rec, counts, heavy, heavy_cap);
 }
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks, double* controls,

@@ -86,6 +86,7 @@ struct mvs_deform_s {
     int32_t *d_counts = nullptr;
     mvs_cand *d_records = nullptr;
     int64_t *d_top_idx = nullptr;
+    int32_t *d_heavy = nullptr;       // [1 + K]: nodes deferred to the workgroup-per-node association kernel
     // target
     GridDev grid{};
     float4 *d_spos = nullptr;
@@ -125,7 +126,8 @@ int scan_exclusive_i32(const int32_t* in, int64_t n, int32_t* out, hipStream_t s
 // assoc.hip
 void launch_assoc_dmin(const GridDev& g, const double* node_pts, int K, float* d2min, hipStream_t s);
 void launch_assoc_select(const GridDev& g, const double* node_pts, const double* node_nrm, int K, int top_k,
-                         const float* d2min, mvs_cand* rec, int32_t* counts, hipStream_t s);
+                         const float* d2min, mvs_cand* rec, int32_t* counts, int32_t* heavy /*[1 + cap] or NULL*/, int heavy_cap,
+                         hipStream_t s);
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks,
                         double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s);
