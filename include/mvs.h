@@ -100,6 +100,20 @@ int mvs_depth_unproject(const float* inv_depth, const mvs_camera* cam,
                         double min_dsp, double max_dsp,
                         double* out_points /* w*h*3 */, uint8_t* out_valid /* w*h */);
 
+/* Model2Depth (R/Model2Depth/Model2Depth.cpp:58-156, R/Camera/Camera.cpp:6-38) without GLUT: mesh -> inverse-depth raster of
+ * one camera by a z-buffer pass.  Vertex stage in float32 as the fixed-function pipeline (modelview = [R|t] with rows
+ * 1,2 negated, glFrustum from the intrinsics, viewport w x h, depth range [0,1]); pixel centres at (i+.5, j+.5),
+ * top-left fill rule, window-space linear depth, GL_LEQUAL against a float32 depth buffer cleared to 1; then
+ * RenderDepth's conversion z_b -> 1/z_e with the clipping planes recovered from the projection matrix and the rows
+ * flipped to image order.  Pixels no triangle covers are 0.  The reference uses znear = 0.01f, zfar = 2000.0f.
+ * What OpenGL leaves implementation-defined (fill-rule ties, 24-bit depth, near-plane clipping: triangles with a
+ * vertex at or behind the eye plane are dropped here) makes parity with a particular driver unpinned. */
+int mvs_render_depth(const double* points, int64_t V, const int32_t* faces, int64_t F, const mvs_camera* cam,
+                     float znear, float zfar, float* out /*w*h*/);
+/* mesh and raster in HBM; hip_stream may be NULL */
+int mvs_render_depth_dev(const double* points_dev, int64_t V, const int32_t* faces_dev, int64_t F, const mvs_camera* cam,
+                         float znear, float zfar, float* out_dev, void* hip_stream);
+
 /* Processor::CheckConsistencyCore (R/Processor/Processor.cpp:72-126): depth-consistency filter of one frame against
  * n_ref (<= 4) reference frames, applied in the given order.  A pixel keeps its inverse depth iff it is inside
  * [min_dsp, max_dsp] and for every reference: its world point lands inside the reference image on a pixel with a valid

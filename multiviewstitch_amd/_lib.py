@@ -73,6 +73,8 @@ _SIGS = {
     "mvs_depth_to_model": (C.c_int, [_VP, _VP, _D, _D, _D, _VP, _VP, _VP, _VP, _VP, _VP]),
     "mvs_depth_to_model_dev": (C.c_int, [_VP, _VP, _D, _D, _D, _VP, _VP, _VP, _VP, _VP, _VP]),
     "mvs_depth_unproject": (C.c_int, [_VP, _VP, _D, _D, _VP, _VP]),
+    "mvs_render_depth": (C.c_int, [_VP, _I64, _VP, _I64, _VP, C.c_float, C.c_float, _VP]),
+    "mvs_render_depth_dev": (C.c_int, [_VP, _I64, _VP, _I64, _VP, C.c_float, C.c_float, _VP, _VP]),
     "mvs_check_consistency": (C.c_int, [_VP, _VP, _I32, _VP, _VP, _D, _D, _I32, _VP]),
     "mvs_check_consistency_seq": (C.c_int, [_I32, _VP, _VP, _D, _D, _I32, _VP]),
     "mvs_check_consistency_seq_dev": (C.c_int, [_I32, _VP, _VP, _D, _D, _I32, _VP, _VP]),

@@ -46,3 +46,20 @@ def CheckConsistency(cameras, depths, min_dsp: float, max_dsp: float, reproj_err
     out = np.empty_like(d)
     L.check(L.lib().mvs_check_consistency_seq(len(cameras), L.ptr(d), cams, float(min_dsp), float(max_dsp), int(reproj_err), L.ptr(out)))
     return out
+
+
+def RenderDepth(points, facets, camera, znear: float = 0.01, zfar: float = 2000.0, out_dev: int | None = None, stream: int | None = None):
+    """Model2Depth::RenderDepth for one camera (R/Model2Depth/Model2Depth.cpp:58-156) without GLUT: float32 raster [h, w]
+    of inverse depths, 0 where no triangle covers the pixel.  With ``out_dev`` the mesh arguments are device addresses
+    (points: V*3 float64, facets: F*3 int32 — pass (address, count) tuples) and nothing is returned."""
+    cc = L.CCamera.of(camera)
+    if out_dev is not None:
+        (pp, V), (fp, F) = points, facets
+        L.check(L.lib().mvs_render_depth_dev(L.ptr(int(pp)), int(V), L.ptr(int(fp)), int(F), C.byref(cc), float(znear), float(zfar),
+                                             L.ptr(int(out_dev)), L.ptr(stream)))
+        return None
+    pts = L.arr(points, np.float64).reshape(-1, 3)
+    fac = L.arr(facets, np.int32).reshape(-1, 3)
+    out = np.empty((camera.h, camera.w), np.float32)
+    L.check(L.lib().mvs_render_depth(L.ptr(pts), len(pts), L.ptr(fac), len(fac), C.byref(cc), float(znear), float(zfar), L.ptr(out)))
+    return out

@@ -443,3 +443,12 @@ def check_consistency_seq(depths, cams, min_dsp, max_dsp, reproj_err):
     out = np.empty_like(depths)
     lib().orc_check_consistency_seq(C.c_int(len(cams)), _p(depths), cc, C.c_double(min_dsp), C.c_double(max_dsp), C.c_int(int(reproj_err)), _p(out))
     return out
+
+
+# ------------------------------------------------------------- render ----
+def render_depth(pts, faces, cam, znear=0.01, zfar=2000.0):
+    pts, faces = _c(pts, np.float64), _c(faces, np.int32)
+    out = np.empty((cam.h, cam.w), np.float32)
+    cc = Camera.of(cam)
+    lib().orc_render_depth(_p(pts), C.c_int64(len(pts)), _p(faces), C.c_int64(len(faces)), C.byref(cc), C.c_float(znear), C.c_float(zfar), _p(out))
+    return out

@@ -52,6 +52,8 @@ void orc_cam_world_to_img(const orc_camera* c, const double* pw, int* u, int* v)
 int  orc_depth_to_model(const float* inv_depth, const orc_camera* cam, double min_dsp,
                         double max_dsp, double smooth, int64_t* n_points, int64_t* n_faces,
                         double* out_points, double* out_normals, int32_t* out_tex, int32_t* out_faces);
+void orc_render_depth(const double* pts, int64_t V, const int32_t* faces, int64_t F, const orc_camera* cam, float znear, float zfar,
+                      float* out);
 void orc_check_consistency(const float* depth, const orc_camera* cur, int n_ref, const float* const* ref_depths,
                            const orc_camera* ref_cams, double min_dsp, double max_dsp, int reproj_err, float* out);
 void orc_check_consistency_seq(int n_frames, const float* depths, const orc_camera* cams, double min_dsp, double max_dsp,
