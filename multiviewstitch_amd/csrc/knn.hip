@@ -135,38 +135,57 @@ __global__ void k_ng_count(const double* __restrict__ pts, int n, const NgGeom* 
 }
 
 // single-workgroup exclusive scan of ncell counts into start[0..ncell]; also clears the counts for reuse as cursors.
-// Tiles of 4096 cells, four consecutive cells per thread so a wave reads 1 KB contiguous; the next tile's loads are
-// issued before the current tile's barrier.
-__global__ __launch_bounds__(1024) void k_ng_scan(int* __restrict__ counts, int ncell, int* __restrict__ start) {
-    __shared__ int sm[2][16];
+// Thread t owns the `per` consecutive cells from t * per (per a multiple of 4, both arrays 16-byte aligned): all of
+// its int4 loads are in flight together, one workgroup scan of the 1024 chunk sums, then the chunk's prefix is
+// written back — two memory round trips and one barrier instead of a barrier per 4096-cell tile (35 us -> 5 us at
+// 32 K cells).
+__global__ __launch_bounds__(1024) void k_ng_scan(int* __restrict__ counts, int ncell, int per, int* __restrict__ start) {
+    __shared__ int sm[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int carry = 0, c[4], nx[4];
-    auto load = [&](int base, int* v) {
+    const int lo = threadIdx.x * per, hi = min(lo + per, ncell);
+    int s = 0;
+    if (per == 32) {                                         // the node-graph size: everything stays in registers
+        int4 v[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = base + threadIdx.x * 4 + u; v[u] = i < ncell ? counts[i] : 0; }
-    };
-    load(0, c);
-    for (int base = 0, it = 0; base < ncell; base += 4096, ++it) {
-        if (base + 4096 < ncell) load(base + 4096, nx);
-        const int t = (c[0] + c[1]) + (c[2] + c[3]);
-        int x = t;
+        for (int j = 0; j < 8; ++j) {
+            const int i = lo + 4 * j;
+            v[j] = i + 3 < ncell ? *reinterpret_cast<const int4*>(counts + i)
+                                 : make_int4(i < ncell ? counts[i] : 0, i + 1 < ncell ? counts[i + 1] : 0, i + 2 < ncell ? counts[i + 2] : 0, 0);
+            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+        int x = s;
         for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-        if (lane == 63) sm[it & 1][w] = x;
-        __syncthreads();                                   // sm is double-buffered: one barrier per tile
+        if (lane == 63) sm[w] = x;
+        __syncthreads();
         int off = 0, tot = 0;
 #pragma unroll
-        for (int ww = 0; ww < 16; ++ww) { const int v = sm[it & 1][ww]; tot += v; if (ww < w) off += v; }
-        int run = carry + off + x - t;
+        for (int ww = 0; ww < 16; ++ww) { const int t = sm[ww]; tot += t; if (ww < w) off += t; }
+        int run = off + x - s;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = base + threadIdx.x * 4 + u;
-            if (i < ncell) { start[i] = run; run += c[u]; counts[i] = 0; }
+        for (int j = 0; j < 8; ++j) {
+            const int i = lo + 4 * j;
+            const int4 o4 = make_int4(run, run + v[j].x, run + v[j].x + v[j].y, run + v[j].x + v[j].y + v[j].z);
+            run = o4.w + v[j].w;
+            if (i + 3 < ncell) { *reinterpret_cast<int4*>(start + i) = o4; *reinterpret_cast<int4*>(counts + i) = make_int4(0, 0, 0, 0); }
+            else {
+                if (i < ncell) { start[i] = o4.x; counts[i] = 0; }
+                if (i + 1 < ncell) { start[i + 1] = o4.y; counts[i + 1] = 0; }
+                if (i + 2 < ncell) { start[i + 2] = o4.z; counts[i + 2] = 0; }
+            }
         }
-        carry += tot;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) c[u] = nx[u];
+        if (threadIdx.x == 1023) start[ncell] = tot;
+        return;
     }
-    if (threadIdx.x == 0) start[ncell] = carry;
+    for (int i = lo; i < hi; ++i) s += counts[i];
+    int x = s;
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) sm[w] = x;
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int ww = 0; ww < 16; ++ww) { const int t = sm[ww]; tot += t; if (ww < w) off += t; }
+    int run = off + x - s;
+    for (int i = lo; i < hi; ++i) { const int c = counts[i]; start[i] = run; run += c; counts[i] = 0; }
+    if (threadIdx.x == 1023) start[ncell] = tot;
 }
 
 __global__ void k_ng_scatter(const double* __restrict__ pts, int n, const int* __restrict__ cell_of, const int* __restrict__ start,
@@ -269,7 +288,7 @@ int knn_grid_cap(int n) {                                   // cells per axis: ~
 }
 size_t knn_grid_ws_bytes(int n) {
     const size_t nc = (size_t)knn_grid_cap(n), ncell = nc * nc * nc;
-    return 64 + sizeof(int) * (ncell + 1) * 2 + sizeof(int) * (size_t)n + sizeof(float4) * (size_t)n + 64;
+    return 64 + sizeof(int) * ((ncell + 1 + 3) / 4 * 4) * 2 + sizeof(int) * (size_t)n + sizeof(float4) * (size_t)n + 64;
 }
 
 struct NgWs { NgGeom* geo; int* counts; int* start; int* cell_of; float4* sorted; int NC; size_t ncell; };
@@ -279,8 +298,8 @@ static NgWs ng_carve(void* ws, int n) {
     w.ncell = (size_t)w.NC * w.NC * w.NC;
     char* p = (char*)ws;
     w.geo = (NgGeom*)p; p += 64;
-    w.counts = (int*)p; p += sizeof(int) * (w.ncell + 1);
-    w.start = (int*)p; p += sizeof(int) * (w.ncell + 1);
+    w.counts = (int*)p; p += sizeof(int) * ((w.ncell + 1 + 3) / 4 * 4);          // both 16-byte aligned (int4 access in k_ng_scan)
+    w.start = (int*)p; p += sizeof(int) * ((w.ncell + 1 + 3) / 4 * 4);
     w.cell_of = (int*)p; p += sizeof(int) * (size_t)n;
     p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
     w.sorted = (float4*)p;
@@ -291,7 +310,7 @@ static void grid_build_ws(const double* pts, int n, const NgWs& w, hipStream_t s
     (void)hipMemsetAsync(w.counts, 0, sizeof(int) * (w.ncell + 1), s);
     k_ng_bbox<<<dim3(1), dim3(1024), 0, s>>>(pts, n, w.NC, w.geo);
     k_ng_count<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.geo, w.counts, w.cell_of);
-    k_ng_scan<<<dim3(1), dim3(1024), 0, s>>>(w.counts, (int)w.ncell, w.start);
+    k_ng_scan<<<dim3(1), dim3(1024), 0, s>>>(w.counts, (int)w.ncell, (int)(((w.ncell + 1023) / 1024 + 3) / 4 * 4), w.start);
     k_ng_scatter<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.cell_of, w.start, w.counts, w.sorted);
 }
 void knn_grid_build(const double* pts, int n, void* ws, hipStream_t s) {
@@ -299,7 +318,7 @@ void knn_grid_build(const double* pts, int n, void* ws, hipStream_t s) {
     (void)hipMemsetAsync(w.counts, 0, sizeof(int) * (w.ncell + 1), s);
     k_ng_bbox<<<dim3(1), dim3(1024), 0, s>>>(pts, n, w.NC, w.geo);
     k_ng_count<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.geo, w.counts, w.cell_of);
-    k_ng_scan<<<dim3(1), dim3(1024), 0, s>>>(w.counts, (int)w.ncell, w.start);
+    k_ng_scan<<<dim3(1), dim3(1024), 0, s>>>(w.counts, (int)w.ncell, (int)(((w.ncell + 1023) / 1024 + 3) / 4 * 4), w.start);
     k_ng_scatter<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.cell_of, w.start, w.counts, w.sorted);
 }
 void launch_knn_grid(const double* pts, int n, int k, int32_t* out, void* ws, hipStream_t s) {
