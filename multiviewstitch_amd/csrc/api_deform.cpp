@@ -140,7 +140,7 @@ struct RasPlan {                     // sweeps per ARAP iteration of the patch s
     int n[8];
     int64_t total(int iters) const { int64_t t = 0; for (int i = 0; i < iters; ++i) t += n[i]; return t; }
 };
-constexpr int RAS_FIRST_PLAN = 16;   // sweeps of an uncalibrated solve (5-7 are needed; the rest degenerate into copies)
+constexpr int RAS_FIRST_PLAN = 64;   // sweeps of an uncalibrated solve (5-7 are needed at the usual node density; the rest degenerate into copies)
 constexpr int RAS_MAX_SWEEPS = 64;
 
 RasPlan probe_ras(const mvs_deform_s* h) {
@@ -419,7 +419,10 @@ int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* s
     if (st) *st = out;
     collect_timers(h);
     if (!all_conv && max_plan >= RAS_MAX_SWEEPS) {
-        mvs_set_error("patch solver did not reach cg_tol in %d sweeps (rel residual %.3e)", max_plan, worst);
+        // the local Chebyshev bracket does not fit this mesh / node layout: this handle solves by CG from now on
+        h->has_ras = false;
+        h->cg_iters = 0;
+        mvs_set_error("patch solver did not reach cg_tol in %d sweeps (rel residual %.3e); the handle now uses CG", max_plan, worst);
         return MVS_E_SOLVER;
     }
     h->cg_iters = std::max(h->cg_iters, 1);                // "calibrated": async solves allowed

@@ -399,11 +399,15 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, const double* xin,
                       double cg_tol, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s) {
     const RasDev& R = h->ras;
     const int nb = arap_grid_blocks(h->sell);
-    const double cheb_a = 0.1;     // lower spectral bound of the Chebyshev steps (the patch matrices of the bench mesh have 0.12..0.16)
-    const int cheb_m = 8;          // steps per sweep (6..12 measured within 5 % of each other: fewer steps, more sweeps)
-    static ChebCoef cc;
-    static bool have = false;
-    if (!have) {                                   // Saad, Iterative Methods, Alg. 12.1 with [a, 2]
+    // Chebyshev parameters from the density of the Dirichlet nodes: the smallest eigenvalue of the Jacobi-scaled patch
+    // matrices falls with the share of fixed vertices (measured 0.12..0.16 at K/V = 1/6.7, the density the reference's
+    // 16-NN sampling produces).  a = 0.67 K/V (capped at 0.1), steps ~ 2.6 / sqrt(a): 8 steps at the usual density, 16
+    // for nodes four times sparser.  An estimate that is still too high only costs sweeps (the sweep plan adapts).
+    const double dens = h->V > 0 ? (double)h->K / (double)h->V : 0.15;
+    const double cheb_a = std::min(0.1, std::max(0.005, 0.67 * dens));
+    const int cheb_m = std::min(16, std::max(6, (int)std::lround(2.6 / std::sqrt(cheb_a))));
+    ChebCoef cc;                                   // Saad, Iterative Methods, Alg. 12.1 with [a, 2]
+    {
         const double theta = 0.5 * (2.0 + cheb_a), delta = 0.5 * (2.0 - cheb_a), sigma1 = theta / delta;
         double rho = 1.0 / sigma1;
         cc.c0 = 1.0 / theta;
@@ -412,7 +416,6 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, const double* xin,
             cc.c1[k] = rho_new * rho; cc.c2[k] = 2.0 * rho_new / delta;
             rho = rho_new;
         }
-        have = true;
     }
     const dim3 grid(R.NP), blk(h->ras_block);     // as many waves as the largest patch has rows (idle waves only add barrier cost)
     if (R.W == 8) k_ras_sweep<8><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, cc, cheb_m, slot_prev, slot_cur, iters_cur);

@@ -197,3 +197,22 @@ def test_arap_on_an_open_irregular_mesh(eng, oracle, solver):
     scale = np.abs(pts).max()
     assert rms(d.vertices(), ref["pts"]) <= 1e-6 * scale
     assert np.allclose(st["energy"][:ref["iters"]], ref["energies"][:ref["iters"]], rtol=1e-5)
+
+
+@pytest.mark.parametrize("stride", [4, 30])
+def test_patch_solver_adapts_to_the_node_density(eng, oracle, stride):
+    """Nodes much denser / much sparser than the 16-NN sampling produces: the Chebyshev bracket of the local solves
+    follows K / V, the sweep plan absorbs the rest; the result is the oracle's."""
+    sc, _, _, _ = scene_and_target(1)
+    nodes = np.arange(0, len(sc.verts), stride, dtype=np.int32)
+    rng = np.random.default_rng(11)
+    tg = sc.verts[nodes] @ (np.eye(3) + 0.04 * rng.normal(size=(3, 3))).T + 0.03 * np.cos(3 * sc.verts[nodes])
+    d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    assert d.solver_info()["kind"] == "patch"
+    d.set_nodes(nodes)
+    st = d.arap(tg)
+    ref = oracle.arap(sc.verts, sc.faces, nodes, tg, 5, 1e-4)
+    assert st["arap_iters_run"] == ref["iters"] and st["cg_rel_residual"] <= 1.5 * d.params.cg_tol
+    assert rms(d.vertices(), ref["pts"]) <= 1e-6
+    st2 = d.arap(tg)                                   # second call runs the calibrated sweep plan
+    assert st2["cg_rel_residual"] <= 1.5 * d.params.cg_tol and st2["cg_launches"] <= st["cg_launches"]
