@@ -201,6 +201,7 @@ def main():
     # (ARAP(5, 1e-4), the timed step above); and the box's device-to-device streaming-copy ceiling.
     single = None
     copy_gbps = None
+    alt = None
     if world == 1:
         keep = d.params.arap_iters
         d.params.arap_iters = 1
@@ -227,7 +228,29 @@ def main():
         if roofline is not None:
             roofline["copy_ceiling_GBps"] = round(copy_gbps, 1)
             roofline["frac_of_copy_ceiling"] = round(roofline["achieved"] / copy_gbps, 4)
-        run(1)                                # CG launch plan back on the 5-iteration schedule for the phase pass
+        run(1)                                # launch plan back on the 5-iteration schedule
+        if info["kind"] == "patch":
+            # the same step with the one-kernel-per-iteration CG (params.solver = MVS_SOLVER_CG), for comparison: its
+            # kernel moves more bytes per second, the step takes twice as long
+            d.params.solver = 1
+            run(max(args.warmup, 1))
+            d.enable_timing(2)
+            fence()
+            ta = time.perf_counter()
+            st_cg = run(args.steps)
+            fence()
+            el2 = time.perf_counter() - ta
+            ms2, l2 = d.kernel_time("cg")
+            d.enable_timing(0)
+            n_entries = int(sum(-(-int(deg[i:i + 8].max()) // 8) * 64 for i in range(0, V, 8)))
+            cgb = 252 * V + 12 * n_entries
+            af = st_cg["cg_active"] / max(1, st_cg["cg_launches"])
+            alt = {"solver": "cg", "ms_per_step": round(1e3 * el2 / args.steps, 4), "kernel": "k_cg_iter",
+                   "avg_launch_us": round(1e3 * ms2 / max(1, l2), 3), "launches_per_step": int(st_cg["cg_launches"]),
+                   "achieved_GBps": round(af * cgb / (1e-3 * ms2 / max(1, l2)) / 1e9, 1),
+                   "frac": round(af * cgb / (1e-3 * ms2 / max(1, l2)) / 1e9 / 8000.0, 4)}
+            d.params.solver = 0
+            run(1)
 
     if args.phases:
         d.enable_timing(1)
@@ -278,6 +301,8 @@ def main():
         }
         if single is not None:
             out["single_solve_schedule"] = single       # one ARAP global+local pass per outer iteration
+        if alt is not None:
+            out["alt_solver"] = alt
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
