@@ -188,6 +188,53 @@ __global__ __launch_bounds__(1024) void k_ng_scan(int* __restrict__ counts, int 
     if (threadIdx.x == 1023) start[ncell] = tot;
 }
 
+// Larger grids (more than 32 K cells): three launches over tiles of 4096 cells — tile sums, scan of the tile sums by
+// one workgroup, then every tile scans itself on top of its offset (and clears the counts).
+__global__ __launch_bounds__(1024) void k_ng_tile_sums(const int* __restrict__ counts, int ncell, int* __restrict__ tsum) {
+    const int i = blockIdx.x * 4096 + threadIdx.x * 4;
+    int s = 0;
+    if (i + 3 < ncell) { const int4 v = *reinterpret_cast<const int4*>(counts + i); s = (v.x + v.y) + (v.z + v.w); }
+    else for (int u = 0; u < 4; ++u) if (i + u < ncell) s += counts[i + u];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ int sm[16];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += sm[w]; tsum[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void k_ng_scan_tiles(int* __restrict__ tsum, int ntiles) {      // ntiles <= 1024: exclusive, in place; tsum[ntiles] = total
+    __shared__ int sm[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int v = (int)threadIdx.x < ntiles ? tsum[threadIdx.x] : 0;
+    int x = v;
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) sm[w] = x;
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int ww = 0; ww < 16; ++ww) { const int t = sm[ww]; tot += t; if (ww < w) off += t; }
+    if ((int)threadIdx.x < ntiles) tsum[threadIdx.x] = off + x - v;
+    if (threadIdx.x == 0) tsum[ntiles] = tot;
+}
+__global__ __launch_bounds__(1024) void k_ng_scan_apply(int* __restrict__ counts, int ncell, const int* __restrict__ tsum, int ntiles,
+                                                        int* __restrict__ start) {
+    __shared__ int sm[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4096 + threadIdx.x * 4;
+    int c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = i + u < ncell ? counts[i + u] : 0;
+    const int s = (c[0] + c[1]) + (c[2] + c[3]);
+    int x = s;
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) sm[w] = x;
+    __syncthreads();
+    int off = tsum[blockIdx.x];
+    for (int ww = 0; ww < w; ++ww) off += sm[ww];
+    int run = off + x - s;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (i + u < ncell) { start[i + u] = run; run += c[u]; counts[i + u] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) start[ncell] = tsum[ntiles];
+}
+
 __global__ void k_ng_scatter(const double* __restrict__ pts, int n, const int* __restrict__ cell_of, const int* __restrict__ start,
                              int* __restrict__ cursor, float4* __restrict__ sorted) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -288,10 +335,11 @@ int knn_grid_cap(int n) {                                   // cells per axis: ~
 }
 size_t knn_grid_ws_bytes(int n) {
     const size_t nc = (size_t)knn_grid_cap(n), ncell = nc * nc * nc;
-    return 64 + sizeof(int) * ((ncell + 1 + 3) / 4 * 4) * 2 + sizeof(int) * (size_t)n + sizeof(float4) * (size_t)n + 64;
+    return 64 + sizeof(int) * ((ncell + 1 + 3) / 4 * 4) * 2 + sizeof(int) * 1028 + sizeof(int) * (size_t)n + sizeof(float4) * (size_t)n + 64;
 }
 
-struct NgWs { NgGeom* geo; int* counts; int* start; int* cell_of; float4* sorted; int NC; size_t ncell; };
+struct NgWs { NgGeom* geo; int* counts; int* start; int* tsum; int* cell_of; float4* sorted; int NC; size_t ncell; };
+static void ng_scan(const NgWs& w, hipStream_t s);
 static NgWs ng_carve(void* ws, int n) {
     NgWs w;
     w.NC = knn_grid_cap(n);
@@ -300,17 +348,28 @@ static NgWs ng_carve(void* ws, int n) {
     w.geo = (NgGeom*)p; p += 64;
     w.counts = (int*)p; p += sizeof(int) * ((w.ncell + 1 + 3) / 4 * 4);          // both 16-byte aligned (int4 access in k_ng_scan)
     w.start = (int*)p; p += sizeof(int) * ((w.ncell + 1 + 3) / 4 * 4);
+    w.tsum = (int*)p; p += sizeof(int) * 1028;                                   // tile sums of the multi-block scan (<= 1024 tiles)
     w.cell_of = (int*)p; p += sizeof(int) * (size_t)n;
     p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
     w.sorted = (float4*)p;
     return w;
+}
+static void ng_scan(const NgWs& w, hipStream_t s) {
+    const int ncell = (int)w.ncell, ntiles = (ncell + 4095) / 4096;
+    if (ncell <= 32768 || ntiles > 1024) {            // one workgroup (the second case cannot occur: NC <= 128 -> 512 tiles)
+        k_ng_scan<<<dim3(1), dim3(1024), 0, s>>>(w.counts, ncell, ((ncell + 1023) / 1024 + 3) / 4 * 4, w.start);
+        return;
+    }
+    k_ng_tile_sums<<<dim3(ntiles), dim3(1024), 0, s>>>(w.counts, ncell, w.tsum);
+    k_ng_scan_tiles<<<dim3(1), dim3(1024), 0, s>>>(w.tsum, ntiles);
+    k_ng_scan_apply<<<dim3(ntiles), dim3(1024), 0, s>>>(w.counts, ncell, w.tsum, ntiles, w.start);
 }
 // build the point grid of `pts` in ws (device workspace of knn_grid_ws_bytes(n) bytes): 1 memset + 4 launches
 static void grid_build_ws(const double* pts, int n, const NgWs& w, hipStream_t s) {
     (void)hipMemsetAsync(w.counts, 0, sizeof(int) * (w.ncell + 1), s);
     k_ng_bbox<<<dim3(1), dim3(1024), 0, s>>>(pts, n, w.NC, w.geo);
     k_ng_count<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.geo, w.counts, w.cell_of);
-    k_ng_scan<<<dim3(1), dim3(1024), 0, s>>>(w.counts, (int)w.ncell, (int)(((w.ncell + 1023) / 1024 + 3) / 4 * 4), w.start);
+    ng_scan(w, s);
     k_ng_scatter<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.cell_of, w.start, w.counts, w.sorted);
 }
 void knn_grid_build(const double* pts, int n, void* ws, hipStream_t s) {
@@ -318,7 +377,7 @@ void knn_grid_build(const double* pts, int n, void* ws, hipStream_t s) {
     (void)hipMemsetAsync(w.counts, 0, sizeof(int) * (w.ncell + 1), s);
     k_ng_bbox<<<dim3(1), dim3(1024), 0, s>>>(pts, n, w.NC, w.geo);
     k_ng_count<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.geo, w.counts, w.cell_of);
-    k_ng_scan<<<dim3(1), dim3(1024), 0, s>>>(w.counts, (int)w.ncell, (int)(((w.ncell + 1023) / 1024 + 3) / 4 * 4), w.start);
+    ng_scan(w, s);
     k_ng_scatter<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.cell_of, w.start, w.counts, w.sorted);
 }
 void launch_knn_grid(const double* pts, int n, int k, int32_t* out, void* ws, hipStream_t s) {
