@@ -217,10 +217,9 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     if (rc) return rc;
     {
         Tic t = tic(h, "weights");
-        launch_cot_weights(h->sell, h->d_pts, ras ? nullptr : h->d_coef, s);                      // preprocess(), :393
-        launch_arap_prepare(h->sell, h->d_pts, ctrl, h->d_sol, h->d_rot, s);                     // :383-392
+        launch_cot_weights(h->sell, h->d_pts, ras ? nullptr : h->d_coef, ctrl, h->d_sol, h->d_rot, s);   // preprocess() :393 + set_target_position :383-392
         if (ras) launch_ras_prepare(h, s);
-        toc(t, 3);
+        toc(t, 2);
     }
     double* x_cur = h->d_sol;            // the patch solver ping-pongs between d_sol and d_ras_x2
     int64_t ras_slot = 0;
@@ -265,10 +264,15 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
         { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, h->d_sol, it, p.arap_tol, h->d_energy, h->d_cov, h->d_rot, s); toc(t, 3); }
     }
     Tic t = tic(h, "finalize");
-    launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, s);       // :400
-    int n = 2;
-    if (p.update_normals) { launch_vertex_normals(h->d_pts, h->d_faces, h->d_vf_ptr, h->d_vf, V, h->d_nrm, s); ++n; }
-    launch_gather_nodes(h->d_pts, h->d_nrm, h->d_nodes, K, h->d_node_pts, h->d_node_nrm, s);
+    int n = 1;
+    if (p.update_normals) {              // the node normals change too: separate gather after the normals kernel
+        launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, nullptr, nullptr, nullptr, s);   // :400
+        launch_vertex_normals(h->d_pts, h->d_faces, h->d_vf_ptr, h->d_vf, V, h->d_nrm, s);
+        launch_gather_nodes(h->d_pts, h->d_nrm, h->d_nodes, K, h->d_node_pts, h->d_node_nrm, s);
+        n = 3;
+    } else {
+        launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, h->d_nrm, h->d_node_pts, h->d_node_nrm, s);
+    }
     toc(t, n);
     (void)V;
     return MVS_OK;

@@ -150,10 +150,19 @@ __device__ inline double cot_clamped(d3 a, d3 b, d3 o) {
 }
 
 // per entry: w_ij = (cot a + cot b) / 2 clamped per angle; per row: diag = sum_j (wij + wji)
-__global__ __launch_bounds__(TPB) void k_cot_weights(SellDev m, const double* __restrict__ pts) {
+// (with ctrl != NULL it also does k_arap_prepare's job for its rows: solution = node target or rest position, R = I)
+__global__ __launch_bounds__(TPB) void k_cot_weights(SellDev m, const double* __restrict__ pts, const double* __restrict__ ctrl,
+                                                     double* __restrict__ sol, double* __restrict__ rot) {
     FOR_ROW_GROUPS(m, g) {
         const RowCtx r = row_ctx(m, g);
         const d3 pi = r.live ? ld3(pts + 3 * r.row) : mk3(0, 0, 0);
+        if (ctrl && r.live) {                                            // set_target_position for every node (Deformation.cpp:383-392)
+            const int c = m.is_ctrl[r.row];
+            if (r.l < 3) sol[3 * r.row + r.l] = c ? ctrl[3 * (c - 1) + r.l] : (r.l == 0 ? pi.x : (r.l == 1 ? pi.y : pi.z));
+            double* R = rot + 9 * (int64_t)r.row;
+            R[r.l] = (r.l == 0 || r.l == 4) ? 1.0 : 0.0;
+            if (r.l == 0) R[8] = 1.0;
+        }
         double diag = 0.0;
         for (int t = 0; t < r.passes; ++t) {
             const int e = r.off + 64 * t;
@@ -539,7 +548,8 @@ __global__ __launch_bounds__(TPB) void k_arap_energy(SellDev m, const double* __
 }
 
 __global__ void k_arap_finalize(SellDev m, int iters, double tol, int nb, double* __restrict__ ered,
-                                const double* __restrict__ sol, double* __restrict__ pts, int32_t* __restrict__ info) {
+                                const double* __restrict__ sol, double* __restrict__ pts, int32_t* __restrict__ info,
+                                const double* __restrict__ nrm, double* __restrict__ node_pts, double* __restrict__ node_nrm) {
     // assign_solution + overwrite_initial_geometry (Deformation.cpp:398-400)
     double* efin = ered + EFIN;
     if (blockIdx.x == 0 && threadIdx.x < 64) {
@@ -558,7 +568,12 @@ __global__ void k_arap_finalize(SellDev m, int iters, double tol, int nb, double
         }
     }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m.V) st3(pts + 3 * i, ld3(sol + 3 * i));
+    if (i < m.V) {
+        const d3 x = ld3(sol + 3 * i);
+        st3(pts + 3 * i, x);
+        const int c = node_pts ? m.is_ctrl[i] : 0;                     // node k sits at its vertex: refresh the node arrays too
+        if (c) { st3(node_pts + 3 * (c - 1), x); st3(node_nrm + 3 * (c - 1), ld3(nrm + 3 * i)); }
+    }
 }
 
 // exportOBJ's normals (R/Deformation/Deformation.h:86-128): unit facet normals summed, / sqrt(n.n)
@@ -596,9 +611,9 @@ void launch_gather_nodes(const double* pts, const double* nrm, const int32_t* no
 void launch_smooth(const double* orig, const double* cur, const int32_t* nbr, int nn, int K, double* out, hipStream_t s) {
     if (K > 0) k_smooth<<<dim3((K + 255) / 256), dim3(256), 0, s>>>(orig, cur, nbr, nn, K, out);
 }
-void launch_cot_weights(const SellDev& m, const double* pts, double* coef, hipStream_t s) {
+void launch_cot_weights(const SellDev& m, const double* pts, double* coef, const double* ctrl, double* sol, double* rot, hipStream_t s) {
     const dim3 g(arap_grid_blocks(m));
-    k_cot_weights<<<g, dim3(TPB), 0, s>>>(m, pts);
+    k_cot_weights<<<g, dim3(TPB), 0, s>>>(m, pts, ctrl, sol, rot);
     if (coef) k_cg_coef<<<g, dim3(TPB), 0, s>>>(m, coef);      // CG only (the patch solver builds its own matrix)
 }
 void launch_arap_prepare(const SellDev& m, const double* pts, const double* ctrl, double* sol, double* rot, hipStream_t s) {
@@ -626,9 +641,10 @@ void launch_arap_local(const SellDev& m, const double* pts, const double* sol, i
     k_arap_svd<<<dim3((m.V + 255) / 256), dim3(256), 0, s>>>(m.V, it, tol, ered, cov, rot);
     k_arap_energy<<<g, dim3(TPB), 0, s>>>(m, pts, sol, rot, it, tol, ered);
 }
+// node_pts != NULL: also gathers the nodes' new positions and (unchanged) normals, as k_gather_nodes would
 void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered, const double* sol,
-                          double* pts, int32_t* info, hipStream_t s) {
-    k_arap_finalize<<<dim3((m.V + 255) / 256), dim3(256), 0, s>>>(m, iters, tol, arap_grid_blocks(m), ered, sol, pts, info);
+                          double* pts, int32_t* info, const double* nrm, double* node_pts, double* node_nrm, hipStream_t s) {
+    k_arap_finalize<<<dim3((m.V + 255) / 256), dim3(256), 0, s>>>(m, iters, tol, arap_grid_blocks(m), ered, sol, pts, info, nrm, node_pts, node_nrm);
 }
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf, int V,
                            double* out, hipStream_t s) {

@@ -139,7 +139,8 @@ void launch_knn_grid(const double* pts, int n, int k, int32_t* out, void* ws, hi
 void launch_gather_nodes(const double* pts, const double* nrm, const int32_t* nodes, int K,
                          double* node_pts, double* node_nrm, hipStream_t s);
 void launch_smooth(const double* orig, const double* cur, const int32_t* nbr, int nn, int K, double* out, hipStream_t s);
-void launch_cot_weights(const SellDev& m, const double* pts, double* coef, hipStream_t s);     // 2 launches
+// ctrl != NULL: also initialises sol (node targets / rest positions) and rot (identity), i.e. launch_arap_prepare
+void launch_cot_weights(const SellDev& m, const double* pts, double* coef, const double* ctrl, double* sol, double* rot, hipStream_t s);
 void launch_arap_prepare(const SellDev& m, const double* pts, const double* ctrl, double* sol, double* rot, hipStream_t s);
 // bout != NULL: patch-solver mode, writes the right-hand side b (V*3) instead of the CG state (rws, p)
 void launch_arap_rhs(const SellDev& m, const double* pts, const double* sol, const double* rot, int it, double tol,
@@ -153,7 +154,7 @@ void launch_cg_iter(const SellDev& m, const double* coef, int it, double tol, co
 void launch_arap_local(const SellDev& m, const double* pts, const double* sol, int it, double tol, double* ered,
                        double* cov, double* rot, hipStream_t s);                                  // 3 launches
 void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered, const double* sol,
-                          double* pts, int32_t* info, hipStream_t s);
+                          double* pts, int32_t* info, const double* nrm, double* node_pts, double* node_nrm, hipStream_t s);
 int  arap_grid_blocks(const SellDev& m);
 // schwarz.hip
 int  ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& rowptr, const std::vector<int32_t>& col,

@@ -84,7 +84,9 @@ namespace {
 
 struct NgGeom { float minx, miny, minz, h, inv_h; int nx, ny, nz; };
 
-__global__ __launch_bounds__(1024) void k_ng_bbox(const double* __restrict__ pts, int n, int NC, NgGeom* __restrict__ geo) {
+__global__ __launch_bounds__(1024) void k_ng_bbox(const double* __restrict__ pts, int n, int NC, NgGeom* __restrict__ geo,
+                                                  int* __restrict__ counts, int nclear) {
+    for (int i = threadIdx.x; i < nclear; i += 1024) counts[i] = 0;       // (saves the memset launch; the grid is rebuilt every outer iteration)
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = threadIdx.x; i < n; i += 1024)
 #pragma unroll
@@ -366,16 +368,16 @@ static void ng_scan(const NgWs& w, hipStream_t s) {
 }
 // build the point grid of `pts` in ws (device workspace of knn_grid_ws_bytes(n) bytes): 1 memset + 4 launches
 static void grid_build_ws(const double* pts, int n, const NgWs& w, hipStream_t s) {
-    (void)hipMemsetAsync(w.counts, 0, sizeof(int) * (w.ncell + 1), s);
-    k_ng_bbox<<<dim3(1), dim3(1024), 0, s>>>(pts, n, w.NC, w.geo);
+    k_ng_bbox<<<dim3(1), dim3(1024), 0, s>>>(pts, n, w.NC, w.geo, w.counts, w.ncell <= 65536 ? (int)w.ncell + 1 : 0);
+    if (w.ncell > 65536) (void)hipMemsetAsync(w.counts, 0, sizeof(int) * (w.ncell + 1), s);
     k_ng_count<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.geo, w.counts, w.cell_of);
     ng_scan(w, s);
     k_ng_scatter<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.cell_of, w.start, w.counts, w.sorted);
 }
 void knn_grid_build(const double* pts, int n, void* ws, hipStream_t s) {
     const NgWs w = ng_carve(ws, n);
-    (void)hipMemsetAsync(w.counts, 0, sizeof(int) * (w.ncell + 1), s);
-    k_ng_bbox<<<dim3(1), dim3(1024), 0, s>>>(pts, n, w.NC, w.geo);
+    k_ng_bbox<<<dim3(1), dim3(1024), 0, s>>>(pts, n, w.NC, w.geo, w.counts, w.ncell <= 65536 ? (int)w.ncell + 1 : 0);
+    if (w.ncell > 65536) (void)hipMemsetAsync(w.counts, 0, sizeof(int) * (w.ncell + 1), s);
     k_ng_count<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.geo, w.counts, w.cell_of);
     ng_scan(w, s);
     k_ng_scatter<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.cell_of, w.start, w.counts, w.sorted);
