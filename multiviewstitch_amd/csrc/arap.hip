@@ -150,7 +150,7 @@ __device__ inline double cot_clamped(d3 a, d3 b, d3 o) {
 }
 
 // per entry: w_ij = (cot a + cot b) / 2 clamped per angle; per row: diag = sum_j (wij + wji)
-// (with ctrl != NULL it also does k_arap_prepare's job for its rows: solution = node target or rest position, R = I)
+// (with ctrl != NULL it also starts the solve for its rows: solution = node target or rest position, R = I)
 __global__ __launch_bounds__(TPB) void k_cot_weights(SellDev m, const double* __restrict__ pts, const double* __restrict__ ctrl,
                                                      double* __restrict__ sol, double* __restrict__ rot) {
     FOR_ROW_GROUPS(m, g) {
@@ -192,17 +192,6 @@ __global__ __launch_bounds__(TPB) void k_cg_coef(SellDev m, double* __restrict__
             coef[e] = (w == 0.0 || m.is_ctrl[j]) ? 0.0 : (2.0 * w) / m.diag[j];
         }
     }
-}
-
-__global__ void k_arap_prepare(SellDev m, const double* __restrict__ pts, const double* __restrict__ ctrl,
-                               double* __restrict__ sol, double* __restrict__ rot) {
-    // set_target_position for every node (Deformation.cpp:383-392); rotations start at identity
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m.V) return;
-    const int c = m.is_ctrl[i];
-    st3(sol + 3 * i, c ? ld3(ctrl + 3 * (c - 1)) : ld3(pts + 3 * i));
-    double* R = rot + 9 * (int64_t)i;
-    R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
 }
 
 // --------------------------------------------------------------- global step --
@@ -615,9 +604,6 @@ void launch_cot_weights(const SellDev& m, const double* pts, double* coef, const
     const dim3 g(arap_grid_blocks(m));
     k_cot_weights<<<g, dim3(TPB), 0, s>>>(m, pts, ctrl, sol, rot);
     if (coef) k_cg_coef<<<g, dim3(TPB), 0, s>>>(m, coef);      // CG only (the patch solver builds its own matrix)
-}
-void launch_arap_prepare(const SellDev& m, const double* pts, const double* ctrl, double* sol, double* rot, hipStream_t s) {
-    k_arap_prepare<<<dim3((m.V + 255) / 256), dim3(256), 0, s>>>(m, pts, ctrl, sol, rot);
 }
 void launch_arap_rhs(const SellDev& m, const double* pts, const double* sol, const double* rot, int it, double tol,
                      double* ered, double* rws, double* p, double* bout, hipStream_t s) {

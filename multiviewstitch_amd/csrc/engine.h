@@ -139,9 +139,8 @@ void launch_knn_grid(const double* pts, int n, int k, int32_t* out, void* ws, hi
 void launch_gather_nodes(const double* pts, const double* nrm, const int32_t* nodes, int K,
                          double* node_pts, double* node_nrm, hipStream_t s);
 void launch_smooth(const double* orig, const double* cur, const int32_t* nbr, int nn, int K, double* out, hipStream_t s);
-// ctrl != NULL: also initialises sol (node targets / rest positions) and rot (identity), i.e. launch_arap_prepare
+// ctrl != NULL: also initialises sol (node targets / rest positions) and rot (identity), Deformation.cpp:383-392
 void launch_cot_weights(const SellDev& m, const double* pts, double* coef, const double* ctrl, double* sol, double* rot, hipStream_t s);
-void launch_arap_prepare(const SellDev& m, const double* pts, const double* ctrl, double* sol, double* rot, hipStream_t s);
 // bout != NULL: patch-solver mode, writes the right-hand side b (V*3) instead of the CG state (rws, p)
 void launch_arap_rhs(const SellDev& m, const double* pts, const double* sol, const double* rot, int it, double tol,
                      double* ered, double* rws, double* p, double* bout, hipStream_t s);
