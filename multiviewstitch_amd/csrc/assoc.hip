@@ -97,10 +97,8 @@ __device__ inline void shell_cell(int t, int S, int* dx, int* dy, int* dz) {
 }
 
 // ------------------------------------------------------------------ dmin ----
-__global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __restrict__ node_pts, int K,
-                                                    float* __restrict__ d2min) {
-    const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (node >= K) return;                       // wave-uniform
+// exact squared distance (float32) of one node to its nearest target point, by one wave; every lane gets the result
+__device__ inline float dmin_node(const GridDev& g, const double* __restrict__ node_pts, int node) {
     ASTAMP_BEGIN;
     const int lane = threadIdx.x & 63;
     const float qx = (float)node_pts[3 * node], qy = (float)node_pts[3 * node + 1], qz = (float)node_pts[3 * node + 2];
@@ -201,8 +199,16 @@ __global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __r
         }
     }
     best = wave_min_f(best);
-    if (lane == 0) d2min[node] = best;
     ASTAMP_END(0);
+    return best;
+}
+
+__global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __restrict__ node_pts, int K,
+                                                    float* __restrict__ d2min) {
+    const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= K) return;                       // wave-uniform
+    const float best = dmin_node(g, node_pts, node);
+    if ((threadIdx.x & 63) == 0) d2min[node] = best;
 }
 
 // ---------------------------------------------------------------- select ----
@@ -218,14 +224,13 @@ struct HeavyLds { double pd[HEAVY_WAVES][8], pl[HEAVY_WAVES][8], x[HEAVY_WAVES][
 
 template <int PARTS>
 __device__ inline void select_node(const GridDev& g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm,
-                                   int node, int top_k, const float* __restrict__ d2min, mvs_cand* __restrict__ rec,
+                                   int node, int top_k, float dm, mvs_cand* __restrict__ rec,
                                    int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap, HeavyLds* lds) {
     ASTAMP_BEGIN;
     const int lane = threadIdx.x & 63, part = PARTS > 1 ? (int)(threadIdx.x >> 6) : 0;
     int k_occ = 0;                                           // running index of the occupied rows (PARTS > 1)
     const d3 orig = ld3(node_pts + 3 * node), nn = ld3(node_nrm + 3 * node);
     const float qx = (float)orig.x, qy = (float)orig.y, qz = (float)orig.z;
-    const float dm = d2min[node];
 
     // wave-resident sorted list: lane i (< len) holds the i-th best candidate
     double L_pd = 0, L_pl = 0, L_x = 0, L_y = 0, L_z = 0;
@@ -433,7 +438,20 @@ __global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* _
                                                       int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap) {
     const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (node >= K) return;
-    select_node<1>(g, node_pts, node_nrm, node, top_k, d2min, rec, counts, heavy, heavy_cap, nullptr);
+    select_node<1>(g, node_pts, node_nrm, node, top_k, d2min[node], rec, counts, heavy, heavy_cap, nullptr);
+}
+
+// single-rank association: nearest distance and ball query of a node by the same wave (no exchange of d2min in between:
+// one launch and one walk over the node's cells less than k_assoc_dmin + k_assoc_select)
+__global__ __launch_bounds__(256) void k_assoc_local(GridDev g, const double* __restrict__ node_pts,
+                                                     const double* __restrict__ node_nrm, int K, int top_k,
+                                                     float* __restrict__ d2min, mvs_cand* __restrict__ rec,
+                                                     int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap) {
+    const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= K) return;
+    const float best = dmin_node(g, node_pts, node);
+    if ((threadIdx.x & 63) == 0) d2min[node] = best;
+    select_node<1>(g, node_pts, node_nrm, node, top_k, best, rec, counts, heavy, heavy_cap, nullptr);
 }
 
 // the deferred nodes: one 16-wave workgroup per node (a far node's ball covers thousands of points; left to one
@@ -446,7 +464,8 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_select_heavy(GridDev
     __shared__ HeavyLds lds;
     const int n = min(heavy[0], heavy_cap);
     for (int h = blockIdx.x; h < n; h += gridDim.x) {
-        select_node<HEAVY_WAVES>(g, node_pts, node_nrm, heavy[1 + h], top_k, d2min, rec, counts, nullptr, 0, &lds);
+        const int node = heavy[1 + h];
+        select_node<HEAVY_WAVES>(g, node_pts, node_nrm, node, top_k, d2min[node], rec, counts, nullptr, 0, &lds);
         __syncthreads();                                     // the LDS lists are reused by the next node
     }
 }
@@ -522,6 +541,14 @@ void launch_assoc_select(const GridDev& g, const double* node_pts, const double*
     if (heavy) (void)hipMemsetAsync(heavy, 0, sizeof(int32_t), s);
     k_assoc_select<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, top_k, d2min, rec, counts, heavy, heavy_cap);
     if (heavy) k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, top_k, d2min, rec, counts, heavy, heavy_cap);
+}
+// dmin + select of a single-rank run in one launch (+ the heavy-node pass); d2min is still written (getters, heavy pass)
+void launch_assoc_local(const GridDev& g, const double* node_pts, const double* node_nrm, int K, int top_k, float* d2min,
+                        mvs_cand* rec, int32_t* counts, int32_t* heavy, int heavy_cap, hipStream_t s) {
+    if (K <= 0) return;
+    (void)hipMemsetAsync(heavy, 0, sizeof(int32_t), s);
+    k_assoc_local<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, top_k, d2min, rec, counts, heavy, heavy_cap);
+    k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, top_k, d2min, rec, counts, heavy, heavy_cap);
 }
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks, double* controls,
