@@ -100,6 +100,27 @@ int mvs_depth_unproject(const float* inv_depth, const mvs_camera* cam,
                         double min_dsp, double max_dsp,
                         double* out_points /* w*h*3 */, uint8_t* out_valid /* w*h */);
 
+/* The match-filter cascade in front of RemoveOutliers — Processor::AlignmentSeq, R/Processor/Processor.cpp:644-735, for the
+ * matches between the generated views of ONE frame of sequence k and ONE frame of sequence k+1:
+ *   raw[n][6] = (view1, u1, v1, view2, u2, v2) pixel matches between generated views;
+ *   tex1 / tex2 [view_count][w*h] = Image3D::texIndex (generated-view pixel -> base-view pixel index, -1 none),
+ *   valid1 / valid2 [w*h] = Image3D::valid, img1 / img2 [h][w][3] = the base 8-bit images in memory order.
+ * Stage 1 drops out-of-range / unmapped / invalid matches and duplicates (std::set order: lexicographic in
+ * (u1,v1,u2,v2)); stage 2 keeps matches whose (2 ssd_win + 1)^2 grey windows differ by an RMS <= ssd_err (SSD(),
+ * R/Common/Utils.h:221-241; windows touching the border are dropped); stage 3 is the greedy gap filter (a match
+ * survives unless it is within sample_interval pixels of a kept one in either image).  out: capacity n x 4
+ * (u1,v1,u2,v2); stage_counts (optional) = sizes after the three stages. */
+typedef struct mvs_match_filter_params {
+    int32_t w, h, view_count;
+    int32_t ssd_win;           /* ParamParser::ssd_win          */
+    double  ssd_err;           /* ParamParser::ssd_err          */
+    int32_t sample_interval;   /* ParamParser::sample_interval  */
+    int32_t reserved;
+} mvs_match_filter_params;
+int mvs_match_filter(const int32_t* raw, int64_t n, const int32_t* tex1, const uint8_t* valid1, const int32_t* tex2,
+                     const uint8_t* valid2, const uint8_t* img1, const uint8_t* img2, const mvs_match_filter_params* p,
+                     int32_t* out, int64_t* n_out, int64_t* stage_counts /*3 or NULL*/);
+
 /* Model2Depth (R/Model2Depth/Model2Depth.cpp:58-156, R/Camera/Camera.cpp:6-38) without GLUT: mesh -> inverse-depth raster of
  * one camera by a z-buffer pass.  Vertex stage in float32 as the fixed-function pipeline (modelview = [R|t] with rows
  * 1,2 negated, glFrustum from the intrinsics, viewport w x h, depth range [0,1]); pixel centres at (i+.5, j+.5),

@@ -51,6 +51,12 @@ class CParams(C.Structure):
                 ("cg_max_iters", C.c_int32), ("update_normals", C.c_int32), ("solver", C.c_int32), ("reserved0", C.c_int32)]
 
 
+class CMatchFilterParams(C.Structure):
+    """struct mvs_match_filter_params."""
+    _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("view_count", C.c_int32), ("ssd_win", C.c_int32), ("ssd_err", C.c_double),
+                ("sample_interval", C.c_int32), ("reserved", C.c_int32)]
+
+
 class CStats(C.Structure):
     """struct mvs_deform_stats."""
     _fields_ = [("outer_done", C.c_int32), ("arap_iters_run", C.c_int32), ("cg_iters", C.c_int32),
@@ -73,6 +79,7 @@ _SIGS = {
     "mvs_depth_to_model": (C.c_int, [_VP, _VP, _D, _D, _D, _VP, _VP, _VP, _VP, _VP, _VP]),
     "mvs_depth_to_model_dev": (C.c_int, [_VP, _VP, _D, _D, _D, _VP, _VP, _VP, _VP, _VP, _VP]),
     "mvs_depth_unproject": (C.c_int, [_VP, _VP, _D, _D, _VP, _VP]),
+    "mvs_match_filter": (C.c_int, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "mvs_render_depth": (C.c_int, [_VP, _I64, _VP, _I64, _VP, C.c_float, C.c_float, _VP]),
     "mvs_render_depth_dev": (C.c_int, [_VP, _I64, _VP, _I64, _VP, C.c_float, C.c_float, _VP, _VP]),
     "mvs_check_consistency": (C.c_int, [_VP, _VP, _I32, _VP, _VP, _D, _D, _I32, _VP]),

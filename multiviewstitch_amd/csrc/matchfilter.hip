@@ -1,0 +1,115 @@
+// matchfilter.hip — the match-filter cascade in front of RemoveOutliers, Processor::AlignmentSeq
+// (R/Processor/Processor.cpp:644-735; SSD: R/Common/Utils.h:221-241), for one (frame 1, frame 2) bucket:
+//
+//   1. duplicates  : every raw match of the generated views is mapped through the frames' texture-index tables to
+//                    base-view pixels; invalid ones are dropped, the rest goes through a std::set (lexicographic order
+//                    of (u1,v1,u2,v2), Vector.h:57-63)                                                   — host
+//   2. SSD window  : root-mean-square difference of the two (2 win + 1)^2 grey windows <= ssd_err; grey as
+//                    cv::cvtColor(COLOR_RGB2GRAY) computes it for 8-bit data                            — k_ssd (GPU)
+//   3. gap         : greedy in list order: a match survives unless it lies within sample_interval pixels of an already
+//                    kept one in EITHER image                                                            — host
+//
+// Stages 1 and 3 are order-dependent container logic on a few thousand items (the reference's own host code); stage 2 is
+// the only arithmetic and runs as one thread per match.  The grey conversion is OpenCV's (un-vendored; recollection of
+// its 8-bit fixed-point path: (4899 c0 + 9617 c1 + 1868 c2 + 8192) >> 14 on the channels in memory order) -> unpinned.
+#include "engine.h"
+#include <algorithm>
+#include <cmath>
+#include <set>
+#include <array>
+#include <vector>
+
+namespace {
+
+__host__ __device__ inline int grey8(const uint8_t* px) { return (4899 * px[0] + 9617 * px[1] + 1868 * px[2] + 8192) >> 14; }
+
+__global__ void k_ssd(const int32_t* __restrict__ m, int n, const uint8_t* __restrict__ img1, const uint8_t* __restrict__ img2, int w,
+                      int h, int win, double* __restrict__ err) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int u1 = m[4 * i], v1 = m[4 * i + 1], u2 = m[4 * i + 2], v2 = m[4 * i + 3];
+    double e = -1.0;                                                     // window outside an image: dropped (Processor.cpp:690-691)
+    if (u1 >= win && v1 >= win && u2 >= win && v2 >= win && u1 < w - win && v1 < h - win && u2 < w - win && v2 < h - win) {
+        double sum = 0.0;
+        const int len = 2 * win + 1;
+        for (int a = 0; a < len; ++a)
+            for (int b = 0; b < len; ++b) {
+                const int g1 = grey8(img1 + 3 * ((int64_t)(v1 - win + a) * w + (u1 - win + b)));
+                const int g2 = grey8(img2 + 3 * ((int64_t)(v2 - win + a) * w + (u2 - win + b)));
+                sum += (double)(g1 - g2) * (double)(g1 - g2);
+            }
+        e = sqrt(sum / (len * len));
+    }
+    err[i] = e;
+}
+
+struct Buf {
+    void* p = nullptr;
+    ~Buf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        if (hipMalloc(&p, n ? n : 1) != hipSuccess) { mvs_set_error("hipMalloc(%zu) failed", n); return MVS_E_OOM; }
+        return MVS_OK;
+    }
+    template <class T> T* as() { return (T*)p; }
+};
+
+}  // namespace
+
+extern "C" int mvs_match_filter(const int32_t* raw, int64_t n, const int32_t* tex1, const uint8_t* valid1, const int32_t* tex2,
+                                const uint8_t* valid2, const uint8_t* img1, const uint8_t* img2, const mvs_match_filter_params* p,
+                                int32_t* out, int64_t* n_out, int64_t* stage_counts) {
+    if (n < 0 || (n && !raw) || !tex1 || !valid1 || !tex2 || !valid2 || !img1 || !img2 || !p || !out || !n_out || p->w <= 0 || p->h <= 0 ||
+        p->view_count <= 0 || p->ssd_win < 0) { mvs_set_error("mvs_match_filter: bad arguments"); return MVS_E_INVALID_ARG; }
+    const int w = p->w, h = p->h;
+    const int64_t npx = (int64_t)w * h;
+    // 1. duplicates (Processor.cpp:650-680)
+    std::set<std::array<int32_t, 4>> uniq;
+    for (int64_t k = 0; k < n; ++k) {
+        const int32_t* r = raw + 6 * k;
+        const int a1 = r[0], u1 = r[1], v1 = r[2], a2 = r[3], u2 = r[4], v2 = r[5];
+        if (a1 < 0 || a1 >= p->view_count || a2 < 0 || a2 >= p->view_count) { mvs_set_error("mvs_match_filter: view index out of range"); return MVS_E_INVALID_ARG; }
+        if (!(u1 >= 0 && u1 < w && v1 >= 0 && v1 < h && u2 >= 0 && u2 < w && v2 >= 0 && v2 < h)) continue;
+        const int idx1 = tex1[a1 * npx + (int64_t)v1 * w + u1], idx2 = tex2[a2 * npx + (int64_t)v2 * w + u2];
+        if (idx1 != -1 && idx2 != -1 && valid1[(int64_t)v1 * w + u1] && valid2[(int64_t)v2 * w + u2])
+            uniq.insert({idx1 % w, idx1 / w, idx2 % w, idx2 / w});
+    }
+    std::vector<int32_t> m;
+    m.reserve(uniq.size() * 4);
+    for (const auto& q : uniq) m.insert(m.end(), q.begin(), q.end());
+    const int n1 = (int)uniq.size();
+    // 2. SSD window (:683-707) on the GPU
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) { mvs_set_error("no HIP device"); return MVS_E_NO_DEVICE; }
+    std::vector<double> err((size_t)n1);
+    if (n1 > 0) {
+        Buf dm, d1, d2, de;
+        int rc;
+        if ((rc = dm.alloc(sizeof(int32_t) * 4 * (size_t)n1)) || (rc = d1.alloc((size_t)npx * 3)) || (rc = d2.alloc((size_t)npx * 3)) ||
+            (rc = de.alloc(sizeof(double) * (size_t)n1))) return rc;
+        HIPCHK(hipMemcpy(dm.p, m.data(), sizeof(int32_t) * 4 * (size_t)n1, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d1.p, img1, (size_t)npx * 3, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d2.p, img2, (size_t)npx * 3, hipMemcpyHostToDevice));
+        k_ssd<<<dim3((n1 + 127) / 128), dim3(128)>>>(dm.as<int32_t>(), n1, d1.as<uint8_t>(), d2.as<uint8_t>(), w, h, p->ssd_win, de.as<double>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(err.data(), de.p, sizeof(double) * (size_t)n1, hipMemcpyDeviceToHost));
+    }
+    std::vector<int32_t> m2;
+    for (int k = 0; k < n1; ++k)
+        if (err[k] >= 0.0 && err[k] <= p->ssd_err) m2.insert(m2.end(), m.begin() + 4 * k, m.begin() + 4 * k + 4);
+    const int n2 = (int)m2.size() / 4;
+    // 3. gap (:711-735)
+    const double gap = (double)p->sample_interval * (double)p->sample_interval;
+    int n3 = 0;
+    for (int k = 0; k < n2; ++k) {
+        bool close = false;
+        for (int k0 = 0; k0 < n3 && !close; ++k0) {
+            const int32_t *a = out + 4 * k0, *b = m2.data() + 4 * k;
+            const int x0 = a[0] - b[0], x1 = a[1] - b[1], y0 = a[2] - b[2], y1 = a[3] - b[3];
+            close = (double)(x0 * x0 + x1 * x1) <= gap || (double)(y0 * y0 + y1 * y1) <= gap;
+        }
+        if (!close) { std::copy(m2.begin() + 4 * k, m2.begin() + 4 * k + 4, out + 4 * n3); ++n3; }
+    }
+    *n_out = n3;
+    if (stage_counts) { stage_counts[0] = n1; stage_counts[1] = n2; stage_counts[2] = n3; }
+    return MVS_OK;
+}

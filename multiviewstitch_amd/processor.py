@@ -63,3 +63,21 @@ def RenderDepth(points, facets, camera, znear: float = 0.01, zfar: float = 2000.
     out = np.empty((camera.h, camera.w), np.float32)
     L.check(L.lib().mvs_render_depth(L.ptr(pts), len(pts), L.ptr(fac), len(fac), C.byref(cc), float(znear), float(zfar), L.ptr(out)))
     return out
+
+
+def MatchFilter(raw, tex1, valid1, tex2, valid2, img1, img2, ssd_win: int, ssd_err: float, sample_interval: int):
+    """The duplicate / SSD / gap cascade in front of RemoveOutliers (R/Processor/Processor.cpp:644-735) for the matches
+    between the generated views of one frame pair.  raw [n, 6] = (view1, u1, v1, view2, u2, v2); tex [views, h*w] int32,
+    valid [h*w] uint8, img [h, w, 3] uint8.  -> (matches [m, 4] = (u1, v1, u2, v2), sizes after the three stages)."""
+    raw = L.arr(raw, np.int32).reshape(-1, 6)
+    tex1, tex2 = L.arr(tex1, np.int32), L.arr(tex2, np.int32)
+    valid1, valid2 = L.arr(valid1, np.uint8), L.arr(valid2, np.uint8)
+    img1, img2 = L.arr(img1, np.uint8), L.arr(img2, np.uint8)
+    h, w = img1.shape[:2]
+    prm = L.CMatchFilterParams(w, h, tex1.shape[0], int(ssd_win), float(ssd_err), int(sample_interval), 0)
+    out = np.empty((max(1, len(raw)), 4), np.int32)
+    n_out = C.c_int64()
+    cnt = np.zeros(3, np.int64)
+    L.check(L.lib().mvs_match_filter(L.ptr(raw), len(raw), L.ptr(tex1), L.ptr(valid1), L.ptr(tex2), L.ptr(valid2), L.ptr(img1), L.ptr(img2),
+                                     C.byref(prm), L.ptr(out), C.byref(n_out), L.ptr(cnt)))
+    return out[:n_out.value].copy(), cnt

@@ -452,3 +452,18 @@ def render_depth(pts, faces, cam, znear=0.01, zfar=2000.0):
     cc = Camera.of(cam)
     lib().orc_render_depth(_p(pts), C.c_int64(len(pts)), _p(faces), C.c_int64(len(faces)), C.byref(cc), C.c_float(znear), C.c_float(zfar), _p(out))
     return out
+
+
+# ------------------------------------------------------- match filter ----
+def match_filter(raw, tex1, valid1, tex2, valid2, img1, img2, ssd_win, ssd_err, sample_interval):
+    raw = _c(raw, np.int32).reshape(-1, 6)
+    tex1, tex2 = _c(tex1, np.int32), _c(tex2, np.int32)
+    valid1, valid2 = _c(valid1, np.uint8), _c(valid2, np.uint8)
+    img1, img2 = _c(img1, np.uint8), _c(img2, np.uint8)
+    h, w = img1.shape[:2]
+    out = np.empty((max(1, len(raw)), 4), np.int32)
+    n_out = C.c_int64()
+    cnt = np.zeros(3, np.int64)
+    lib().orc_match_filter(_p(raw), C.c_int64(len(raw)), _p(tex1), _p(valid1), _p(tex2), _p(valid2), _p(img1), _p(img2), C.c_int(w), C.c_int(h),
+                           C.c_int(tex1.shape[0]), C.c_int(ssd_win), C.c_double(ssd_err), C.c_int(sample_interval), _p(out), C.byref(n_out), _p(cnt))
+    return out[:n_out.value].copy(), cnt

@@ -52,6 +52,9 @@ void orc_cam_world_to_img(const orc_camera* c, const double* pw, int* u, int* v)
 int  orc_depth_to_model(const float* inv_depth, const orc_camera* cam, double min_dsp,
                         double max_dsp, double smooth, int64_t* n_points, int64_t* n_faces,
                         double* out_points, double* out_normals, int32_t* out_tex, int32_t* out_faces);
+int orc_match_filter(const int32_t* raw, int64_t n, const int32_t* tex1, const uint8_t* valid1, const int32_t* tex2,
+                     const uint8_t* valid2, const uint8_t* img1, const uint8_t* img2, int w, int h, int view_count, int ssd_win,
+                     double ssd_err, int sample_interval, int32_t* out, int64_t* n_out, int64_t* stage_counts);
 void orc_render_depth(const double* pts, int64_t V, const int32_t* faces, int64_t F, const orc_camera* cam, float znear, float zfar,
                       float* out);
 void orc_check_consistency(const float* depth, const orc_camera* cur, int n_ref, const float* const* ref_depths,
