@@ -51,4 +51,12 @@ tm = sc["src"] / np.abs(sc["src"]).max() * np.abs(big).max()
 for _ in range(3):
     alignment.part_recog(tm, sc["s_labels"], big)
 rows["k_label_nn"] = {"bytes": 28 * len(big), "note": "24 B query + 4 B label per scan point (template grid stays in L2)", "points": len(big)}
+# f3: render the 9 K-vertex template and a 314 K-vertex depth mesh back into a 1280x960 raster
+_, _, _, faces0 = srt_mod.depth_to_model(d[0], cams[0], S.MIN_DSP, S.MAX_DSP, S.SMOOTH)
+mesh_p = p
+mesh_f = torch.from_numpy(np.ascontiguousarray(faces0)).to(dev)
+out = torch.empty((960, 1280), dtype=torch.float32, device=dev)
+for _ in range(REPS):
+    processor.RenderDepth((mesh_p.data_ptr(), npnt), (mesh_f.data_ptr(), len(faces0)), cams[1], out_dev=out.data_ptr())
+rows["k_rd_raster"] = {"bytes": 12 * len(faces0) + 3 * 16 * len(faces0) + 4 * 1280 * 960, "note": "12 B indices + 3 x 16 B window vertices per triangle, one 4 B depth atomic per covered pixel", "triangles": len(faces0)}
 print(json.dumps(rows))
