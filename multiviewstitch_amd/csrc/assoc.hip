@@ -8,15 +8,17 @@
 //                    order (projDist, |projLen|, index)  
 //   k_assoc_merge  : merge rank lists, means (:338-349), rejection tests (:350-353)
 //
-// One wave64 per node.  The dense grid is x-fastest, so every (y,z) row of a
-// search box is one contiguous, coalesced run of float4 points.  Nodes close to
-// the target (the common case) touch the 3x3x3 fine cells around them; nodes far
-// from it (uncovered regions: the tail that would otherwise set the kernel's
-// duration) walk a COARSE occupancy grid (8x8x8 fine cells per coarse cell) in
-// expanding shells and only descend into occupied coarse cells that can still
-// beat the current best.  The running top-k lives across lanes 0..top_k-1 of the
-// wave (one element per lane) and is updated by ballot/readlane/shfl_up — no LDS,
-// no atomics, deterministic.
+// One wave64 per node.  Points are counting-sorted into a dense grid stored TILED (coarse cell = 8x8x8 fine cells,
+// grid_dev.h), so a run of x-adjacent fine cells or a whole coarse cell is one contiguous, coalesced range of float4
+// points.  Nodes close to the target (the common case) touch the fine cells around them; nodes far from it (uncovered
+// regions) walk the COARSE occupancy grid and only descend into occupied coarse cells that can still matter.  The
+// running top-k lives across lanes 0..top_k-1 of the wave (one element per lane) and is updated by
+// ballot/readlane/shfl_up — no atomics on the data path, deterministic.
+//
+// Far nodes set the duration of the whole search when left to one wave (300 K cycles against a median of 12 K,
+// scripts/assoc_cycles.py): k_assoc_select defers every node whose ball spans more than HEAVY_ROWS grid rows to
+// k_assoc_select_heavy, a 16-wave workgroup per node (cell look-ups shared through an LDS list, ranges scanned
+// round-robin, the 16 top-k lists merged in LDS).  A single-rank run fuses dmin + select into k_assoc_local.
 #include "engine.h"
 #include "dev_common.h"
 #include "grid_dev.h"
