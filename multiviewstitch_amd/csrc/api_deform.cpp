@@ -240,7 +240,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
             }
             toc(t, rp.n[it]);
         }
-        { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, x_cur, it, p.arap_tol, h->d_energy, h->d_cov, h->d_rot, s); toc(t, 3); }
+        { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, x_cur, it, p.arap_tol, h->d_energy, h->d_rot, s); toc(t, 1); }
     }
     for (int it = 0; !ras && it < p.arap_iters; ++it) {                                           // deform(5, 1e-4), :398
         double* slots = h->d_slots + plan.offset(it);
@@ -260,7 +260,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
             }
             toc(t, cg);
         }
-        { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, h->d_sol, it, p.arap_tol, h->d_energy, h->d_cov, h->d_rot, s); toc(t, 3); }
+        { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, h->d_sol, it, p.arap_tol, h->d_energy, h->d_rot, s); toc(t, 1); }
     }
     Tic t = tic(h, "finalize");
     int n = 1;
@@ -536,7 +536,7 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals, in
     TRY(dmalloc(&h->d_opp1, (size_t)ne)); TRY(dmalloc(&h->d_w, (size_t)ne)); TRY(dmalloc(&h->d_diag, (size_t)V));
     TRY(dmalloc(&h->d_is_ctrl, (size_t)V));
     for (int k = 0; k < 2; ++k) TRY(dmalloc(&h->d_rws[k], (size_t)V * 9));
-    TRY(dmalloc(&h->d_p, (size_t)V * 3)); TRY(dmalloc(&h->d_coef, (size_t)ne)); TRY(dmalloc(&h->d_cov, (size_t)V * 9)); TRY(dmalloc(&h->d_energy, MVS_ERED_SIZE)); TRY(dmalloc(&h->d_info, 8));
+    TRY(dmalloc(&h->d_p, (size_t)V * 3)); TRY(dmalloc(&h->d_coef, (size_t)ne)); TRY(dmalloc(&h->d_energy, MVS_ERED_SIZE)); TRY(dmalloc(&h->d_info, 8));
     auto up = [&](void* d, const void* s, size_t n) { return mvs_check_hip(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, h->stream), "upload"); };
     TRY(up(h->d_pts, points, sizeof(double) * V * 3)); TRY(up(h->d_nrm, normals, sizeof(double) * V * 3));
     TRY(up(h->d_sol, points, sizeof(double) * V * 3));
@@ -565,7 +565,7 @@ int mvs_deform_destroy(mvs_deform_t h) {
     dfree(h->d_slice_off); dfree(h->d_col); dfree(h->d_opp0); dfree(h->d_opp1); dfree(h->d_is_ctrl); dfree(h->d_w); dfree(h->d_diag);
     dfree(h->d_spos); dfree(h->d_tpos); dfree(h->d_tnrm); dfree(h->d_cell_start); dfree(h->d_coarse_cnt);
     for (int k = 0; k < 2; ++k) dfree(h->d_rws[k]);
-    dfree(h->d_p); dfree(h->d_coef); dfree(h->d_cov); dfree(h->d_slots); dfree(h->d_energy); dfree(h->d_info);
+    dfree(h->d_p); dfree(h->d_coef); dfree(h->d_slots); dfree(h->d_energy); dfree(h->d_info);
     ras_free(h);
     for (auto& pr : h->pending) { (void)hipEventDestroy(pr.second.first); (void)hipEventDestroy(pr.second.second); }
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);

@@ -462,18 +462,23 @@ __global__ __launch_bounds__(TPB) void k_cg_iter(SellDev m, const double* __rest
 }
 
 // ---------------------------------------------------------------- local step --
-// cov_i = sum_j wij p_ij q_ij^T  (8 lanes per row)
-__global__ __launch_bounds__(TPB) void k_arap_cov(SellDev m, const double* __restrict__ pts,
-                                                  const double* __restrict__ sol, int it, double tol,
-                                                  const double* __restrict__ ered, double* __restrict__ cov) {
+// The whole local step of one ARAP iteration in ONE launch, a thread per vertex: covariance of the 1-ring
+// (cov_i = sum_j wij p_ij q_ij^T), closest rotation, and the vertex's energy term sum_j wij |q_ij - R_i p_ij|^2 with
+// the rotation still in registers.  (Three kernels before — 8 lanes per row for the two gathers, a thread per vertex
+// for the Jacobi chain: the gathers were never the cost, the two extra kernel boundaries were.)  The grid is the row
+// kernels' grid so that the energy partials land where their consumers fold them.
+__global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __restrict__ pts, const double* __restrict__ sol,
+                                                    int it, double tol, double* __restrict__ ered, double* __restrict__ rot) {
     if (block_done(ered + EFIN, it, tol)) return;
-    FOR_ROW_GROUPS(m, g) {
-        const RowCtx r = row_ctx(m, g);
+    double e_acc = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < m.V; i += gridDim.x * 256) {
+        const int g = i >> 3, r = i & 7, off = m.slice_off[g], passes = (m.slice_off[g + 1] - off) >> 6;
+        const d3 pi = ld3(pts + 3 * i), qi = ld3(sol + 3 * i);
         double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (r.live) {
-            const d3 pi = ld3(pts + 3 * r.row), qi = ld3(sol + 3 * r.row);
-            for (int t = 0; t < r.passes; ++t) {
-                const int e = r.off + 64 * t;
+        for (int t = 0; t < passes; ++t)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                const int e = off + (8 * t + r) * 8 + l;
                 const double w = m.w[e];
                 if (w == 0.0) continue;
                 const int j = m.col[e];
@@ -482,58 +487,26 @@ __global__ __launch_bounds__(TPB) void k_arap_cov(SellDev m, const double* __res
                 c[3] += w * (pp.y * qq.x); c[4] += w * (pp.y * qq.y); c[5] += w * (pp.y * qq.z);
                 c[6] += w * (pp.z * qq.x); c[7] += w * (pp.z * qq.y); c[8] += w * (pp.z * qq.z);
             }
-        }
+        double R[9];
+        closest_rotation(c, R);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) c[k] = red8(c[k]);
-        if (r.live) {
-            double* o = cov + 9 * (int64_t)r.row;
-            // lane l writes element l (lane 0 also element 8): static selects keep c[] in registers
-            double val = c[0];
+        for (int k = 0; k < 9; ++k) rot[9 * (int64_t)i + k] = R[k];
+        for (int t = 0; t < passes; ++t)
 #pragma unroll
-            for (int k = 1; k < 8; ++k) val = r.l == k ? c[k] : val;
-            o[r.l] = val;
-            if (r.l == 0) o[8] = c[8];
-        }
-    }
-}
-
-// R_i = closest rotation of cov_i (one thread per vertex: the Jacobi SVD is a serial chain)
-__global__ __launch_bounds__(256) void k_arap_svd(int V, int it, double tol, const double* __restrict__ ered,
-                                                  const double* __restrict__ cov, double* __restrict__ rot) {
-    if (block_done(ered + EFIN, it, tol)) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= V) return;
-    double c[9], R[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) c[k] = cov[9 * (int64_t)i + k];
-    closest_rotation(c, R);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) rot[9 * (int64_t)i + k] = R[k];
-}
-
-// E = sum_i sum_j wij |q_ij - R_i p_ij|^2  -> partials ered[it*EIT + workgroup]
-__global__ __launch_bounds__(TPB) void k_arap_energy(SellDev m, const double* __restrict__ pts,
-                                                     const double* __restrict__ sol, const double* __restrict__ rot,
-                                                     int it, double tol, double* __restrict__ ered) {
-    if (block_done(ered + EFIN, it, tol)) return;
-    double e_acc = 0.0;
-    FOR_ROW_GROUPS(m, g) {
-        const RowCtx r = row_ctx(m, g);
-        if (r.live) {
-            const d3 pi = ld3(pts + 3 * r.row), qi = ld3(sol + 3 * r.row);
-            const double* Ri = rot + 9 * (int64_t)r.row;
-            for (int t = 0; t < r.passes; ++t) {
-                const int e = r.off + 64 * t;
+            for (int l = 0; l < 8; ++l) {
+                const int e = off + (8 * t + r) * 8 + l;
                 const double w = m.w[e];
                 if (w == 0.0) continue;
                 const int j = m.col[e];
                 const d3 pp = pi - ld3(pts + 3 * j), qq = qi - ld3(sol + 3 * j);
-                e_acc += w * sqn3(qq - mulMv(Ri, pp));
+                e_acc += w * sqn3(qq - mulMv(R, pp));
             }
-        }
     }
-    double v[1] = {wave_total(e_acc)};
-    block_store_partials<1>(v, ered + it * EIT);
+    e_acc = wave_total(e_acc);
+    __shared__ double sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = e_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) ered[it * EIT + blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
 __global__ void k_arap_finalize(SellDev m, int iters, double tol, int nb, double* __restrict__ ered,
@@ -621,11 +594,8 @@ void launch_cg_iter(const SellDev& m, const double* coef, int it, double tol, co
                                                              slot_next, rws_in, rws_out, p, x);
 }
 void launch_arap_local(const SellDev& m, const double* pts, const double* sol, int it, double tol, double* ered,
-                       double* cov, double* rot, hipStream_t s) {
-    const dim3 g(arap_grid_blocks(m));
-    k_arap_cov<<<g, dim3(TPB), 0, s>>>(m, pts, sol, it, tol, ered, cov);
-    k_arap_svd<<<dim3((m.V + 255) / 256), dim3(256), 0, s>>>(m.V, it, tol, ered, cov, rot);
-    k_arap_energy<<<g, dim3(TPB), 0, s>>>(m, pts, sol, rot, it, tol, ered);
+                       double* rot, hipStream_t s) {
+    k_arap_local<<<dim3(arap_grid_blocks(m)), dim3(256), 0, s>>>(m, pts, sol, it, tol, ered, rot);
 }
 // node_pts != NULL: also gathers the nodes' new positions and (unchanged) normals, as k_gather_nodes would
 void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered, const double* sol,

@@ -93,8 +93,8 @@ struct mvs_deform_s {
     double *d_tpos = nullptr, *d_tnrm = nullptr;
     int32_t *d_cell_start = nullptr, *d_coarse_cnt = nullptr;
     bool has_target = false;
-    // CG work: ping-pong packed {r,w,s} records (V*9), p (V*3), per-entry 2w/diag_j, per-vertex covariance
-    double *d_rws[2] = {nullptr, nullptr}, *d_p = nullptr, *d_coef = nullptr, *d_cov = nullptr;
+    // CG work: ping-pong packed {r,w,s} records (V*9), p (V*3), per-entry 2w/diag_j
+    double *d_rws[2] = {nullptr, nullptr}, *d_p = nullptr, *d_coef = nullptr;
     double *d_slots = nullptr;      // per ARAP iteration: (cg_plan[it] + 2) slots of MVS_CG_SLOT doubles
     double *d_energy = nullptr;     // [MVS_ERED_SIZE] replicated energy / bnorm accumulators + reduced energies
     int32_t *d_info = nullptr;      // [8] : arap iterations run, ...
@@ -153,7 +153,7 @@ void launch_cg_iter(const SellDev& m, const double* coef, int it, double tol, co
                     const double* slot0, double* slot_i, double* slot_next, const double* rws_in, double* rws_out,
                     double* p, double* x, hipStream_t s);
 void launch_arap_local(const SellDev& m, const double* pts, const double* sol, int it, double tol, double* ered,
-                       double* cov, double* rot, hipStream_t s);                                  // 3 launches
+                       double* rot, hipStream_t s);
 void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered, const double* sol,
                           double* pts, int32_t* info, const double* nrm, double* node_pts, double* node_nrm, hipStream_t s);
 int  arap_grid_blocks(const SellDev& m);
