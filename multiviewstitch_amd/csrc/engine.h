@@ -42,11 +42,11 @@ struct SellDev {               // "ELL-8 by row group" adjacency of the template
 };
 
 struct RasDev {                // patches of the restricted additive Schwarz solver (schwarz.hip)
-    int32_t NP, NPpad, W;      // patches, 4*NP partial sums rounded up to 64, entries per local row (8 / 12 / 16)
-    const int32_t* prow;       // NP+1: first local row of each patch in the row tables
+    int32_t NP, NPpad, W, LS;  // patches, 4*NP partial sums rounded up to 64, entries per local row (8 / 12 / 16), rows per patch slot
+    const int32_t* pnloc;      // NP: local rows of each patch (its slot holds LS >= nloc rows, the rest inert padding)
     const int32_t* pown;       // NP: owned rows (they come first in a patch)
     const int32_t* l2g;        // local row -> vertex
-    const int16_t* lcol;       // per patch entry-major [W][nloc]: local column, -1 padding, -2 outside the patch
+    const int16_t* lcol;       // per patch entry-major [W][LS]: local column, -1 padding, -2 outside the patch
     const int32_t* gent;       // same layout: entry id in the ELL-8 adjacency (addresses SellDev::w), -1 padding
     const int32_t* gcol;       // same layout: vertex of the column, -1 padding
 };

@@ -106,18 +106,18 @@ struct ChebCoef { double c0, c1[16], c2[16]; };      // d_0 = c0 D^-1 r ;  d_{k+
 template <int W>
 __global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, double* __restrict__ pw, double* __restrict__ pd) {
     const int p = blockIdx.x, row = threadIdx.x;
-    const int base = R.prow[p], nloc = R.prow[p + 1] - base;
-    if (row >= nloc) return;
+    const int LS = R.LS, base = p * LS, nloc = R.pnloc[p];
+    const bool live = row < nloc;                                      // rows nloc..LS-1 are padding: inert (pd = 0, pw = 0)
     const int g = R.l2g[base + row];
-    const bool fixed = m.is_ctrl[g] != 0;
+    const bool fixed = !live || m.is_ctrl[g] != 0;
     pd[base + row] = fixed ? 0.0 : m.diag[g];
     const int32_t* gent = R.gent + (int64_t)base * W;
     const int32_t* gcol = R.gcol + (int64_t)base * W;
     double* o = pw + (int64_t)base * W;
 #pragma unroll
     for (int e = 0; e < W; ++e) {
-        const int ge = gent[e * nloc + row], gc = gcol[e * nloc + row];
-        o[e * nloc + row] = (ge >= 0 && !fixed && !m.is_ctrl[gc]) ? 2.0 * m.w[ge] : 0.0;
+        const int ge = gent[e * LS + row], gc = gcol[e * LS + row];
+        o[e * LS + row] = (ge >= 0 && !fixed && !m.is_ctrl[gc]) ? 2.0 * m.w[ge] : 0.0;
     }
 }
 
@@ -137,13 +137,13 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     double (*xs)[3] = reinterpret_cast<double (*)[3]>(smem);
     float4* dbuf = reinterpret_cast<float4*>(smem);
     const int p = blockIdx.x, row = threadIdx.x, lane = row & 63, wv = row >> 6;
-    const int base = R.prow[p], nloc = R.prow[p + 1] - base, nown = R.pown[p];
-    const bool live = row < nloc;
+    const int LS = R.LS, base = p * LS;                                 // fixed table stride: the loads below need only p
+    const int nloc = R.pnloc[p], nown = R.pown[p];
     const int NPpad = R.NPpad;
     RSTAMP(0);
     // ---- operand loads, issued before the convergence scalars are known (a frozen sweep wastes them, a planned one
     //      overlaps them with the fold of the previous sweep's partials): tables, then this row's x, b, diagonal
-    const int g = live ? R.l2g[base + row] : 0;
+    const int g = R.l2g[base + row];                                   // (padding rows: vertex 0, pd = 0 -> inert)
     int lc[W], gc[W];
     double w2[W];
     {
@@ -152,15 +152,15 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         const double* pwp = pw + (int64_t)base * W;
 #pragma unroll
         for (int e = 0; e < W; ++e) {                  // entry-major inside the patch: consecutive rows, consecutive addresses
-            lc[e] = live ? (int)lcol[e * nloc + row] : -1;
-            gc[e] = live ? gcol[e * nloc + row] : -1;
-            w2[e] = live ? pwp[e * nloc + row] : 0.0;
+            lc[e] = (int)lcol[e * LS + row];
+            gc[e] = gcol[e * LS + row];
+            w2[e] = pwp[e * LS + row];
         }
     }
-    const d3 xi = live ? ld3(xin + 3 * (int64_t)g) : mk3(0, 0, 0);
-    const double dd = live ? pd[base + row] : 0.0;
+    const d3 xi = ld3(xin + 3 * (int64_t)g);
+    const double dd = pd[base + row];
     const bool fixed = dd == 0.0;
-    d3 rhs = live ? ld3(bvec + 3 * (int64_t)g) : mk3(0, 0, 0);      // (b is 0 on control rows)
+    d3 rhs = ld3(bvec + 3 * (int64_t)g);                               // (b is 0 on control rows; padding rows are fixed)
     // columns outside the patch: frozen at the previous sweep's value, moved to the right-hand side (branch-free gathers)
 #pragma unroll
     for (int e = 0; e < W; ++e) {
@@ -265,7 +265,7 @@ extern "C" int mvs_debug_ras_stamps(unsigned long long* out, int n) {
 
 void ras_free(mvs_deform_s* h) {
     auto fr = [](const void* p) { if (p) (void)hipFree(const_cast<void*>(p)); };
-    fr(h->ras.prow); fr(h->ras.pown); fr(h->ras.l2g); fr(h->ras.lcol); fr(h->ras.gent); fr(h->ras.gcol);
+    fr(h->ras.pnloc); fr(h->ras.pown); fr(h->ras.l2g); fr(h->ras.lcol); fr(h->ras.gent); fr(h->ras.gcol);
     fr(h->d_ras_x2); fr(h->d_ras_b); fr(h->d_ras_pw); fr(h->d_ras_pd); fr(h->d_ras_slots); fr(h->d_ras_iters);
     h->ras = RasDev{}; h->d_ras_x2 = h->d_ras_b = h->d_ras_slots = h->d_ras_pw = h->d_ras_pd = nullptr; h->d_ras_iters = nullptr;
     h->has_ras = false; h->ras_slots_cap = 0;
@@ -316,13 +316,15 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
         }
         part_begin[NP] = V;
     }
-    std::vector<int32_t> prow(NP + 1, 0), pown(NP), l2g;
-    std::vector<int16_t> lcol;
-    std::vector<int32_t> gent, gcolv;
+    // pass 1: the rows of every patch (owned rows, then the overlap ring by ring)
+    std::vector<std::vector<int32_t>> prows(NP);
+    std::vector<int32_t> pnloc(NP), pown(NP);
     std::vector<int32_t> mark(V, -1), lidx(V, -1);
-    l2g.reserve((size_t)V * 3);
+    int max_nloc = 0;
+    int64_t total_rows = 0;
     for (int p = 0; p < NP; ++p) {
-        std::vector<int32_t> rows(order.begin() + part_begin[p], order.begin() + part_begin[p + 1]);
+        std::vector<int32_t>& rows = prows[p];
+        rows.assign(order.begin() + part_begin[p], order.begin() + part_begin[p + 1]);
         std::sort(rows.begin(), rows.end());            // owned rows in vertex order (gather locality)
         for (int v : rows) mark[v] = p;
         const int nown = (int)rows.size();
@@ -338,36 +340,42 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
             rows.insert(rows.end(), next.begin(), next.end());
             level_begin = level_end;
         }
-        if ((int)rows.size() > RTPB) return MVS_OK;  // cannot happen with OWN <= RTPB
-        const int nloc = (int)rows.size();
-        for (int q = 0; q < nloc; ++q) lidx[rows[q]] = q;
+        if ((int)rows.size() > RTPB || nown > 256) return MVS_OK;     // cannot happen (<= 240 owned rows, rings cut at RTPB)
         pown[p] = nown;
-        prow[p + 1] = prow[p] + nloc;
-        const size_t e0 = lcol.size();
-        lcol.resize(e0 + (size_t)nloc * W, (int16_t)-1);
-        gent.resize(e0 + (size_t)nloc * W, -1);
-        gcolv.resize(e0 + (size_t)nloc * W, -1);
+        pnloc[p] = (int)rows.size();
+        max_nloc = std::max(max_nloc, pnloc[p]);
+        total_rows += pnloc[p];
+        for (size_t q = nown; q < rows.size(); ++q) mark[rows[q]] = -1;      // overlap rows may be owned by a later patch
+    }
+    // pass 2: tables with a FIXED stride of LS rows per patch (= the workgroup size), padded with inert rows, so that
+    // a workgroup's table loads need nothing but its patch number (one dependent hop less per sweep)
+    const int LS = std::max(448, (max_nloc + 63) / 64 * 64);          // the preamble of the sweep kernel uses seven waves
+    std::vector<int32_t> l2g((size_t)NP * LS, 0), gent((size_t)NP * LS * W, -1), gcolv((size_t)NP * LS * W, -1);
+    std::vector<int16_t> lcol((size_t)NP * LS * W, (int16_t)-1);
+    for (int p = 0; p < NP; ++p) {
+        const std::vector<int32_t>& rows = prows[p];
+        const int nloc = pnloc[p];
+        for (int q = 0; q < nloc; ++q) { lidx[rows[q]] = q; l2g[(size_t)p * LS + q] = rows[q]; }
+        const size_t e0 = (size_t)p * LS * W;
         for (int q = 0; q < nloc; ++q) {
             const int i = rows[q], deg = rowptr[i + 1] - rowptr[i];
             for (int k = 0; k < deg; ++k) {
                 const int j = col[rowptr[i] + k];
                 const int gidx = slice_off[i / 8] + (8 * (k / 8) + (i % 8)) * 8 + (k % 8);     // entry (row i, k-th neighbour) of the ELL-8 layout
-                lcol[e0 + (size_t)k * nloc + q] = (int16_t)((mark[j] == p && lidx[j] >= 0 && lidx[j] < nloc && rows[lidx[j]] == j) ? lidx[j] : -2);
-                gent[e0 + (size_t)k * nloc + q] = gidx;
-                gcolv[e0 + (size_t)k * nloc + q] = j;
+                lcol[e0 + (size_t)k * LS + q] = (int16_t)((lidx[j] >= 0 && lidx[j] < nloc && rows[lidx[j]] == j) ? lidx[j] : -2);
+                gent[e0 + (size_t)k * LS + q] = gidx;
+                gcolv[e0 + (size_t)k * LS + q] = j;
             }
         }
-        l2g.insert(l2g.end(), rows.begin(), rows.end());
-        for (int v : rows) { lidx[v] = -1; }
-        for (int q = nown; q < nloc; ++q) mark[rows[q]] = -1;      // overlap rows may be owned by a later patch
+        for (int v : rows) lidx[v] = -1;
     }
     RasDev R{};
     R.NP = NP; R.NPpad = (4 * NP + 63) / 64 * 64; R.W = W;
     int rc;
-    int32_t *d_prow, *d_pown, *d_l2g, *d_gent, *d_gcol;
+    int32_t *d_pnloc, *d_pown, *d_l2g, *d_gent, *d_gcol;
     int16_t* d_lcol;
-    if ((rc = up(&d_prow, prow)) || (rc = up(&d_pown, pown)) || (rc = up(&d_l2g, l2g)) || (rc = up(&d_lcol, lcol)) || (rc = up(&d_gent, gent)) || (rc = up(&d_gcol, gcolv))) return rc;
-    R.prow = d_prow; R.pown = d_pown; R.l2g = d_l2g; R.lcol = d_lcol; R.gent = d_gent; R.gcol = d_gcol;
+    if ((rc = up(&d_pnloc, pnloc)) || (rc = up(&d_pown, pown)) || (rc = up(&d_l2g, l2g)) || (rc = up(&d_lcol, lcol)) || (rc = up(&d_gent, gent)) || (rc = up(&d_gcol, gcolv))) return rc;
+    R.pnloc = d_pnloc; R.pown = d_pown; R.LS = LS; R.l2g = d_l2g; R.lcol = d_lcol; R.gent = d_gent; R.gcol = d_gcol;
     h->ras = R;
     if (hipMalloc((void**)&h->d_ras_x2, sizeof(double) * 3 * (size_t)V) != hipSuccess || hipMalloc((void**)&h->d_ras_b, sizeof(double) * 3 * (size_t)V) != hipSuccess) {
         mvs_set_error("hipMalloc failed (patch solver vectors)"); return MVS_E_OOM;
@@ -375,9 +383,8 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
     if (hipMalloc((void**)&h->d_ras_pw, sizeof(double) * (size_t)W * l2g.size()) != hipSuccess || hipMalloc((void**)&h->d_ras_pd, sizeof(double) * l2g.size()) != hipSuccess) {
         mvs_set_error("hipMalloc failed (patch matrix)"); return MVS_E_OOM;
     }
-    h->ras_rows = (int64_t)l2g.size();
-    h->ras_block = 448;                                            // the preamble uses seven waves
-    for (int p = 0; p < NP; ++p) h->ras_block = std::max(h->ras_block, (prow[p + 1] - prow[p] + 63) / 64 * 64);
+    h->ras_rows = total_rows;
+    h->ras_block = LS;
     h->has_ras = true;
     if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] patch solver: %d patches, %lld local rows for %d vertices, workgroup %d threads, %d entries per row\n", NP, (long long)h->ras_rows, V, h->ras_block, W);
     return MVS_OK;
