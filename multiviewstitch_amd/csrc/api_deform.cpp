@@ -550,7 +550,7 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals, in
     TRY(mvs_check_hip(hipStreamSynchronize(h->stream), "sync"));
     TRY(ras_build(h, points, rowptr, col, slice_off));
 #undef TRY
-    h->sell.V = (int32_t)V; h->sell.nslices = nslices; h->sell.slice_off = h->d_slice_off; h->sell.col = h->d_col;
+    h->sell.V = (int32_t)V; h->sell.nslices = nslices; h->sell.single_pass = (ne == (int64_t)nslices * 64) ? 1 : 0; h->sell.slice_off = h->d_slice_off; h->sell.col = h->d_col;
     h->sell.opp0 = h->d_opp0; h->sell.opp1 = h->d_opp1; h->sell.w = h->d_w; h->sell.diag = h->d_diag; h->sell.is_ctrl = h->d_is_ctrl;
     *out = h;
     return MVS_OK;

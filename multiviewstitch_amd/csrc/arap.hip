@@ -67,8 +67,11 @@ __device__ inline RowCtx row_ctx(const SellDev& m, int g) {
     r.row = g * 8 + (lane >> 3);
     r.l = lane & 7;
     r.live = r.row < m.V;
-    r.off = m.slice_off[g] + lane;                                   // + 64 * pass
-    r.passes = (m.slice_off[g + 1] - m.slice_off[g]) >> 6;
+    if (m.single_pass) { r.off = 64 * g + lane; r.passes = 1; }     // (saves the dependent look-up: one memory hop per kernel)
+    else {
+        r.off = m.slice_off[g] + lane;                               // + 64 * pass
+        r.passes = (m.slice_off[g + 1] - m.slice_off[g]) >> 6;
+    }
     return r;
 }
 #define FOR_ROW_GROUPS(m, g) \
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
     if (block_done(ered + EFIN, it, tol)) return;
     double e_acc = 0.0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < m.V; i += gridDim.x * 256) {
-        const int g = i >> 3, r = i & 7, off = m.slice_off[g], passes = (m.slice_off[g + 1] - off) >> 6;
+        const int g = i >> 3, r = i & 7, off = m.single_pass ? 64 * g : m.slice_off[g], passes = m.single_pass ? 1 : (m.slice_off[g + 1] - off) >> 6;
         const d3 pi = ld3(pts + 3 * i), qi = ld3(sol + 3 * i);
         double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int t = 0; t < passes; ++t)

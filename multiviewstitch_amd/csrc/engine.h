@@ -32,6 +32,7 @@ struct GridDev {
 
 struct SellDev {               // "ELL-8 by row group" adjacency of the template mesh (see arap.hip)
     int32_t  V, nslices;       // nslices = number of 8-row groups
+    int32_t  single_pass;      // every group stores exactly one pass (max degree <= 8): slice_off[g] == 64 g, no look-up needed
     const int32_t* slice_off;  // nslices+1, in entries (64 per pass)
     const int32_t* col;
     const int32_t* opp0;
