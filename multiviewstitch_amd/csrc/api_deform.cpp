@@ -177,10 +177,9 @@ int ensure_slots(mvs_deform_s* h, int arap_iters, const CgPlan& cg) {
 void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
     Tic t = tic(h, "assoc");
     const int K = (int)h->K;
-    launch_assoc_local(h->grid, h->d_node_pts, h->d_node_nrm, K, p.top_k, h->d_d2min, h->d_records, h->d_counts, h->d_heavy, K, h->stream);
-    launch_assoc_merge(h->d_node_pts, h->d_node_nrm, K, p, h->d_records, h->d_counts, 1, h->d_ctrl_raw, h->d_valid,
-                       h->d_top_idx, h->stream);
-    toc(t, 3);
+    launch_assoc_local(h->grid, h->d_node_pts, h->d_node_nrm, K, p, h->d_d2min, h->d_records, h->d_counts, h->d_heavy, K, h->d_ctrl_raw,
+                       h->d_valid, h->d_top_idx, h->stream);
+    toc(t, 2);
 }
 
 // graph smoothing (optional) + ARAP + geometry update.  ctrl_src: K*3 node targets.

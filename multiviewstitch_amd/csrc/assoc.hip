@@ -224,10 +224,18 @@ struct HeavyLds { double pd[HEAVY_WAVES][8], pl[HEAVY_WAVES][8], x[HEAVY_WAVES][
                   long long idx[HEAVY_WAVES][8]; int nb[HEAVY_WAVES], np[HEAVY_WAVES];
                   int nr, ra[HEAVY_RANGES], rb[HEAVY_RANGES]; };      // occupied coarse cells of the ball, found by all waves
 
+// single-rank mode: what k_assoc_merge would compute from this node's (only) list, written straight from the wave
+struct LocalMerge {
+    double* controls; uint8_t* valid; int64_t* top_idx;      // controls == NULL: sharded run, the lists go to k_assoc_merge
+    double proj_len_err, proj_dist_err, min_cos;
+    int max_result;
+};
+
 template <int PARTS>
 __device__ inline void select_node(const GridDev& g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm,
                                    int node, int top_k, float dm, mvs_cand* __restrict__ rec,
-                                   int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap, HeavyLds* lds) {
+                                   int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap, HeavyLds* lds,
+                                   const LocalMerge& lm) {
     ASTAMP_BEGIN;
     const int lane = threadIdx.x & 63, part = PARTS > 1 ? (int)(threadIdx.x >> 6) : 0;
     int k_occ = 0;                                           // running index of the occupied rows (PARTS > 1)
@@ -431,6 +439,30 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
         o->index = live ? L_idx : -1;
     }
     if (lane == 0) { counts[2 * node] = n_ball; counts[2 * node + 1] = n_pass; }
+    if (lm.controls) {
+        // means over the list, best first (Deformation.cpp:338-349), and the rejection tests (:286-297, :350-353) —
+        // the same operations in the same order as k_assoc_merge with one rank
+        bool ok = n_ball < lm.max_result && len > 0;
+        d3 mp = orig;
+        double m_pl = 0, m_pd = 0;
+        d3 acc = mk3(0, 0, 0);
+        for (int sidx = 0; sidx < len; ++sidx) {
+            m_pl += rl_d(L_pl, sidx); m_pd += rl_d(L_pd, sidx);
+            acc = acc + mk3(rl_d(L_x, sidx), rl_d(L_y, sidx), rl_d(L_z, sidx));
+        }
+        if (ok) {
+            const double dn = (double)len;
+            m_pl /= dn; m_pd /= dn; acc = acc / dn;
+            if (m_pl >= lm.proj_len_err || m_pd >= lm.proj_dist_err) ok = false;
+            if (ok) {
+                const d3 dir = acc - orig;
+                if (fabs(dot3(dir, nn) / (norm3(dir) * norm3(nn))) < lm.min_cos) ok = false;
+            }
+            if (ok) mp = acc;
+        }
+        if (lm.top_idx && lane < 8) lm.top_idx[(int64_t)node * 8 + lane] = (n_ball < lm.max_result && len > 0 && lane < len) ? L_idx : -1;
+        if (lane == 0) { lm.valid[node] = ok ? 1 : 0; st3(lm.controls + 3 * node, mp); }
+    }
     ASTAMP_END(1);
 }
 
@@ -440,7 +472,7 @@ __global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* _
                                                       int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap) {
     const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (node >= K) return;
-    select_node<1>(g, node_pts, node_nrm, node, top_k, d2min[node], rec, counts, heavy, heavy_cap, nullptr);
+    select_node<1>(g, node_pts, node_nrm, node, top_k, d2min[node], rec, counts, heavy, heavy_cap, nullptr, LocalMerge{});
 }
 
 // single-rank association: nearest distance and ball query of a node by the same wave (no exchange of d2min in between:
@@ -448,12 +480,12 @@ __global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* _
 __global__ __launch_bounds__(256) void k_assoc_local(GridDev g, const double* __restrict__ node_pts,
                                                      const double* __restrict__ node_nrm, int K, int top_k,
                                                      float* __restrict__ d2min, mvs_cand* __restrict__ rec,
-                                                     int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap) {
+                                                     int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap, LocalMerge lm) {
     const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (node >= K) return;
     const float best = dmin_node(g, node_pts, node);
     if ((threadIdx.x & 63) == 0) d2min[node] = best;
-    select_node<1>(g, node_pts, node_nrm, node, top_k, best, rec, counts, heavy, heavy_cap, nullptr);
+    select_node<1>(g, node_pts, node_nrm, node, top_k, best, rec, counts, heavy, heavy_cap, nullptr, lm);
 }
 
 // the deferred nodes: one 16-wave workgroup per node (a far node's ball covers thousands of points; left to one
@@ -462,12 +494,12 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_select_heavy(GridDev
                                                                          const double* __restrict__ node_nrm, int top_k,
                                                                          const float* __restrict__ d2min, mvs_cand* __restrict__ rec,
                                                                          int32_t* __restrict__ counts, const int32_t* __restrict__ heavy,
-                                                                         int heavy_cap) {
+                                                                         int heavy_cap, LocalMerge lm) {
     __shared__ HeavyLds lds;
     const int n = min(heavy[0], heavy_cap);
     for (int h = blockIdx.x; h < n; h += gridDim.x) {
         const int node = heavy[1 + h];
-        select_node<HEAVY_WAVES>(g, node_pts, node_nrm, node, top_k, d2min[node], rec, counts, nullptr, 0, &lds);
+        select_node<HEAVY_WAVES>(g, node_pts, node_nrm, node, top_k, d2min[node], rec, counts, nullptr, 0, &lds, lm);
         __syncthreads();                                     // the LDS lists are reused by the next node
     }
 }
@@ -542,15 +574,18 @@ void launch_assoc_select(const GridDev& g, const double* node_pts, const double*
     if (K <= 0) return;
     if (heavy) (void)hipMemsetAsync(heavy, 0, sizeof(int32_t), s);
     k_assoc_select<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, top_k, d2min, rec, counts, heavy, heavy_cap);
-    if (heavy) k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, top_k, d2min, rec, counts, heavy, heavy_cap);
+    if (heavy) k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, top_k, d2min, rec, counts, heavy, heavy_cap, LocalMerge{});
 }
 // dmin + select of a single-rank run in one launch (+ the heavy-node pass); d2min is still written (getters, heavy pass)
-void launch_assoc_local(const GridDev& g, const double* node_pts, const double* node_nrm, int K, int top_k, float* d2min,
-                        mvs_cand* rec, int32_t* counts, int32_t* heavy, int heavy_cap, hipStream_t s) {
+// ... and the merge: with one rank a node's list is final, its wave writes the node target itself
+void launch_assoc_local(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, float* d2min,
+                        mvs_cand* rec, int32_t* counts, int32_t* heavy, int heavy_cap, double* controls, uint8_t* valid,
+                        int64_t* top_idx, hipStream_t s) {
     if (K <= 0) return;
+    const LocalMerge lm{controls, valid, top_idx, p.proj_len_err, p.proj_dist_err, p.min_cos, p.max_result};
     (void)hipMemsetAsync(heavy, 0, sizeof(int32_t), s);
-    k_assoc_local<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, top_k, d2min, rec, counts, heavy, heavy_cap);
-    k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, top_k, d2min, rec, counts, heavy, heavy_cap);
+    k_assoc_local<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm);
+    k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm);
 }
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks, double* controls,

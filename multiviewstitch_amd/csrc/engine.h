@@ -129,8 +129,9 @@ void launch_assoc_dmin(const GridDev& g, const double* node_pts, int K, float* d
 void launch_assoc_select(const GridDev& g, const double* node_pts, const double* node_nrm, int K, int top_k,
                          const float* d2min, mvs_cand* rec, int32_t* counts, int32_t* heavy /*[1 + cap] or NULL*/, int heavy_cap,
                          hipStream_t s);
-void launch_assoc_local(const GridDev& g, const double* node_pts, const double* node_nrm, int K, int top_k, float* d2min,
-                        mvs_cand* rec, int32_t* counts, int32_t* heavy, int heavy_cap, hipStream_t s);
+void launch_assoc_local(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, float* d2min,
+                        mvs_cand* rec, int32_t* counts, int32_t* heavy, int heavy_cap, double* controls, uint8_t* valid,
+                        int64_t* top_idx, hipStream_t s);
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks,
                         double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s);
