@@ -124,7 +124,7 @@ void collect_timers(mvs_deform_s* h) {
 void free_nodes(mvs_deform_s* h) {
     dfree(h->d_nodes); dfree(h->d_nbr); dfree(h->d_node_pts); dfree(h->d_node_nrm); dfree(h->d_ctrl_raw);
     dfree(h->d_ctrl_a); dfree(h->d_ctrl_b); dfree(h->d_valid); dfree(h->d_d2min); dfree(h->d_counts);
-    dfree(h->d_records); dfree(h->d_top_idx); dfree(h->d_heavy);
+    dfree(h->d_records); dfree(h->d_top_idx); dfree(h->d_heavy); dfree(h->d_heavy2);
     if (h->d_knn_ws) { (void)hipFree(h->d_knn_ws); h->d_knn_ws = nullptr; }
     h->d_ctrl_final = nullptr; h->K = 0; h->nbr_k = 0; h->h_nodes.clear();
 }
@@ -177,7 +177,10 @@ int ensure_slots(mvs_deform_s* h, int arap_iters, const CgPlan& cg) {
 void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
     Tic t = tic(h, "assoc");
     const int K = (int)h->K;
-    launch_assoc_local(h->grid, h->d_node_pts, h->d_node_nrm, K, p, h->d_d2min, h->d_records, h->d_counts, h->d_heavy, K, h->d_ctrl_raw,
+    int32_t* cur = h->heavy_flip ? h->d_heavy2 : h->d_heavy;
+    int32_t* nxt = h->heavy_flip ? h->d_heavy : h->d_heavy2;
+    h->heavy_flip ^= 1;
+    launch_assoc_local(h->grid, h->d_node_pts, h->d_node_nrm, K, p, h->d_d2min, h->d_records, h->d_counts, cur, nxt, K, h->d_ctrl_raw,
                        h->d_valid, h->d_top_idx, h->stream);
     toc(t, 2);
 }
@@ -593,7 +596,9 @@ int mvs_deform_set_nodes(mvs_deform_t h, const int32_t* vertex_idx, int64_t K) {
     TRY(dmalloc(&h->d_nodes, (size_t)K)); TRY(dmalloc(&h->d_node_pts, (size_t)K * 3)); TRY(dmalloc(&h->d_node_nrm, (size_t)K * 3));
     TRY(dmalloc(&h->d_ctrl_raw, (size_t)K * 3)); TRY(dmalloc(&h->d_ctrl_a, (size_t)K * 3)); TRY(dmalloc(&h->d_ctrl_b, (size_t)K * 3));
     TRY(dmalloc(&h->d_valid, (size_t)K)); TRY(dmalloc(&h->d_d2min, (size_t)K)); TRY(dmalloc(&h->d_counts, (size_t)K * 2));
-    TRY(dmalloc(&h->d_records, (size_t)K * 8)); TRY(dmalloc(&h->d_top_idx, (size_t)K * 8)); TRY(dmalloc(&h->d_heavy, (size_t)K + 1));
+    TRY(dmalloc(&h->d_records, (size_t)K * 8)); TRY(dmalloc(&h->d_top_idx, (size_t)K * 8)); TRY(dmalloc(&h->d_heavy, (size_t)K + 1)); TRY(dmalloc(&h->d_heavy2, (size_t)K + 1));
+    TRY(mvs_check_hip(hipMemsetAsync(h->d_heavy, 0, sizeof(int32_t), h->stream), "memset")); TRY(mvs_check_hip(hipMemsetAsync(h->d_heavy2, 0, sizeof(int32_t), h->stream), "memset"));
+    h->heavy_flip = 0;
     if (K >= 1024) TRY(mvs_check_hip(hipMalloc(&h->d_knn_ws, knn_grid_ws_bytes((int)K)), "hipMalloc"));   // small graphs: brute force
 #undef TRY
     HIPCHK(hipMemcpyAsync(h->d_is_ctrl, ctrl_id.data(), sizeof(int32_t) * h->V, hipMemcpyHostToDevice, h->stream));

@@ -480,7 +480,9 @@ __global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* _
 __global__ __launch_bounds__(256) void k_assoc_local(GridDev g, const double* __restrict__ node_pts,
                                                      const double* __restrict__ node_nrm, int K, int top_k,
                                                      float* __restrict__ d2min, mvs_cand* __restrict__ rec,
-                                                     int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap, LocalMerge lm) {
+                                                     int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap, LocalMerge lm,
+                                                     int32_t* __restrict__ heavy_next) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) heavy_next[0] = 0;       // the list of the NEXT outer iteration (they alternate): no memset launch
     const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (node >= K) return;
     const float best = dmin_node(g, node_pts, node);
@@ -579,12 +581,11 @@ void launch_assoc_select(const GridDev& g, const double* node_pts, const double*
 // dmin + select of a single-rank run in one launch (+ the heavy-node pass); d2min is still written (getters, heavy pass)
 // ... and the merge: with one rank a node's list is final, its wave writes the node target itself
 void launch_assoc_local(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, float* d2min,
-                        mvs_cand* rec, int32_t* counts, int32_t* heavy, int heavy_cap, double* controls, uint8_t* valid,
+                        mvs_cand* rec, int32_t* counts, int32_t* heavy, int32_t* heavy_next, int heavy_cap, double* controls, uint8_t* valid,
                         int64_t* top_idx, hipStream_t s) {
     if (K <= 0) return;
     const LocalMerge lm{controls, valid, top_idx, p.proj_len_err, p.proj_dist_err, p.min_cos, p.max_result};
-    (void)hipMemsetAsync(heavy, 0, sizeof(int32_t), s);
-    k_assoc_local<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm);
+    k_assoc_local<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm, heavy_next);
     k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm);
 }
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,

@@ -88,6 +88,8 @@ struct mvs_deform_s {
     mvs_cand *d_records = nullptr;
     int64_t *d_top_idx = nullptr;
     int32_t *d_heavy = nullptr;       // [1 + K]: nodes deferred to the workgroup-per-node association kernel
+    int32_t *d_heavy2 = nullptr;      // second list: single-rank iterations alternate (each resets the other's counter)
+    int heavy_flip = 0;
     // target
     GridDev grid{};
     float4 *d_spos = nullptr;
@@ -130,8 +132,8 @@ void launch_assoc_select(const GridDev& g, const double* node_pts, const double*
                          const float* d2min, mvs_cand* rec, int32_t* counts, int32_t* heavy /*[1 + cap] or NULL*/, int heavy_cap,
                          hipStream_t s);
 void launch_assoc_local(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, float* d2min,
-                        mvs_cand* rec, int32_t* counts, int32_t* heavy, int heavy_cap, double* controls, uint8_t* valid,
-                        int64_t* top_idx, hipStream_t s);
+                        mvs_cand* rec, int32_t* counts, int32_t* heavy /*counter already 0*/, int32_t* heavy_next /*reset for the next call*/,
+                        int heavy_cap, double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s);
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks,
                         double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s);
