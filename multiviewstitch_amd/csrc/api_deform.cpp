@@ -198,18 +198,24 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
             if (rc) return rc;
             h->nbr_k = nn;
         }
+        int first_sweep = 0;
         {                                                                                       // Deformation.cpp:359
             Tic t = tic(h, "graph");
-            if (h->d_knn_ws) { launch_knn_grid(h->d_node_pts, K, nn, h->d_nbr, h->d_knn_ws, s); toc(t, 5); }
-            else { launch_knn(h->d_node_pts, K, nn, h->d_nbr, s); toc(t, 1); }
+            if (h->d_knn_ws) {
+                // the grid kNN also performs the first smoothing sweep (its wave holds the neighbour list)
+                const bool fuse = p.smooth_sweeps > 0;
+                launch_knn_grid(h->d_node_pts, K, nn, h->d_nbr, h->d_knn_ws, s, fuse ? ctrl : nullptr, fuse ? h->d_ctrl_a : nullptr);
+                if (fuse) { ctrl = h->d_ctrl_a; first_sweep = 1; }
+                toc(t, 5);
+            } else { launch_knn(h->d_node_pts, K, nn, h->d_nbr, s); toc(t, 1); }
         }
         Tic t = tic(h, "smooth");
         double* bufs[2] = {h->d_ctrl_a, h->d_ctrl_b};
-        for (int sw = 0; sw < p.smooth_sweeps; ++sw) {                                            // :362-381
+        for (int sw = first_sweep; sw < p.smooth_sweeps; ++sw) {                                  // :362-381
             launch_smooth(h->d_node_pts, ctrl, h->d_nbr, nn, K, bufs[sw & 1], s);
             ctrl = bufs[sw & 1];
         }
-        toc(t, p.smooth_sweeps);
+        toc(t, p.smooth_sweeps - first_sweep);
     }
     h->d_ctrl_final = const_cast<double*>(ctrl);
     const bool ras = use_ras(h, p);

@@ -248,7 +248,8 @@ __global__ void k_ng_scatter(const double* __restrict__ pts, int n, const int* _
 
 __global__ __launch_bounds__(256) void k_ng_knn(const double* __restrict__ pts, int n, int k, const NgGeom* __restrict__ geo,
                                                 const int* __restrict__ cs, const float4* __restrict__ sorted,
-                                                int32_t* __restrict__ out) {
+                                                int32_t* __restrict__ out, const double* __restrict__ sm_cur,
+                                                double* __restrict__ sm_out) {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= n) return;
     const int lane = threadIdx.x & 63;
@@ -327,6 +328,23 @@ __global__ __launch_bounds__(256) void k_ng_knn(const double* __restrict__ pts, 
         }
     }
     if (lane < k) out[(int64_t)q * k + lane] = lane < len ? L_i : -1;
+    if (sm_out) {
+        // first Jacobi sweep of the node-target smoothing (Deformation.cpp:364-379) straight from the list just found:
+        // c_q = o_q + sum_j w (cur_j - o_j), j in list order — the same operations in the same order as k_smooth
+        const double w = 1.0 / k;
+        d3 dj = mk3(0, 0, 0);
+        if (lane < len) dj = w * (ld3(sm_cur + 3 * (int64_t)L_i) - ld3(pts + 3 * (int64_t)L_i));
+        d3 acc = mk3(0, 0, 0);
+        for (int sidx = 0; sidx < len; ++sidx) {
+            const long long bx = __double_as_longlong(dj.x), by = __double_as_longlong(dj.y), bz = __double_as_longlong(dj.z);
+            auto rl = [&](long long b) {
+                const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), sidx), hi = __builtin_amdgcn_readlane((int)(b >> 32), sidx);
+                return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+            };
+            acc = acc + mk3(rl(bx), rl(by), rl(bz));
+        }
+        if (lane == 0) st3(sm_out + 3 * (int64_t)q, ld3(pts + 3 * (int64_t)q) + acc);
+    }
 }
 
 }  // namespace
@@ -382,11 +400,14 @@ void knn_grid_build(const double* pts, int n, void* ws, hipStream_t s) {
     ng_scan(w, s);
     k_ng_scatter<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.cell_of, w.start, w.counts, w.sorted);
 }
-void launch_knn_grid(const double* pts, int n, int k, int32_t* out, void* ws, hipStream_t s) {
+// smooth_cur / smooth_out != NULL: the queries are the deformation nodes; also performs the first smoothing sweep of the
+// node targets `smooth_cur` into `smooth_out` (k = graph_k + 1 neighbours incl. self, weight 1/k each)
+void launch_knn_grid(const double* pts, int n, int k, int32_t* out, void* ws, hipStream_t s, const double* smooth_cur,
+                     double* smooth_out) {
     if (n <= 0) return;
     knn_grid_build(pts, n, ws, s);
     const NgWs w = ng_carve(ws, n);
-    k_ng_knn<<<dim3((n + 3) / 4), dim3(256), 0, s>>>(pts, n, k, w.geo, w.start, w.sorted, out);
+    k_ng_knn<<<dim3((n + 3) / 4), dim3(256), 0, s>>>(pts, n, k, w.geo, w.start, w.sorted, out, smooth_cur, smooth_out);
 }
 
 // PartRecognition::PartRecog (R/PartRecognition/PartRecognition.cpp:50-77): label of the exact nearest template
