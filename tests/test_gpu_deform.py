@@ -216,3 +216,17 @@ def test_patch_solver_adapts_to_the_node_density(eng, oracle, stride):
     assert rms(d.vertices(), ref["pts"]) <= 1e-6
     st2 = d.arap(tg)                                   # second call runs the calibrated sweep plan
     assert st2["cg_rel_residual"] <= 1.5 * d.params.cg_tol and st2["cg_launches"] <= st["cg_launches"]
+
+
+def test_results_are_bit_reproducible(eng):
+    """Fixed-order reductions everywhere (no floating-point atomics): two fresh handles give identical bits."""
+    sc, tp, tn, _ = scene_and_target(1)
+    outs = []
+    for _ in range(2):
+        d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+        d.UniformSampling(16)
+        d.set_target(tp, tn)
+        d.iterate(1)
+        st = d.iterate(2)
+        outs.append((d.vertices(), d.rotations(), np.array(st["energy"])))
+    assert all(np.array_equal(a, b) for a, b in zip(*outs))
