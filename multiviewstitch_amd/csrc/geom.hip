@@ -80,18 +80,24 @@ __global__ void k_depth_emit(const float* __restrict__ dsp, CamDev cam, double m
     if (!out_nrm) return;
     // vertex normal = normalised mean of the unit normals of the incident facets, facet order:
     // quad(y-1,x-1): A,B ; quad(y-1,x): A ; quad(y,x-1): B ; quad(y,x): A,B
-    auto pt = [&](int yy, int xx) { return world_from_img(cam, xx, yy, 1.0 / (double)dsp[yy * w + xx]); };
+    // the six neighbours any incident facet can use, each back-projected ONCE (a neighbour that is invalid or outside
+    // the raster yields a value no flagged facet reads: the quad flags imply the validity of their corners)
+    auto pt = [&](int yy, int xx) {
+        const bool in = yy >= 0 && yy < h && xx >= 0 && xx < w;
+        return world_from_img(cam, xx, yy, 1.0 / (double)dsp[in ? yy * w + xx : i]);
+    };
+    const d3 Pmm = pt(y - 1, x - 1), P0m = pt(y, x - 1), Pm0 = pt(y - 1, x), P0p = pt(y, x + 1), Pp0 = pt(y + 1, x), Ppp = pt(y + 1, x + 1);
     d3 sum = mk3(0, 0, 0);
     int cnt = 0;
     const QuadTris q0 = quad_tris(dsp, w, h, y - 1, x - 1, mn, mx, thr);
-    if (q0.a) { sum = sum + tri_normal_plyobj(pt(y - 1, x - 1), pt(y, x - 1), P); ++cnt; }
-    if (q0.b) { sum = sum + tri_normal_plyobj(pt(y - 1, x - 1), P, pt(y - 1, x)); ++cnt; }
+    if (q0.a) { sum = sum + tri_normal_plyobj(Pmm, P0m, P); ++cnt; }
+    if (q0.b) { sum = sum + tri_normal_plyobj(Pmm, P, Pm0); ++cnt; }
     const QuadTris q1 = quad_tris(dsp, w, h, y - 1, x, mn, mx, thr);
-    if (q1.a) { sum = sum + tri_normal_plyobj(pt(y - 1, x), P, pt(y, x + 1)); ++cnt; }
+    if (q1.a) { sum = sum + tri_normal_plyobj(Pm0, P, P0p); ++cnt; }
     const QuadTris q2 = quad_tris(dsp, w, h, y, x - 1, mn, mx, thr);
-    if (q2.b) { sum = sum + tri_normal_plyobj(pt(y, x - 1), pt(y + 1, x), P); ++cnt; }
-    if (own.a) { sum = sum + tri_normal_plyobj(P, pt(y + 1, x), pt(y + 1, x + 1)); ++cnt; }
-    if (own.b) { sum = sum + tri_normal_plyobj(P, pt(y + 1, x + 1), pt(y, x + 1)); ++cnt; }
+    if (q2.b) { sum = sum + tri_normal_plyobj(P0m, Pp0, P); ++cnt; }
+    if (own.a) { sum = sum + tri_normal_plyobj(P, Pp0, Ppp); ++cnt; }
+    if (own.b) { sum = sum + tri_normal_plyobj(P, Ppp, P0p); ++cnt; }
     const d3 m = sum / (double)cnt;                                       // PlyObj.cpp:154 (0/0 -> NaN when isolated)
     st3(out_nrm + 3 * (int64_t)o, m / norm3(m));                          // :155
 }
