@@ -239,14 +239,40 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
         {
             Tic t = tic(h, "cg");
             const int ss = ras_slot_size(h);
-            for (int i = 0; i < rp.n[it]; ++i, ++ras_slot) {
+            auto sweep = [&](int i) {
                 double* x_next = x_cur == h->d_sol ? h->d_ras_x2 : h->d_sol;
                 double* cur = h->d_ras_slots + (size_t)ras_slot * ss;
                 launch_ras_sweep(h, h->d_ras_b, x_cur, x_next, it, p.arap_tol, i, p.cg_tol, i > 0 ? cur - ss : nullptr, cur,
                                  h->d_ras_iters + (size_t)ras_slot * h->ras.NP, s);
                 x_cur = x_next;
+                ++ras_slot;
+            };
+            int launched = 0;
+            if (h->ras_plan[it] > 0) {
+                for (int i = 0; i < rp.n[it]; ++i) sweep(i);
+                launched = rp.n[it];
+            } else {
+                // this solve has no calibrated sweep count yet (first call on the handle): sweeps go out in chunks and the
+                // host looks at the residual after each — a few synchronisations once, instead of a worst-case plan
+                const int NPpad = h->ras.NPpad;
+                std::vector<double> part((size_t)3 * NPpad + 8);
+                bool conv = false;
+                while (!conv && launched < RAS_FIRST_PLAN) {
+                    const int chunk = std::min(launched == 0 ? 6 : 4, RAS_FIRST_PLAN - launched);
+                    for (int i = 0; i < chunk; ++i) sweep(launched + i);
+                    launched += chunk;
+                    HIPCHK(hipMemcpyAsync(part.data(), h->d_ras_slots + (size_t)(ras_slot - 1) * ss, sizeof(double) * part.size(), hipMemcpyDeviceToHost, s));
+                    HIPCHK(hipStreamSynchronize(s));
+                    conv = true;                                  // residual of the INPUT of the last sweep launched
+                    for (int c = 0; c < 3; ++c) {
+                        double g = 0.0;
+                        for (int q = 0; q < 4 * h->ras.NP; ++q) g += part[(size_t)c * NPpad + q];
+                        if (g > 0.0 && g > p.cg_tol * p.cg_tol * part[(size_t)3 * NPpad + 3 + c]) conv = false;
+                    }
+                }
+                h->ras_plan[it] = launched;                       // harvest_ras reads the slots with this layout, then re-plans
             }
-            toc(t, rp.n[it]);
+            toc(t, launched);
         }
         { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, x_cur, it, p.arap_tol, h->d_energy, h->d_rot, s); toc(t, 1); }
     }
@@ -364,10 +390,20 @@ int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* s
     const RasPlan rp = probe_ras(h);
     const int ss = ras_slot_size(h), NP = h->ras.NP, NPpad = h->ras.NPpad;
     const size_t nslots = (size_t)rp.total(p.arap_iters);
-    std::vector<double> slots(nslots * ss), ered(MVS_ERED_SIZE);
+    // per sweep only its 8 reduced scalars (gamma[3] of its input, folded by the following sweep; bn[3]) travel to the
+    // host, plus the per-patch partials of each solve's LAST sweep (nobody folded those) and the local step counts
+    std::vector<double> fin(nslots * 8), ered(MVS_ERED_SIZE), lastp((size_t)p.arap_iters * 3 * NPpad);
     std::vector<int32_t> iters(nslots * NP);
     int32_t info[8];
-    HIPCHK(hipMemcpyAsync(slots.data(), h->d_ras_slots, slots.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpy2DAsync(fin.data(), 8 * sizeof(double), h->d_ras_slots + 3 * (size_t)NPpad, (size_t)ss * sizeof(double), 8 * sizeof(double), nslots,
+                            hipMemcpyDeviceToHost, h->stream));
+    {
+        size_t slot = 0;
+        for (int it = 0; it < p.arap_iters; ++it) {
+            slot += rp.n[it];
+            HIPCHK(hipMemcpyAsync(lastp.data() + (size_t)it * 3 * NPpad, h->d_ras_slots + (slot - 1) * ss, sizeof(double) * 3 * NPpad, hipMemcpyDeviceToHost, h->stream));
+        }
+    }
     HIPCHK(hipMemcpyAsync(iters.data(), h->d_ras_iters, iters.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(ered.data(), h->d_energy, sizeof(double) * MVS_ERED_SIZE, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(info, h->d_info, sizeof info, hipMemcpyDeviceToHost, h->stream));
@@ -383,15 +419,15 @@ int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* s
         const int n = rp.n[it];
         max_plan = std::max(max_plan, n);
         if (it >= run) { slot += n; continue; }
-        const double* last = slots.data() + (slot + n - 1) * ss;
-        const double bn[3] = {last[3 * NPpad + 3], last[3 * NPpad + 4], last[3 * NPpad + 5]};
-        // gamma of the INPUT of sweep i (folded here from the per-patch partials, patch order)
+        const double* F = fin.data() + (slot + n - 1) * 8;
+        const double bn[3] = {F[3], F[4], F[5]};
+        // gamma of the INPUT of sweep i: reduced on the device for i < n-1, folded here (patch order) for the last sweep
         auto conv_at = [&](int i, double* rel) {
-            const double* S = slots.data() + (slot + i) * ss;
             bool ok = true;
             for (int c = 0; c < 3; ++c) {
                 double g = 0.0;
-                for (int q = 0; q < 4 * NP; ++q) g += S[c * NPpad + q];
+                if (i < n - 1) g = fin[(slot + i) * 8 + c];
+                else for (int q = 0; q < 4 * NP; ++q) g += lastp[(size_t)it * 3 * NPpad + (size_t)c * NPpad + q];
                 if (g > 0.0 && g > p.cg_tol * p.cg_tol * bn[c]) ok = false;
                 if (rel && bn[c] > 0) *rel = std::max(*rel, std::sqrt(std::max(0.0, g) / bn[c]));
             }
@@ -459,46 +495,47 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals, in
     if (V <= 0 || F < 0 || !points || !normals || (F > 0 && !faces) || V > 0x7ffffff0LL || F > 0x2aaaaaa0LL) {
         mvs_set_error("bad mesh arguments"); return MVS_E_INVALID_ARG;
     }
-    // validity (what Polyhedron_incremental_builder_3 / is_valid reject, Deformation.cpp:36-45)
-    std::vector<std::tuple<int, int, int>> he;            // (i, j, opposite)
-    he.reserve((size_t)F * 6);
-    std::vector<std::pair<int, int>> dir;
-    dir.reserve((size_t)F * 3);
+    // validity (what Polyhedron_incremental_builder_3 / is_valid reject, Deformation.cpp:36-45) and the adjacency rows
+    // (neighbours ascending, the <= 2 opposite vertices ascending).  Half-edges are bucketed by their source vertex
+    // (counting sort), each vertex then orders its own dozen entries: linear in F instead of two global sorts.
+    std::vector<int32_t> hptr(V + 1, 0);
     for (int64_t f = 0; f < F; ++f) {
         const int v[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
         for (int k = 0; k < 3; ++k)
             if (v[k] < 0 || v[k] >= V) { mvs_set_error("facet %lld: vertex index out of range", (long long)f); return MVS_E_BAD_MESH; }
         if (v[0] == v[1] || v[1] == v[2] || v[0] == v[2]) { mvs_set_error("facet %lld: repeated vertex", (long long)f); return MVS_E_BAD_MESH; }
-        for (int k = 0; k < 3; ++k) {
-            const int a = v[k], b = v[(k + 1) % 3], c = v[(k + 2) % 3];
-            dir.push_back({a, b});
-            he.push_back({a, b, c});
-            he.push_back({b, a, c});
-        }
+        for (int k = 0; k < 3; ++k) hptr[v[k] + 1] += 2;                 // every corner is the source of two half-edges of its facet
     }
-    std::sort(dir.begin(), dir.end());
-    for (size_t i = 1; i < dir.size(); ++i)
-        if (dir[i] == dir[i - 1]) { mvs_set_error("directed edge (%d,%d) used twice: non-manifold or inconsistently oriented", dir[i].first, dir[i].second); return MVS_E_NONMANIFOLD; }
+    for (int64_t i = 0; i < V; ++i) hptr[i + 1] += hptr[i];
+    struct Half { int32_t j, opp, fwd; };                                // neighbour, opposite vertex, 1 = in facet orientation
+    std::vector<Half> hal((size_t)F * 6);
+    {
+        std::vector<int32_t> cur(hptr.begin(), hptr.end() - 1);
+        for (int64_t f = 0; f < F; ++f)
+            for (int k = 0; k < 3; ++k) {
+                const int a = faces[3 * f + k], b = faces[3 * f + (k + 1) % 3], c = faces[3 * f + (k + 2) % 3];
+                hal[cur[a]++] = {b, c, 1};
+                hal[cur[b]++] = {a, c, 0};
+            }
+    }
+    std::vector<int32_t> rowptr(V + 1, 0), col, o0, o1;
+    col.reserve((size_t)F * 3); o0.reserve((size_t)F * 3); o1.reserve((size_t)F * 3);
+    for (int64_t i = 0; i < V; ++i) {
+        Half* b = hal.data() + hptr[i];
+        Half* e = hal.data() + hptr[i + 1];
+        std::sort(b, e, [](const Half& x, const Half& y) { return x.j != y.j ? x.j < y.j : x.opp < y.opp; });
+        for (Half* q = b; q < e;) {
+            Half* r = q;
+            int fwd = 0;
+            while (r < e && r->j == q->j) { fwd += r->fwd; ++r; }
+            if (fwd > 1) { mvs_set_error("directed edge (%d,%d) used twice: non-manifold or inconsistently oriented", (int)i, q->j); return MVS_E_NONMANIFOLD; }
+            col.push_back(q->j); o0.push_back(q->opp); o1.push_back(r - q > 1 ? (q + 1)->opp : -1);
+            q = r;
+        }
+        rowptr[i + 1] = (int32_t)col.size();
+    }
     int rc = need_device();
     if (rc) return rc;
-
-    // adjacency rows: neighbours ascending, the (<=2) opposite vertices ascending
-    std::sort(he.begin(), he.end());
-    std::vector<int32_t> rowptr(V + 1, 0), col, o0, o1;
-    col.reserve(he.size() / 2); o0.reserve(he.size() / 2); o1.reserve(he.size() / 2);
-    {
-        size_t e = 0;
-        for (int64_t i = 0; i < V; ++i) {
-            while (e < he.size() && std::get<0>(he[e]) == i) {
-                const int j = std::get<1>(he[e]);
-                col.push_back(j); o0.push_back(std::get<2>(he[e])); o1.push_back(-1);
-                ++e;
-                if (e < he.size() && std::get<0>(he[e]) == i && std::get<1>(he[e]) == j) { o1.back() = std::get<2>(he[e]); ++e; }
-                while (e < he.size() && std::get<0>(he[e]) == i && std::get<1>(he[e]) == j) ++e;   // unreachable after the check above
-            }
-            rowptr[i + 1] = (int32_t)col.size();
-        }
-    }
     // ELL-8 by row group: group = 8 rows = one wave; entry (row r of group, pass t, lane l) at goff + (8 t + r) * 8 + l
     const int nslices = (int)((V + 7) / 8);
     std::vector<int32_t> slice_off(nslices + 1, 0);
