@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <cstdlib>
 #include <tuple>
@@ -495,6 +496,8 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals, in
     if (V <= 0 || F < 0 || !points || !normals || (F > 0 && !faces) || V > 0x7ffffff0LL || F > 0x2aaaaaa0LL) {
         mvs_set_error("bad mesh arguments"); return MVS_E_INVALID_ARG;
     }
+    const auto t_create0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] create: %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count()); };
     // validity (what Polyhedron_incremental_builder_3 / is_valid reject, Deformation.cpp:36-45) and the adjacency rows
     // (neighbours ascending, the <= 2 opposite vertices ascending).  Half-edges are bucketed by their source vertex
     // (counting sort), each vertex then orders its own dozen entries: linear in F instead of two global sorts.
@@ -569,6 +572,7 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals, in
         for (int64_t f = 0; f < F; ++f) for (int k = 0; k < 3; ++k) vf[cur[faces[3 * f + k]]++] = (int32_t)f;
     }
 
+    lap("ELL tables");
     mvs_deform_s* h = new mvs_deform_s;
     h->device = g_device; h->V = V; h->F = F; h->n_entries = ne;
 #define TRY(x) do { rc = (x); if (rc) { mvs_deform_destroy(h); return rc; } } while (0)
@@ -593,7 +597,9 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals, in
     TRY(mvs_check_hip(hipMemsetAsync(h->d_rot, 0, sizeof(double) * V * 9, h->stream), "memset"));
     TRY(mvs_check_hip(hipMemsetAsync(h->d_info, 0, sizeof(int32_t) * 8, h->stream), "memset"));
     TRY(mvs_check_hip(hipStreamSynchronize(h->stream), "sync"));
+    lap("allocations + uploads");
     TRY(ras_build(h, points, rowptr, col, slice_off));
+    lap("patch tables");
 #undef TRY
     h->sell.V = (int32_t)V; h->sell.nslices = nslices; h->sell.single_pass = (ne == (int64_t)nslices * 64) ? 1 : 0; h->sell.slice_off = h->d_slice_off; h->sell.col = h->d_col;
     h->sell.opp0 = h->d_opp0; h->sell.opp1 = h->d_opp1; h->sell.w = h->d_w; h->sell.diag = h->d_diag; h->sell.is_ctrl = h->d_is_ctrl;
