@@ -289,7 +289,9 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
     int cus = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
     const int rounds = std::max(1, (V + cus * 240 - 1) / (cus * 240));
-    const int NP = std::min(V / 64, cus * rounds);
+    // small meshes: ~214 owned rows per patch as on the large ones (fewer, larger patches need fewer sweeps; a sweep costs
+    // the same few microseconds whether 40 or 256 CUs take part)
+    const int NP = std::min(cus * rounds, std::max(1, (V + 213) / 214));
     if (NP > 4096) return MVS_OK;                     // slot layout limit (V > 850 K): keep CG
     // recursive coordinate bisection of the rest positions into NP parts of equal size: compact, box-like patches
     // (a Z-curve cut left ragged patches whose three-ring halo was up to 832 rows; bisection keeps it near 450)
