@@ -451,6 +451,22 @@ int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* s
         if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] arap it %d: patch solver converged input at sweep %d of %d (rel %.3e)\n", it, first, n, rel);
         slot += n;
     }
+    {   // adapt the Chebyshev bracket of the local solves to what the sweeps showed: many sweeps (or none converged) mean
+        // the smooth modes are under-damped -> lower the bracket and take more steps; very few sweeps -> drift back up
+        double a0; int m0;
+        ras_default_bracket(h, &a0, &m0);
+        double a = h->ras_a > 0.0 ? h->ras_a : a0;
+        int worst_first = 0;
+        for (int it = 0; it < run; ++it) worst_first = std::max(worst_first, h->ras_plan[it] - 2);
+        if (!all_conv || worst_first > 9) {
+            a = std::max(a / 3.0, 0.002);
+        } else if (worst_first <= 4 && a < a0) {
+            a = std::min(a0, a * 1.5);
+            for (int it = 0; it < run; ++it) h->ras_plan[it] = std::min(RAS_MAX_SWEEPS, h->ras_plan[it] + 2);   // the old plan was measured with stronger local solves
+        }
+        if (a != h->ras_a) { h->ras_a = a; h->ras_m = ras_steps_for(a); }
+        if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] patch solver bracket a = %.4f, %d steps per sweep\n", h->ras_a, h->ras_m);
+    }
     for (int it = run; it < p.arap_iters; ++it)            // solves skipped by the energy stop rule keep a safe count
         if (h->ras_plan[it] == 0) h->ras_plan[it] = h->ras_plan[std::max(0, run - 1)];
     if (converged) *converged = all_conv;
@@ -466,8 +482,8 @@ int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* s
     h->last = out;
     if (st) *st = out;
     collect_timers(h);
-    if (!all_conv && max_plan >= RAS_MAX_SWEEPS) {
-        // the local Chebyshev bracket does not fit this mesh / node layout: this handle solves by CG from now on
+    if (!all_conv && max_plan >= RAS_MAX_SWEEPS && h->ras_a <= 0.0021) {
+        // even the lowest Chebyshev bracket does not fit this mesh / node layout: this handle solves by CG from now on
         h->has_ras = false;
         h->cg_iters = 0;
         mvs_set_error("patch solver did not reach cg_tol in %d sweeps (rel residual %.3e); the handle now uses CG", max_plan, worst);
@@ -656,7 +672,9 @@ int mvs_deform_set_nodes(mvs_deform_t h, const int32_t* vertex_idx, int64_t K) {
     launch_gather_nodes(h->d_pts, h->d_nrm, h->d_nodes, (int)K, h->d_node_pts, h->d_node_nrm, h->stream);
     if (K) HIPCHK(hipMemcpyAsync(h->d_ctrl_raw, h->d_node_pts, sizeof(double) * K * 3, hipMemcpyDeviceToDevice, h->stream));
     h->d_ctrl_final = h->d_ctrl_raw;
-    h->cg_iters = 0;
+    h->cg_iters = 0;                                  // new node set: every launch plan and the solver bracket start over
+    for (int i = 0; i < 8; ++i) { h->cg_plan[i] = 0; h->ras_plan[i] = 0; }
+    h->ras_a = 0.0; h->ras_m = 0;
     HIPCHK(hipStreamSynchronize(h->stream));
     return MVS_OK;
 }

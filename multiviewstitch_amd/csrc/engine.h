@@ -113,6 +113,8 @@ struct mvs_deform_s {
     int32_t *d_ras_iters = nullptr;
     int64_t ras_slots_cap = 0;
     int ras_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // calibrated sweeps per ARAP iteration (0 = not calibrated)
+    double ras_a = 0.0;             // lower end of the Chebyshev bracket of the local solves (0 = default from the node density)
+    int ras_m = 0;                  // Chebyshev steps per sweep
     // timing
     int timing = 0;                 // 0 off, 1 all phases, 2 "cg" groups only
     std::map<std::string, PhaseTimer> timers;
@@ -168,6 +170,8 @@ int  ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& r
 void ras_free(mvs_deform_s* h);
 int  ras_slot_size(const mvs_deform_s* h);       // doubles per sweep slot: part[3][NPpad] | gamma[3] bn[3] pad
 void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s);
+void ras_default_bracket(const mvs_deform_s* h, double* a, int* m);
+int  ras_steps_for(double a);
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, const double* xin, double* xout, int it, double arap_tol, int sweep,
                       double cg_tol, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s);
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf,

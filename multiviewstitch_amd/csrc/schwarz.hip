@@ -98,7 +98,7 @@ __device__ inline double fold_n(const double* __restrict__ part, int n) {
 // patch (<= 256) sit in its first four waves, so no workgroup-level reduction is needed for the residual norm.
 __host__ __device__ inline int ras_slot_doubles(int NPpad) { return 3 * NPpad + 8; }
 
-struct ChebCoef { double c0, c1[16], c2[16]; };      // d_0 = c0 D^-1 r ;  d_{k+1} = c1[k] d_k + c2[k] D^-1 r_{k+1}
+struct ChebCoef { double c0, c1[32], c2[32]; };      // d_0 = c0 D^-1 r ;  d_{k+1} = c1[k] d_k + c2[k] D^-1 r_{k+1}
 
 // Once per outer iteration (after the cotangent weights and the control set are known): the patch-local matrix.
 //   pw[e][row] = 2 w_ij for a free row i and a free column j (inside OR outside the patch), else 0
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
             if (fixed) adv = mk3(0, 0, 0);
             e = e + dv;
             r = r - adv;
-            const double c1 = cc.c1[k & 15], c2 = cc.c2[k & 15] * inv_d;
+            const double c1 = cc.c1[k & 31], c2 = cc.c2[k & 31] * inv_d;
             dv = mk3(__builtin_fma(c1, dv.x, c2 * r.x), __builtin_fma(c1, dv.y, c2 * r.y), __builtin_fma(c1, dv.z, c2 * r.z));
         }
     }
@@ -403,24 +403,31 @@ void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s) {
     else k_ras_prepare<16><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd);
 }
 
+// a = 0.67 K/V (capped at 0.1), steps ~ 2.6 / sqrt(a): 8 steps at the density the reference's 16-NN sampling produces
+void ras_default_bracket(const mvs_deform_s* h, double* a, int* m) {
+    const double dens = h->V > 0 ? (double)h->K / (double)h->V : 0.15;
+    *a = std::min(0.1, std::max(0.002, 0.67 * dens));
+    *m = ras_steps_for(*a);
+}
+int ras_steps_for(double a) { return std::min(32, std::max(6, (int)std::lround(2.6 / std::sqrt(a)))); }
+
 // one sweep of ARAP iteration `it`: slot_prev / slot_cur are the slots of sweeps (sweep-1) / sweep
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, const double* xin, double* xout, int it, double arap_tol, int sweep,
                       double cg_tol, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s) {
     const RasDev& R = h->ras;
     const int nb = arap_grid_blocks(h->sell);
-    // Chebyshev parameters from the density of the Dirichlet nodes: the smallest eigenvalue of the Jacobi-scaled patch
-    // matrices falls with the share of fixed vertices (measured 0.12..0.16 at K/V = 1/6.7, the density the reference's
-    // 16-NN sampling produces).  a = 0.67 K/V (capped at 0.1), steps ~ 2.6 / sqrt(a): 8 steps at the usual density, 16
-    // for nodes four times sparser.  An estimate that is still too high only costs sweeps (the sweep plan adapts).
-    const double dens = h->V > 0 ? (double)h->K / (double)h->V : 0.15;
-    const double cheb_a = std::min(0.1, std::max(0.005, 0.67 * dens));
-    const int cheb_m = std::min(16, std::max(6, (int)std::lround(2.6 / std::sqrt(cheb_a))));
+    // Chebyshev parameters: the bracket's lower end `a` and the step count live in the handle — initialised from the density
+    // of the Dirichlet nodes (ras_default_bracket), then adapted by harvest_ras to the convergence it observes (the
+    // spectrum moves as the mesh deforms: 0.12..0.16 on the rest pose of the bench mesh, ~0.01 after 200 outer iterations)
+    double cheb_a = h->ras_a;
+    int cheb_m = h->ras_m;
+    if (!(cheb_a > 0.0) || cheb_m <= 0) ras_default_bracket(h, &cheb_a, &cheb_m);
     ChebCoef cc;                                   // Saad, Iterative Methods, Alg. 12.1 with [a, 2]
     {
         const double theta = 0.5 * (2.0 + cheb_a), delta = 0.5 * (2.0 - cheb_a), sigma1 = theta / delta;
         double rho = 1.0 / sigma1;
         cc.c0 = 1.0 / theta;
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < 32; ++k) {
             const double rho_new = 1.0 / (2.0 * sigma1 - rho);
             cc.c1[k] = rho_new * rho; cc.c2[k] = 2.0 * rho_new / delta;
             rho = rho_new;
