@@ -152,11 +152,11 @@ GridGeom make_geom(const float mn[3], const float mx[3], float h) {
 
 int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* nrm_dev, int64_t index_base) {
     hipStream_t s = h->stream;
-    if (h->d_spos) { hipFree(h->d_spos); h->d_spos = nullptr; }
-    if (h->d_tpos) { hipFree(h->d_tpos); h->d_tpos = nullptr; }
-    if (h->d_tnrm) { hipFree(h->d_tnrm); h->d_tnrm = nullptr; }
-    if (h->d_cell_start) { hipFree(h->d_cell_start); h->d_cell_start = nullptr; }
-    if (h->d_coarse_cnt) { hipFree(h->d_coarse_cnt); h->d_coarse_cnt = nullptr; }
+    if (h->d_spos) { (void)hipFree(h->d_spos); h->d_spos = nullptr; }
+    if (h->d_tpos) { (void)hipFree(h->d_tpos); h->d_tpos = nullptr; }
+    if (h->d_tnrm) { (void)hipFree(h->d_tnrm); h->d_tnrm = nullptr; }
+    if (h->d_cell_start) { (void)hipFree(h->d_cell_start); h->d_cell_start = nullptr; }
+    if (h->d_coarse_cnt) { (void)hipFree(h->d_coarse_cnt); h->d_coarse_cnt = nullptr; }
     h->P = P;
     h->grid = GridDev{};
     h->grid.P = P; h->grid.index_base = index_base;
