@@ -478,7 +478,26 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
         const int g = i >> 3, r = i & 7, off = m.single_pass ? 64 * g : m.slice_off[g], passes = m.single_pass ? 1 : (m.slice_off[g + 1] - off) >> 6;
         const d3 pi = ld3(pts + 3 * i), qi = ld3(sol + 3 * i);
         double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int t = 0; t < passes; ++t)
+        // the first eight edges (all of them when the degree is <= 8) stay in registers for the energy term
+        double w0[8];
+        d3 pp0[8], qq0[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const int e = off + r * 8 + l;
+            w0[l] = m.w[e];
+            const int j = w0[l] == 0.0 ? i : m.col[e];
+            pp0[l] = pi - ld3(pts + 3 * j); qq0[l] = qi - ld3(sol + 3 * j);
+        }
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            if (w0[l] == 0.0) continue;
+            const double w = w0[l];
+            const d3 pp = pp0[l], qq = qq0[l];
+            c[0] += w * (pp.x * qq.x); c[1] += w * (pp.x * qq.y); c[2] += w * (pp.x * qq.z);
+            c[3] += w * (pp.y * qq.x); c[4] += w * (pp.y * qq.y); c[5] += w * (pp.y * qq.z);
+            c[6] += w * (pp.z * qq.x); c[7] += w * (pp.z * qq.y); c[8] += w * (pp.z * qq.z);
+        }
+        for (int t = 1; t < passes; ++t)
 #pragma unroll
             for (int l = 0; l < 8; ++l) {
                 const int e = off + (8 * t + r) * 8 + l;
@@ -494,7 +513,12 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
         closest_rotation(c, R);
 #pragma unroll
         for (int k = 0; k < 9; ++k) rot[9 * (int64_t)i + k] = R[k];
-        for (int t = 0; t < passes; ++t)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            if (w0[l] == 0.0) continue;
+            e_acc += w0[l] * sqn3(qq0[l] - mulMv(R, pp0[l]));
+        }
+        for (int t = 1; t < passes; ++t)
 #pragma unroll
             for (int l = 0; l < 8; ++l) {
                 const int e = off + (8 * t + r) * 8 + l;
