@@ -325,6 +325,11 @@ int mvs_deform_set_target_dev(mvs_deform_t h, int64_t P, const double* pts_dev,
  * overwrite_initial_geometry. */
 int mvs_deform_iterate(mvs_deform_t h, const mvs_deform_params* p, int n_outer,
                        mvs_deform_stats* stats);
+/* stats == NULL after the handle's first (calibrating) call: mvs_deform_iterate only ENQUEUES the passes on the
+ * handle's stream and returns — independent handles (e.g. one per body part, each on its own stream) then overlap
+ * on the device.  mvs_deform_collect waits for the handle's stream and reads the statistics of the last pass back
+ * (and re-plans the solver's launch counts from them, as a synchronous call does). */
+int mvs_deform_collect(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stats* stats);
 
 /* The same body split at its exchange points for view-sharded targets
  * (one process per GPU).  All *_dev buffers are caller-owned

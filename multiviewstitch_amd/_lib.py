@@ -110,6 +110,7 @@ _SIGS = {
     "mvs_deform_set_target": (C.c_int, [_VP, _I64, _VP, _VP, _I64]),
     "mvs_deform_set_target_dev": (C.c_int, [_VP, _I64, _VP, _VP, _I64]),
     "mvs_deform_iterate": (C.c_int, [_VP, _VP, _I32, _VP]),
+    "mvs_deform_collect": (C.c_int, [_VP, _VP, _VP]),
     "mvs_deform_assoc_dmin": (C.c_int, [_VP, _VP, _VP]),
     "mvs_deform_assoc_select": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "mvs_deform_assoc_merge": (C.c_int, [_VP, _VP, _VP, _VP, _I32]),

@@ -761,6 +761,17 @@ int mvs_deform_iterate(mvs_deform_t h, const mvs_deform_params* p, int n_outer, 
     if (n_outer < 0) return MVS_E_INVALID_ARG;
     int done = 0;
     mvs_deform_stats st = h->last;
+    if (!stats && h->cg_iters > 0) {
+        // enqueue only (no host synchronisation): several handles on their own streams overlap this way; the launch plan
+        // stays the one of the last harvest until mvs_deform_collect (or a call with stats) reads the statistics back
+        const CgPlan cg = probe_cg(h, *p);
+        for (int o = 0; o < n_outer; ++o) {
+            enqueue_assoc_local(h, *p);
+            rc = enqueue_solve(h, *p, h->d_ctrl_raw, true, cg);
+            if (rc) return rc;
+        }
+        return MVS_OK;
+    }
     while (done < n_outer) {
         // enqueue as many outer iterations as the current calibration allows, then harvest once
         const bool calibrated = h->cg_iters > 0;
@@ -821,6 +832,12 @@ int mvs_deform_solve(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stat
     // stats == NULL on a calibrated handle: enqueue only (no host sync); the next call with stats harvests
     if (!stats && h->cg_iters > 0) return MVS_OK;
     return harvest(h, *p, cg, stats, nullptr);
+}
+int mvs_deform_collect(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stats* stats) {
+    int rc = ready(h, p, false);
+    if (rc) return rc;
+    if (h->cg_iters <= 0) { mvs_set_error("nothing enqueued: the first mvs_deform_iterate / _solve of a handle runs synchronously"); return MVS_E_STATE; }
+    return harvest(h, *p, probe_cg(h, *p), stats, nullptr);
 }
 int mvs_deform_arap(mvs_deform_t h, const mvs_deform_params* p, const double* ctrl_targets, mvs_deform_stats* stats) {
     int rc = ready(h, p, false);

@@ -121,6 +121,15 @@ class Deformation:
         L.check(L.lib().mvs_deform_iterate(self._h, C.byref(self.params), n_outer, C.byref(st)))
         return _stats(st)
 
+    def enqueue(self, n_outer: int = 1):
+        """``iterate`` without the host synchronisation (needs one earlier synchronous call); pair with ``collect``."""
+        L.check(L.lib().mvs_deform_iterate(self._h, C.byref(self.params), n_outer, None))
+
+    def collect(self) -> dict:
+        st = L.CStats()
+        L.check(L.lib().mvs_deform_collect(self._h, C.byref(self.params), C.byref(st)))
+        return _stats(st)
+
     # sharded phases (mvs.h: mvs_deform_assoc_*), device addresses in / out
     def assoc_dmin(self, d2min_dev: int):
         L.check(L.lib().mvs_deform_assoc_dmin(self._h, C.byref(self.params), L.ptr(int(d2min_dev))))

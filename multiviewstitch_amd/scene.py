@@ -33,6 +33,7 @@ CONFIGS = {
     2: dict(n_views=4, w=640, h=480, n=37, f=1.56),       # ~500K pts, ~2K nodes
     3: dict(n_views=8, w=1280, h=960, n=74, f=1.09),      # ~2M pts, ~8K nodes
     4: dict(n_views=16, w=1280, h=960, n=105, f=1.09),    # ~4M pts, ~16K nodes
+    5: dict(n_views=8, w=1280, h=960, n=147, f=1.09),     # ~2M pts, ~32K nodes in 16 per-part graphs (partwise.py)
 }
 
 

@@ -1,0 +1,129 @@
+"""Per-part deformation graphs (BASELINE config 5, multiviewstitch_amd/partwise.py): the split is host logic (checked
+here against a brute-force restatement), every part is an ordinary Deformation handle checked against the oracle on the
+part's sub-mesh with the scan points PartRecog labelled alike; the enqueue / collect path must give the bits of the
+synchronous one."""
+from collections import defaultdict
+
+import numpy as np
+import pytest
+
+from multiviewstitch_amd import partwise as PW, scene as S
+from tests.util import rms, scene_and_target
+
+
+def fans_of(faces):
+    """brute force: number of edge-connected face fans around every vertex"""
+    inc = defaultdict(list)
+    for r, f in enumerate(faces):
+        for v in f:
+            inc[int(v)].append(r)
+    out = {}
+    for v, fl in inc.items():
+        left, n = set(fl), 0
+        while left:
+            n += 1
+            stack = [left.pop()]
+            while stack:
+                x = stack.pop()
+                for y in list(left):
+                    if len(set(faces[x]) & set(faces[y])) >= 2:
+                        left.discard(y)
+                        stack.append(y)
+        out[v] = n
+    return out
+
+
+def test_split_parts_yields_single_fan_submeshes():
+    dirs, faces = S.geodesic_sphere(9)
+    labels = PW.sector_labels(dirs, 16)
+    assert set(np.unique(labels)) == set(range(16))
+    parts = PW.split_parts(faces, labels, 16)
+    assert len(parts) == 16
+    used = np.zeros(len(faces), int)
+    key = {tuple(f): r for r, f in enumerate(faces.tolist())}
+    for k, p in enumerate(parts):
+        g = p["vid"][p["faces"]]                                  # back to global ids: same triangles, same orientation
+        assert (labels[g] == k).all() and np.array_equal(p["vid"], np.unique(g))
+        for f in g.tolist():
+            used[key[tuple(f)]] += 1
+        assert max(fans_of(p["faces"]).values()) == 1
+    assert used.max() == 1                                        # a face belongs to at most one part
+    straddle = (labels[faces] != labels[faces][:, :1]).any(1)
+    assert (used[straddle] == 0).all()
+    dropped = (~straddle) & (used == 0)                           # faces given up for the single-fan rule: a few at the poles
+    assert dropped.sum() <= 0.02 * len(faces)
+
+
+def test_split_parts_drops_the_smaller_fan_of_a_pinched_vertex():
+    # vertex 23 carries two fans that touch only there: two faces of the open fan around vertex 20, and three faces of
+    # its own.  Pass 1 drops the smaller one; that splits the fan of vertex 20 into two single faces, so a second pass
+    # has to drop one of those (equal size: the one with the lower face id stays).
+    faces = np.array([[20, 21, 22], [20, 22, 23], [20, 23, 24], [20, 24, 25], [23, 30, 31], [23, 31, 32], [23, 32, 33]], np.int32)
+    assert fans_of(faces)[23] == 2 and fans_of(faces)[20] == 1
+    p = PW.split_parts(faces, np.zeros(34, np.int32), 1)[0]
+    g = p["vid"][p["faces"]].tolist()
+    assert g == [[20, 21, 22], [23, 30, 31], [23, 31, 32], [23, 32, 33]]
+    assert max(fans_of(p["faces"]).values()) == 1
+
+
+def test_sector_labels_and_empty_parts():
+    pts = np.array([[1, 0, 0], [0, 1, 0], [-1, 1e-9, 0], [0, -1, 0.5]], float)
+    assert PW.sector_labels(pts, 4).tolist() == [2, 3, 3, 1]
+    parts = PW.split_parts(np.array([[0, 1, 2]], np.int32), np.array([0, 0, 1], np.int32), 3)
+    assert all(len(p["faces"]) == 0 and len(p["vid"]) == 0 for p in parts)
+
+
+@pytest.mark.gpu
+def test_partwise_deformation_matches_oracle_part_by_part(oracle):
+    from multiviewstitch_amd import alignment
+    sc, tp, tn, _ = scene_and_target(2)                          # 13.7 K vertices -> four parts of ~3.3 K: the patch solver runs
+    labels = PW.sector_labels(sc.verts, 4)
+    tl = alignment.part_recog(sc.verts, labels, tp)              # a14 on the GPU ...
+    assert np.array_equal(tl, oracle.part_recog(sc.verts, labels, tp))   # ... bit-equal to the oracle's labels
+    pd = PW.PartwiseDeformation(sc.verts, sc.normals, sc.faces, labels, 4)
+    K = pd.UniformSampling(16)
+    pd.set_target(tp, tn, tl)
+    assert any(h.solver_info()["kind"] == "patch" for _, h in pd.live)
+    st = pd.iterate(1)
+    got = pd.vertices()
+    want = sc.verts.copy()
+    p = oracle.Params.default()
+    k_or = 0
+    for k, part in enumerate(pd.parts):
+        vid = part["vid"]
+        o = oracle.Deform(sc.verts[vid], sc.normals[vid], part["faces"])
+        k_or += o.sample_nodes(16)
+        sel = np.flatnonzero(tl == k)
+        o.set_target(tp[sel], tn[sel])
+        so = o.iterate(p, 1)
+        assert so["n_valid"] == st[k]["n_valid"] and so["arap_iters_run"] == st[k]["arap_iters_run"]
+        want[vid] = o.vertices()
+        assert rms(got[vid], want[vid]) <= 1e-6, f"part {k}"
+    assert K == k_or == pd.K
+    untouched = np.setdiff1d(np.arange(len(sc.verts)), np.concatenate([p_["vid"] for p_ in pd.parts]))
+    assert np.array_equal(got[untouched], sc.verts[untouched])
+    pd.close()
+
+
+@pytest.mark.gpu
+def test_enqueued_parts_give_the_bits_of_the_synchronous_path():
+    sc, tp, tn, _ = scene_and_target(1)
+    labels = PW.sector_labels(sc.verts, 4)
+    tl = PW.sector_labels(tp, 4)
+    runs = []
+    for mode in ("sync", "async"):
+        pd = PW.PartwiseDeformation(sc.verts, sc.normals, sc.faces, labels, 4)
+        pd.UniformSampling(16)
+        pd.set_target(tp, tn, tl)
+        pd.iterate(1)
+        if mode == "sync":
+            for _ in range(3):
+                stats = [h.iterate(1) for _, h in pd.live]
+        else:
+            pd.iterate(2)
+            stats = pd.iterate(1)
+        runs.append((pd.vertices(), [s["energy"].copy() for s in stats]))
+        pd.close()
+    assert np.array_equal(runs[0][0], runs[1][0])
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert np.array_equal(a, b)
