@@ -116,8 +116,8 @@ def main():
 
         def run(n):
             st = None
-            for k in range(n):                    # only the last step of a batch synchronises with the host
-                st = mdist.sharded_step(shard, bufs, world, sync=(k == n - 1))
+            for k in range(n):                    # the last step synchronises with the host (and every 32nd: the solver
+                st = mdist.sharded_step(shard, bufs, world, sync=(k == n - 1 or k % 32 == 31))   # re-plans, as iterate() does)
             return st
     else:
         def run(n):

@@ -325,6 +325,8 @@ int mvs_deform_set_target_dev(mvs_deform_t h, int64_t P, const double* pts_dev,
  * overwrite_initial_geometry. */
 int mvs_deform_iterate(mvs_deform_t h, const mvs_deform_params* p, int n_outer,
                        mvs_deform_stats* stats);
+/* (n_outer passes are enqueued in batches of at most 32 between host synchronisations: each batch ends with a read-back
+ * of the solver statistics from which the launch plan of the next one is made.) */
 /* stats == NULL after the handle's first (calibrating) call: mvs_deform_iterate only ENQUEUES the passes on the
  * handle's stream and returns — independent handles (e.g. one per body part, each on its own stream) then overlap
  * on the device.  mvs_deform_collect waits for the handle's stream and reads the statistics of the last pass back

@@ -755,6 +755,8 @@ static int ready(mvs_deform_t h, const mvs_deform_params* p, bool need_target) {
     return mvs_check_hip(hipSetDevice(h->device), "hipSetDevice");
 }
 
+static constexpr int MAX_BATCH = 32;
+
 int mvs_deform_iterate(mvs_deform_t h, const mvs_deform_params* p, int n_outer, mvs_deform_stats* stats) {
     int rc = ready(h, p, true);
     if (rc) return rc;
@@ -776,7 +778,9 @@ int mvs_deform_iterate(mvs_deform_t h, const mvs_deform_params* p, int n_outer, 
         // enqueue as many outer iterations as the current calibration allows, then harvest once
         const bool calibrated = h->cg_iters > 0;
         const CgPlan cg = probe_cg(h, *p);
-        const int batch = calibrated ? (n_outer - done) : 1;
+        // (at most MAX_BATCH passes share one launch plan: the spectrum of the system drifts as the template deforms, and a
+        //  stale plan leaves solves under-converged until the next harvest — scripts/soak.py)
+        const int batch = calibrated ? std::min(n_outer - done, MAX_BATCH) : 1;
         for (int o = 0; o < batch; ++o) {
             enqueue_assoc_local(h, *p);
             rc = enqueue_solve(h, *p, h->d_ctrl_raw, true, cg);

@@ -9,13 +9,30 @@
 
 // One-sided (Hestenes) Jacobi SVD of a 3x3, then R = V U^T with the CGAL
 // reflection fix (det < 0 -> flip the smallest singular direction).
+// 1/sqrt(x) for x > 0: hardware estimate + two Newton steps (relative error ~1e-16); the rotation below needs
+// c^2 + s^2 = 1 to rounding, which this delivers, while the tangent t itself only has to be close (it steers the sweep,
+// the limit does not depend on it)
+__device__ inline double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - (0.5 * x) * (y * y));
+    y = y * (1.5 - (0.5 * x) * (y * y));
+    return y;
+}
 __device__ inline void jacobi_pair(d3& bp, d3& bq, d3& vp, d3& vq, bool& rotated) {
     const double al = sqn3(bp), be = sqn3(bq), ga = dot3(bp, bq);
-    if (ga == 0.0 || fabs(ga) <= 1e-15 * sqrt(al * be)) return;   // columns orthogonal to rounding
+    if (ga == 0.0 || ga * ga <= 1e-30 * (al * be)) return;         // columns orthogonal to rounding
     rotated = true;
-    const double zeta = (be - al) / (2.0 * ga);
-    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+    // t = sgn(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (be - al) / (2 ga), written with one square root and one
+    // reciprocal: t = 2 ga sgn(d) / (|d| + sqrt(d^2 + 4 ga^2)), d = be - al
+    const double d = be - al, g2 = 2.0 * ga;
+    const double h2 = d * d + g2 * g2;
+    const double hyp = h2 * rsqrt_nr(h2);
+    const double den = fabs(d) + hyp;
+    double inv = __builtin_amdgcn_rcp(den);
+    inv = inv * (2.0 - den * inv);
+    inv = inv * (2.0 - den * inv);
+    const double t = (d >= 0 ? g2 : -g2) * inv;
+    const double c = rsqrt_nr(1.0 + t * t), s = c * t;
     const d3 nbp = mk3(c * bp.x - s * bq.x, c * bp.y - s * bq.y, c * bp.z - s * bq.z);
     const d3 nbq = mk3(s * bp.x + c * bq.x, s * bp.y + c * bq.y, s * bp.z + c * bq.z);
     const d3 nvp = mk3(c * vp.x - s * vq.x, c * vp.y - s * vq.y, c * vp.z - s * vq.z);
