@@ -207,7 +207,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
                 const bool fuse = p.smooth_sweeps > 0;
                 launch_knn_grid(h->d_node_pts, K, nn, h->d_nbr, h->d_knn_ws, s, fuse ? ctrl : nullptr, fuse ? h->d_ctrl_a : nullptr);
                 if (fuse) { ctrl = h->d_ctrl_a; first_sweep = 1; }
-                toc(t, 5);
+                toc(t, knn_grid_launches(K));
             } else { launch_knn(h->d_node_pts, K, nn, h->d_nbr, s); toc(t, 1); }
         }
         Tic t = tic(h, "smooth");

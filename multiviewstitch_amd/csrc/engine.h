@@ -142,6 +142,7 @@ void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, c
 // knn.hip
 void launch_knn(const double* pts, int n, int k, int32_t* out, hipStream_t s);                 // brute force, LDS tiles
 size_t knn_grid_ws_bytes(int n);
+int knn_grid_launches(int n);
 void launch_knn_grid(const double* pts, int n, int k, int32_t* out, void* ws, hipStream_t s, const double* smooth_cur = nullptr,
                      double* smooth_out = nullptr);                                           // 5 launches
 // arap.hip
