@@ -14,6 +14,11 @@
 
 namespace {
 
+// value of the lane below across the whole wave (lane 0 keeps its own): DPP wave_shr:1 — one VALU move instead of a
+// trip through the LDS crossbar (ds_bpermute); the sorted neighbour lists shift by one lane on every insertion
+__device__ inline int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+
+
 constexpr int TPB = 1024;
 constexpr int TILE = 1024;
 
@@ -49,8 +54,8 @@ __global__ __launch_bounds__(TPB) void k_knn(const double* __restrict__ pts, int
                     const int c_i = __builtin_amdgcn_readlane(j, src);
                     const bool less = lane < len && dl_less(L_d, L_i, c_d, c_i);
                     const int pos = __popcll(__ballot(less));
-                    const float u_d = __shfl_up(L_d, 1, 64);
-                    const int u_i = __shfl_up(L_i, 1, 64);
+                    const float u_d = __int_as_float(wave_shr1(__float_as_int(L_d)));
+                    const int u_i = wave_shr1(L_i);
                     if (lane > pos && lane <= len && lane < k) { L_d = u_d; L_i = u_i; }
                     else if (lane == pos) { L_d = c_d; L_i = c_i; }
                     len = min(len + 1, k);
@@ -388,8 +393,8 @@ __global__ __launch_bounds__(256) void k_ng_knn(const double* __restrict__ pts, 
                     const int c_i = __builtin_amdgcn_readlane(j, src);
                     const bool less = lane < len && dl_less(L_d, L_i, c_d, c_i);
                     const int pos = __popcll(__ballot(less));
-                    const float u_d = __shfl_up(L_d, 1, 64);
-                    const int u_i = __shfl_up(L_i, 1, 64);
+                    const float u_d = __int_as_float(wave_shr1(__float_as_int(L_d)));
+                    const int u_i = wave_shr1(L_i);
                     if (lane > pos && lane <= len && lane < k) { L_d = u_d; L_i = u_i; }
                     else if (lane == pos) { L_d = c_d; L_i = c_i; }
                     len = min(len + 1, k);
