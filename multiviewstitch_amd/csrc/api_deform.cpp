@@ -181,9 +181,12 @@ void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
     int32_t* cur = h->heavy_flip ? h->d_heavy2 : h->d_heavy;
     int32_t* nxt = h->heavy_flip ? h->d_heavy : h->d_heavy2;
     h->heavy_flip ^= 1;
+    // the heavy-node pass shares a launch with the node-graph search of enqueue_solve when that search runs on the grid
+    const bool defer = h->d_knn_ws != nullptr && p.graph_k + 1 <= 64;
     launch_assoc_local(h->grid, h->d_node_pts, h->d_node_nrm, K, p, h->d_d2min, h->d_records, h->d_counts, cur, nxt, K, h->d_ctrl_raw,
-                       h->d_valid, h->d_top_idx, h->stream);
-    toc(t, 2);
+                       h->d_valid, h->d_top_idx, h->stream, defer);
+    h->heavy_pending = defer ? cur : nullptr;
+    toc(t, defer ? 1 : 2);
 }
 
 // graph smoothing (optional) + ARAP + geometry update.  ctrl_src: K*3 node targets.
@@ -202,7 +205,15 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
         int first_sweep = 0;
         {                                                                                       // Deformation.cpp:359
             Tic t = tic(h, "graph");
-            if (h->d_knn_ws) {
+            if (h->d_knn_ws && h->heavy_pending) {
+                // single-rank iteration: the deferred heavy nodes of the association and the graph queries in one launch
+                // (the node targets are complete only after it: every smoothing sweep is a k_smooth launch)
+                knn_grid_build(h->d_node_pts, K, h->d_knn_ws, s);
+                launch_assoc_heavy_knn(h->grid, h->d_node_pts, h->d_node_nrm, K, p, h->d_d2min, h->d_records, h->d_counts, h->heavy_pending, K,
+                                       h->d_ctrl_raw, h->d_valid, h->d_top_idx, nn, h->d_nbr, h->d_knn_ws, s);
+                h->heavy_pending = nullptr;
+                toc(t, knn_grid_launches(K));
+            } else if (h->d_knn_ws) {
                 // the grid kNN also performs the first smoothing sweep (its wave holds the neighbour list)
                 const bool fuse = p.smooth_sweeps > 0;
                 launch_knn_grid(h->d_node_pts, K, nn, h->d_nbr, h->d_knn_ws, s, fuse ? ctrl : nullptr, fuse ? h->d_ctrl_a : nullptr);

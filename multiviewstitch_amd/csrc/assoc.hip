@@ -22,6 +22,7 @@
 #include "engine.h"
 #include "dev_common.h"
 #include "grid_dev.h"
+#include "knn_dev.h"
 #include <algorithm>
 
 namespace {
@@ -512,6 +513,31 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_select_heavy(GridDev
     }
 }
 
+// Single-rank outer iteration: the heavy nodes (a handful of long dependent chains, 40-50 us) and the 9-NN graph of the
+// nodes (33 us) are independent — both need only the node positions and what k_assoc_local left — so they share ONE
+// launch: the first `heavy_blocks` workgroups take the heavy nodes, the others one graph query per wave.
+__global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_heavy_knn(GridDev g, const double* __restrict__ node_pts,
+                                                                      const double* __restrict__ node_nrm, int top_k,
+                                                                      const float* __restrict__ d2min, mvs_cand* __restrict__ rec,
+                                                                      int32_t* __restrict__ counts, const int32_t* __restrict__ heavy,
+                                                                      int heavy_cap, LocalMerge lm, int heavy_blocks,
+                                                                      int K, int nn, const NgGeom* __restrict__ geo,
+                                                                      const int* __restrict__ cs, const float4* __restrict__ sorted,
+                                                                      int32_t* __restrict__ nbr) {
+    __shared__ HeavyLds lds;
+    if ((int)blockIdx.x < heavy_blocks) {
+        const int n = min(heavy[0], heavy_cap);
+        for (int h = blockIdx.x; h < n; h += heavy_blocks) {
+            const int node = heavy[1 + h];
+            select_node<HEAVY_WAVES>(g, node_pts, node_nrm, node, top_k, d2min[node], rec, counts, nullptr, 0, &lds, lm);
+            __syncthreads();                                 // the LDS lists are reused by the next node
+        }
+        return;
+    }
+    const int q = ((int)blockIdx.x - heavy_blocks) * HEAVY_WAVES + (int)(threadIdx.x >> 6);
+    if (q < K) ng_knn_query(q, node_pts, K, nn, geo, cs, sorted, nbr, nullptr, nullptr);
+}
+
 // ----------------------------------------------------------------- merge ----
 __global__ void k_assoc_merge(const double* __restrict__ node_pts, const double* __restrict__ node_nrm, int K,
                               mvs_deform_params p, const mvs_cand* __restrict__ rec_all,
@@ -588,11 +614,27 @@ void launch_assoc_select(const GridDev& g, const double* node_pts, const double*
 // ... and the merge: with one rank a node's list is final, its wave writes the node target itself
 void launch_assoc_local(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, float* d2min,
                         mvs_cand* rec, int32_t* counts, int32_t* heavy, int32_t* heavy_next, int heavy_cap, double* controls, uint8_t* valid,
-                        int64_t* top_idx, hipStream_t s) {
+                        int64_t* top_idx, hipStream_t s, bool defer_heavy) {
     if (K <= 0) return;
     const LocalMerge lm{controls, valid, top_idx, p.proj_len_err, p.proj_dist_err, p.min_cos, p.max_result};
     k_assoc_local<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm, heavy_next);
-    k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm);
+    if (!defer_heavy)
+        k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm);
+}
+// the deferred heavy-node pass of launch_assoc_local together with the node graph (grid already built in ws by
+// knn_grid_build on the same node positions): nbr[K * nn] = each node's nn nearest nodes, itself included
+void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
+                            const float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, int heavy_cap,
+                            double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s) {
+    if (K <= 0) return;
+    const LocalMerge lm{controls, valid, top_idx, p.proj_len_err, p.proj_dist_err, p.min_cos, p.max_result};
+    const void *geo, *sorted;
+    const int* cs;
+    knn_grid_views(knn_ws, K, &geo, &cs, &sorted);
+    const int heavy_blocks = std::min(heavy_cap, 256), knn_blocks = (K + HEAVY_WAVES - 1) / HEAVY_WAVES;
+    k_assoc_heavy_knn<<<dim3(heavy_blocks + knn_blocks), dim3(64 * HEAVY_WAVES), 0, s>>>(
+        g, node_pts, node_nrm, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm, heavy_blocks, K, nn, (const NgGeom*)geo, cs,
+        (const float4*)sorted, nbr);
 }
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks, double* controls,

@@ -89,6 +89,7 @@ struct mvs_deform_s {
     int64_t *d_top_idx = nullptr;
     int32_t *d_heavy = nullptr;       // [1 + K]: nodes deferred to the workgroup-per-node association kernel
     int32_t *d_heavy2 = nullptr;      // second list: single-rank iterations alternate (each resets the other's counter)
+    const int32_t* heavy_pending = nullptr;   // heavy list of an association whose heavy pass rides with the node graph (enqueue_solve)
     int heavy_flip = 0;
     // target
     GridDev grid{};
@@ -135,7 +136,10 @@ void launch_assoc_select(const GridDev& g, const double* node_pts, const double*
                          hipStream_t s);
 void launch_assoc_local(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, float* d2min,
                         mvs_cand* rec, int32_t* counts, int32_t* heavy /*counter already 0*/, int32_t* heavy_next /*reset for the next call*/,
-                        int heavy_cap, double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s);
+                        int heavy_cap, double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s, bool defer_heavy = false);
+void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
+                            const float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, int heavy_cap,
+                            double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s);
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks,
                         double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s);
@@ -143,6 +147,8 @@ void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, c
 void launch_knn(const double* pts, int n, int k, int32_t* out, hipStream_t s);                 // brute force, LDS tiles
 size_t knn_grid_ws_bytes(int n);
 int knn_grid_launches(int n);
+void knn_grid_build(const double* pts, int n, void* ws, hipStream_t s);
+void knn_grid_views(void* ws, int n, const void** geo, const int** cs, const void** sorted);
 void launch_knn_grid(const double* pts, int n, int k, int32_t* out, void* ws, hipStream_t s, const double* smooth_cur = nullptr,
                      double* smooth_out = nullptr);                                           // 5 launches
 // arap.hip

@@ -11,18 +11,15 @@
 #include <cstdlib>
 #include <algorithm>
 #include "dev_common.h"
+#include "knn_dev.h"
 
 namespace {
 
-// value of the lane below across the whole wave (lane 0 keeps its own): DPP wave_shr:1 — one VALU move instead of a
-// trip through the LDS crossbar (ds_bpermute); the sorted neighbour lists shift by one lane on every insertion
-__device__ inline int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
 
 
 constexpr int TPB = 1024;
 constexpr int TILE = 1024;
 
-__device__ inline bool dl_less(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
 
 __global__ __launch_bounds__(TPB) void k_knn(const double* __restrict__ pts, int n, int k, int32_t* __restrict__ out) {
     __shared__ float4 tile[TILE];
@@ -87,7 +84,6 @@ void launch_knn(const double* pts, int n, int k, int32_t* out, hipStream_t s) {
 // ===================================================================================================
 namespace {
 
-struct NgGeom { float minx, miny, minz, h, inv_h; int nx, ny, nz; };
 
 __global__ __launch_bounds__(1024) void k_ng_bbox(const double* __restrict__ pts, int n, int NC, NgGeom* __restrict__ geo,
                                                   int* __restrict__ counts, int nclear) {
@@ -123,11 +119,6 @@ __global__ __launch_bounds__(1024) void k_ng_bbox(const double* __restrict__ pts
     }
 }
 
-__device__ inline int ng_axis(float x, float mn, float inv_h, int n) {
-    float f = floorf((x - mn) * inv_h);
-    f = fminf(fmaxf(f, 0.0f), (float)(n - 1));
-    return (int)f;
-}
 
 __global__ void k_ng_count(const double* __restrict__ pts, int n, const NgGeom* __restrict__ geo, int* __restrict__ counts,
                            int* __restrict__ cell_of) {
@@ -364,99 +355,7 @@ __global__ __launch_bounds__(256) void k_ng_knn(const double* __restrict__ pts, 
                                                 double* __restrict__ sm_out) {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= n) return;
-    const int lane = threadIdx.x & 63;
-    const NgGeom g = *geo;
-    const float qx = (float)pts[3 * q], qy = (float)pts[3 * q + 1], qz = (float)pts[3 * q + 2];
-    float L_d = INFINITY; int L_i = -1; int len = 0;
-    float t_d = INFINITY; int t_i = 0x7fffffff;
-    const bool finite_q = (qx - qx == 0.0f) && (qy - qy == 0.0f) && (qz - qz == 0.0f);
-    if (finite_q) {
-        const float fx = (qx - g.minx) * g.inv_h, fy = (qy - g.miny) * g.inv_h, fz = (qz - g.minz) * g.inv_h;
-        const int cx = ng_axis(qx, g.minx, g.inv_h, g.nx), cy = ng_axis(qy, g.miny, g.inv_h, g.ny), cz = ng_axis(qz, g.minz, g.inv_h, g.nz);
-        float m = fminf(fminf(fminf(fx - cx, cx + 1 - fx), fminf(fy - cy, cy + 1 - fy)), fminf(fz - cz, cz + 1 - fz));
-        m = fmaxf(m, 0.0f);
-        auto scan = [&](int A, int B) {
-            for (int cb = A; cb < B; cb += 64) {
-                const int i = cb + lane;
-                float d = INFINITY; int j = -1;
-                bool has = false;
-                if (i < B) {
-                    const float4 p = sorted[i];
-                    d = d2f(qx, qy, qz, p.x, p.y, p.z);
-                    j = __float_as_int(p.w);
-                    has = !(d != d);
-                }
-                unsigned long long pend = __ballot(has && (len < k || dl_less(d, j, t_d, t_i)));
-                while (pend) {
-                    const int src = __ffsll((long long)pend) - 1;
-                    const float c_d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), src));
-                    const int c_i = __builtin_amdgcn_readlane(j, src);
-                    const bool less = lane < len && dl_less(L_d, L_i, c_d, c_i);
-                    const int pos = __popcll(__ballot(less));
-                    const float u_d = __int_as_float(wave_shr1(__float_as_int(L_d)));
-                    const int u_i = wave_shr1(L_i);
-                    if (lane > pos && lane <= len && lane < k) { L_d = u_d; L_i = u_i; }
-                    else if (lane == pos) { L_d = c_d; L_i = c_i; }
-                    len = min(len + 1, k);
-                    if (len == k) {
-                        t_d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L_d), k - 1));
-                        t_i = __builtin_amdgcn_readlane(L_i, k - 1);
-                    }
-                    if (lane == src) has = false;
-                    pend = __ballot(has && (len < k || dl_less(d, j, t_d, t_i)));
-                }
-            }
-        };
-        const int smax = max(g.nx, max(g.ny, g.nz));
-        for (int s = 0; s <= smax; ++s) {                    // bounded: every cell has been visited at s == smax
-            const int side = 2 * s + 1, nrows = side * side;
-            for (int base = 0; base < nrows; base += 64) {
-                int a0 = 0, b0 = 0, a1 = 0, b1 = 0;
-                const int ridx = base + lane;
-                if (ridx < nrows) {
-                    const int dy = ridx / side - s, dz = ridx % side - s;
-                    const int y = cy + dy, z = cz + dz;
-                    if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
-                        const int rb = (z * g.ny + y) * g.nx;
-                        if (abs(dy) == s || abs(dz) == s) {
-                            const int x0 = max(cx - s, 0), x1 = min(cx + s, g.nx - 1);
-                            if (x0 <= x1) { a0 = cs[rb + x0]; b0 = cs[rb + x1 + 1]; }
-                        } else {
-                            if (cx - s >= 0) { a0 = cs[rb + cx - s]; b0 = cs[rb + cx - s + 1]; }
-                            if (cx + s < g.nx) { a1 = cs[rb + cx + s]; b1 = cs[rb + cx + s + 1]; }
-                        }
-                    }
-                }
-                unsigned long long mask = __ballot(b0 > a0 || b1 > a1);
-                while (mask) {
-                    const int l = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    scan(__builtin_amdgcn_readlane(a0, l), __builtin_amdgcn_readlane(b0, l));
-                    scan(__builtin_amdgcn_readlane(a1, l), __builtin_amdgcn_readlane(b1, l));
-                }
-            }
-            const float bound = ((float)s + m - 0.01f) * g.h;
-            if (len == k && bound > 0.0f && t_d <= bound * bound) break;
-        }
-    }
-    if (lane < k) out[(int64_t)q * k + lane] = lane < len ? L_i : -1;
-    if (sm_out) {
-        // first Jacobi sweep of the node-target smoothing (Deformation.cpp:364-379) straight from the list just found:
-        // c_q = o_q + sum_j w (cur_j - o_j), j in list order — the same operations in the same order as k_smooth
-        const double w = 1.0 / k;
-        d3 dj = mk3(0, 0, 0);
-        if (lane < len) dj = w * (ld3(sm_cur + 3 * (int64_t)L_i) - ld3(pts + 3 * (int64_t)L_i));
-        d3 acc = mk3(0, 0, 0);
-        for (int sidx = 0; sidx < len; ++sidx) {
-            const long long bx = __double_as_longlong(dj.x), by = __double_as_longlong(dj.y), bz = __double_as_longlong(dj.z);
-            auto rl = [&](long long b) {
-                const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), sidx), hi = __builtin_amdgcn_readlane((int)(b >> 32), sidx);
-                return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-            };
-            acc = acc + mk3(rl(bx), rl(by), rl(bz));
-        }
-        if (lane == 0) st3(sm_out + 3 * (int64_t)q, ld3(pts + 3 * (int64_t)q) + acc);
-    }
+    ng_knn_query(q, pts, n, k, geo, cs, sorted, out, sm_cur, sm_out);
 }
 
 }  // namespace
@@ -515,6 +414,11 @@ void knn_grid_build(const double* pts, int n, void* ws, hipStream_t s) {
     k_ng_count<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.geo, w.counts, w.cell_of);
     ng_scan(w, s);
     k_ng_scatter<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.cell_of, w.start, w.counts, w.sorted);
+}
+// where knn_grid_build left the grid inside ws (for the fused heavy-node + node-graph kernel of assoc.hip)
+void knn_grid_views(void* ws, int n, const void** geo, const int** cs, const void** sorted) {
+    const NgWs w = ng_carve(ws, n);
+    *geo = w.geo; *cs = w.start; *sorted = w.sorted;
 }
 // smooth_cur / smooth_out != NULL: the queries are the deformation nodes; also performs the first smoothing sweep of the
 // node targets `smooth_cur` into `smooth_out` (k = graph_k + 1 neighbours incl. self, weight 1/k each)
