@@ -194,6 +194,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     hipStream_t s = h->stream;
     const int K = (int)h->K, V = (int)h->V;
     const double* ctrl = ctrl_src;
+    bool weights_done = false;
     if (graph_smooth) {
         const int nn = p.graph_k + 1;
         if (nn != h->nbr_k) {
@@ -209,8 +210,12 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
                 // single-rank iteration: the deferred heavy nodes of the association and the graph queries in one launch
                 // (the node targets are complete only after it: every smoothing sweep is a k_smooth launch)
                 knn_grid_build(h->d_node_pts, K, h->d_knn_ws, s);
+                // ... and, for the patch solver, the cotangent weights (they need the rest geometry only; the start of the
+                // solve, which needs the smoothed targets, moves into k_ras_prepare)
+                weights_done = use_ras(h, p);
                 launch_assoc_heavy_knn(h->grid, h->d_node_pts, h->d_node_nrm, K, p, h->d_d2min, h->d_records, h->d_counts, h->heavy_pending, K,
-                                       h->d_ctrl_raw, h->d_valid, h->d_top_idx, nn, h->d_nbr, h->d_knn_ws, s);
+                                       h->d_ctrl_raw, h->d_valid, h->d_top_idx, nn, h->d_nbr, h->d_knn_ws, s,
+                                       weights_done ? &h->sell : nullptr, h->d_pts, arap_grid_blocks(h->sell));
                 h->heavy_pending = nullptr;
                 toc(t, knn_grid_launches(K));
             } else if (h->d_knn_ws) {
@@ -236,9 +241,14 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     if (rc) return rc;
     {
         Tic t = tic(h, "weights");
-        launch_cot_weights(h->sell, h->d_pts, ras ? nullptr : h->d_coef, ctrl, h->d_sol, h->d_rot, s);   // preprocess() :393 + set_target_position :383-392
-        if (ras) launch_ras_prepare(h, s);
-        toc(t, 2);
+        if (weights_done) {
+            launch_ras_prepare(h, s, ctrl);                                                               // set_target_position :383-392
+            toc(t, 1);
+        } else {
+            launch_cot_weights(h->sell, h->d_pts, ras ? nullptr : h->d_coef, ctrl, h->d_sol, h->d_rot, s);   // preprocess() :393 + set_target_position :383-392
+            if (ras) launch_ras_prepare(h, s);
+            toc(t, 2);
+        }
     }
     double* x_cur = h->d_sol;            // the patch solver ping-pongs between d_sol and d_ras_x2
     int64_t ras_slot = 0;

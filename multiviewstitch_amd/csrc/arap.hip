@@ -56,24 +56,6 @@ __device__ unsigned long long g_stamps[8192 * 8];
 #define STAMPW(k)
 #endif
 
-struct RowCtx {
-    int row, l, off, passes;
-    bool live;
-};
-// row context of row group g (wave-uniform g) for this lane
-__device__ inline RowCtx row_ctx(const SellDev& m, int g) {
-    RowCtx r;
-    const int lane = threadIdx.x & 63;
-    r.row = g * 8 + (lane >> 3);
-    r.l = lane & 7;
-    r.live = r.row < m.V;
-    if (m.single_pass) { r.off = 64 * g + lane; r.passes = 1; }     // (saves the dependent look-up: one memory hop per kernel)
-    else {
-        r.off = m.slice_off[g] + lane;                               // + 64 * pass
-        r.passes = (m.slice_off[g + 1] - m.slice_off[g]) >> 6;
-    }
-    return r;
-}
 #define FOR_ROW_GROUPS(m, g) \
     for (int g = blockIdx.x * NW + (threadIdx.x >> 6); g < (m).nslices; g += gridDim.x * NW)
 
@@ -143,14 +125,6 @@ __global__ void k_smooth(const double* __restrict__ orig, const double* __restri
     st3(out + 3 * i, ld3(orig + 3 * i) + acc);
 }
 
-__device__ inline double cot_clamped(d3 a, d3 b, d3 o) {
-    const d3 u = a - o, v = b - o;
-    const double duv = dot3(u, v), duu = dot3(u, u), dvv = dot3(v, v);
-    const double den2 = duu * dvv - duv * duv;
-    if (!(den2 > 0)) return 0.0;
-    const double c = duv / sqrt(den2);
-    return c > 0 ? c : 0.0;
-}
 
 // per entry: w_ij = (cot a + cot b) / 2 clamped per angle; per row: diag = sum_j (wij + wji)
 // (with ctrl != NULL it also starts the solve for its rows: solution = node target or rest position, R = I)
@@ -166,21 +140,7 @@ __global__ __launch_bounds__(TPB) void k_cot_weights(SellDev m, const double* __
             R[r.l] = (r.l == 0 || r.l == 4) ? 1.0 : 0.0;
             if (r.l == 0) R[8] = 1.0;
         }
-        double diag = 0.0;
-        for (int t = 0; t < r.passes; ++t) {
-            const int e = r.off + 64 * t;
-            const int o0 = m.opp0[e], o1 = m.opp1[e];
-            double s = 0.0;
-            if (o0 >= 0) {
-                const d3 pj = ld3(pts + 3 * m.col[e]);
-                s = cot_clamped(pi, pj, ld3(pts + 3 * o0)) / 2.0;
-                if (o1 >= 0) s = s + cot_clamped(pi, pj, ld3(pts + 3 * o1)) / 2.0;
-            }
-            m.w[e] = s;
-            diag += s + s;                       // wij + wji
-        }
-        diag = red8(diag);
-        if (r.live && r.l == 0) m.diag[r.row] = diag;
+        cot_weight_row(m, pts, r, pi);
     }
 }
 

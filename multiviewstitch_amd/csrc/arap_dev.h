@@ -33,6 +33,63 @@ __device__ inline double red_rows(double v) {
     return v;
 }
 __device__ inline double wave_total(double v) { return red_rows(red8(v)); }
+// ------------------------------------------------------------ row groups --
+// A wave owns a group of 8 rows of the ELL-8 adjacency, 8 lanes per row (SellDev, engine.h)
+struct RowCtx {
+    int row, l, off, passes;
+    bool live;
+};
+// row context of row group g (wave-uniform g) for this lane
+__device__ inline RowCtx row_ctx(const SellDev& m, int g) {
+    RowCtx r;
+    const int lane = threadIdx.x & 63;
+    r.row = g * 8 + (lane >> 3);
+    r.l = lane & 7;
+    r.live = r.row < m.V;
+    if (m.single_pass) { r.off = 64 * g + lane; r.passes = 1; }     // (saves the dependent look-up: one memory hop per kernel)
+    else {
+        r.off = m.slice_off[g] + lane;                               // + 64 * pass
+        r.passes = (m.slice_off[g + 1] - m.slice_off[g]) >> 6;
+    }
+    return r;
+}
+
+__device__ inline double cot_clamped(d3 a, d3 b, d3 o) {
+    const d3 u = a - o, v = b - o;
+    const double duv = dot3(u, v), duu = dot3(u, u), dvv = dot3(v, v);
+    const double den2 = duu * dvv - duv * duv;
+    if (!(den2 > 0)) return 0.0;
+    const double c = duv / sqrt(den2);
+    return c > 0 ? c : 0.0;
+}
+
+// cotangent weights of one row group (k_cot_weights in arap.hip; also run by the fused launch of assoc.hip):
+// per entry w_ij = (cot a + cot b) / 2 clamped per angle; per row diag = sum_j (w_ij + w_ji)
+__device__ inline void cot_weight_row(const SellDev& m, const double* __restrict__ pts, const RowCtx& r, const d3 pi) {
+    double diag = 0.0;
+    for (int t = 0; t < r.passes; ++t) {
+        const int e = r.off + 64 * t;
+        const int o0 = m.opp0[e], o1 = m.opp1[e];
+        double s = 0.0;
+        if (o0 >= 0) {
+            const d3 pj = ld3(pts + 3 * m.col[e]);
+            s = cot_clamped(pi, pj, ld3(pts + 3 * o0)) / 2.0;
+            if (o1 >= 0) s = s + cot_clamped(pi, pj, ld3(pts + 3 * o1)) / 2.0;
+        }
+        m.w[e] = s;
+        diag += s + s;                       // wij + wji
+    }
+    diag = red8(diag);
+    if (r.live && r.l == 0) m.diag[r.row] = diag;
+}
+// all row groups by `vgrid` virtual workgroups of 16 waves (this one is number vblock)
+__device__ inline void cot_weight_rows(const SellDev& m, const double* __restrict__ pts, int vblock, int vgrid) {
+    for (int g = vblock * 16 + (int)(threadIdx.x >> 6); g < m.nslices; g += vgrid * 16) {
+        const RowCtx r = row_ctx(m, g);
+        cot_weight_row(m, pts, r, r.live ? ld3(pts + 3 * r.row) : mk3(0, 0, 0));
+    }
+}
+
 // fixed-order fold of nb partial sums by ONE wave (every lane gets the total)
 // (all loads are issued before the first add: a runtime-trip-count loop would serialise the memory latencies —
 //  measured with the stamps build: 7.6 K cycles of preamble per launch, scripts/cg_stamps.py)

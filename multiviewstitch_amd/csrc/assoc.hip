@@ -23,6 +23,7 @@
 #include "dev_common.h"
 #include "grid_dev.h"
 #include "knn_dev.h"
+#include "arap_dev.h"
 #include <algorithm>
 
 namespace {
@@ -513,9 +514,10 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_select_heavy(GridDev
     }
 }
 
-// Single-rank outer iteration: the heavy nodes (a handful of long dependent chains, 40-50 us) and the 9-NN graph of the
-// nodes (33 us) are independent — both need only the node positions and what k_assoc_local left — so they share ONE
-// launch: the first `heavy_blocks` workgroups take the heavy nodes, the others one graph query per wave.
+// Single-rank outer iteration: the heavy nodes (a handful of long dependent chains, 40-50 us), the 9-NN graph of the
+// nodes (33 us) and the cotangent weights of the template (9 us) are independent — they need only the node positions,
+// what k_assoc_local left, and the rest geometry — so they share ONE launch: the first `heavy_blocks` workgroups take the
+// heavy nodes, the next `knn_blocks` one graph query per wave, the rest (cot_blocks >= 0) the weight rows.
 __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_heavy_knn(GridDev g, const double* __restrict__ node_pts,
                                                                       const double* __restrict__ node_nrm, int top_k,
                                                                       const float* __restrict__ d2min, mvs_cand* __restrict__ rec,
@@ -523,7 +525,8 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_heavy_knn(GridDev g,
                                                                       int heavy_cap, LocalMerge lm, int heavy_blocks,
                                                                       int K, int nn, const NgGeom* __restrict__ geo,
                                                                       const int* __restrict__ cs, const float4* __restrict__ sorted,
-                                                                      int32_t* __restrict__ nbr) {
+                                                                      int32_t* __restrict__ nbr, int knn_blocks, SellDev m,
+                                                                      const double* __restrict__ mesh_pts) {
     __shared__ HeavyLds lds;
     if ((int)blockIdx.x < heavy_blocks) {
         const int n = min(heavy[0], heavy_cap);
@@ -532,6 +535,10 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_heavy_knn(GridDev g,
             select_node<HEAVY_WAVES>(g, node_pts, node_nrm, node, top_k, d2min[node], rec, counts, nullptr, 0, &lds, lm);
             __syncthreads();                                 // the LDS lists are reused by the next node
         }
+        return;
+    }
+    if ((int)blockIdx.x >= heavy_blocks + knn_blocks) {      // third passenger: the cotangent weights of the template (rest geometry only)
+        cot_weight_rows(m, mesh_pts, (int)blockIdx.x - heavy_blocks - knn_blocks, (int)gridDim.x - heavy_blocks - knn_blocks);
         return;
     }
     const int q = ((int)blockIdx.x - heavy_blocks) * HEAVY_WAVES + (int)(threadIdx.x >> 6);
@@ -625,16 +632,18 @@ void launch_assoc_local(const GridDev& g, const double* node_pts, const double* 
 // knn_grid_build on the same node positions): nbr[K * nn] = each node's nn nearest nodes, itself included
 void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                             const float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, int heavy_cap,
-                            double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s) {
+                            double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s,
+                            const SellDev* mesh, const double* mesh_pts, int cot_blocks) {
     if (K <= 0) return;
     const LocalMerge lm{controls, valid, top_idx, p.proj_len_err, p.proj_dist_err, p.min_cos, p.max_result};
     const void *geo, *sorted;
     const int* cs;
     knn_grid_views(knn_ws, K, &geo, &cs, &sorted);
     const int heavy_blocks = std::min(heavy_cap, 256), knn_blocks = (K + HEAVY_WAVES - 1) / HEAVY_WAVES;
-    k_assoc_heavy_knn<<<dim3(heavy_blocks + knn_blocks), dim3(64 * HEAVY_WAVES), 0, s>>>(
+    const int cot = mesh ? cot_blocks : 0;
+    k_assoc_heavy_knn<<<dim3(heavy_blocks + knn_blocks + cot), dim3(64 * HEAVY_WAVES), 0, s>>>(
         g, node_pts, node_nrm, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm, heavy_blocks, K, nn, (const NgGeom*)geo, cs,
-        (const float4*)sorted, nbr);
+        (const float4*)sorted, nbr, knn_blocks, mesh ? *mesh : SellDev{}, mesh_pts);
 }
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks, double* controls,

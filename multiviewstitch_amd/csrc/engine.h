@@ -139,7 +139,8 @@ void launch_assoc_local(const GridDev& g, const double* node_pts, const double* 
                         int heavy_cap, double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s, bool defer_heavy = false);
 void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                             const float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, int heavy_cap,
-                            double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s);
+                            double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s,
+                            const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks);
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks,
                         double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s);
@@ -176,7 +177,9 @@ int  ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& r
                const std::vector<int32_t>& slice_off);
 void ras_free(mvs_deform_s* h);
 int  ras_slot_size(const mvs_deform_s* h);       // doubles per sweep slot: part[3][NPpad] | gamma[3] bn[3] pad
-void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s);
+// init_ctrl != NULL: also starts the solve like launch_cot_weights(ctrl != NULL) does — solution = node target or rest
+// position, R = I — for the rows each patch owns (the weights were then made earlier, by the fused association launch)
+void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s, const double* init_ctrl = nullptr);
 void ras_default_bracket(const mvs_deform_s* h, double* a, int* m);
 int  ras_steps_for(double a);
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, const double* xin, double* xout, int it, double arap_tol, int sweep,

@@ -104,11 +104,20 @@ struct ChebCoef { double c0, c1[32], c2[32]; };      // d_0 = c0 D^-1 r ;  d_{k+
 //   pw[e][row] = 2 w_ij for a free row i and a free column j (inside OR outside the patch), else 0
 //   pd[row]    = diag_i for a free row, 0 for a control vertex
 template <int W>
-__global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, double* __restrict__ pw, double* __restrict__ pd) {
+__global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, double* __restrict__ pw, double* __restrict__ pd,
+                                                      const double* __restrict__ ctrl, const double* __restrict__ pts,
+                                                      double* __restrict__ sol, double* __restrict__ rot) {
     const int p = blockIdx.x, row = threadIdx.x;
     const int LS = R.LS, base = p * LS, nloc = R.pnloc[p];
     const bool live = row < nloc;                                      // rows nloc..LS-1 are padding: inert (pd = 0, pw = 0)
     const int g = R.l2g[base + row];
+    if (ctrl && row < R.pown[p]) {                                     // set_target_position for every node (Deformation.cpp:383-392)
+        const int c = m.is_ctrl[g];
+        st3(sol + 3 * (int64_t)g, c ? ld3(ctrl + 3 * (int64_t)(c - 1)) : ld3(pts + 3 * (int64_t)g));
+        double* Rg = rot + 9 * (int64_t)g;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rg[k] = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
+    }
     const bool fixed = !live || m.is_ctrl[g] != 0;
     pd[base + row] = fixed ? 0.0 : m.diag[g];
     const int32_t* gent = R.gent + (int64_t)base * W;
@@ -395,12 +404,12 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
 int ras_slot_size(const mvs_deform_s* h) { return ras_slot_doubles(h->ras.NPpad); }
 
 // once per outer iteration, after launch_cot_weights and the control set: the patch-local matrix
-void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s) {
+void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s, const double* init_ctrl) {
     const RasDev& R = h->ras;
     const dim3 grid(R.NP), blk(h->ras_block);
-    if (R.W == 8) k_ras_prepare<8><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd);
-    else if (R.W == 12) k_ras_prepare<12><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd);
-    else k_ras_prepare<16><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd);
+    if (R.W == 8) k_ras_prepare<8><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot);
+    else if (R.W == 12) k_ras_prepare<12><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot);
+    else k_ras_prepare<16><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot);
 }
 
 // a = 0.67 K/V (capped at 0.1), steps ~ 2.6 / sqrt(a): 8 steps at the density the reference's 16-NN sampling produces
