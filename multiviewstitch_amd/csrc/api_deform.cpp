@@ -195,6 +195,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     const int K = (int)h->K, V = (int)h->V;
     const double* ctrl = ctrl_src;
     bool weights_done = false;
+    RasSmooth last_sweep{nullptr, nullptr, 0, nullptr};
     if (graph_smooth) {
         const int nn = p.graph_k + 1;
         if (nn != h->nbr_k) {
@@ -228,13 +229,20 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
         }
         Tic t = tic(h, "smooth");
         double* bufs[2] = {h->d_ctrl_a, h->d_ctrl_b};
-        for (int sw = first_sweep; sw < p.smooth_sweeps; ++sw) {                                  // :362-381
+        // (patch-solver iteration: the last sweep is done by k_ras_prepare, node by node, as it starts the solve)
+        const int by_prepare = (weights_done && p.smooth_sweeps > first_sweep) ? 1 : 0;
+        for (int sw = first_sweep; sw < p.smooth_sweeps - by_prepare; ++sw) {                     // :362-381
             launch_smooth(h->d_node_pts, ctrl, h->d_nbr, nn, K, bufs[sw & 1], s);
             ctrl = bufs[sw & 1];
         }
-        toc(t, p.smooth_sweeps - first_sweep);
+        toc(t, p.smooth_sweeps - first_sweep - by_prepare);
+        if (by_prepare) {
+            double* out = bufs[(p.smooth_sweeps - 1) & 1];
+            last_sweep = RasSmooth{h->d_node_pts, h->d_nbr, nn, out};
+            h->d_ctrl_final = out;
+        }
     }
-    h->d_ctrl_final = const_cast<double*>(ctrl);
+    if (!last_sweep.out) h->d_ctrl_final = const_cast<double*>(ctrl);
     const bool ras = use_ras(h, p);
     const RasPlan rp = probe_ras(h);
     int rc = ras ? ensure_ras_slots(h, p.arap_iters, rp) : ensure_slots(h, p.arap_iters, plan);
@@ -242,7 +250,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     {
         Tic t = tic(h, "weights");
         if (weights_done) {
-            launch_ras_prepare(h, s, ctrl);                                                               // set_target_position :383-392
+            launch_ras_prepare(h, s, ctrl, last_sweep);                                                   // set_target_position :383-392
             toc(t, 1);
         } else {
             launch_cot_weights(h->sell, h->d_pts, ras ? nullptr : h->d_coef, ctrl, h->d_sol, h->d_rot, s);   // preprocess() :393 + set_target_position :383-392

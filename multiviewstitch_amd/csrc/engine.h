@@ -179,7 +179,10 @@ void ras_free(mvs_deform_s* h);
 int  ras_slot_size(const mvs_deform_s* h);       // doubles per sweep slot: part[3][NPpad] | gamma[3] bn[3] pad
 // init_ctrl != NULL: also starts the solve like launch_cot_weights(ctrl != NULL) does — solution = node target or rest
 // position, R = I — for the rows each patch owns (the weights were then made earlier, by the fused association launch)
-void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s, const double* init_ctrl = nullptr);
+// sm.out != NULL: init_ctrl holds the node targets BEFORE the last smoothing sweep; the kernel performs that sweep for
+// each node on the way (its result also goes to sm.out[K*3])
+struct RasSmooth { const double* orig; const int32_t* nbr; int nn; double* out; };
+void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s, const double* init_ctrl = nullptr, const RasSmooth& sm = RasSmooth{nullptr, nullptr, 0, nullptr});
 void ras_default_bracket(const mvs_deform_s* h, double* a, int* m);
 int  ras_steps_for(double a);
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, const double* xin, double* xout, int it, double arap_tol, int sweep,

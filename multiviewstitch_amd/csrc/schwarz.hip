@@ -106,14 +106,31 @@ struct ChebCoef { double c0, c1[32], c2[32]; };      // d_0 = c0 D^-1 r ;  d_{k+
 template <int W>
 __global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, double* __restrict__ pw, double* __restrict__ pd,
                                                       const double* __restrict__ ctrl, const double* __restrict__ pts,
-                                                      double* __restrict__ sol, double* __restrict__ rot) {
+                                                      double* __restrict__ sol, double* __restrict__ rot, RasSmooth sm) {
     const int p = blockIdx.x, row = threadIdx.x;
     const int LS = R.LS, base = p * LS, nloc = R.pnloc[p];
     const bool live = row < nloc;                                      // rows nloc..LS-1 are padding: inert (pd = 0, pw = 0)
     const int g = R.l2g[base + row];
     if (ctrl && row < R.pown[p]) {                                     // set_target_position for every node (Deformation.cpp:383-392)
         const int c = m.is_ctrl[g];
-        st3(sol + 3 * (int64_t)g, c ? ld3(ctrl + 3 * (int64_t)(c - 1)) : ld3(pts + 3 * (int64_t)g));
+        d3 x = ld3(pts + 3 * (int64_t)g);
+        if (c && sm.out) {
+            // the LAST Jacobi sweep of the node-target smoothing for this node (Deformation.cpp:364-379), the operations of
+            // k_smooth in its order: c_i = o_i + sum_j w (cur_j - o_j) over the node's graph neighbours
+            const int i = c - 1;
+            const double w = 1.0 / sm.nn;
+            d3 acc = mk3(0, 0, 0);
+            for (int j = 0; j < sm.nn; ++j) {
+                const int idx = sm.nbr[(int64_t)i * sm.nn + j];
+                if (idx < 0) continue;
+                acc = acc + w * (ld3(ctrl + 3 * idx) - ld3(sm.orig + 3 * idx));
+            }
+            x = ld3(sm.orig + 3 * i) + acc;
+            st3(sm.out + 3 * i, x);
+        } else if (c) {
+            x = ld3(ctrl + 3 * (int64_t)(c - 1));
+        }
+        st3(sol + 3 * (int64_t)g, x);
         double* Rg = rot + 9 * (int64_t)g;
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rg[k] = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
@@ -404,12 +421,12 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
 int ras_slot_size(const mvs_deform_s* h) { return ras_slot_doubles(h->ras.NPpad); }
 
 // once per outer iteration, after launch_cot_weights and the control set: the patch-local matrix
-void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s, const double* init_ctrl) {
+void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s, const double* init_ctrl, const RasSmooth& sm) {
     const RasDev& R = h->ras;
     const dim3 grid(R.NP), blk(h->ras_block);
-    if (R.W == 8) k_ras_prepare<8><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot);
-    else if (R.W == 12) k_ras_prepare<12><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot);
-    else k_ras_prepare<16><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot);
+    if (R.W == 8) k_ras_prepare<8><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
+    else if (R.W == 12) k_ras_prepare<12><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
+    else k_ras_prepare<16><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
 }
 
 // a = 0.67 K/V (capped at 0.1), steps ~ 2.6 / sqrt(a): 8 steps at the density the reference's 16-NN sampling produces
