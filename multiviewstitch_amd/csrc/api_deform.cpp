@@ -128,6 +128,7 @@ void free_nodes(mvs_deform_s* h) {
     dfree(h->d_records); dfree(h->d_top_idx); dfree(h->d_heavy); dfree(h->d_heavy2);
     if (h->d_knn_ws) { (void)hipFree(h->d_knn_ws); h->d_knn_ws = nullptr; }
     h->d_ctrl_final = nullptr; h->K = 0; h->nbr_k = 0; h->h_nodes.clear();
+    h->graph_ready_nn = 0; h->weights_ready = false; h->heavy_pending = nullptr;
 }
 
 struct CgPlan {                      // CG launches per ARAP iteration and where each solve's slots start
@@ -189,6 +190,16 @@ void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
     toc(t, defer ? 1 : 2);
 }
 
+static int ensure_nbr(mvs_deform_s* h, int nn) {
+    if (nn == h->nbr_k) return MVS_OK;
+    dfree(h->d_nbr);
+    h->nbr_k = 0;
+    int rc = dmalloc(&h->d_nbr, (size_t)h->K * nn);
+    if (rc) return rc;
+    h->nbr_k = nn;
+    return MVS_OK;
+}
+
 // graph smoothing (optional) + ARAP + geometry update.  ctrl_src: K*3 node targets.
 int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctrl_src, bool graph_smooth, const CgPlan& plan) {
     hipStream_t s = h->stream;
@@ -198,16 +209,16 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     RasSmooth last_sweep{nullptr, nullptr, 0, nullptr};
     if (graph_smooth) {
         const int nn = p.graph_k + 1;
-        if (nn != h->nbr_k) {
-            dfree(h->d_nbr);
-            int rc = dmalloc(&h->d_nbr, (size_t)K * nn);
-            if (rc) return rc;
-            h->nbr_k = nn;
-        }
+        int rc = ensure_nbr(h, nn);
+        if (rc) return rc;
         int first_sweep = 0;
         {                                                                                       // Deformation.cpp:359
             Tic t = tic(h, "graph");
-            if (h->d_knn_ws && h->heavy_pending) {
+            if (h->graph_ready_nn == nn) {
+                // sharded step: the graph (and the weights) came with the heavy-node pass of mvs_deform_assoc_select
+                weights_done = h->weights_ready && use_ras(h, p);
+                toc(t, 0);
+            } else if (h->d_knn_ws && h->heavy_pending) {
                 // single-rank iteration: the deferred heavy nodes of the association and the graph queries in one launch
                 // (the node targets are complete only after it: every smoothing sweep is a k_smooth launch)
                 knn_grid_build(h->d_node_pts, K, h->d_knn_ws, s);
@@ -338,6 +349,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     }
     toc(t, n);
     (void)V;
+    h->graph_ready_nn = 0; h->weights_ready = false;     // the nodes have moved
     return MVS_OK;
 }
 
@@ -841,8 +853,21 @@ int mvs_deform_assoc_select(mvs_deform_t h, const mvs_deform_params* p, const fl
     if (rc) return rc;
     if (!d2min_dev || !records_dev || !counts_dev) return MVS_E_INVALID_ARG;
     Tic t = tic(h, "assoc");
-    launch_assoc_select(h->grid, h->d_node_pts, h->d_node_nrm, (int)h->K, p->top_k, d2min_dev, records_dev, counts_dev, h->d_heavy, (int)h->K, h->stream);
-    toc(t, 1);
+    // The heavy-node pass shares its launch with two pieces of the solve that need nothing from the exchange: the node
+    // graph and (patch solver) the cotangent weights — they then overlap with the heavy nodes instead of following the
+    // collectives (mvs_deform_solve finds them done).
+    const int K = (int)h->K, nn = p->graph_k + 1;
+    const bool fuse = h->d_knn_ws != nullptr && nn <= 64 && ensure_nbr(h, nn) == MVS_OK;
+    launch_assoc_select(h->grid, h->d_node_pts, h->d_node_nrm, K, p->top_k, d2min_dev, records_dev, counts_dev, h->d_heavy, K, h->stream, fuse);
+    if (fuse) {
+        const bool w = use_ras(h, *p);
+        knn_grid_build(h->d_node_pts, K, h->d_knn_ws, h->stream);
+        launch_assoc_heavy_knn(h->grid, h->d_node_pts, h->d_node_nrm, K, *p, d2min_dev, records_dev, counts_dev, h->d_heavy, K,
+                               nullptr, nullptr, nullptr, nn, h->d_nbr, h->d_knn_ws, h->stream, w ? &h->sell : nullptr, h->d_pts,
+                               arap_grid_blocks(h->sell));
+        h->graph_ready_nn = nn; h->weights_ready = w;
+    }
+    toc(t, fuse ? 3 : 2);
     return mvs_check_hip(hipGetLastError(), "assoc_select");
 }
 int mvs_deform_assoc_merge(mvs_deform_t h, const mvs_deform_params* p, const mvs_cand* records_all_dev,

@@ -611,11 +611,11 @@ void launch_assoc_dmin(const GridDev& g, const double* node_pts, int K, float* d
     k_assoc_dmin<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, K, d2min);
 }
 void launch_assoc_select(const GridDev& g, const double* node_pts, const double* node_nrm, int K, int top_k,
-                         const float* d2min, mvs_cand* rec, int32_t* counts, int32_t* heavy, int heavy_cap, hipStream_t s) {
+                         const float* d2min, mvs_cand* rec, int32_t* counts, int32_t* heavy, int heavy_cap, hipStream_t s, bool defer_heavy) {
     if (K <= 0) return;
     if (heavy) (void)hipMemsetAsync(heavy, 0, sizeof(int32_t), s);
     k_assoc_select<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, top_k, d2min, rec, counts, heavy, heavy_cap);
-    if (heavy) k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, top_k, d2min, rec, counts, heavy, heavy_cap, LocalMerge{});
+    if (heavy && !defer_heavy) k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, top_k, d2min, rec, counts, heavy, heavy_cap, LocalMerge{});
 }
 // dmin + select of a single-rank run in one launch (+ the heavy-node pass); d2min is still written (getters, heavy pass)
 // ... and the merge: with one rank a node's list is final, its wave writes the node target itself
