@@ -359,9 +359,11 @@ int mvs_deform_assoc_merge(mvs_deform_t h, const mvs_deform_params* p,
 int mvs_deform_solve(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stats* stats);
 int mvs_deform_sync(mvs_deform_t h);            /* wait for the handle's stream */
 void* mvs_deform_stream(mvs_deform_t h);        /* hipStream_t of the handle     */
-/* Run the handle's kernels on a caller-owned stream (e.g. torch's current
- * stream, so RCCL collectives and engine kernels order without host syncs).
- * NULL restores the handle's own stream.  The handle's stream is drained first. */
+/* Run the handle's kernels on a caller-owned stream (e.g. the stream the caller
+ * issues its RCCL collectives on, so that collectives and engine kernels order
+ * without host syncs).  NULL restores the handle's own (non-blocking) stream —
+ * note that the legacy default stream IS the NULL handle and therefore cannot
+ * be selected: create a stream.  The handle's stream is drained first. */
 int mvs_deform_set_stream(mvs_deform_t h, void* hip_stream);
 
 /* Read-back (host buffers). */

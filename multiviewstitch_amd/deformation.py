@@ -158,7 +158,11 @@ class Deformation:
         return int(L.lib().mvs_deform_stream(self._h) or 0)
 
     def set_stream(self, hip_stream: int | None):
-        """Enqueue on a caller-owned stream (torch.cuda.current_stream().cuda_stream); None restores the own one."""
+        """Enqueue on a caller-owned stream (``torch.cuda.Stream(dev).cuda_stream``); None restores the own one.
+        torch's DEFAULT stream has handle 0, which the C-ABI reads as NULL = "own stream": refuse it rather than let a
+        caller believe the engine follows the default stream."""
+        if hip_stream is not None and int(hip_stream) == 0:
+            raise ValueError("stream handle 0 (the default stream) cannot be set: create a torch.cuda.Stream and pass its cuda_stream")
         L.check(L.lib().mvs_deform_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
 
     def arap(self, ctrl_targets) -> dict:

@@ -34,11 +34,20 @@ class EngineShard:
     def __init__(self, deform, device):
         self.d = deform
         self.device = device
-        # engine kernels and RCCL collectives share torch's current stream: ordering without host syncs
-        self.d.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        # Engine kernels and the collectives must be ordered without host syncs: the engine is put on a torch stream of
+        # its own and ``sharded_step`` makes that stream torch's current one, against which ProcessGroupNCCL orders its
+        # collectives (events).  torch's DEFAULT stream cannot serve: its handle is 0, which mvs_deform_set_stream
+        # reads as "restore the handle's own stream" — a non-blocking stream the collectives would not wait for.
+        self.stream = torch.cuda.Stream(device)
+        self.d.set_stream(self.stream.cuda_stream)
 
     def buffers(self, K, world):
         dev = self.device
+        with torch.cuda.stream(self.stream):
+            return self._buffers(K, world, dev)
+
+    @staticmethod
+    def _buffers(K, world, dev):
         return dict(d2min=torch.empty(K, dtype=torch.float32, device=dev),
                     rec=torch.empty(K * 8 * REC_BYTES, dtype=torch.uint8, device=dev),
                     cnt=torch.empty(K * 2, dtype=torch.int32, device=dev),
@@ -61,6 +70,14 @@ class EngineShard:
 def sharded_step(shard, bufs, world: int, group=None, sync: bool = True):
     """One outer iteration of Deformation::Deform's body over view-sharded targets.
     sync=False leaves the step enqueued (no host synchronisation, returns None)."""
+    stream = getattr(shard, "stream", None)
+    if stream is not None:
+        with torch.cuda.stream(stream):
+            return _sharded_step(shard, bufs, world, group, sync)
+    return _sharded_step(shard, bufs, world, group, sync)
+
+
+def _sharded_step(shard, bufs, world, group, sync):
     shard.dmin(bufs)
     if world > 1:
         dist.all_reduce(bufs["d2min"], op=dist.ReduceOp.MIN, group=group)
