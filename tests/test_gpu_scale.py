@@ -102,3 +102,24 @@ def test_sharded_phases_reproduce_the_fused_path(big):
     assert np.array_equal(ga["top_idx"], gr["top_idx"]) and np.array_equal(ga["valid"], gr["valid"])
     assert np.array_equal(ga["controls"], gr["controls"])
     assert np.array_equal(a.vertices(), ref.vertices())
+
+
+@pytest.mark.gpu
+def test_engine_shard_orders_with_the_collectives_stream(big):
+    """The exchange of dist.py orders engine kernels and collectives through a torch stream: the default stream's handle
+    (0) would silently mean "the handle's own stream", so the mirror refuses it and EngineShard brings its own."""
+    from multiviewstitch_amd import dist as mdist
+    torch, dev = big["torch"], big["dev"]
+    d, _, _ = make(big)
+    with pytest.raises(ValueError, match="default stream"):
+        d.set_stream(0)
+    own = d.stream()
+    sh = mdist.EngineShard(d, dev)
+    assert sh.stream.cuda_stream != 0 and d.stream() == sh.stream.cuda_stream != own
+    bufs = sh.buffers(d.K, 1)
+    st = mdist.sharded_step(sh, bufs, 1)                                          # world 1: no collectives, same phases
+    ref, _, _ = make(big)
+    rs = ref.iterate(1)
+    assert st["n_valid"] == rs["n_valid"] and np.array_equal(d.vertices(), ref.vertices())
+    d.set_stream(None)
+    assert d.stream() == own
