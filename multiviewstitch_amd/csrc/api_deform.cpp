@@ -125,7 +125,8 @@ void collect_timers(mvs_deform_s* h) {
 void free_nodes(mvs_deform_s* h) {
     dfree(h->d_nodes); dfree(h->d_nbr); dfree(h->d_node_pts); dfree(h->d_node_nrm); dfree(h->d_ctrl_raw);
     dfree(h->d_ctrl_a); dfree(h->d_ctrl_b); dfree(h->d_valid); dfree(h->d_d2min); dfree(h->d_counts);
-    dfree(h->d_records); dfree(h->d_top_idx); dfree(h->d_heavy); dfree(h->d_heavy2);
+    dfree(h->d_records); dfree(h->d_top_idx); dfree(h->d_heavy); dfree(h->d_heavy2); dfree(h->d_prev_d2); dfree(h->d_prev_node);
+    h->prev_valid = false;
     if (h->d_knn_ws) { (void)hipFree(h->d_knn_ws); h->d_knn_ws = nullptr; }
     h->d_ctrl_final = nullptr; h->K = 0; h->nbr_k = 0; h->h_nodes.clear();
     h->graph_ready_nn = 0; h->weights_ready = false; h->heavy_pending = nullptr;
@@ -702,6 +703,7 @@ int mvs_deform_set_nodes(mvs_deform_t h, const int32_t* vertex_idx, int64_t K) {
     TRY(dmalloc(&h->d_nodes, (size_t)K)); TRY(dmalloc(&h->d_node_pts, (size_t)K * 3)); TRY(dmalloc(&h->d_node_nrm, (size_t)K * 3));
     TRY(dmalloc(&h->d_ctrl_raw, (size_t)K * 3)); TRY(dmalloc(&h->d_ctrl_a, (size_t)K * 3)); TRY(dmalloc(&h->d_ctrl_b, (size_t)K * 3));
     TRY(dmalloc(&h->d_valid, (size_t)K)); TRY(dmalloc(&h->d_d2min, (size_t)K)); TRY(dmalloc(&h->d_counts, (size_t)K * 2));
+    TRY(dmalloc(&h->d_prev_d2, (size_t)K)); TRY(dmalloc(&h->d_prev_node, (size_t)K * 3));
     TRY(dmalloc(&h->d_records, (size_t)K * 8)); TRY(dmalloc(&h->d_top_idx, (size_t)K * 8)); TRY(dmalloc(&h->d_heavy, (size_t)K + 1)); TRY(dmalloc(&h->d_heavy2, (size_t)K + 1));
     TRY(mvs_check_hip(hipMemsetAsync(h->d_heavy, 0, sizeof(int32_t), h->stream), "memset")); TRY(mvs_check_hip(hipMemsetAsync(h->d_heavy2, 0, sizeof(int32_t), h->stream), "memset"));
     h->heavy_flip = 0;
@@ -843,7 +845,7 @@ int mvs_deform_assoc_dmin(mvs_deform_t h, const mvs_deform_params* p, float* d2m
     if (rc) return rc;
     if (!d2min_dev) return MVS_E_INVALID_ARG;
     Tic t = tic(h, "assoc");
-    launch_assoc_dmin(h->grid, h->d_node_pts, (int)h->K, d2min_dev, h->stream);
+    launch_assoc_dmin(h->grid, h->d_node_pts, (int)h->K, d2min_dev, h->stream, h->prev_valid ? h->d_prev_d2 : nullptr, h->d_prev_node);
     toc(t, 1);
     return mvs_check_hip(hipGetLastError(), "assoc_dmin");
 }
@@ -858,7 +860,9 @@ int mvs_deform_assoc_select(mvs_deform_t h, const mvs_deform_params* p, const fl
     // collectives (mvs_deform_solve finds them done).
     const int K = (int)h->K, nn = p->graph_k + 1;
     const bool fuse = h->d_knn_ws != nullptr && nn <= 64 && ensure_nbr(h, nn) == MVS_OK;
-    launch_assoc_select(h->grid, h->d_node_pts, h->d_node_nrm, K, p->top_k, d2min_dev, records_dev, counts_dev, h->d_heavy, K, h->stream, fuse);
+    launch_assoc_select(h->grid, h->d_node_pts, h->d_node_nrm, K, p->top_k, d2min_dev, records_dev, counts_dev, h->d_heavy, K, h->stream, fuse,
+                        h->d_prev_d2, h->d_prev_node);
+    h->prev_valid = h->d_prev_d2 != nullptr;
     if (fuse) {
         const bool w = use_ras(h, *p);
         knn_grid_build(h->d_node_pts, K, h->d_knn_ws, h->stream);

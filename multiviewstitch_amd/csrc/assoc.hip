@@ -107,7 +107,11 @@ __device__ inline void shell_cell(int t, int S, int* dx, int* dy, int* dz) {
 
 // ------------------------------------------------------------------ dmin ----
 // exact squared distance (float32) of one node to its nearest target point, by one wave; every lane gets the result
-__device__ inline float dmin_node(const GridDev& g, const double* __restrict__ node_pts, int node) {
+// limit2: an UPPER bound on the squared distance of the node to the nearest point of the WHOLE target (all ranks), or
+// INFINITY.  A rank whose own points all lie beyond it cannot hold that nearest point: the search stops as soon as it has
+// covered the bound and returns what it has (>= the true global minimum, which the all-reduce(MIN) takes from the rank
+// that does hold the point — that rank's search is not cut short, its best is inside the bound).
+__device__ inline float dmin_node(const GridDev& g, const double* __restrict__ node_pts, int node, float limit2 = INFINITY) {
     ASTAMP_BEGIN;
     const int lane = threadIdx.x & 63;
     const float qx = (float)node_pts[3 * node], qy = (float)node_pts[3 * node + 1], qz = (float)node_pts[3 * node + 2];
@@ -164,7 +168,7 @@ __device__ inline float dmin_node(const GridDev& g, const double* __restrict__ n
             }
             best = wave_min_f(best);
             const float bound = ((float)s + m - 0.01f) * g.h;    // everything within `bound` has been seen
-            found = bound > 0.0f && best <= bound * bound;
+            found = bound > 0.0f && (best <= bound * bound || bound * bound > limit2);
         }
         // ---- stage B: coarse occupancy grid, expanding shells with pruning; a coarse cell is ONE range
         if (!found) {
@@ -203,7 +207,7 @@ __device__ inline float dmin_node(const GridDev& g, const double* __restrict__ n
                     }
                 }
                 const float bound = (((float)S) * 8.f + Mc - 0.08f) * g.h;
-                if (bound > 0.0f && best <= bound * bound) break;
+                if (bound > 0.0f && (best <= bound * bound || bound * bound > limit2)) break;
             }
         }
     }
@@ -212,11 +216,24 @@ __device__ inline float dmin_node(const GridDev& g, const double* __restrict__ n
     return best;
 }
 
+// prev_d2 / prev_node (NULL on the first pass): the GLOBAL nearest distance and the node positions of the previous outer
+// iteration against the same target.  The node has moved by delta since, the target has not: the new global nearest
+// distance is at most sqrt(prev_d2) + delta (triangle inequality) — the limit of dmin_node, with slack for the float32
+// rounding of coordinates and distances.
 __global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __restrict__ node_pts, int K,
-                                                    float* __restrict__ d2min) {
+                                                    float* __restrict__ d2min, const float* __restrict__ prev_d2,
+                                                    const double* __restrict__ prev_node) {
     const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (node >= K) return;                       // wave-uniform
-    const float best = dmin_node(g, node_pts, node);
+    float limit2 = INFINITY;
+    if (prev_d2) {
+        const double dx = node_pts[3 * node] - prev_node[3 * node], dy = node_pts[3 * node + 1] - prev_node[3 * node + 1],
+                     dz = node_pts[3 * node + 2] - prev_node[3 * node + 2];
+        const double r = sqrt((double)prev_d2[node]) + sqrt(dx * dx + dy * dy + dz * dz);
+        const double l2 = r * r * 1.001 + 1e-12;
+        limit2 = (l2 == l2 && l2 < 3.0e38) ? (float)l2 : INFINITY;       // (NaN / inf: no limit)
+    }
+    const float best = dmin_node(g, node_pts, node, limit2);
     if ((threadIdx.x & 63) == 0) d2min[node] = best;
 }
 
@@ -476,9 +493,15 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
 __global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* __restrict__ node_pts,
                                                       const double* __restrict__ node_nrm, int K, int top_k,
                                                       const float* __restrict__ d2min, mvs_cand* __restrict__ rec,
-                                                      int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap) {
+                                                      int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap,
+                                                      float* __restrict__ prev_d2, double* __restrict__ prev_node) {
     const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (node >= K) return;
+    if (prev_d2 && (threadIdx.x & 63) < 3) {     // remember the global nearest distance and where the node stood (k_assoc_dmin)
+        const int c = threadIdx.x & 63;
+        if (c == 0) prev_d2[node] = d2min[node];
+        prev_node[3 * node + c] = node_pts[3 * node + c];
+    }
     select_node<1>(g, node_pts, node_nrm, node, top_k, d2min[node], rec, counts, heavy, heavy_cap, nullptr, LocalMerge{});
 }
 
@@ -606,15 +629,17 @@ extern "C" int mvs_debug_assoc_cycles(unsigned long long* out, int n) {
 }
 #endif
 
-void launch_assoc_dmin(const GridDev& g, const double* node_pts, int K, float* d2min, hipStream_t s) {
+void launch_assoc_dmin(const GridDev& g, const double* node_pts, int K, float* d2min, hipStream_t s, const float* prev_d2,
+                       const double* prev_node) {
     if (K <= 0) return;
-    k_assoc_dmin<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, K, d2min);
+    k_assoc_dmin<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, K, d2min, prev_d2, prev_node);
 }
 void launch_assoc_select(const GridDev& g, const double* node_pts, const double* node_nrm, int K, int top_k,
-                         const float* d2min, mvs_cand* rec, int32_t* counts, int32_t* heavy, int heavy_cap, hipStream_t s, bool defer_heavy) {
+                         const float* d2min, mvs_cand* rec, int32_t* counts, int32_t* heavy, int heavy_cap, hipStream_t s, bool defer_heavy,
+                         float* prev_d2, double* prev_node) {
     if (K <= 0) return;
     if (heavy) (void)hipMemsetAsync(heavy, 0, sizeof(int32_t), s);
-    k_assoc_select<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, top_k, d2min, rec, counts, heavy, heavy_cap);
+    k_assoc_select<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, top_k, d2min, rec, counts, heavy, heavy_cap, prev_d2, prev_node);
     if (heavy && !defer_heavy) k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, top_k, d2min, rec, counts, heavy, heavy_cap, LocalMerge{});
 }
 // dmin + select of a single-rank run in one launch (+ the heavy-node pass); d2min is still written (getters, heavy pass)

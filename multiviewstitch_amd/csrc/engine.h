@@ -89,6 +89,9 @@ struct mvs_deform_s {
     int64_t *d_top_idx = nullptr;
     int32_t *d_heavy = nullptr;       // [1 + K]: nodes deferred to the workgroup-per-node association kernel
     int32_t *d_heavy2 = nullptr;      // second list: single-rank iterations alternate (each resets the other's counter)
+    float* d_prev_d2 = nullptr;        // sharded step: global nearest distance of every node at the previous association ...
+    double* d_prev_node = nullptr;     // ... and where the node stood (bound for the next nearest-distance search)
+    bool prev_valid = false;
     int graph_ready_nn = 0;           // sharded step: mvs_deform_assoc_select already made the node graph with this many neighbours ...
     bool weights_ready = false;       // ... and the cotangent weights (patch solver), in the launch of its heavy-node pass
     const int32_t* heavy_pending = nullptr;   // heavy list of an association whose heavy pass rides with the node graph (enqueue_solve)
@@ -132,10 +135,12 @@ struct mvs_deform_s {
 int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* nrm_dev, int64_t index_base);
 int scan_exclusive_i32(const int32_t* in, int64_t n, int32_t* out, hipStream_t s);
 // assoc.hip
-void launch_assoc_dmin(const GridDev& g, const double* node_pts, int K, float* d2min, hipStream_t s);
+void launch_assoc_dmin(const GridDev& g, const double* node_pts, int K, float* d2min, hipStream_t s, const float* prev_d2 = nullptr,
+                       const double* prev_node = nullptr);
 void launch_assoc_select(const GridDev& g, const double* node_pts, const double* node_nrm, int K, int top_k,
                          const float* d2min, mvs_cand* rec, int32_t* counts, int32_t* heavy /*[1 + cap] or NULL*/, int heavy_cap,
-                         hipStream_t s, bool defer_heavy = false /*the caller launches launch_assoc_heavy_knn*/);
+                         hipStream_t s, bool defer_heavy = false /*the caller launches launch_assoc_heavy_knn*/,
+                         float* prev_d2 = nullptr, double* prev_node = nullptr /*out: what the next launch_assoc_dmin may use*/);
 void launch_assoc_local(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, float* d2min,
                         mvs_cand* rec, int32_t* counts, int32_t* heavy /*counter already 0*/, int32_t* heavy_next /*reset for the next call*/,
                         int heavy_cap, double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s, bool defer_heavy = false);

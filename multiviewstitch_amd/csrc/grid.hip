@@ -152,6 +152,7 @@ GridGeom make_geom(const float mn[3], const float mx[3], float h) {
 
 int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* nrm_dev, int64_t index_base) {
     hipStream_t s = h->stream;
+    h->prev_valid = false;                              // a new target: the remembered nearest distances say nothing about it
     if (h->d_spos) { (void)hipFree(h->d_spos); h->d_spos = nullptr; }
     if (h->d_tpos) { (void)hipFree(h->d_tpos); h->d_tpos = nullptr; }
     if (h->d_tnrm) { (void)hipFree(h->d_tnrm); h->d_tnrm = nullptr; }
