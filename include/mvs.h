@@ -349,6 +349,10 @@ typedef struct mvs_cand {      /* 48 bytes */
     int64_t index;             /* global target index, -1 = empty slot */
 } mvs_cand;
 
+/* NOTE on _assoc_dmin: from the second pass against the same target on, the search of a node is bounded by the GLOBAL
+ * distance _assoc_select was given last time plus the distance the node has moved since (triangle inequality).  A rank
+ * none of whose points can be the nearest one then reports some value ABOVE the global minimum instead of its own
+ * exact minimum; the MIN over ranks is unaffected.  _assoc_select must therefore always receive the reduced array. */
 int mvs_deform_assoc_dmin(mvs_deform_t h, const mvs_deform_params* p, float* d2min_dev);
 int mvs_deform_assoc_select(mvs_deform_t h, const mvs_deform_params* p,
                             const float* d2min_dev, mvs_cand* records_dev, int32_t* counts_dev);
