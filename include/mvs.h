@@ -359,6 +359,10 @@ int mvs_deform_assoc_select(mvs_deform_t h, const mvs_deform_params* p,
 int mvs_deform_assoc_merge(mvs_deform_t h, const mvs_deform_params* p,
                            const mvs_cand* records_all_dev, const int32_t* counts_all_dev,
                            int nranks);
+/* The same merge over ONE gathered buffer: rank r's block = [K*8 mvs_cand records][K*2 int32 counts], blocks back to back
+ * (K*392 bytes each) — what a single all-gather of each rank's packed [records | counts] buffer produces (one collective
+ * per outer iteration less than gathering the two arrays separately). */
+int mvs_deform_assoc_merge_packed(mvs_deform_t h, const mvs_deform_params* p, const void* packed_all_dev, int nranks);
 /* stats == NULL (after the first, calibrating call): enqueue only, no host synchronisation. */
 int mvs_deform_solve(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stats* stats);
 int mvs_deform_sync(mvs_deform_t h);            /* wait for the handle's stream */

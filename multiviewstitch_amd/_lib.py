@@ -114,6 +114,7 @@ _SIGS = {
     "mvs_deform_assoc_dmin": (C.c_int, [_VP, _VP, _VP]),
     "mvs_deform_assoc_select": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "mvs_deform_assoc_merge": (C.c_int, [_VP, _VP, _VP, _VP, _I32]),
+    "mvs_deform_assoc_merge_packed": (C.c_int, [_VP, _VP, _VP, _I32]),
     "mvs_deform_solve": (C.c_int, [_VP, _VP, _VP]),
     "mvs_deform_sync": (C.c_int, [_VP]),
     "mvs_deform_stream": (C.c_void_p, [_VP]),

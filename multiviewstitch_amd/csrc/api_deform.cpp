@@ -885,6 +885,18 @@ int mvs_deform_assoc_merge(mvs_deform_t h, const mvs_deform_params* p, const mvs
     toc(t, 1);
     return mvs_check_hip(hipGetLastError(), "assoc_merge");
 }
+int mvs_deform_assoc_merge_packed(mvs_deform_t h, const mvs_deform_params* p, const void* packed_all_dev, int nranks) {
+    int rc = ready(h, p, false);
+    if (rc) return rc;
+    if (!packed_all_dev || nranks < 1) return MVS_E_INVALID_ARG;
+    const int64_t K = h->K, rec_bytes = K * 8 * (int64_t)sizeof(mvs_cand), stride = rec_bytes + K * 2 * (int64_t)sizeof(int32_t);
+    Tic t = tic(h, "assoc");
+    launch_assoc_merge(h->d_node_pts, h->d_node_nrm, (int)K, *p, (const mvs_cand*)packed_all_dev,
+                       (const int32_t*)((const char*)packed_all_dev + rec_bytes), nranks, h->d_ctrl_raw, h->d_valid, h->d_top_idx, h->stream,
+                       stride, stride);
+    toc(t, 1);
+    return mvs_check_hip(hipGetLastError(), "assoc_merge");
+}
 int mvs_deform_solve(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stats* stats) {
     int rc = ready(h, p, false);
     if (rc) return rc;

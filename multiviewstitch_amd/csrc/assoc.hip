@@ -572,7 +572,9 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_heavy_knn(GridDev g,
 __global__ void k_assoc_merge(const double* __restrict__ node_pts, const double* __restrict__ node_nrm, int K,
                               mvs_deform_params p, const mvs_cand* __restrict__ rec_all,
                               const int32_t* __restrict__ counts_all, int nranks, double* __restrict__ controls,
-                              uint8_t* __restrict__ valid, int64_t* __restrict__ top_idx) {
+                              uint8_t* __restrict__ valid, int64_t* __restrict__ top_idx, int64_t rec_stride, int64_t cnt_stride) {
+    // rank r's records start rec_stride BYTES after rank r-1's, its counts cnt_stride bytes (dense arrays: K*8*48 and K*2*4;
+    // one packed buffer per rank [records | counts]: both = the packed size)
     const int node = blockIdx.x * blockDim.x + threadIdx.x;
     if (node >= K) return;
     const d3 orig = ld3(node_pts + 3 * node), nn = ld3(node_nrm + 3 * node);
@@ -582,9 +584,9 @@ __global__ void k_assoc_merge(const double* __restrict__ node_pts, const double*
     long long ball = 0;
     const int tk = p.top_k;
     for (int r = 0; r < nranks; ++r) {
-        ball += counts_all[((int64_t)r * K + node) * 2];
+        ball += reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(counts_all) + r * cnt_stride)[(int64_t)node * 2];
         for (int s = 0; s < 8; ++s) {
-            const mvs_cand c = rec_all[((int64_t)r * K + node) * 8 + s];
+            const mvs_cand c = reinterpret_cast<const mvs_cand*>(reinterpret_cast<const char*>(rec_all) + r * rec_stride)[(int64_t)node * 8 + s];
             if (c.index < 0) continue;
             int pos = len;
             while (pos > 0 && key_less(c.proj_dist, fabs(c.proj_len), c.index, l_pd[pos - 1], fabs(l_pl[pos - 1]), l_i[pos - 1])) --pos;
@@ -672,8 +674,10 @@ void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const doub
 }
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks, double* controls,
-                        uint8_t* valid, int64_t* top_idx, hipStream_t s) {
+                        uint8_t* valid, int64_t* top_idx, hipStream_t s, int64_t rec_stride, int64_t cnt_stride) {
     if (K <= 0) return;
+    if (rec_stride == 0) rec_stride = (int64_t)K * 8 * sizeof(mvs_cand);
+    if (cnt_stride == 0) cnt_stride = (int64_t)K * 2 * sizeof(int32_t);
     k_assoc_merge<<<dim3((K + 127) / 128), dim3(128), 0, s>>>(node_pts, node_nrm, K, p, rec_all, counts_all, nranks,
-                                                             controls, valid, top_idx);
+                                                             controls, valid, top_idx, rec_stride, cnt_stride);
 }

@@ -150,7 +150,8 @@ void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const doub
                             const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks);
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks,
-                        double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s);
+                        double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s,
+                        int64_t rec_stride_bytes = 0, int64_t cnt_stride_bytes = 0 /*0 = dense arrays*/);
 // knn.hip
 void launch_knn(const double* pts, int n, int k, int32_t* out, hipStream_t s);                 // brute force, LDS tiles
 size_t knn_grid_ws_bytes(int n);

@@ -142,6 +142,10 @@ class Deformation:
         L.check(L.lib().mvs_deform_assoc_merge(self._h, C.byref(self.params), L.ptr(int(records_all_dev)),
                                                L.ptr(int(counts_all_dev)), nranks))
 
+    def assoc_merge_packed(self, packed_all_dev: int, nranks: int):
+        """rank r's block of ``packed_all``: [K*8 records (48 B)][K*2 int32 counts] — one all-gather instead of two."""
+        L.check(L.lib().mvs_deform_assoc_merge_packed(self._h, C.byref(self.params), L.ptr(int(packed_all_dev)), nranks))
+
     def solve(self, sync: bool = True):
         """sync=False: enqueue only (no host synchronisation, no stats) — for back-to-back sharded steps."""
         if not sync:

@@ -5,7 +5,7 @@ Per outer iteration the ranks exchange, over ``torch.distributed`` (backend
 "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests):
 
   1. all-reduce(MIN)  of d2min[K]           float32   (32 KB at K = 8 K)
-  2. all-gather       of counts[K,2] int32 and the local best-8 records[K,8] (48 B each)
+  2. all-gather       of ONE packed buffer per rank: the local best-8 records[K,8] (48 B each) | counts[K,2] int32
   3. every rank merges the N record sets with the same total order -> identical
      node targets everywhere; smoothing + ARAP run replicated, so the meshes
      never diverge and nothing else is communicated.
@@ -48,6 +48,14 @@ class EngineShard:
 
     @staticmethod
     def _buffers(K, world, dev):
+        # records and counts of a rank live in ONE buffer [K*8 records | K*2 counts] so that one all-gather moves both
+        R, Cn = K * 8 * REC_BYTES, K * 2 * 4
+        pack = torch.empty(R + Cn, dtype=torch.uint8, device=dev)
+        return dict(d2min=torch.empty(K, dtype=torch.float32, device=dev), pack=pack, rec=pack[:R], cnt=pack[R:].view(torch.int32),
+                    pack_all=torch.empty(world * (R + Cn), dtype=torch.uint8, device=dev))
+
+    @staticmethod
+    def _buffers_two_arrays(K, world, dev):
         return dict(d2min=torch.empty(K, dtype=torch.float32, device=dev),
                     rec=torch.empty(K * 8 * REC_BYTES, dtype=torch.uint8, device=dev),
                     cnt=torch.empty(K * 2, dtype=torch.int32, device=dev),
@@ -61,7 +69,10 @@ class EngineShard:
         self.d.assoc_select(b["d2min"].data_ptr(), b["rec"].data_ptr(), b["cnt"].data_ptr())
 
     def merge(self, b, world):
-        self.d.assoc_merge(b["rec_all"].data_ptr(), b["cnt_all"].data_ptr(), world)
+        if "pack_all" in b:
+            self.d.assoc_merge_packed(b["pack_all"].data_ptr(), world)
+        else:
+            self.d.assoc_merge(b["rec_all"].data_ptr(), b["cnt_all"].data_ptr(), world)
 
     def solve(self, sync=True):
         return self.d.solve(sync)
@@ -82,10 +93,15 @@ def _sharded_step(shard, bufs, world, group, sync):
     if world > 1:
         dist.all_reduce(bufs["d2min"], op=dist.ReduceOp.MIN, group=group)
     shard.select(bufs)
-    if world > 1:
+    if world > 1 and "pack" in bufs:
+        dist.all_gather_into_tensor(bufs["pack_all"], bufs["pack"], group=group)      # records and counts in one collective
+        shard.merge(bufs, world)
+    elif world > 1:
         dist.all_gather_into_tensor(bufs["rec_all"], bufs["rec"], group=group)
         dist.all_gather_into_tensor(bufs["cnt_all"], bufs["cnt"], group=group)
         shard.merge(bufs, world)
+    elif "pack" in bufs:
+        shard.merge(dict(bufs, pack_all=bufs["pack"]), 1)
     else:
         shard.merge(dict(bufs, rec_all=bufs["rec"], cnt_all=bufs["cnt"]), 1)
     return shard.solve(sync) if not sync else shard.solve()

@@ -23,8 +23,14 @@ class OracleShard:
         self.pts, self.nrm, self.faces = g["verts"].copy(), g["normals"], g["faces"]
         self.tgt = O.Target(g["tp"][lo:hi], g["tn"][lo:hi], lo)
         self.result = None
+        self.packed = True
 
     def buffers(self, K, world):
+        if self.packed:                                     # the layout bench.py exchanges: one all-gather per step
+            R, Cn = K * 8 * 48, K * 2 * 4
+            pack = torch.empty(R + Cn, dtype=torch.uint8)
+            return dict(d2min=torch.empty(K, dtype=torch.float32), pack=pack, rec=pack[:R], cnt=pack[R:].view(torch.int32),
+                        pack_all=torch.empty(world * (R + Cn), dtype=torch.uint8))
         return dict(d2min=torch.empty(K, dtype=torch.float32), rec=torch.empty(K * 8 * 48, dtype=torch.uint8),
                     cnt=torch.empty(K * 2, dtype=torch.int32), rec_all=torch.empty(world * K * 8 * 48, dtype=torch.uint8),
                     cnt_all=torch.empty(world * K * 2, dtype=torch.int32))
@@ -39,8 +45,14 @@ class OracleShard:
 
     def merge(self, b, world):
         K = len(self.nodes)
-        rec = b["rec_all"].numpy().view(self.O.CAND_DTYPE).reshape(world, K, 8)
-        self.merged = self.O.assoc_merge(self.pts[self.nodes], self.nrm[self.nodes], self.p, rec, b["cnt_all"].numpy().reshape(world, K, 2))
+        if "pack_all" in b:
+            blk = b["pack_all"].numpy().reshape(world, -1)
+            rec = np.ascontiguousarray(blk[:, :K * 8 * 48]).view(self.O.CAND_DTYPE).reshape(world, K, 8)
+            cnt = np.ascontiguousarray(blk[:, K * 8 * 48:]).view(np.int32).reshape(world, K, 2)
+        else:
+            rec = b["rec_all"].numpy().view(self.O.CAND_DTYPE).reshape(world, K, 8)
+            cnt = b["cnt_all"].numpy().reshape(world, K, 2)
+        self.merged = self.O.assoc_merge(self.pts[self.nodes], self.nrm[self.nodes], self.p, rec, cnt)
 
     def solve(self, sync=True):
         O = self.O
@@ -51,7 +63,7 @@ class OracleShard:
         return r
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, packed=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import binding as O
@@ -63,6 +75,7 @@ def _worker(rank, world, port, q):
     offs, counts = mdist.exclusive_offsets(cuts[rank + 1] - cuts[rank], world, torch.device("cpu"))
     assert offs[rank] == cuts[rank] and counts.sum() == P
     shard = OracleShard(O, g, cuts[rank], cuts[rank + 1])
+    shard.packed = packed
     bufs = shard.buffers(len(g["nodes"]), world)
     for _ in range(2):
         mdist.sharded_step(shard, bufs, world)
@@ -71,14 +84,18 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_step_world2_matches_single_rank():
+import pytest
+
+
+@pytest.mark.parametrize("packed", [True, False])           # one all-gather of [records | counts], or the two arrays separately
+def test_sharded_step_world2_matches_single_rank(packed):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, packed)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
