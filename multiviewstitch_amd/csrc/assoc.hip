@@ -584,7 +584,9 @@ __global__ void k_assoc_merge(const double* __restrict__ node_pts, const double*
     long long ball = 0;
     const int tk = p.top_k;
     for (int r = 0; r < nranks; ++r) {
-        ball += reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(counts_all) + r * cnt_stride)[(int64_t)node * 2];
+        const int32_t* cnt_r = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(counts_all) + r * cnt_stride) + (int64_t)node * 2;
+        ball += cnt_r[0];
+        if (cnt_r[1] == 0) continue;             // nothing of this rank passed the normal filter: its list is empty (most rank/node pairs)
         for (int s = 0; s < 8; ++s) {
             const mvs_cand c = reinterpret_cast<const mvs_cand*>(reinterpret_cast<const char*>(rec_all) + r * rec_stride)[(int64_t)node * 8 + s];
             if (c.index < 0) continue;
