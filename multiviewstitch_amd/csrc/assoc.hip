@@ -569,49 +569,75 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_heavy_knn(GridDev g,
 }
 
 // ----------------------------------------------------------------- merge ----
-__global__ void k_assoc_merge(const double* __restrict__ node_pts, const double* __restrict__ node_nrm, int K,
+// One wave per node: the ranks' records of the node (8 per rank, 64 per pass of the wave) are loaded one per lane —
+// 384 contiguous bytes per rank — and inserted into the wave-resident sorted list exactly as select_node does; the node
+// target is then formed as in the single-rank path (same operations, same order).  (The first version, a thread per
+// node with its list in scratch memory, took 187 us per step at 8 ranks against 15 us at one: scripts/shard_steady.py.)
+__global__ __launch_bounds__(256) void k_assoc_merge(const double* __restrict__ node_pts, const double* __restrict__ node_nrm, int K,
                               mvs_deform_params p, const mvs_cand* __restrict__ rec_all,
                               const int32_t* __restrict__ counts_all, int nranks, double* __restrict__ controls,
                               uint8_t* __restrict__ valid, int64_t* __restrict__ top_idx, int64_t rec_stride, int64_t cnt_stride) {
     // rank r's records start rec_stride BYTES after rank r-1's, its counts cnt_stride bytes (dense arrays: K*8*48 and K*2*4;
     // one packed buffer per rank [records | counts]: both = the packed size)
-    const int node = blockIdx.x * blockDim.x + threadIdx.x;
-    if (node >= K) return;
+    const int node = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (node >= K) return;                                    // wave-uniform
+    const int lane = threadIdx.x & 63;
     const d3 orig = ld3(node_pts + 3 * node), nn = ld3(node_nrm + 3 * node);
-    double l_pd[8], l_pl[8], l_x[8], l_y[8], l_z[8];
-    long long l_i[8];
+    const int top_k = p.top_k;
+    double L_pd = 0, L_pl = 0, L_x = 0, L_y = 0, L_z = 0;
+    long long L_idx = -1;
     int len = 0;
+    double t_pd = 0, t_apl = 0; long long t_idx = 0;
     long long ball = 0;
-    const int tk = p.top_k;
-    for (int r = 0; r < nranks; ++r) {
-        const int32_t* cnt_r = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(counts_all) + r * cnt_stride) + (int64_t)node * 2;
-        ball += cnt_r[0];
-        if (cnt_r[1] == 0) continue;             // nothing of this rank passed the normal filter: its list is empty (most rank/node pairs)
-        for (int s = 0; s < 8; ++s) {
-            const mvs_cand c = reinterpret_cast<const mvs_cand*>(reinterpret_cast<const char*>(rec_all) + r * rec_stride)[(int64_t)node * 8 + s];
-            if (c.index < 0) continue;
-            int pos = len;
-            while (pos > 0 && key_less(c.proj_dist, fabs(c.proj_len), c.index, l_pd[pos - 1], fabs(l_pl[pos - 1]), l_i[pos - 1])) --pos;
-            if (pos >= tk) continue;
-            const int last = min(len, tk - 1);
-            for (int k = last; k > pos; --k) {
-                l_pd[k] = l_pd[k - 1]; l_pl[k] = l_pl[k - 1]; l_x[k] = l_x[k - 1]; l_y[k] = l_y[k - 1]; l_z[k] = l_z[k - 1]; l_i[k] = l_i[k - 1];
+    for (int base = 0; base < nranks * 8; base += 64) {
+        const int q = base + lane, r = q >> 3, sl = q & 7;
+        bool has = false;
+        double pd = 0, pl = 0; d3 tp = mk3(0, 0, 0); long long gi = 0;
+        if (r < nranks) {
+            const int32_t* cnt_r = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(counts_all) + r * cnt_stride) + (int64_t)node * 2;
+            if (sl == 0) ball += cnt_r[0];
+            if (cnt_r[1] > 0) {                               // (an empty list — most rank/node pairs — is not fetched)
+                const mvs_cand c = reinterpret_cast<const mvs_cand*>(reinterpret_cast<const char*>(rec_all) + r * rec_stride)[(int64_t)node * 8 + sl];
+                if (c.index >= 0) { has = true; pd = c.proj_dist; pl = c.proj_len; tp = mk3(c.pos[0], c.pos[1], c.pos[2]); gi = c.index; }
             }
-            l_pd[pos] = c.proj_dist; l_pl[pos] = c.proj_len; l_x[pos] = c.pos[0]; l_y[pos] = c.pos[1]; l_z[pos] = c.pos[2]; l_i[pos] = c.index;
-            len = min(len + 1, tk);
+        }
+        const double apl = fabs(pl);
+        unsigned long long pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
+        while (pend) {
+            const int src = __ffsll((long long)pend) - 1;
+            const double c_pd = rl_d(pd, src), c_pl = rl_d(pl, src);
+            const double c_x = rl_d(tp.x, src), c_y = rl_d(tp.y, src), c_z = rl_d(tp.z, src);
+            const long long c_i = rl_ll(gi, src);
+            const bool less = lane < len && key_less(L_pd, fabs(L_pl), L_idx, c_pd, fabs(c_pl), c_i);
+            const int pos = __popcll(__ballot(less));
+            const double u_pd = shfl_up_d(L_pd), u_pl = shfl_up_d(L_pl);
+            const double u_x = shfl_up_d(L_x), u_y = shfl_up_d(L_y), u_z = shfl_up_d(L_z);
+            const long long u_i = shfl_up_ll(L_idx);
+            if (lane > pos && lane <= len && lane < top_k) {
+                L_pd = u_pd; L_pl = u_pl; L_x = u_x; L_y = u_y; L_z = u_z; L_idx = u_i;
+            } else if (lane == pos) {
+                L_pd = c_pd; L_pl = c_pl; L_x = c_x; L_y = c_y; L_z = c_z; L_idx = c_i;
+            }
+            len = min(len + 1, top_k);
+            if (len == top_k) {
+                t_pd = rl_d(L_pd, top_k - 1); t_apl = fabs(rl_d(L_pl, top_k - 1)); t_idx = rl_ll(L_idx, top_k - 1);
+            }
+            if (lane == src) has = false;
+            pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
         }
     }
+    // total ball count over the ranks (lanes with sl == 0 hold one rank's count each)
+    for (int o = 32; o > 0; o >>= 1) ball += __shfl_xor(ball, o, 64);
     bool ok = ball < (long long)p.max_result && len > 0;     // :286-297 (full result dropped), :315
     d3 mp = orig;
-    if (top_idx)
-        for (int s = 0; s < 8; ++s) top_idx[(int64_t)node * 8 + s] = (ok && s < len) ? l_i[s] : -1;
+    double m_pl = 0, m_pd = 0;
+    d3 acc = mk3(0, 0, 0);
+    for (int sidx = 0; sidx < len; ++sidx) {                  // :341-346, best first
+        m_pl += rl_d(L_pl, sidx); m_pd += rl_d(L_pd, sidx);
+        acc = acc + mk3(rl_d(L_x, sidx), rl_d(L_y, sidx), rl_d(L_z, sidx));
+    }
+    if (top_idx && lane < 8) top_idx[(int64_t)node * 8 + lane] = (ok && lane < len) ? L_idx : -1;
     if (ok) {
-        double m_pl = 0, m_pd = 0;
-        d3 acc = mk3(0, 0, 0);
-        for (int s = 0; s < len; ++s) {                       // :341-346, best first
-            m_pl += l_pl[s]; m_pd += l_pd[s];
-            acc = acc + mk3(l_x[s], l_y[s], l_z[s]);
-        }
         const double dn = (double)len;
         m_pl /= dn; m_pd /= dn; acc = acc / dn;               // :347-349
         if (m_pl >= p.proj_len_err || m_pd >= p.proj_dist_err) ok = false;            // :350
@@ -621,8 +647,7 @@ __global__ void k_assoc_merge(const double* __restrict__ node_pts, const double*
         }
         if (ok) mp = acc;
     }
-    valid[node] = ok ? 1 : 0;                                 // :355-356 (controls stay at orig otherwise, :271-272)
-    st3(controls + 3 * node, mp);
+    if (lane == 0) { valid[node] = ok ? 1 : 0; st3(controls + 3 * node, mp); }   // :355-356 (controls stay at orig otherwise, :271-272)
 }
 
 }  // namespace
@@ -680,6 +705,6 @@ void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, c
     if (K <= 0) return;
     if (rec_stride == 0) rec_stride = (int64_t)K * 8 * sizeof(mvs_cand);
     if (cnt_stride == 0) cnt_stride = (int64_t)K * 2 * sizeof(int32_t);
-    k_assoc_merge<<<dim3((K + 127) / 128), dim3(128), 0, s>>>(node_pts, node_nrm, K, p, rec_all, counts_all, nranks,
+    k_assoc_merge<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(node_pts, node_nrm, K, p, rec_all, counts_all, nranks,
                                                              controls, valid, top_idx, rec_stride, cnt_stride);
 }
