@@ -89,19 +89,25 @@ __device__ inline float box_lb2(const QCell& c, float x0, float x1, float y0, fl
     return (ex * ex + ey * ey) + ez * ez;
 }
 
-// decode the t-th cell of the cubic shell of radius S >= 1 (n = 2S+1): two z faces, two y faces, two x faces
+// decode the t-th cell of the cubic shell of radius S >= 1 (n = 2S+1): two z faces, two y faces, two x faces.
+// No integer divisions (each is a ~40-instruction sequence on this hardware and the shell walk of a far node decodes
+// hundreds of cells per lane — they were most of its cycles, scripts/dmin_shells.py): which of the two faces is a
+// comparison, the row inside a face one float multiply, exact for the sizes that occur (t < 2^20, n <= 257: the
+// quotient is taken at t + 0.5, at least 0.5/n away from an integer, against a float error below 1e-5).
+__device__ inline int div_small(int t, int d, float inv_d) { (void)d; return (int)(((float)t + 0.5f) * inv_d); }
 __device__ inline void shell_cell(int t, int S, int* dx, int* dy, int* dz) {
     const int n = 2 * S + 1, m = n - 2;
     const int nzf = n * n, nyf = n * m;
+    const float inv_n = 1.0f / (float)n, inv_m = 1.0f / (float)m;      // (wave-uniform: scalar work)
     if (t < 2 * nzf) {
-        const int f = t / nzf, r = t - f * nzf;
-        *dz = f ? S : -S; *dy = r / n - S; *dx = r % n - S;
+        const int f = t >= nzf, r = t - f * nzf, q = div_small(r, n, inv_n);
+        *dz = f ? S : -S; *dy = q - S; *dx = r - q * n - S;
     } else if (t < 2 * nzf + 2 * nyf) {
-        const int t1 = t - 2 * nzf, f = t1 / nyf, r = t1 - f * nyf;
-        *dy = f ? S : -S; *dz = r / n - (S - 1); *dx = r % n - S;
+        const int t1 = t - 2 * nzf, f = t1 >= nyf, r = t1 - f * nyf, q = div_small(r, n, inv_n);
+        *dy = f ? S : -S; *dz = q - (S - 1); *dx = r - q * n - S;
     } else {
-        const int t2 = t - 2 * nzf - 2 * nyf, f = t2 / (m * m), r = t2 - f * m * m;
-        *dx = f ? S : -S; *dz = r / m - (S - 1); *dy = r % m - (S - 1);
+        const int t2 = t - 2 * nzf - 2 * nyf, f = t2 >= m * m, r = t2 - f * m * m, q = div_small(r, m, inv_m);
+        *dx = f ? S : -S; *dz = q - (S - 1); *dy = r - q * m - (S - 1);
     }
 }
 
@@ -181,29 +187,45 @@ __device__ inline float dmin_node(const GridDev& g, const double* __restrict__ n
             for (int S = 0; S <= SmaxC; ++S) {                   // bounded: at S == SmaxC every coarse cell was visited
                 const int n = 2 * S + 1;
                 const int total = S == 0 ? 1 : 6 * n * n - 12 * n + 8;
-                for (int base = 0; base < total; base += 64) {
-                    const int t = base + lane;
-                    int a = 0, b = 0;
-                    float lb2 = INFINITY;
-                    if (t < total) {
-                        int dx = 0, dy = 0, dz = 0;
-                        if (S > 0) shell_cell(t, S, &dx, &dy, &dz);
-                        const int X = CX + dx, Y = CY + dy, Z = CZ + dz;
-                        if (X >= 0 && X < g.NX && Y >= 0 && Y < g.NY && Z >= 0 && Z < g.NZ) {
-                            const int64_t C = grid_coarse(g.NX, g.NY, X, Y, Z);
-                            if (g.coarse_cnt[C] > 0) {
-                                lb2 = box_lb2(c, 8.f * X, 8.f * X + 8.f, 8.f * Y, 8.f * Y + 8.f, 8.f * Z, 8.f * Z + 8.f);
-                                if (lb2 <= best * ih2) { a = cs[C * 512]; b = cs[(C + 1) * 512]; }   // best == inf -> true
+                // SB groups of 64 cells of the shell go through the two dependent look-ups (occupancy, then the cell's point
+                // range) TOGETHER: a far node's search is a walk over hundreds of mostly empty coarse cells, and one group at
+                // a time it paid two cold round trips per group (20 K cycles for the 218 cells of shell 3: scripts/dmin_shells.py)
+                constexpr int SB = 4;
+                for (int base = 0; base < total; base += 64 * SB) {
+                    int a[SB], b[SB];
+                    float lb2[SB];
+                    int64_t Cc[SB];
+                    int occ[SB];
+#pragma unroll
+                    for (int j = 0; j < SB; ++j) {
+                        const int t = base + 64 * j + lane;
+                        a[j] = 0; b[j] = 0; lb2[j] = INFINITY; Cc[j] = -1; occ[j] = 0;
+                        if (t < total) {
+                            int dx = 0, dy = 0, dz = 0;
+                            if (S > 0) shell_cell(t, S, &dx, &dy, &dz);
+                            const int X = CX + dx, Y = CY + dy, Z = CZ + dz;
+                            if (X >= 0 && X < g.NX && Y >= 0 && Y < g.NY && Z >= 0 && Z < g.NZ) {
+                                Cc[j] = grid_coarse(g.NX, g.NY, X, Y, Z);
+                                a[j] = g.coarse_start[Cc[j]]; b[j] = g.coarse_start[Cc[j] + 1];
+                                occ[j] = b[j] - a[j];
+                                lb2[j] = box_lb2(c, 8.f * X, 8.f * X + 8.f, 8.f * Y, 8.f * Y + 8.f, 8.f * Z, 8.f * Z + 8.f);
                             }
                         }
                     }
-                    unsigned long long cmask = __ballot(b > a);
-                    while (cmask) {
-                        const int l = __ffsll((long long)cmask) - 1;
-                        cmask &= cmask - 1;
-                        if (__int_as_float(rl_i(__float_as_int(lb2), l)) > best * ih2) continue;   // a closer point turned up meanwhile
-                        scan(rl_i(a, l), rl_i(b, l));
-                        best = wave_min_f(best);
+#pragma unroll
+                    for (int j = 0; j < SB; ++j) {
+                        if (!(occ[j] > 0 && lb2[j] <= best * ih2)) { a[j] = 0; b[j] = 0; lb2[j] = INFINITY; }   // (best == inf: every occupied cell stays)
+                    }
+#pragma unroll
+                    for (int j = 0; j < SB; ++j) {
+                        unsigned long long cmask = __ballot(b[j] > a[j]);
+                        while (cmask) {
+                            const int l = __ffsll((long long)cmask) - 1;
+                            cmask &= cmask - 1;
+                            if (__int_as_float(rl_i(__float_as_int(lb2[j]), l)) > best * ih2) continue;   // a closer point turned up meanwhile
+                            scan(rl_i(a[j], l), rl_i(b[j], l));
+                            best = wave_min_f(best);
+                        }
                     }
                 }
                 const float bound = (((float)S) * 8.f + Mc - 0.08f) * g.h;
@@ -379,10 +401,8 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
                     if (t < ncc) {
                         const int X = X0 + t % nX, Y = Y0 + (t / nX) % nY, Z = Z0 + t / (nX * nY);
                         const int64_t C = grid_coarse(g.NX, g.NY, X, Y, Z);
-                        if (g.coarse_cnt[C] > 0 &&
-                            box_lb2(c, 8.f * X, 8.f * X + 8.f, 8.f * Y, 8.f * Y + 8.f, 8.f * Z, 8.f * Z + 8.f) <= lim) {
-                            a = cs[C * 512]; b = cs[(C + 1) * 512];
-                        }
+                        const int a0 = g.coarse_start[C], b0 = g.coarse_start[C + 1];
+                        if (b0 > a0 && box_lb2(c, 8.f * X, 8.f * X + 8.f, 8.f * Y, 8.f * Y + 8.f, 8.f * Z, 8.f * Z + 8.f) <= lim) { a = a0; b = b0; }
                     }
                     if (PARTS > 1) {
                         int slot = HEAVY_RANGES;

@@ -27,7 +27,7 @@ struct GridDev {
     const double*  tnrm;        // P*3 cell-sorted double normals
     const int32_t* cell_start;  // nx*ny*nz + 1
     int32_t  NX, NY, NZ;        // coarse occupancy grid: 8x8x8 fine cells per coarse cell
-    const int32_t* coarse_cnt;  // NX*NY*NZ point counts
+    const int32_t* coarse_start; // NX*NY*NZ + 1: first point of every coarse cell (= cell_start[C * 512], compact)
 };
 
 struct SellDev {               // "ELL-8 by row group" adjacency of the template mesh (see arap.hip)

@@ -114,10 +114,13 @@ __global__ void k_scatter(const double* __restrict__ pts, const double* __restri
     tnrm[3 * d] = nrm[3 * i]; tnrm[3 * d + 1] = nrm[3 * i + 1]; tnrm[3 * d + 2] = nrm[3 * i + 2];
 }
 
-// points per coarse cell: a coarse cell is one contiguous run of 512 tiled fine cells
-__global__ void k_coarse_count(const int32_t* __restrict__ cs, int64_t ncoarse, int32_t* __restrict__ cnt) {
+// first point of every coarse cell (a coarse cell is one contiguous run of 512 tiled fine cells), ncoarse + 1 entries:
+// the COMPACT copy of cell_start[C * 512].  The walks over coarse cells (far nodes) read their ranges from here — a few
+// tens of KB that stay cached — instead of one line (and one page-table look-up) per coarse cell out of the tens of MB of
+// cell_start; the occupancy of cell C is start[C + 1] - start[C].
+__global__ void k_coarse_start(const int32_t* __restrict__ cs, int64_t ncoarse, int32_t* __restrict__ start) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < ncoarse) cnt[i] = cs[(i + 1) * 512] - cs[i * 512];
+    if (i <= ncoarse) start[i] = cs[i * 512];
 }
 
 }  // namespace
@@ -235,10 +238,10 @@ int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* 
     h->grid.cell_start = h->d_cell_start;
     h->grid.NX = g.NX; h->grid.NY = g.NY; h->grid.NZ = g.NZ;
     const int64_t ncoarse = (int64_t)g.NX * g.NY * g.NZ;
-    HIPCHK(hipMalloc(&h->d_coarse_cnt, sizeof(int32_t) * ncoarse));
-    k_coarse_count<<<dim3((unsigned)((ncoarse + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(h->d_cell_start, ncoarse, h->d_coarse_cnt);
+    HIPCHK(hipMalloc(&h->d_coarse_cnt, sizeof(int32_t) * (ncoarse + 1)));
+    k_coarse_start<<<dim3((unsigned)((ncoarse + 1 + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(h->d_cell_start, ncoarse, h->d_coarse_cnt);
     HIPCHK(hipStreamSynchronize(s));
-    h->grid.coarse_cnt = h->d_coarse_cnt;
+    h->grid.coarse_start = h->d_coarse_cnt;
     h->has_target = true;
     return MVS_OK;
 }
