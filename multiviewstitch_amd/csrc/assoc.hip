@@ -132,6 +132,21 @@ __device__ inline float dmin_node(const GridDev& g, const double* __restrict__ n
                 best = fminf(best, d2f(qx, qy, qz, p.x, p.y, p.z));
             }
         };
+        // four ranges at once: their first 64 points are fetched together (the cells a search meets hold a few dozen
+        // points each; one range after the other, every one of them cost a full memory round trip — 18 for the nine
+        // rows of the first shell), the rest of a longer range follows the plain way
+        auto scan4 = [&](const int (&ra)[4], const int (&rb)[4]) {
+            float d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = ra[q] + lane;
+                d[q] = INFINITY;
+                if (i < rb[q]) { const float4 p = g.spos[i]; d[q] = d2f(qx, qy, qz, p.x, p.y, p.z); }
+            }
+            best = fminf(fminf(best, fminf(d[0], d[1])), fminf(d[2], d[3]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (rb[q] - ra[q] > 64) scan(ra[q] + 64, rb[q]);
+        };
         // (start,end) of the x-run [xlo, xhi] (length <= 8) of row (y,z): at most two tiled pieces
         auto run2 = [&](int y, int z, int xlo, int xhi, int& a0, int& b0, int& a1, int& b1) {
             const int X0 = xlo >> 3, X1 = xhi >> 3;
@@ -167,10 +182,15 @@ __device__ inline float dmin_node(const GridDev& g, const double* __restrict__ n
             }
             unsigned long long mask = __ballot(b0 > a0 || b1 > a1);
             while (mask) {
-                const int l = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                scan(rl_i(a0, l), rl_i(b0, l));
-                scan(rl_i(a1, l), rl_i(b1, l));
+                int ra[4] = {0, 0, 0, 0}, rb[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    if (mask) {
+                        const int l = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        ra[2 * q] = rl_i(a0, l); rb[2 * q] = rl_i(b0, l); ra[2 * q + 1] = rl_i(a1, l); rb[2 * q + 1] = rl_i(b1, l);
+                    }
+                scan4(ra, rb);
             }
             best = wave_min_f(best);
             const float bound = ((float)s + m - 0.01f) * g.h;    // everything within `bound` has been seen
@@ -220,10 +240,16 @@ __device__ inline float dmin_node(const GridDev& g, const double* __restrict__ n
                     for (int j = 0; j < SB; ++j) {
                         unsigned long long cmask = __ballot(b[j] > a[j]);
                         while (cmask) {
-                            const int l = __ffsll((long long)cmask) - 1;
-                            cmask &= cmask - 1;
-                            if (__int_as_float(rl_i(__float_as_int(lb2[j]), l)) > best * ih2) continue;   // a closer point turned up meanwhile
-                            scan(rl_i(a[j], l), rl_i(b[j], l));
+                            int ra[4] = {0, 0, 0, 0}, rb[4] = {0, 0, 0, 0};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (cmask) {
+                                    const int l = __ffsll((long long)cmask) - 1;
+                                    cmask &= cmask - 1;
+                                    if (__int_as_float(rl_i(__float_as_int(lb2[j]), l)) > best * ih2) continue;   // a closer point turned up meanwhile
+                                    ra[q] = rl_i(a[j], l); rb[q] = rl_i(b[j], l);
+                                }
+                            scan4(ra, rb);
                             best = wave_min_f(best);
                         }
                     }
