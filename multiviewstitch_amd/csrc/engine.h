@@ -47,9 +47,13 @@ struct RasDev {                // patches of the restricted additive Schwarz sol
     const int32_t* pnloc;      // NP: local rows of each patch (its slot holds LS >= nloc rows, the rest inert padding)
     const int32_t* pown;       // NP: owned rows (they come first in a patch)
     const int32_t* l2g;        // local row -> vertex
-    const int16_t* lcol;       // per patch entry-major [W][LS]: local column, -1 padding, -2 outside the patch
+    const int16_t* lcol;       // per patch entry-major [W][LS]: slot of the column in the patch's x staging — a local row (< LS) or,
+                               // for a vertex outside the patch, LS + its place in the patch's halo list; -1 padding
     const int32_t* gent;       // same layout: entry id in the ELL-8 adjacency (addresses SellDev::w), -1 padding
-    const int32_t* gcol;       // same layout: vertex of the column, -1 padding
+    const int32_t* gcol;       // same layout: vertex of the column, -1 padding (k_ras_prepare only)
+    int32_t HS;                // halo slots per patch (stride of hl2g)
+    const int32_t* pnh;        // NP: halo vertices of each patch (columns outside the patch, each listed once)
+    const int32_t* hl2g;       // [NP][HS] halo slot -> vertex
 };
 
 #define MVS_NBMAX 256                      /* max workgroups of a row kernel = partial sums per global sum (arap.hip) */

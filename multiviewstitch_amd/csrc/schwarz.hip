@@ -170,32 +170,25 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     // ---- operand loads, issued before the convergence scalars are known (a frozen sweep wastes them, a planned one
     //      overlaps them with the fold of the previous sweep's partials): tables, then this row's x, b, diagonal
     const int g = R.l2g[base + row];                                   // (padding rows: vertex 0, pd = 0 -> inert)
-    int lc[W], gc[W];
+    const int nh = R.pnh[p];
+    const int gh = row < nh ? R.hl2g[p * R.HS + row] : g;              // the halo vertex this thread fetches (columns outside the patch)
+    int lc[W];
     double w2[W];
     {
         const int16_t* lcol = R.lcol + (int64_t)base * W;
-        const int32_t* gcol = R.gcol + (int64_t)base * W;
         const double* pwp = pw + (int64_t)base * W;
 #pragma unroll
         for (int e = 0; e < W; ++e) {                  // entry-major inside the patch: consecutive rows, consecutive addresses
             lc[e] = (int)lcol[e * LS + row];
-            gc[e] = gcol[e * LS + row];
             w2[e] = pwp[e * LS + row];
+            if (lc[e] < 0) { lc[e] = row; w2[e] = 0.0; }              // padding entries
         }
     }
     const d3 xi = ld3(xin + 3 * (int64_t)g);
+    const d3 xh = ld3(xin + 3 * (int64_t)gh);                          // frozen at the previous sweep's value for this sweep
     const double dd = pd[base + row];
     const bool fixed = dd == 0.0;
-    d3 rhs = ld3(bvec + 3 * (int64_t)g);                               // (b is 0 on control rows; padding rows are fixed)
-    // columns outside the patch: frozen at the previous sweep's value, moved to the right-hand side (branch-free gathers)
-#pragma unroll
-    for (int e = 0; e < W; ++e) {
-        const bool outside = lc[e] == -2 && w2[e] != 0.0;
-        const d3 xo = ld3(xin + 3 * (int64_t)(outside ? gc[e] : g));
-        const double wo = outside ? w2[e] : 0.0;
-        rhs = mk3(__builtin_fma(wo, xo.x, rhs.x), __builtin_fma(wo, xo.y, rhs.y), __builtin_fma(wo, xo.z, rhs.z));
-        if (lc[e] < 0) { lc[e] = row; w2[e] = 0.0; }
-    }
+    const d3 rhs = ld3(bvec + 3 * (int64_t)g);                         // (b is 0 on control rows; padding rows are fixed)
     // ---- preamble: waves 0..2 fold the residual partials of the previous sweep, waves 3..5 the bnorm partials of the rhs kernel
     if (wv < 3) {
         const double gam = sweep > 0 ? fold_n(slot_prev + wv * NPpad, R.NP * 4) : INFINITY;
@@ -207,6 +200,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         s_done = arap_done_before(ered + EFIN, it, arap_tol) ? 1 : 0;
     }
     xs[row][0] = xi.x; xs[row][1] = xi.y; xs[row][2] = xi.z;
+    if (row < nh) { xs[LS + row][0] = xh.x; xs[LS + row][1] = xh.y; xs[LS + row][2] = xh.z; }
     __syncthreads();
     RSTAMP(1);
     const double bn[3] = {s_bn[0], s_bn[1], s_bn[2]};
@@ -250,6 +244,10 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     d3 e = mk3(0, 0, 0);
     d3 dv = cc.c0 * (inv_d * r);
     __syncthreads();                                                   // xs has been read by everyone: the buffer turns into dbuf
+    if (row < nh) {                                                    // halo columns do not move during a sweep: zero direction, both buffers
+        dbuf[LS + row] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dbuf[RTPB + LS + row] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     for (int k = 0; k < cheb_m; ++k) {
         float4* buf = dbuf + (k & 1) * RTPB;
         buf[row] = make_float4((float)dv.x, (float)dv.y, (float)dv.z, 0.0f);
@@ -291,7 +289,7 @@ extern "C" int mvs_debug_ras_stamps(unsigned long long* out, int n) {
 
 void ras_free(mvs_deform_s* h) {
     auto fr = [](const void* p) { if (p) (void)hipFree(const_cast<void*>(p)); };
-    fr(h->ras.pnloc); fr(h->ras.pown); fr(h->ras.l2g); fr(h->ras.lcol); fr(h->ras.gent); fr(h->ras.gcol);
+    fr(h->ras.pnloc); fr(h->ras.pown); fr(h->ras.l2g); fr(h->ras.lcol); fr(h->ras.gent); fr(h->ras.gcol); fr(h->ras.pnh); fr(h->ras.hl2g);
     fr(h->d_ras_x2); fr(h->d_ras_b); fr(h->d_ras_pw); fr(h->d_ras_pd); fr(h->d_ras_slots); fr(h->d_ras_iters);
     h->ras = RasDev{}; h->d_ras_x2 = h->d_ras_b = h->d_ras_slots = h->d_ras_pw = h->d_ras_pd = nullptr; h->d_ras_iters = nullptr;
     h->has_ras = false; h->ras_slots_cap = 0;
@@ -380,30 +378,47 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
     const int LS = std::max(448, (max_nloc + 63) / 64 * 64);          // the preamble of the sweep kernel uses seven waves
     std::vector<int32_t> l2g((size_t)NP * LS, 0), gent((size_t)NP * LS * W, -1), gcolv((size_t)NP * LS * W, -1);
     std::vector<int16_t> lcol((size_t)NP * LS * W, (int16_t)-1);
+    // columns outside a patch (the ring beyond its last overlap ring) get a slot of their own behind the local rows: the
+    // sweep loads each such vertex ONCE into the x staging instead of gathering it per matrix entry, and needs no
+    // vertex-of-the-column table at all
+    std::vector<std::vector<int32_t>> phalo(NP);
+    std::vector<int32_t> pnh(NP, 0);
+    int max_nh = 0;
     for (int p = 0; p < NP; ++p) {
         const std::vector<int32_t>& rows = prows[p];
         const int nloc = pnloc[p];
         for (int q = 0; q < nloc; ++q) { lidx[rows[q]] = q; l2g[(size_t)p * LS + q] = rows[q]; }
+        std::vector<int32_t>& halo = phalo[p];
         const size_t e0 = (size_t)p * LS * W;
         for (int q = 0; q < nloc; ++q) {
             const int i = rows[q], deg = rowptr[i + 1] - rowptr[i];
             for (int k = 0; k < deg; ++k) {
                 const int j = col[rowptr[i] + k];
                 const int gidx = slice_off[i / 8] + (8 * (k / 8) + (i % 8)) * 8 + (k % 8);     // entry (row i, k-th neighbour) of the ELL-8 layout
-                lcol[e0 + (size_t)k * LS + q] = (int16_t)((lidx[j] >= 0 && lidx[j] < nloc && rows[lidx[j]] == j) ? lidx[j] : -2);
+                if (lidx[j] < 0) { lidx[j] = LS + (int)halo.size(); halo.push_back(j); }       // first sight of an outside vertex
+                lcol[e0 + (size_t)k * LS + q] = (int16_t)lidx[j];
                 gent[e0 + (size_t)k * LS + q] = gidx;
                 gcolv[e0 + (size_t)k * LS + q] = j;
             }
         }
         for (int v : rows) lidx[v] = -1;
+        for (int v : halo) lidx[v] = -1;
+        pnh[p] = (int)halo.size();
+        max_nh = std::max(max_nh, pnh[p]);
     }
+    if (LS + max_nh > RTPB || max_nh > LS) return MVS_OK;            // x staging holds RTPB slots; a thread loads at most one halo vertex
+    const int HS = std::max(64, (max_nh + 63) / 64 * 64);
+    std::vector<int32_t> hl2g((size_t)NP * HS, 0);
+    for (int p = 0; p < NP; ++p) std::copy(phalo[p].begin(), phalo[p].end(), hl2g.begin() + (size_t)p * HS);
     RasDev R{};
     R.NP = NP; R.NPpad = (4 * NP + 63) / 64 * 64; R.W = W;
     int rc;
-    int32_t *d_pnloc, *d_pown, *d_l2g, *d_gent, *d_gcol;
+    int32_t *d_pnloc, *d_pown, *d_l2g, *d_gent, *d_gcol, *d_pnh, *d_hl2g;
     int16_t* d_lcol;
-    if ((rc = up(&d_pnloc, pnloc)) || (rc = up(&d_pown, pown)) || (rc = up(&d_l2g, l2g)) || (rc = up(&d_lcol, lcol)) || (rc = up(&d_gent, gent)) || (rc = up(&d_gcol, gcolv))) return rc;
+    if ((rc = up(&d_pnloc, pnloc)) || (rc = up(&d_pown, pown)) || (rc = up(&d_l2g, l2g)) || (rc = up(&d_lcol, lcol)) || (rc = up(&d_gent, gent)) || (rc = up(&d_gcol, gcolv)) ||
+        (rc = up(&d_pnh, pnh)) || (rc = up(&d_hl2g, hl2g))) return rc;
     R.pnloc = d_pnloc; R.pown = d_pown; R.LS = LS; R.l2g = d_l2g; R.lcol = d_lcol; R.gent = d_gent; R.gcol = d_gcol;
+    R.HS = HS; R.pnh = d_pnh; R.hl2g = d_hl2g;
     h->ras = R;
     if (hipMalloc((void**)&h->d_ras_x2, sizeof(double) * 3 * (size_t)V) != hipSuccess || hipMalloc((void**)&h->d_ras_b, sizeof(double) * 3 * (size_t)V) != hipSuccess) {
         mvs_set_error("hipMalloc failed (patch solver vectors)"); return MVS_E_OOM;
