@@ -158,10 +158,11 @@ def main():
     if info["kind"] == "patch":
         # k_ras_sweep (schwarz.hip): one launch = one overlapping-patch sweep over all V rows, 3 rhs fused.
         # Algorithmic bytes per launch: the patch tables are distinct data per patch-local row
-        # (lcol 2 + gcol 4 + weight 8 per stored entry, l2g 4, diagonal 8), every vertex's x and b are needed once
-        # (24 + 24; re-reads by the overlap rows are not counted) and every vertex's x is written once (24).
+        # (local column slot 2 + weight 8 per stored entry, l2g 4, diagonal 8), every vertex's x and b are needed once
+        # (24 + 24; re-reads by the overlap rows and by the halo slots are not counted) and every vertex's x is written
+        # once (24).  (Until the halo-slot layout the sweep also read a 4-byte vertex id per entry: 14 W + 12 per row.)
         kernel = "k_ras_sweep"
-        solve_bytes = (14 * info["width"] + 12) * info["local_rows"] + 72 * V
+        solve_bytes = (10 * info["width"] + 12) * info["local_rows"] + 72 * V
     else:
         # k_cg_iter (arap.hip): one launch = one CG iteration over all V rows: every CG vector r,w,s,p,x read once and
         # written once (fp64 AoS, 24 B) + diag 8 B + ctrl id 4 B per vertex row, + 12 B (col 4, w 8) per stored entry
