@@ -30,6 +30,7 @@ namespace {
 
 #ifdef MVS_STAMPS
 __device__ unsigned long long g_assoc_cycles[2 * 16384];      // per node: cycles of k_assoc_dmin, k_assoc_select
+__device__ unsigned long long g_dmin_shell[16384 * 8];          // per node: cycles at the end of coarse shells 0..5, cycles at the start of the coarse walk
 #define ASTAMP_BEGIN unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory")
 #define ASTAMP_END(slot) do { unsigned long long t1_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory"); \
         if ((threadIdx.x & 63) == 0 && node < 16384) g_assoc_cycles[2 * node + (slot)] = t1_ - t0_; } while (0)
@@ -198,6 +199,10 @@ __device__ inline float dmin_node(const GridDev& g, const double* __restrict__ n
         }
         // ---- stage B: coarse occupancy grid, expanding shells with pruning; a coarse cell is ONE range
         if (!found) {
+#ifdef MVS_STAMPS
+            { unsigned long long t1_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory");
+              if (lane == 0 && node < 16384) g_dmin_shell[8 * node + 6] = t1_ - t0_; }
+#endif
             const int CX = c.cx >> 3, CY = c.cy >> 3, CZ = c.cz >> 3;
             const float ih2 = g.inv_h * g.inv_h;
             float Mc = fminf(fminf(fminf(c.fx - 8.f * CX, 8.f * CX + 8.f - c.fx), fminf(c.fy - 8.f * CY, 8.f * CY + 8.f - c.fy)),
@@ -254,6 +259,10 @@ __device__ inline float dmin_node(const GridDev& g, const double* __restrict__ n
                         }
                     }
                 }
+#ifdef MVS_STAMPS
+                if (S < 6) { unsigned long long t1_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory");
+                             if (lane == 0 && node < 16384) g_dmin_shell[8 * node + S] = t1_ - t0_; }
+#endif
                 const float bound = (((float)S) * 8.f + Mc - 0.08f) * g.h;
                 if (bound > 0.0f && (best <= bound * bound || bound * bound > limit2)) break;
             }
@@ -444,8 +453,18 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
                 }
                 if (PARTS > 1) {
                     __syncthreads();
+#ifdef MVS_STAMPS
+                    unsigned long long tA_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tA_) :: "memory");
+#endif
                     const int nr = min(lds->nr, HEAVY_RANGES);
                     for (int r = part; r < nr; r += PARTS) scan(lds->ra[r], lds->rb[r]);
+#ifdef MVS_STAMPS   // (scripts/heavy_stats.py: list built / this wave done scanning / all waves done, in 16-cycle units, + ranges)
+                    unsigned long long tB_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tB_) :: "memory");
+                    __syncthreads();
+                    unsigned long long tC_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tC_) :: "memory");
+                    if (threadIdx.x == 0 && node < 16384)
+                        g_assoc_cycles[2 * node] = (((tA_ - t0_) >> 4) & 0xffff) | ((((tB_ - t0_) >> 4) & 0xffff) << 16) | ((((tC_ - t0_) >> 4) & 0xffff) << 32) | ((unsigned long long)nr << 48);
+#endif
                 }
             }
         }
@@ -699,6 +718,9 @@ __global__ __launch_bounds__(256) void k_assoc_merge(const double* __restrict__ 
 }  // namespace
 
 #ifdef MVS_STAMPS
+extern "C" int mvs_debug_dmin_shells(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dmin_shell), sizeof(unsigned long long) * n);
+}
 extern "C" int mvs_debug_assoc_cycles(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_assoc_cycles), sizeof(unsigned long long) * n);
 }

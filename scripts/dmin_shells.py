@@ -1,5 +1,5 @@
 """Diagnostic (assoc.o built with -DMVS_STAMPS): where a far node's nearest-distance search spends its cycles — cumulative
-cycles at the end of each coarse shell, coarse-cell ranges scanned, points scanned."""
+cycles at the end of each coarse shell and at the start of the coarse walk."""
 import ctypes as C
 import sys
 
@@ -25,4 +25,4 @@ sh = np.zeros(8 * 16384, np.uint64)
 assert lib.mvs_debug_dmin_shells(sh.ctypes.data_as(C.c_void_p), len(sh)) == 0
 sh = sh.reshape(-1, 8)[:K].astype(np.int64)
 for i in np.argsort(-tot)[:12]:
-    print(f"node {i}: dmin total {tot[i]} cycles; end of shells 0..5 at {sh[i, :6].tolist()}; ranges scanned {sh[i, 6]}, points scanned {sh[i, 7]}")
+    print(f"node {i}: dmin total {tot[i]} cycles; end of shells 0..5 at {sh[i, :6].tolist()}; coarse walk entered at {sh[i, 6]}")
