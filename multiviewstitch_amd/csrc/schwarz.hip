@@ -171,7 +171,9 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     //      overlaps them with the fold of the previous sweep's partials): tables, then this row's x, b, diagonal
     const int g = R.l2g[base + row];                                   // (padding rows: vertex 0, pd = 0 -> inert)
     const int nh = R.pnh[p];
-    const int gh = row < nh ? R.hl2g[p * R.HS + row] : g;              // the halo vertex this thread fetches (columns outside the patch)
+    const int gh = R.hl2g[base + row];                                 // the halo vertex this thread fetches (columns outside the patch);
+                                                                       // the list has LS slots (padding: vertex 0) so that this load,
+                                                                       // like l2g, waits for nothing but the patch number
     int lc[W];
     double w2[W];
     {
@@ -407,7 +409,7 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
         max_nh = std::max(max_nh, pnh[p]);
     }
     if (LS + max_nh > RTPB || max_nh > LS) return MVS_OK;            // x staging holds RTPB slots; a thread loads at most one halo vertex
-    const int HS = std::max(64, (max_nh + 63) / 64 * 64);
+    const int HS = LS;                                                // as many slots as threads: the load needs no bound check (max_nh <= LS)
     std::vector<int32_t> hl2g((size_t)NP * HS, 0);
     for (int p = 0; p < NP; ++p) std::copy(phalo[p].begin(), phalo[p].end(), hl2g.begin() + (size_t)p * HS);
     RasDev R{};
