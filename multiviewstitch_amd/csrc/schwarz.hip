@@ -243,8 +243,17 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     // M-matrix; the lower end is a parameter — measured 0.12..0.16 on the bench mesh — and an estimate above the true
     // value only slows the smooth modes down, it cannot diverge).  No inner products: one workgroup barrier per step;
     // the step coefficients come precomputed from the host.
-    d3 e = mk3(0, 0, 0);
-    d3 dv = cc.c0 * (inv_d * r);
+    // The steps run in float32: they only shape the correction e of an INEXACT local solve (the residual that decides
+    // convergence is formed in fp64 from x at the start of every sweep, the fixed point is untouched), and in fp64 a step
+    // was bound by 24 float->double conversions + 33 fp64 FMAs per thread (1460 cycles per step on a CU, half of a sweep).
+    float ex = 0.f, ey = 0.f, ez = 0.f;
+    const float di_f = (float)di, inv_d_f = (float)inv_d;
+    float rx = (float)r.x, ry = (float)r.y, rz = (float)r.z;
+    const float c0f = (float)cc.c0 * inv_d_f;
+    float dx = c0f * rx, dy = c0f * ry, dz = c0f * rz;
+    float w2f[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) w2f[q] = (float)w2[q];
     __syncthreads();                                                   // xs has been read by everyone: the buffer turns into dbuf
     if (row < nh) {                                                    // halo columns do not move during a sweep: zero direction, both buffers
         dbuf[LS + row] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -252,22 +261,23 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     }
     for (int k = 0; k < cheb_m; ++k) {
         float4* buf = dbuf + (k & 1) * RTPB;
-        buf[row] = make_float4((float)dv.x, (float)dv.y, (float)dv.z, 0.0f);
+        buf[row] = make_float4(dx, dy, dz, 0.0f);
         __syncthreads();
         if (wv < nw) {
-            d3 adv = mk3(di * dv.x, di * dv.y, di * dv.z);
+            float ax = di_f * dx, ay = di_f * dy, az = di_f * dz;
 #pragma unroll
             for (int q = 0; q < W; ++q) {
                 const float4 t = buf[lc[q]];
-                adv = mk3(__builtin_fma(-w2[q], (double)t.x, adv.x), __builtin_fma(-w2[q], (double)t.y, adv.y), __builtin_fma(-w2[q], (double)t.z, adv.z));
+                ax = __builtin_fmaf(-w2f[q], t.x, ax); ay = __builtin_fmaf(-w2f[q], t.y, ay); az = __builtin_fmaf(-w2f[q], t.z, az);
             }
-            if (fixed) adv = mk3(0, 0, 0);
-            e = e + dv;
-            r = r - adv;
-            const double c1 = cc.c1[k & 31], c2 = cc.c2[k & 31] * inv_d;
-            dv = mk3(__builtin_fma(c1, dv.x, c2 * r.x), __builtin_fma(c1, dv.y, c2 * r.y), __builtin_fma(c1, dv.z, c2 * r.z));
+            if (fixed) { ax = 0.f; ay = 0.f; az = 0.f; }
+            ex += dx; ey += dy; ez += dz;
+            rx -= ax; ry -= ay; rz -= az;
+            const float c1 = (float)cc.c1[k & 31], c2 = (float)cc.c2[k & 31] * inv_d_f;
+            dx = __builtin_fmaf(c1, dx, c2 * rx); dy = __builtin_fmaf(c1, dy, c2 * ry); dz = __builtin_fmaf(c1, dz, c2 * rz);
         }
     }
+    const d3 e = mk3((double)ex, (double)ey, (double)ez);
     RSTAMP(4);
     if (row < nown) st3(xout + 3 * (int64_t)g, xi + e);
     if (row == 0) iters_cur[p] = cheb_m;
