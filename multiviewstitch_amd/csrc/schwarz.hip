@@ -160,7 +160,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * RTPB * sizeof(float4)];
     __shared__ double s_gam[3], s_bn[3];
     __shared__ int s_done;
-    double (*xs)[3] = reinterpret_cast<double (*)[3]>(smem);
+    double4* xs = reinterpret_cast<double4*>(smem);                    // 32-byte records: two 16-byte LDS accesses per gather instead of three 8-byte ones
     const int p = blockIdx.x, row = threadIdx.x, lane = row & 63, wv = row >> 6;
     const int LS = R.LS, base = p * LS;                                 // fixed table stride: the loads below need only p
     const int nloc = R.pnloc[p], nown = R.pown[p];
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     } else if (row == 6 * 64) {
         s_done = arap_done_before(ered + EFIN, it, arap_tol) ? 1 : 0;
     }
-    xs[row][0] = xi.x; xs[row][1] = xi.y; xs[row][2] = xi.z;
-    if (row < nh) { xs[LS + row][0] = xh.x; xs[LS + row][1] = xh.y; xs[LS + row][2] = xh.z; }
+    xs[row] = make_double4(xi.x, xi.y, xi.z, 0.0);
+    if (row < nh) xs[LS + row] = make_double4(xh.x, xh.y, xh.z, 0.0);
     __syncthreads();
     RSTAMP(1);
     const double bn[3] = {s_bn[0], s_bn[1], s_bn[2]};
@@ -224,7 +224,10 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         d3 acc = mk3(0, 0, 0);
 #pragma unroll
         for (int e = 0; e < W; ++e)
-            acc = mk3(__builtin_fma(w2[e], xs[lc[e]][0], acc.x), __builtin_fma(w2[e], xs[lc[e]][1], acc.y), __builtin_fma(w2[e], xs[lc[e]][2], acc.z));
+        {
+            const double4 t = xs[lc[e]];
+            acc = mk3(__builtin_fma(w2[e], t.x, acc.x), __builtin_fma(w2[e], t.y, acc.y), __builtin_fma(w2[e], t.z, acc.z));
+        }
         if (!fixed) r = rhs - (mk3(di * xi.x, di * xi.y, di * xi.z) - acc);
     }
     RSTAMP(2);
