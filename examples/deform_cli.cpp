@@ -22,7 +22,8 @@ int main(int argc, char** argv) {
     mvs_deform_default_params(&prm);
     mvs_deform_stats st;
     const int rc = mvs_processor_deform(argv[1], argv[2], argv[3], R, std::atof(argv[5]), &prm, argv[4], &st);
-    if (rc != MVS_OK) { std::fprintf(stderr, "mvs_processor_deform failed (%d): %s\n", rc, mvs_last_error()); return 1; }
+    if (rc < 0) { std::fprintf(stderr, "mvs_processor_deform failed (%d): %s\n", rc, mvs_last_error()); return 1; }
+    if (rc > 0) std::fprintf(stderr, "warning (%d): %s\n", rc, mvs_last_error());
     std::printf("deformed: %d ARAP iterations, %d valid nodes, energy %.6g, solver residual %.2e -> %s\n", st.arap_iters_run, st.n_valid,
                 st.energy[st.arap_iters_run > 0 ? st.arap_iters_run - 1 : 0], st.cg_rel_residual, argv[4]);
     return 0;

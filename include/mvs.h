@@ -27,6 +27,14 @@
  *     call and writes outputs into caller buffers.
  * Pointers named *_dev are DEVICE (HBM) pointers, everything else is host.
  *
+ * Stream ordering of *_dev arguments: entries that take a `hip_stream` enqueue on it (NULL = the
+ * legacy default stream) and read their inputs in stream order — produce the inputs on that stream
+ * or complete them first.  The mvs_deform_* handle owns a NON-BLOCKING stream that is ordered after
+ * nothing else: mvs_deform_set_target_dev waits for the whole device (hipDeviceSynchronize) before
+ * it reads the target, so buffers written by any stream of the caller are complete; the per-step
+ * entries (mvs_deform_assoc_*, _solve) read caller buffers in the order of the handle's stream —
+ * put the handle on the stream that produces them (mvs_deform_set_stream) or synchronise first.
+ *
  * The library needs a gfx950 GPU; with none present every compute entry
  * returns MVS_E_NO_DEVICE.  There is no CPU fallback.
  */
@@ -39,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MVS_ABI_VERSION 1
+#define MVS_ABI_VERSION 2
 
 enum mvs_status {
     MVS_OK            =  0,
@@ -52,7 +60,11 @@ enum mvs_status {
     MVS_E_SOLVER      = -7,  /* global solve failed (Deformation.cpp:393-397)   */
     MVS_E_STATE       = -8,  /* call order violated (e.g. no target set)        */
     MVS_E_DEGENERATE  = -9,  /* fewer than 3 matches etc.                       */
-    MVS_E_IO          = -10  /* file cannot be opened / parsed (mvs_io.h)        */
+    MVS_E_IO          = -10, /* file cannot be opened / parsed (mvs_io.h)        */
+    /* positive = the call did its work, with a caveat the caller should look at:   */
+    MVS_W_UNCONVERGED =  1   /* at least one global ARAP solve covered by the returned statistics ended above
+                                cg_tol (mvs_deform_stats.unconverged_solves / worst_rel_residual_in_batch say how
+                                many and by how much); the geometry is that of the inexact solves               */
 };
 
 const char* mvs_last_error(void);     /* thread-local message of the last failure */
@@ -278,7 +290,11 @@ typedef struct mvs_deform_params {
     int32_t solver;          /* MVS_SOLVER_AUTO: overlapping-patch sweeps with LDS-resident local
                                 solves when the mesh fits (>= 2048 vertices, degree <= 16), else
                                 CG; MVS_SOLVER_CG: always the one-kernel-per-iteration CG.  Both
-                                stop at cg_tol                                               */
+                                run a launch plan sized from the handle's previous solves (the host
+                                follows every solve's measured residual while it enqueues and adds
+                                sweeps as soon as a margin gets thin); EVERY solve's result is
+                                checked on the device against cg_tol (true residual b - A x, taken
+                                by the local step) and a miss is reported: MVS_W_UNCONVERGED      */
     int32_t reserved0;
 } mvs_deform_params;
 enum { MVS_SOLVER_AUTO = 0, MVS_SOLVER_CG = 1 };
@@ -291,9 +307,18 @@ typedef struct mvs_deform_stats {
     int32_t cg_iters;         /* largest per-solve CG launch count      */
     int32_t n_valid;          /* nodes with isValid (Deformation.cpp:355) */
     double  energy[8];        /* ARAP energy after each iteration      */
-    double  cg_rel_residual;  /* worst over the solves of the last outer iteration */
+    double  cg_rel_residual;  /* worst TRUE relative residual (|b - A x| / |b|, M^-1 norm) over the solves of the
+                                 last outer iteration                                         */
     int32_t cg_launches;      /* CG-iteration kernels launched in the last outer iteration   */
     int32_t cg_active;        /* ... of which did work (the rest exited early: converged)    */
+    /* every solve since the handle's statistics were last read (the whole batch of an mvs_deform_iterate call, or
+     * everything enqueued with stats == NULL before this mvs_deform_collect): */
+    double  worst_rel_residual_in_batch;
+    int32_t solves_in_batch;
+    int32_t unconverged_solves;   /* of those, how many ended above cg_tol (0 <=> return value MVS_OK)           */
+    int32_t escalated;            /* 1: after a miss the device switched the remaining solves of the batch to the
+                                     strong local-solve coefficients (patch solver)                               */
+    int32_t reserved1;
 } mvs_deform_stats;
 
 /* Deformation(points,normals,facets)  R/Deformation/Deformation.cpp:29-46.
@@ -326,7 +351,10 @@ int mvs_deform_set_target_dev(mvs_deform_t h, int64_t P, const double* pts_dev,
 int mvs_deform_iterate(mvs_deform_t h, const mvs_deform_params* p, int n_outer,
                        mvs_deform_stats* stats);
 /* (n_outer passes are enqueued in batches of at most 32 between host synchronisations: each batch ends with a read-back
- * of the solver statistics from which the launch plan of the next one is made.) */
+ * of the solver statistics from which the launch plan of the next one is made.  Inside a batch the host stays at most
+ * 3 passes ahead of the device and reads, without synchronising, the residual every finished solve reported into a
+ * pinned ring: a solve whose margin got thin gets one more sweep from the next pass it enqueues.  Returns
+ * MVS_W_UNCONVERGED (> 0) when any solve of the call ended above cg_tol.) */
 /* stats == NULL after the handle's first (calibrating) call: mvs_deform_iterate only ENQUEUES the passes on the
  * handle's stream and returns — independent handles (e.g. one per body part, each on its own stream) then overlap
  * on the device.  mvs_deform_collect waits for the handle's stream and reads the statistics of the last pass back

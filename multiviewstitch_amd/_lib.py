@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "libmvs_hip.so")
 MVS_OK = 0
 STATUS = {0: "MVS_OK", -1: "MVS_E_INVALID_ARG", -2: "MVS_E_BAD_MESH", -3: "MVS_E_NONMANIFOLD",
           -4: "MVS_E_NO_DEVICE", -5: "MVS_E_HIP", -6: "MVS_E_OOM", -7: "MVS_E_SOLVER", -8: "MVS_E_STATE",
-          -9: "MVS_E_DEGENERATE", -10: "MVS_E_IO"}
+          -9: "MVS_E_DEGENERATE", -10: "MVS_E_IO", 1: "MVS_W_UNCONVERGED"}
+MVS_W_UNCONVERGED = 1
 
 
 class MvsError(RuntimeError):
@@ -61,7 +62,9 @@ class CStats(C.Structure):
     """struct mvs_deform_stats."""
     _fields_ = [("outer_done", C.c_int32), ("arap_iters_run", C.c_int32), ("cg_iters", C.c_int32),
                 ("n_valid", C.c_int32), ("energy", C.c_double * 8), ("cg_rel_residual", C.c_double),
-                ("cg_launches", C.c_int32), ("cg_active", C.c_int32)]
+                ("cg_launches", C.c_int32), ("cg_active", C.c_int32),
+                ("worst_rel_residual_in_batch", C.c_double), ("solves_in_batch", C.c_int32),
+                ("unconverged_solves", C.c_int32), ("escalated", C.c_int32), ("reserved1", C.c_int32)]
 
 
 CAND_DTYPE = np.dtype([("proj_dist", "<f8"), ("proj_len", "<f8"), ("pos", "<f8", (3,)), ("index", "<i8")])
@@ -170,8 +173,10 @@ def lib():
 
 
 def check(rc):
-    if rc != MVS_OK:
+    """Negative statuses raise; positive ones (MVS_W_*: the call did its work, with a caveat) are returned."""
+    if rc < 0:
         raise MvsError(rc, lib().mvs_last_error().decode(errors="replace"))
+    return rc
 
 
 def device_count():

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <tuple>
+#include <sched.h>
 
 // ------------------------------------------------------------------ errors ----
 static thread_local char g_err[512] = "";
@@ -154,7 +155,10 @@ RasPlan probe_ras(const mvs_deform_s* h) {
 bool use_ras(const mvs_deform_s* h, const mvs_deform_params& p) { return h->has_ras && p.solver != MVS_SOLVER_CG; }
 
 int ensure_ras_slots(mvs_deform_s* h, int arap_iters, const RasPlan& rp) {
-    const int64_t need = rp.total(arap_iters);
+    // sized once for the largest plan: the host may add sweeps to a solve between two passes of a batch (peek_ring), and a
+    // re-allocation would pull the buffer from under the passes still in flight
+    (void)rp;
+    const int64_t need = (int64_t)RAS_MAX_SWEEPS * arap_iters;
     if (need > h->ras_slots_cap) {
         dfree(h->d_ras_slots); dfree(h->d_ras_iters);
         int rc = dmalloc(&h->d_ras_slots, (size_t)need * ras_slot_size(h));
@@ -166,9 +170,10 @@ int ensure_ras_slots(mvs_deform_s* h, int arap_iters, const RasPlan& rp) {
 }
 
 int ensure_slots(mvs_deform_s* h, int arap_iters, const CgPlan& cg) {
-    const int64_t need = cg.total_slots(arap_iters) * MVS_CG_SLOT;
+    int64_t need = cg.total_slots(arap_iters) * MVS_CG_SLOT;
     if (need > h->slots_cap) {
-        dfree(h->d_slots);
+        need += need / 2;                                     // headroom: the host may lengthen a plan inside a batch (peek_ring)
+        dfree(h->d_slots);                                    // (hipFree waits for the device: passes in flight are safe)
         int rc = dmalloc(&h->d_slots, (size_t)need);
         if (rc) return rc;
         h->slots_cap = need;
@@ -205,6 +210,8 @@ static int ensure_nbr(mvs_deform_s* h, int nn) {
 int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctrl_src, bool graph_smooth, const CgPlan& plan) {
     hipStream_t s = h->stream;
     const int K = (int)h->K, V = (int)h->V;
+    const int slot = (int)(h->seq_enqueued % MVS_RING);          // this pass's row of the residual ring (MVS_CTL_RING)
+    double* host_ctl = const_cast<double*>(h->h_ctl);
     const double* ctrl = ctrl_src;
     bool weights_done = false;
     RasSmooth last_sweep{nullptr, nullptr, 0, nullptr};
@@ -275,7 +282,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     for (int it = 0; ras && it < p.arap_iters; ++it) {
         {
             Tic t = tic(h, "rhs");
-            launch_arap_rhs(h->sell, h->d_pts, x_cur, h->d_rot, it, p.arap_tol, h->d_energy, nullptr, nullptr, h->d_ras_b, s);
+            launch_arap_rhs(h->sell, h->d_pts, x_cur, h->d_rot, it, p.arap_tol, h->d_energy, nullptr, nullptr, h->d_ras_b, p.cg_tol, h->d_ctl, slot, s);
             toc(t, 1);
         }
         {
@@ -316,14 +323,14 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
             }
             toc(t, launched);
         }
-        { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, x_cur, it, p.arap_tol, h->d_energy, h->d_rot, s); toc(t, 1); }
+        { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, x_cur, it, p.arap_tol, h->d_energy, h->d_rot, h->d_ras_b, s); toc(t, 1); }
     }
     for (int it = 0; !ras && it < p.arap_iters; ++it) {                                           // deform(5, 1e-4), :398
         double* slots = h->d_slots + plan.offset(it);
         const int cg = plan.n[it];
         {
             Tic t = tic(h, "rhs");
-            launch_arap_rhs(h->sell, h->d_pts, h->d_sol, h->d_rot, it, p.arap_tol, h->d_energy, h->d_rws[0], h->d_p, nullptr, s);
+            launch_arap_rhs(h->sell, h->d_pts, h->d_sol, h->d_rot, it, p.arap_tol, h->d_energy, h->d_rws[0], h->d_p, h->d_ras_b, p.cg_tol, h->d_ctl, slot, s);
             launch_cg_w0(h->sell, h->d_coef, it, p.arap_tol, h->d_energy, h->d_rws[0], slots, s);
             toc(t, 2);
         }
@@ -336,22 +343,104 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
             }
             toc(t, cg);
         }
-        { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, h->d_sol, it, p.arap_tol, h->d_energy, h->d_rot, s); toc(t, 1); }
+        { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, h->d_sol, it, p.arap_tol, h->d_energy, h->d_rot, h->d_ras_b, s); toc(t, 1); }
     }
     Tic t = tic(h, "finalize");
     int n = 1;
     if (p.update_normals) {              // the node normals change too: separate gather after the normals kernel
-        launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, nullptr, nullptr, nullptr, s);   // :400
+        launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, nullptr, nullptr, nullptr, p.cg_tol, h->d_ctl, slot, host_ctl, s);   // :400
         launch_vertex_normals(h->d_pts, h->d_faces, h->d_vf_ptr, h->d_vf, V, h->d_nrm, s);
         launch_gather_nodes(h->d_pts, h->d_nrm, h->d_nodes, K, h->d_node_pts, h->d_node_nrm, s);
         n = 3;
     } else {
-        launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, h->d_nrm, h->d_node_pts, h->d_node_nrm, s);
+        launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, h->d_nrm, h->d_node_pts, h->d_node_nrm, p.cg_tol, h->d_ctl, slot, host_ctl, s);
     }
     toc(t, n);
     (void)V;
     h->graph_ready_nn = 0; h->weights_ready = false;     // the nodes have moved
+    h->seq_enqueued++;
     return MVS_OK;
+}
+
+// ---- the closed loop around the launch plans (MVS_CTL_*, engine.h) ------------------------------------------------
+// Every solve's result is judged on the device (true residual, k_arap_local -> judge_solve); the verdicts reach the host
+// two ways: (a) the pinned mirror h_ctl, refreshed by the last kernel of every pass — read WITHOUT synchronising while a
+// batch is being enqueued (throttle + peek_ring); (b) at a harvest, after the stream has been drained.
+constexpr int THROTTLE_LAG = 3;          // passes the host may be ahead of the device inside a batch
+constexpr double THIN = 1.0 / 8.0;       // a solve that ends above THIN * cg_tol has used up its margin
+
+// wait (spinning on the mirror, no HIP synchronisation) until the device is at most THROTTLE_LAG passes behind
+int throttle(mvs_deform_s* h) {
+    if (!h->h_ctl) return MVS_OK;
+    for (unsigned spins = 0;; ++spins) {
+        const uint64_t done = (uint64_t)h->h_ctl[MVS_CTL_SEQ];
+        if (h->seq_enqueued <= done + THROTTLE_LAG) return MVS_OK;
+        if ((spins & 0x3ff) == 0x3ff) {
+            // a faulted kernel would leave the counter behind forever: ask the runtime now and then
+            const hipError_t e = hipStreamQuery(h->stream);
+            if (e == hipSuccess) return MVS_OK;                     // idle stream: nothing left to wait for
+            if (e != hipErrorNotReady) return mvs_check_hip(e, "stream (throttle)");
+            sched_yield();
+        }
+    }
+}
+
+// rows of the passes finalized since the last look: a solve that ended above THIN * cg_tol gets one more sweep (a
+// longer CG plan) in the passes enqueued from now on.  One correction per plan generation: reports of passes that were
+// enqueued before the previous correction of the same solve say nothing new.
+void peek_ring(mvs_deform_s* h, const mvs_deform_params& p, bool ras) {
+    if (!h->h_ctl) return;
+    const uint64_t done = (uint64_t)h->h_ctl[MVS_CTL_SEQ];
+    uint64_t q = h->seq_peeked;
+    if (done > MVS_RING && q < done - MVS_RING) q = done - MVS_RING;
+    const double thin2 = THIN * THIN * p.cg_tol * p.cg_tol;
+    for (; q < done; ++q) {
+        const volatile double* row = h->h_ctl + MVS_CTL_RING + (q % MVS_RING) * 8;
+        for (int it = 0; it < p.arap_iters; ++it) {
+            const double rel2 = row[it];
+            if (!(rel2 > thin2) || q < h->bump_seq[it]) continue;
+            if (ras) {
+                if (h->ras_plan[it] > 0) h->ras_plan[it] = std::min(RAS_MAX_SWEEPS, h->ras_plan[it] + 1);
+                h->ras_bump[it] = 2;
+            } else if (h->cg_plan[it] > 0) {
+                h->cg_plan[it] = std::min(p.cg_max_iters, h->cg_plan[it] + std::max(2, h->cg_plan[it] / 8));
+            }
+            h->bump_seq[it] = h->seq_enqueued;
+            if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] pass %llu solve %d ended at %.2e of cg_tol: plan lengthened from pass %llu on\n",
+                                                (unsigned long long)q, it, std::sqrt(rel2) / p.cg_tol, (unsigned long long)h->seq_enqueued);
+        }
+    }
+    h->seq_peeked = done;
+}
+
+// after the stream has been drained: the verdicts since the last harvest -> stats; resets the sticky part of the control block
+struct Judgement { double worst2 = 0.0, last_worst2 = 0.0; int solves = 0, missed = 0; bool esc = false; double last_row[8]; };
+int read_judgement(mvs_deform_s* h, const mvs_deform_params& p, Judgement* j) {
+    double ctl[MVS_CTL_SIZE];
+    HIPCHK(hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    j->esc = ctl[MVS_CTL_ESC] != 0.0;
+    j->worst2 = ctl[MVS_CTL_WORST];
+    j->missed = (int)ctl[MVS_CTL_MISSED];
+    j->solves = (int)ctl[MVS_CTL_SOLVES];
+    const double* row = ctl + MVS_CTL_RING + ((h->seq_enqueued + MVS_RING - 1) % MVS_RING) * 8;
+    for (int it = 0; it < 8; ++it) { j->last_row[it] = row[it]; if (it < p.arap_iters && row[it] > j->last_worst2) j->last_worst2 = row[it]; }
+    HIPCHK(hipMemsetAsync(h->d_ctl, 0, sizeof(double) * 4, h->stream));       // ESC, WORST, MISSED, SOLVES
+    h->seq_peeked = h->seq_enqueued;
+    return MVS_OK;
+}
+void fill_judgement(const Judgement& j, mvs_deform_stats* out) {
+    out->cg_rel_residual = std::sqrt(std::max(0.0, j.last_worst2));
+    out->worst_rel_residual_in_batch = std::sqrt(std::max(0.0, j.worst2));
+    out->solves_in_batch = j.solves;
+    out->unconverged_solves = j.missed;
+    out->escalated = j.esc ? 1 : 0;
+}
+int judged_status(const Judgement& j, const mvs_deform_params& p) {
+    if (j.missed == 0) return MVS_OK;
+    mvs_set_error("%d of %d global solves ended above cg_tol = %.1e (worst relative residual %.3e)%s", j.missed, j.solves, p.cg_tol,
+                  std::sqrt(j.worst2), j.esc ? "; the device switched the remaining solves to the strong local-solve coefficients" : "");
+    return MVS_W_UNCONVERGED;
 }
 
 // after a sync: read the CG slots of the last solve, fill stats, re-calibrate cg_iters
@@ -368,11 +457,12 @@ int harvest(mvs_deform_s* h, const mvs_deform_params& p, const CgPlan& plan, mvs
     HIPCHK(hipMemcpyAsync(info, h->d_info, sizeof info, hipMemcpyDeviceToHost, h->stream));
     std::vector<uint8_t> valid(h->K);
     if (h->K) HIPCHK(hipMemcpyAsync(valid.data(), h->d_valid, (size_t)h->K, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    Judgement jd;
+    int rc = read_judgement(h, p, &jd);                    // (synchronises the stream)
+    if (rc) return rc;
     const int run = info[0];
     const int nb = arap_grid_blocks(h->sell);
     int need = 0, launches = 0, active = 0;
-    double worst = 0.0;
     bool all_conv = true;
     for (int it = 0; it < run; ++it) {
         const double* S = slots.data() + plan.offset(it);
@@ -396,13 +486,9 @@ int harvest(mvs_deform_s* h, const mvs_deform_params& p, const CgPlan& plan, mvs
         else h->cg_plan[it] = std::min(p.cg_max_iters, first + first / 8 + 2);
         need = std::max(need, first);
         launches += cg; active += first;
-        if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] arap it %d: CG frozen at %d of %d (gamma0 %.3e bn %.3e)\n", it, first, cg, gamma_of(0, 0), S[MVS_CG_FIN + 6]);
-        for (int c = 0; c < 3; ++c) {
-            const double gam = gamma_of(cg, c), bn = S[MVS_CG_FIN + 6 + c];
-            if (bn > 0) worst = std::max(worst, std::sqrt(std::max(0.0, gam) / bn));
-        }
+        if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] arap it %d: CG frozen at %d of %d (gamma0 %.3e bn %.3e), true residual %.3e\n", it, first, cg, gamma_of(0, 0), S[MVS_CG_FIN + 6], std::sqrt(std::max(0.0, jd.last_row[it])));
     }
-    if (converged) *converged = all_conv;
+    if (converged) *converged = all_conv && jd.missed == 0;
     for (int it = run; it < p.arap_iters; ++it)            // solves skipped by the energy stop rule keep a safe count
         if (h->cg_plan[it] == 0 || h->cg_iters == 0) h->cg_plan[it] = h->cg_plan[std::max(0, run - 1)];
     h->cg_iters = 1;
@@ -412,7 +498,7 @@ int harvest(mvs_deform_s* h, const mvs_deform_params& p, const CgPlan& plan, mvs
     out.arap_iters_run = run;
     out.cg_iters = cg;
     for (int i = 0; i < 8; ++i) out.energy[i] = i < p.arap_iters ? ered[MVS_ERED_FIN + i] : 0.0;
-    out.cg_rel_residual = worst;
+    fill_judgement(jd, &out);
     out.cg_launches = launches; out.cg_active = active;
     int nv = 0;
     for (uint8_t v : valid) nv += v;
@@ -421,10 +507,10 @@ int harvest(mvs_deform_s* h, const mvs_deform_params& p, const CgPlan& plan, mvs
     if (st) *st = out;
     collect_timers(h);
     if (!all_conv && cg >= p.cg_max_iters) {
-        mvs_set_error("global solve did not reach cg_tol in cg_max_iters=%d (rel residual %.3e)", cg, worst);
+        mvs_set_error("global solve did not reach cg_tol in cg_max_iters=%d (rel residual %.3e)", cg, out.worst_rel_residual_in_batch);
         return MVS_E_SOLVER;
     }
-    return MVS_OK;
+    return judged_status(jd, p);
 }
 
 // patch solver: read the sweep slots of the last solve, fill stats, re-plan the sweep counts.
@@ -452,10 +538,12 @@ int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* s
     HIPCHK(hipMemcpyAsync(info, h->d_info, sizeof info, hipMemcpyDeviceToHost, h->stream));
     std::vector<uint8_t> valid(h->K);
     if (h->K) HIPCHK(hipMemcpyAsync(valid.data(), h->d_valid, (size_t)h->K, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    Judgement jd;
+    int rc = read_judgement(h, p, &jd);                    // (synchronises the stream)
+    if (rc) return rc;
     const int run = info[0];
-    int launches = 0, active = 0, max_local = 0, max_plan = 0;
-    double worst = 0.0;
+    const double tol2 = p.cg_tol * p.cg_tol;
+    int launches = 0, active = 0, max_local = 0, max_plan = 0, worst_first = 0;
     bool all_conv = true;
     size_t slot = 0;
     for (int it = 0; it < p.arap_iters; ++it) {
@@ -465,22 +553,29 @@ int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* s
         const double* F = fin.data() + (slot + n - 1) * 8;
         const double bn[3] = {F[3], F[4], F[5]};
         // gamma of the INPUT of sweep i: reduced on the device for i < n-1, folded here (patch order) for the last sweep
-        auto conv_at = [&](int i, double* rel) {
-            bool ok = true;
+        auto rel2_at = [&](int i) {
+            double worst = 0.0;
             for (int c = 0; c < 3; ++c) {
                 double g = 0.0;
                 if (i < n - 1) g = fin[(slot + i) * 8 + c];
                 else for (int q = 0; q < 4 * NP; ++q) g += lastp[(size_t)it * 3 * NPpad + (size_t)c * NPpad + q];
-                if (g > 0.0 && g > p.cg_tol * p.cg_tol * bn[c]) ok = false;
-                if (rel && bn[c] > 0) *rel = std::max(*rel, std::sqrt(std::max(0.0, g) / bn[c]));
+                if (g > 0.0 && bn[c] > 0.0) worst = std::max(worst, g / bn[c]);
+                else if (g > 0.0) worst = INFINITY;
             }
-            return ok;
+            return worst;
         };
+        // `first` = sweeps after which x met cg_tol: the first sweep whose INPUT is converged, or n when only the result
+        // of the last sweep is (its true residual was measured by the local step: jd.last_row)
         int first = -1;
-        for (int i = 0; i < n; ++i) if (conv_at(i, nullptr)) { first = i; break; }
-        double rel = 0.0;
-        conv_at(n - 1, &rel);                              // what the last sweep started from (its output is better still)
-        worst = std::max(worst, rel);
+        double rho2 = 0.0;                                 // residual reduction (squared) of the sweep before `first`
+        double prev = INFINITY;
+        for (int i = 0; i < n; ++i) {
+            const double r2 = rel2_at(i);
+            if (r2 <= tol2) { first = i; if (i > 0 && prev > 0.0 && prev < INFINITY) rho2 = r2 / prev; break; }
+            prev = r2;
+        }
+        const double final2 = jd.last_row[it];
+        if (first < 0 && final2 >= 0.0 && final2 <= tol2) { first = n; if (prev > 0.0 && prev < INFINITY) rho2 = final2 / prev; }
         for (int i = 0; i < n; ++i) {
             int mx = 0;
             for (int q = 0; q < NP; ++q) mx = std::max(mx, iters[(slot + i) * NP + q]);
@@ -488,19 +583,26 @@ int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* s
             if (mx > 0 || i == 0) ++active;
         }
         launches += n;
-        if (first < 0) { all_conv = false; h->ras_plan[it] = std::min(RAS_MAX_SWEEPS, 2 * n); }
-        else h->ras_plan[it] = std::min(RAS_MAX_SWEEPS, first + 2);           // sweep `first` confirms, one spare
-        if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] arap it %d: patch solver converged input at sweep %d of %d (rel %.3e)\n", it, first, n, rel);
+        if (first < 0) { all_conv = false; h->ras_plan[it] = std::min(RAS_MAX_SWEEPS, 2 * n); worst_first = std::max(worst_first, n); }
+        else {
+            // margin: as many further sweeps as bring the residual from cg_tol to THIN * cg_tol at the rate just observed
+            // (one at the usual 15-20x per sweep; more when the patches converge slowly) — what peek_ring watches for
+            int margin = 1;
+            if (rho2 > 0.0 && rho2 < 1.0) margin = std::min(4, std::max(1, (int)std::ceil(std::log(THIN * THIN) / std::log(rho2))));
+            h->ras_plan[it] = std::min(RAS_MAX_SWEEPS, first + margin + (h->ras_bump[it] > 0 ? 1 : 0));
+            worst_first = std::max(worst_first, first);
+        }
+        if (h->ras_bump[it] > 0) h->ras_bump[it]--;
+        if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] arap it %d: x converged after %d of %d sweeps (true final residual %.3e, rate %.3f) -> plan %d\n", it, first, n,
+                                            std::sqrt(std::max(0.0, final2)), std::sqrt(rho2), h->ras_plan[it]);
         slot += n;
     }
-    {   // adapt the Chebyshev bracket of the local solves to what the sweeps showed: many sweeps (or none converged) mean
+    {   // adapt the Chebyshev bracket of the local solves to what the sweeps showed: many sweeps (or a miss) mean
         // the smooth modes are under-damped -> lower the bracket and take more steps; very few sweeps -> drift back up
         double a0; int m0;
         ras_default_bracket(h, &a0, &m0);
         double a = h->ras_a > 0.0 ? h->ras_a : a0;
-        int worst_first = 0;
-        for (int it = 0; it < run; ++it) worst_first = std::max(worst_first, h->ras_plan[it] - 2);
-        if (!all_conv || worst_first > 9) {
+        if (!all_conv || jd.esc || worst_first > 9) {
             a = std::max(a / 3.0, 0.002);
         } else if (worst_first <= 4 && a < a0) {
             a = std::min(a0, a * 1.5);
@@ -511,12 +613,12 @@ int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* s
     }
     for (int it = run; it < p.arap_iters; ++it)            // solves skipped by the energy stop rule keep a safe count
         if (h->ras_plan[it] == 0) h->ras_plan[it] = h->ras_plan[std::max(0, run - 1)];
-    if (converged) *converged = all_conv;
+    if (converged) *converged = all_conv && jd.missed == 0;
     mvs_deform_stats out{};
     out.arap_iters_run = run;
-    out.cg_iters = max_local;                              // local PCG iterations on the critical path (max over patches, summed over sweeps)
+    out.cg_iters = max_local;                              // local Chebyshev steps on the critical path (max over patches, summed over sweeps)
     for (int i = 0; i < 8; ++i) out.energy[i] = i < p.arap_iters ? ered[MVS_ERED_FIN + i] : 0.0;
-    out.cg_rel_residual = worst;
+    fill_judgement(jd, &out);
     out.cg_launches = launches; out.cg_active = active;
     int nv = 0;
     for (uint8_t v : valid) nv += v;
@@ -528,11 +630,11 @@ int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* s
         // even the lowest Chebyshev bracket does not fit this mesh / node layout: this handle solves by CG from now on
         h->has_ras = false;
         h->cg_iters = 0;
-        mvs_set_error("patch solver did not reach cg_tol in %d sweeps (rel residual %.3e); the handle now uses CG", max_plan, worst);
+        mvs_set_error("patch solver did not reach cg_tol in %d sweeps (rel residual %.3e); the handle now uses CG", max_plan, out.worst_rel_residual_in_batch);
         return MVS_E_SOLVER;
     }
     h->cg_iters = std::max(h->cg_iters, 1);                // "calibrated": async solves allowed
-    return MVS_OK;
+    return judged_status(jd, p);
 }
 
 CgPlan probe_cg(const mvs_deform_s* h, const mvs_deform_params& p) {
@@ -644,6 +746,14 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals, in
     TRY(dmalloc(&h->d_is_ctrl, (size_t)V));
     for (int k = 0; k < 2; ++k) TRY(dmalloc(&h->d_rws[k], (size_t)V * 9));
     TRY(dmalloc(&h->d_p, (size_t)V * 3)); TRY(dmalloc(&h->d_coef, (size_t)ne)); TRY(dmalloc(&h->d_energy, MVS_ERED_SIZE)); TRY(dmalloc(&h->d_info, 8));
+    TRY(dmalloc(&h->d_ras_b, (size_t)V * 3)); TRY(dmalloc(&h->d_ctl, MVS_CTL_SIZE));
+    {   // pinned, host-coherent mirror of the control block: the last kernel of every pass writes it, the host reads it
+        // without synchronising (throttle / peek_ring)
+        void* hp = nullptr;
+        TRY(mvs_check_hip(hipHostMalloc(&hp, sizeof(double) * MVS_CTL_SIZE, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc"));
+        std::memset(hp, 0, sizeof(double) * MVS_CTL_SIZE);
+        h->h_ctl = (volatile double*)hp;
+    }
     auto up = [&](void* d, const void* s, size_t n) { return mvs_check_hip(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, h->stream), "upload"); };
     TRY(up(h->d_pts, points, sizeof(double) * V * 3)); TRY(up(h->d_nrm, normals, sizeof(double) * V * 3));
     TRY(up(h->d_sol, points, sizeof(double) * V * 3));
@@ -654,6 +764,8 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals, in
     TRY(mvs_check_hip(hipMemsetAsync(h->d_is_ctrl, 0, sizeof(int32_t) * V, h->stream), "memset"));
     TRY(mvs_check_hip(hipMemsetAsync(h->d_rot, 0, sizeof(double) * V * 9, h->stream), "memset"));
     TRY(mvs_check_hip(hipMemsetAsync(h->d_info, 0, sizeof(int32_t) * 8, h->stream), "memset"));
+    TRY(mvs_check_hip(hipMemsetAsync(h->d_ctl, 0, sizeof(double) * MVS_CTL_SIZE, h->stream), "memset"));
+    TRY(mvs_check_hip(hipMemsetAsync(h->d_energy, 0, sizeof(double) * MVS_ERED_SIZE, h->stream), "memset"));
     TRY(mvs_check_hip(hipStreamSynchronize(h->stream), "sync"));
     lap("allocations + uploads");
     TRY(ras_build(h, points, rowptr, col, slice_off));
@@ -674,7 +786,8 @@ int mvs_deform_destroy(mvs_deform_t h) {
     dfree(h->d_slice_off); dfree(h->d_col); dfree(h->d_opp0); dfree(h->d_opp1); dfree(h->d_is_ctrl); dfree(h->d_w); dfree(h->d_diag);
     dfree(h->d_spos); dfree(h->d_tpos); dfree(h->d_tnrm); dfree(h->d_cell_start); dfree(h->d_coarse_cnt);
     for (int k = 0; k < 2; ++k) dfree(h->d_rws[k]);
-    dfree(h->d_p); dfree(h->d_coef); dfree(h->d_slots); dfree(h->d_energy); dfree(h->d_info);
+    dfree(h->d_p); dfree(h->d_coef); dfree(h->d_slots); dfree(h->d_energy); dfree(h->d_info); dfree(h->d_ctl);
+    if (h->h_ctl) { (void)hipHostFree((void*)h->h_ctl); h->h_ctl = nullptr; }
     ras_free(h);
     for (auto& pr : h->pending) { (void)hipEventDestroy(pr.second.first); (void)hipEventDestroy(pr.second.second); }
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
@@ -716,7 +829,8 @@ int mvs_deform_set_nodes(mvs_deform_t h, const int32_t* vertex_idx, int64_t K) {
     if (K) HIPCHK(hipMemcpyAsync(h->d_ctrl_raw, h->d_node_pts, sizeof(double) * K * 3, hipMemcpyDeviceToDevice, h->stream));
     h->d_ctrl_final = h->d_ctrl_raw;
     h->cg_iters = 0;                                  // new node set: every launch plan and the solver bracket start over
-    for (int i = 0; i < 8; ++i) { h->cg_plan[i] = 0; h->ras_plan[i] = 0; }
+    for (int i = 0; i < 8; ++i) { h->cg_plan[i] = 0; h->ras_plan[i] = 0; h->ras_bump[i] = 0; h->bump_seq[i] = 0; }
+    HIPCHK(hipMemsetAsync(h->d_ctl, 0, sizeof(double) * 4, h->stream));     // verdicts of the old node set say nothing about the new one
     h->ras_a = 0.0; h->ras_m = 0;
     HIPCHK(hipStreamSynchronize(h->stream));
     return MVS_OK;
@@ -771,7 +885,10 @@ int mvs_deform_sizes(mvs_deform_t h, int64_t* V, int64_t* F, int64_t* K, int64_t
 int mvs_deform_set_target_dev(mvs_deform_t h, int64_t P, const double* pts_dev, const double* normals_dev, int64_t index_base) {
     if (!h || P < 0 || (P > 0 && (!pts_dev || !normals_dev))) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    // the caller's buffers were produced on some other stream (torch's current stream, the legacy default stream ...);
+    // the handle's stream is non-blocking and is not ordered after any of them.  This is a set-up call that synchronises
+    // several times anyway: wait for the whole device once so that the index is never built from a half-written target.
+    HIPCHK(hipDeviceSynchronize());
     return grid_build(h, P, pts_dev, normals_dev, index_base);
 }
 int mvs_deform_set_target(mvs_deform_t h, int64_t P, const double* pts, const double* normals, int64_t index_base) {
@@ -808,7 +925,9 @@ int mvs_deform_iterate(mvs_deform_t h, const mvs_deform_params* p, int n_outer, 
     mvs_deform_stats st = h->last;
     if (!stats && h->cg_iters > 0) {
         // enqueue only (no host synchronisation): several handles on their own streams overlap this way; the launch plan
-        // stays the one of the last harvest until mvs_deform_collect (or a call with stats) reads the statistics back
+        // stays the one of the last harvest until mvs_deform_collect (or a call with stats) reads the statistics back.
+        // Nobody follows the ring here: a solve that misses cg_tol raises the device-side escalation (strong local solves
+        // for the rest of what is enqueued) and is reported by the collecting call.
         const CgPlan cg = probe_cg(h, *p);
         for (int o = 0; o < n_outer; ++o) {
             enqueue_assoc_local(h, *p);
@@ -817,27 +936,39 @@ int mvs_deform_iterate(mvs_deform_t h, const mvs_deform_params* p, int n_outer, 
         }
         return MVS_OK;
     }
+    int status = MVS_OK;
+    double worst = 0.0;
+    int solves = 0, missed = 0, esc = 0;
     while (done < n_outer) {
         // enqueue as many outer iterations as the current calibration allows, then harvest once
         const bool calibrated = h->cg_iters > 0;
-        const CgPlan cg = probe_cg(h, *p);
-        // (at most MAX_BATCH passes share one launch plan: the spectrum of the system drifts as the template deforms, and a
-        //  stale plan leaves solves under-converged until the next harvest — scripts/soak.py)
+        // (at most MAX_BATCH passes between two harvests; inside a batch the host follows the residual ring — throttle,
+        //  peek_ring — and lengthens the plan of a solve as soon as its margin gets thin)
         const int batch = calibrated ? std::min(n_outer - done, MAX_BATCH) : 1;
+        CgPlan cg = probe_cg(h, *p);
         for (int o = 0; o < batch; ++o) {
+            if (calibrated && o > 0) {
+                if ((rc = throttle(h))) return rc;
+                peek_ring(h, *p, use_ras(h, *p));
+                cg = probe_cg(h, *p);
+            }
             enqueue_assoc_local(h, *p);
             rc = enqueue_solve(h, *p, h->d_ctrl_raw, true, cg);
             if (rc) return rc;
         }
         bool conv = true;
         rc = harvest(h, *p, cg, &st, &conv);
-        if (rc) return rc;
+        if (rc < 0) return rc;
+        if (rc > 0) status = rc;
+        worst = std::max(worst, st.worst_rel_residual_in_batch);
+        solves += st.solves_in_batch; missed += st.unconverged_solves; esc |= st.escalated;
         done += batch;
     }
     st.outer_done = done;
+    st.worst_rel_residual_in_batch = worst; st.solves_in_batch = solves; st.unconverged_solves = missed; st.escalated = esc;
     h->last = st;
     if (stats) *stats = st;
-    return MVS_OK;
+    return status;
 }
 
 int mvs_deform_assoc_dmin(mvs_deform_t h, const mvs_deform_params* p, float* d2min_dev) {

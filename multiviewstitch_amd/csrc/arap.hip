@@ -165,9 +165,12 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
                                                   const double* __restrict__ sol, const double* __restrict__ rot,
                                                   int it, double tol, double* __restrict__ ered,
                                                   double* __restrict__ rws, double* __restrict__ p,
-                                                  double* __restrict__ bout) {
+                                                  double* __restrict__ bout, double cg_tol, double* __restrict__ ctl,
+                                                  int ring_slot) {
     double* efin = ered + EFIN;
     __shared__ int s_done;
+    // block 0 judges the global solve of the previous ARAP iteration (true residual measured by its local step)
+    if (blockIdx.x == 0 && it >= 1 && ctl) judge_solve(ered, it - 1, gridDim.x, cg_tol, ctl, ring_slot, !arap_done_before(efin, it - 1, tol));
     if (threadIdx.x < 64) {                      // wave 0 decides
         bool done = arap_done_before(efin, it - 1, tol);
         if (it >= 1) {
@@ -214,9 +217,8 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
                 res = b_c - a_c;
                 bn_acc += b_c * b_c / di;                        // ||b||^2 in the M^-1 norm: scale of the CG stop test
             }
-            if (bout) {                                              // patch solver: it wants b itself
-                bout[3 * r.row + r.l] = freerow ? (r.l == 0 ? bb.x : (r.l == 1 ? bb.y : bb.z)) : 0.0;
-            } else {
+            bout[3 * r.row + r.l] = freerow ? (r.l == 0 ? bb.x : (r.l == 1 ? bb.y : bb.z)) : 0.0;
+            if (rws) {                                               // CG start state
                 double* o = rws + 9 * (int64_t)r.row;
                 o[r.l] = res; o[3 + r.l] = 0.0; o[6 + r.l] = 0.0;
                 p[3 * r.row + r.l] = 0.0;
@@ -431,9 +433,11 @@ __global__ __launch_bounds__(TPB) void k_cg_iter(SellDev m, const double* __rest
 // for the Jacobi chain: the gathers were never the cost, the two extra kernel boundaries were.)  The grid is the row
 // kernels' grid so that the energy partials land where their consumers fold them.
 __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __restrict__ pts, const double* __restrict__ sol,
-                                                    int it, double tol, double* __restrict__ ered, double* __restrict__ rot) {
+                                                    int it, double tol, double* __restrict__ ered, double* __restrict__ rot,
+                                                    const double* __restrict__ bvec) {
     if (block_done(ered + EFIN, it, tol)) return;
     double e_acc = 0.0;
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0;          // true residual of the global solve whose result `sol` is: sum r_c^2 / d_i over the free rows
     for (int i = blockIdx.x * 256 + threadIdx.x; i < m.V; i += gridDim.x * 256) {
         const int g = i >> 3, r = i & 7, off = m.single_pass ? 64 * g : m.slice_off[g], passes = m.single_pass ? 1 : (m.slice_off[g + 1] - off) >> 6;
         const d3 pi = ld3(pts + 3 * i), qi = ld3(sol + 3 * i);
@@ -441,11 +445,16 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
         // the first eight edges (all of them when the degree is <= 8) stay in registers for the energy term
         double w0[8];
         d3 pp0[8], qq0[8];
+        int cj0[8];
+        const bool judge = bvec != nullptr && m.is_ctrl[i] == 0;
+        // r_i = b_i - (d_i x_i - sum_{free j} 2 w_ij x_j) = b_i - sum_j 2 w_ij (x_i - x_j) - sum_{ctrl j} 2 w_ij x_j
+        d3 ax = mk3(0, 0, 0);
 #pragma unroll
         for (int l = 0; l < 8; ++l) {
             const int e = off + r * 8 + l;
             w0[l] = m.w[e];
             const int j = w0[l] == 0.0 ? i : m.col[e];
+            cj0[l] = judge ? m.is_ctrl[j] : 0;
             pp0[l] = pi - ld3(pts + 3 * j); qq0[l] = qi - ld3(sol + 3 * j);
         }
 #pragma unroll
@@ -453,6 +462,7 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
             if (w0[l] == 0.0) continue;
             const double w = w0[l];
             const d3 pp = pp0[l], qq = qq0[l];
+            if (judge) ax = ax + (2.0 * w) * (cj0[l] ? qi : qq);            // ctrl column: (x_i - x_j) + x_j
             c[0] += w * (pp.x * qq.x); c[1] += w * (pp.x * qq.y); c[2] += w * (pp.x * qq.z);
             c[3] += w * (pp.y * qq.x); c[4] += w * (pp.y * qq.y); c[5] += w * (pp.y * qq.z);
             c[6] += w * (pp.z * qq.x); c[7] += w * (pp.z * qq.y); c[8] += w * (pp.z * qq.z);
@@ -465,10 +475,16 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
                 if (w == 0.0) continue;
                 const int j = m.col[e];
                 const d3 pp = pi - ld3(pts + 3 * j), qq = qi - ld3(sol + 3 * j);
+                if (judge) ax = ax + (2.0 * w) * (m.is_ctrl[j] ? qi : qq);
                 c[0] += w * (pp.x * qq.x); c[1] += w * (pp.x * qq.y); c[2] += w * (pp.x * qq.z);
                 c[3] += w * (pp.y * qq.x); c[4] += w * (pp.y * qq.y); c[5] += w * (pp.y * qq.z);
                 c[6] += w * (pp.z * qq.x); c[7] += w * (pp.z * qq.y); c[8] += w * (pp.z * qq.z);
             }
+        if (judge) {
+            const d3 res = ld3(bvec + 3 * (int64_t)i) - ax;
+            const double inv_d = 1.0 / m.diag[i];
+            g0 += res.x * res.x * inv_d; g1 += res.y * res.y * inv_d; g2 += res.z * res.z * inv_d;
+        }
         double R[9];
         closest_rotation(c, R);
 #pragma unroll
@@ -490,30 +506,52 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
             }
     }
     e_acc = wave_total(e_acc);
-    __shared__ double sm[4];
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = e_acc;
+    __shared__ double sm[4][4];
+    if (bvec) { g0 = wave_total(g0); g1 = wave_total(g1); g2 = wave_total(g2); }
+    if ((threadIdx.x & 63) == 0) { double* q = sm[threadIdx.x >> 6]; q[0] = e_acc; q[1] = g0; q[2] = g1; q[3] = g2; }
     __syncthreads();
-    if (threadIdx.x == 0) ered[it * EIT + blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    if (threadIdx.x == 0) ered[it * EIT + blockIdx.x] = (sm[0][0] + sm[1][0]) + (sm[2][0] + sm[3][0]);
+    if (bvec && threadIdx.x >= 1 && threadIdx.x < 4)
+        ered[it * EIT + (3 + threadIdx.x) * NBMAX + blockIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
 __global__ void k_arap_finalize(SellDev m, int iters, double tol, int nb, double* __restrict__ ered,
                                 const double* __restrict__ sol, double* __restrict__ pts, int32_t* __restrict__ info,
-                                const double* __restrict__ nrm, double* __restrict__ node_pts, double* __restrict__ node_nrm) {
+                                const double* __restrict__ nrm, double* __restrict__ node_pts, double* __restrict__ node_nrm,
+                                double cg_tol, double* __restrict__ ctl, int ring_slot, double* __restrict__ host_ctl) {
     // assign_solution + overwrite_initial_geometry (Deformation.cpp:398-400)
     double* efin = ered + EFIN;
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
+    if (blockIdx.x == 0) {
         // the last iteration's energy is only meaningful if that iteration ran (its kernels exit once the rule fired)
         const bool done = arap_done_before(efin, iters - 1, tol);
-        const double e_last = fold_partials(ered + (iters - 1) * EIT, nb);
-        if (threadIdx.x == 0) {
-            efin[iters - 1] = done ? 0.0 : e_last;
-            int run = iters;
-            if (tol > 0.0)
-                for (int t = 1; t + 1 < iters; ++t) {
-                    const double dif = fabs((efin[t - 1] - efin[t]) / efin[t]);
-                    if (dif < tol) { run = t + 1; break; }
+        if (ctl) judge_solve(ered, iters - 1, nb, cg_tol, ctl, ring_slot, !done);       // (contains the block's barrier)
+        if (threadIdx.x < 64) {
+            const double e_last = fold_partials(ered + (iters - 1) * EIT, nb);
+            if (threadIdx.x == 0) {
+                efin[iters - 1] = done ? 0.0 : e_last;
+                int run = iters;
+                if (tol > 0.0)
+                    for (int t = 1; t + 1 < iters; ++t) {
+                        const double dif = fabs((efin[t - 1] - efin[t]) / efin[t]);
+                        if (dif < tol) { run = t + 1; break; }
+                    }
+                info[0] = run;
+                if (ctl) {
+                    // close this outer iteration's ring row and publish the control block to the host mirror (pinned,
+                    // host-coherent): the host follows the solves without synchronising the stream
+                    double* row = ctl + MVS_CTL_RING + ring_slot * 8;
+                    for (int t = run; t < 8; ++t) row[t] = -1.0;
+                    ctl[MVS_CTL_SEQ] += 1.0;
+                    if (host_ctl) {
+                        double* hrow = host_ctl + MVS_CTL_RING + ring_slot * 8;
+                        for (int t = 0; t < 8; ++t) hrow[t] = row[t];
+                        for (int t = 0; t < MVS_CTL_SEQ; ++t) host_ctl[t] = ctl[t];
+                        __threadfence_system();
+                        host_ctl[MVS_CTL_SEQ] = ctl[MVS_CTL_SEQ];                 // last: a row is complete when its sequence number shows
+                        __threadfence_system();
+                    }
                 }
-            info[0] = run;
+            }
         }
     }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -566,8 +604,8 @@ void launch_cot_weights(const SellDev& m, const double* pts, double* coef, const
     if (coef) k_cg_coef<<<g, dim3(TPB), 0, s>>>(m, coef);      // CG only (the patch solver builds its own matrix)
 }
 void launch_arap_rhs(const SellDev& m, const double* pts, const double* sol, const double* rot, int it, double tol,
-                     double* ered, double* rws, double* p, double* bout, hipStream_t s) {
-    k_arap_rhs<<<dim3(arap_grid_blocks(m)), dim3(TPB), 0, s>>>(m, pts, sol, rot, it, tol, ered, rws, p, bout);
+                     double* ered, double* rws, double* p, double* bout, double cg_tol, double* ctl, int ring_slot, hipStream_t s) {
+    k_arap_rhs<<<dim3(arap_grid_blocks(m)), dim3(TPB), 0, s>>>(m, pts, sol, rot, it, tol, ered, rws, p, bout, cg_tol, ctl, ring_slot);
 }
 void launch_cg_w0(const SellDev& m, const double* coef, int it, double tol, const double* ered, double* rws,
                   double* slot0, hipStream_t s) {
@@ -581,13 +619,15 @@ void launch_cg_iter(const SellDev& m, const double* coef, int it, double tol, co
                                                              slot_next, rws_in, rws_out, p, x);
 }
 void launch_arap_local(const SellDev& m, const double* pts, const double* sol, int it, double tol, double* ered,
-                       double* rot, hipStream_t s) {
-    k_arap_local<<<dim3(arap_grid_blocks(m)), dim3(256), 0, s>>>(m, pts, sol, it, tol, ered, rot);
+                       double* rot, const double* b, hipStream_t s) {
+    k_arap_local<<<dim3(arap_grid_blocks(m)), dim3(256), 0, s>>>(m, pts, sol, it, tol, ered, rot, b);
 }
 // node_pts != NULL: also gathers the nodes' new positions and (unchanged) normals, as k_gather_nodes would
 void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered, const double* sol,
-                          double* pts, int32_t* info, const double* nrm, double* node_pts, double* node_nrm, hipStream_t s) {
-    k_arap_finalize<<<dim3((m.V + 255) / 256), dim3(256), 0, s>>>(m, iters, tol, arap_grid_blocks(m), ered, sol, pts, info, nrm, node_pts, node_nrm);
+                          double* pts, int32_t* info, const double* nrm, double* node_pts, double* node_nrm,
+                          double cg_tol, double* ctl, int ring_slot, double* host_ctl, hipStream_t s) {
+    k_arap_finalize<<<dim3((m.V + 255) / 256), dim3(256), 0, s>>>(m, iters, tol, arap_grid_blocks(m), ered, sol, pts, info, nrm, node_pts, node_nrm,
+                                                                  cg_tol, ctl, ring_slot, host_ctl);
 }
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf, int V,
                            double* out, hipStream_t s) {

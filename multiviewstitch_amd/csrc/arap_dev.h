@@ -134,5 +134,32 @@ __device__ inline bool arap_done_before(const double* __restrict__ efin, int it,
     return false;
 }
 
+// Judge the global solve of ARAP iteration `it` from the residual partials its local step left (block 0 only, called by
+// the whole block, blockDim >= 256; contains a __syncthreads).  Waves 1..3 fold gamma_c = sum r_c^2 / d and the bnorm of
+// right-hand side c; thread 0 writes rel^2 = max_c gamma_c / bnorm_c into the ring row and keeps the control block's
+// sticky summary (MVS_CTL_*, engine.h).  `ran` (thread 0's value counts): the iteration ran at all.
+__device__ inline void judge_solve(const double* __restrict__ ered, int it, int nb, double cg_tol, double* __restrict__ ctl,
+                                   int ring_slot, bool ran) {
+    __shared__ double s_rel[3];
+    const int wv = threadIdx.x >> 6;
+    if (wv >= 1 && wv <= 3) {
+        const int c = wv - 1;
+        double gam, bn;
+        fold_partials2(ered + it * EIT + (4 + c) * NBMAX, ered + it * EIT + (1 + c) * NBMAX, nb, &gam, &bn);
+        if ((threadIdx.x & 63) == 0) s_rel[c] = bn > 0.0 ? gam / bn : 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* row = ctl + MVS_CTL_RING + ring_slot * 8;
+        if (!ran) { row[it] = -1.0; return; }
+        double rel2 = fmax(s_rel[0], fmax(s_rel[1], s_rel[2]));
+        if (!(rel2 == rel2)) rel2 = INFINITY;                             // a NaN residual is a miss
+        row[it] = rel2;
+        ctl[MVS_CTL_WORST] = fmax(ctl[MVS_CTL_WORST], rel2);
+        ctl[MVS_CTL_SOLVES] += 1.0;
+        if (rel2 > cg_tol * cg_tol) { ctl[MVS_CTL_MISSED] += 1.0; ctl[MVS_CTL_ESC] = 1.0; }
+    }
+}
+
 }  // namespace
 #endif

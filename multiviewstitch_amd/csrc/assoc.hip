@@ -286,7 +286,11 @@ __global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __r
     if (prev_d2) {
         const double dx = node_pts[3 * node] - prev_node[3 * node], dy = node_pts[3 * node + 1] - prev_node[3 * node + 1],
                      dz = node_pts[3 * node + 2] - prev_node[3 * node + 2];
-        const double r = sqrt((double)prev_d2[node]) + sqrt(dx * dx + dy * dy + dz * dz);
+        // the search runs on float32-rounded coordinates: a sub-ulp move of the node can shift the rounded query by one
+        // float32 ulp per axis (more than |delta| for a nearly converged node), so both roundings (previous and current
+        // query) enter the radius before it is squared
+        const double ulp = 4.0 * 1.1920929e-7 * (fabs(node_pts[3 * node]) + fabs(node_pts[3 * node + 1]) + fabs(node_pts[3 * node + 2]));
+        const double r = sqrt((double)prev_d2[node]) + sqrt(dx * dx + dy * dy + dz * dz) + ulp;
         const double l2 = r * r * 1.001 + 1e-12;
         limit2 = (l2 == l2 && l2 < 3.0e38) ? (float)l2 : INFINITY;       // (NaN / inf: no limit)
     }

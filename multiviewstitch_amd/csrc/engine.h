@@ -59,9 +59,23 @@ struct RasDev {                // patches of the restricted additive Schwarz sol
 #define MVS_NBMAX 256                      /* max workgroups of a row kernel = partial sums per global sum (arap.hip) */
 #define MVS_CG_FIN (6 * MVS_NBMAX)
 #define MVS_CG_SLOT (MVS_CG_FIN + 16)      /* doubles per CG slot: part[6][NBMAX] (gamma, delta) | alpha[3] gamma[3] bnorm[3] pad */
-#define MVS_ERED_IT (4 * MVS_NBMAX)        /* per ARAP iteration: e_part[NBMAX] | bn_part[3][NBMAX] */
+#define MVS_ERED_IT (7 * MVS_NBMAX)        /* per ARAP iteration: e_part[NBMAX] | bn_part[3][NBMAX] | res_part[3][NBMAX] */
 #define MVS_ERED_FIN (8 * MVS_ERED_IT)     /* then e_fin[8] */
 #define MVS_ERED_SIZE (MVS_ERED_FIN + 8)
+
+// Solver control block of a handle (doubles, device; the first MVS_CTL_HOST entries are mirrored into pinned host memory at
+// the end of every outer iteration so that the host can follow the solves without synchronising the stream):
+//   the local step of every ARAP iteration measures the TRUE residual of the global solve's result (r = b - A x on the
+//   free rows, M^-1 norm); the next kernel of the chain folds it, writes rel^2 = max_c gamma_c / bnorm_c into the ring and,
+//   when it exceeds cg_tol^2, counts a miss and raises the escalation flag (the sweeps then take the strong coefficient set).
+#define MVS_CTL_ESC    0     /* != 0: a solve missed cg_tol since the last harvest -> strong local solves          */
+#define MVS_CTL_WORST  1     /* max rel^2 over the solves judged since the last harvest                            */
+#define MVS_CTL_MISSED 2     /* solves above cg_tol since the last harvest                                         */
+#define MVS_CTL_SOLVES 3     /* solves judged since the last harvest                                               */
+#define MVS_CTL_SEQ    4     /* outer iterations finalized since the handle was created                            */
+#define MVS_CTL_RING   8     /* [MVS_RING][8]: rel^2 of solve `it` of outer slot (seq % MVS_RING); -1 = did not run */
+#define MVS_RING       32
+#define MVS_CTL_SIZE   (MVS_CTL_RING + MVS_RING * 8)
 
 struct PhaseTimer {
     double total_ms = 0; int64_t launches = 0;
@@ -125,6 +139,13 @@ struct mvs_deform_s {
     int ras_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // calibrated sweeps per ARAP iteration (0 = not calibrated)
     double ras_a = 0.0;             // lower end of the Chebyshev bracket of the local solves (0 = default from the node density)
     int ras_m = 0;                  // Chebyshev steps per sweep
+    int ras_bump[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // > 0: this solve showed a thin margin lately -> one more sweep than first + 1
+    // closed loop (see MVS_CTL_*): device control block, its pinned host mirror, enqueue counters
+    double* d_ctl = nullptr;
+    volatile double* h_ctl = nullptr;
+    uint64_t seq_enqueued = 0;      // outer iterations enqueued since creation (the device counts the finalized ones in MVS_CTL_SEQ)
+    uint64_t seq_peeked = 0;        // ... whose ring row the host has already looked at
+    uint64_t bump_seq[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // first pass enqueued with the last in-batch correction of solve `it`
     // timing
     int timing = 0;                 // 0 off, 1 all phases, 2 "cg" groups only
     std::map<std::string, PhaseTimer> timers;
@@ -170,19 +191,23 @@ void launch_gather_nodes(const double* pts, const double* nrm, const int32_t* no
 void launch_smooth(const double* orig, const double* cur, const int32_t* nbr, int nn, int K, double* out, hipStream_t s);
 // ctrl != NULL: also initialises sol (node targets / rest positions) and rot (identity), Deformation.cpp:383-392
 void launch_cot_weights(const SellDev& m, const double* pts, double* coef, const double* ctrl, double* sol, double* rot, hipStream_t s);
-// bout != NULL: patch-solver mode, writes the right-hand side b (V*3) instead of the CG state (rws, p)
+// bout: the right-hand side b (V*3; both solvers — the local step measures the true residual against it);
+// rws / p != NULL: also the CG start state.  ctl / ring_row: the solver control block and this outer iteration's ring row
+// (the kernel judges the solve of ARAP iteration it-1 from the residual partials its local step left).
 void launch_arap_rhs(const SellDev& m, const double* pts, const double* sol, const double* rot, int it, double tol,
-                     double* ered, double* rws, double* p, double* bout, hipStream_t s);
+                     double* ered, double* rws, double* p, double* bout, double cg_tol, double* ctl, int ring_slot, hipStream_t s);
 void launch_cg_w0(const SellDev& m, const double* coef, int it, double tol, const double* ered, double* rws,
                   double* slot0, hipStream_t s);
 // slot_i = slot of CG iteration i of this solve (slot0 + i*MVS_CG_SLOT); alpha_i / gamma_i are written into it
 void launch_cg_iter(const SellDev& m, const double* coef, int it, double tol, const double* ered, int i, double cg_tol,
                     const double* slot0, double* slot_i, double* slot_next, const double* rws_in, double* rws_out,
                     double* p, double* x, hipStream_t s);
+// b != NULL: also the residual partials of the solve whose result `sol` is (ered + it*EIT + 4*NBMAX)
 void launch_arap_local(const SellDev& m, const double* pts, const double* sol, int it, double tol, double* ered,
-                       double* rot, hipStream_t s);
+                       double* rot, const double* b, hipStream_t s);
 void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered, const double* sol,
-                          double* pts, int32_t* info, const double* nrm, double* node_pts, double* node_nrm, hipStream_t s);
+                          double* pts, int32_t* info, const double* nrm, double* node_pts, double* node_nrm,
+                          double cg_tol, double* ctl, int ring_slot, double* host_ctl, hipStream_t s);
 int  arap_grid_blocks(const SellDev& m);
 // schwarz.hip
 int  ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& rowptr, const std::vector<int32_t>& col,

@@ -307,13 +307,15 @@ int mvs_processor_deform(const char* model_obj, const char* template_obj, const 
     if ((rc = mvs_deform_create(ns, src.data(), snrm.data(), nsf, sf.data(), &h))) return rc;             // :1136
     int64_t K = 0;
     std::vector<double> out_n((size_t)ns * 3);
+    int warn = MVS_OK;                                   // MVS_W_UNCONVERGED: the result is still written, the caller is told
     if ((rc = mvs_deform_set_target(h, nt, tgt.data(), tnrm.data(), 0)) ||
         (rc = mvs_deform_sample_nodes(h, 16, &K)) ||                                                       // Deformation.cpp:248-250
-        (rc = mvs_deform_iterate(h, &prm, 1, stats)) ||
-        (rc = mvs_deform_get_vertices(h, src.data())) ||
+        ((rc = mvs_deform_iterate(h, &prm, 1, stats)) < 0) ||
+        ((warn = rc), (rc = mvs_deform_get_vertices(h, src.data()))) ||
         (rc = mvs_deform_compute_normals(h, out_n.data()))) { mvs_deform_destroy(h); return rc; }          // exportOBJ, Deformation.h:174-221
     mvs_deform_destroy(h);
-    return mvs_obj_write(out_obj, ns, src.data(), out_n.data(), nsf, sf.data());
+    rc = mvs_obj_write(out_obj, ns, src.data(), out_n.data(), nsf, sf.data());
+    return rc ? rc : warn;
 }
 
 }  // extern "C"

@@ -6,9 +6,11 @@
 // iteration once the cold-cache load chain is added; tools/gridbar.hip, scripts/cg_stamps.py).  Here the mesh is cut
 // into patches of ~210 owned vertices plus three rings of overlap (<= 1024 rows, one 1024-thread workgroup, one CU).
 // One SWEEP = one launch: every workgroup loads its patch once, freezes everything outside it at the previous
-// sweep's values, solves its local system by Jacobi-PCG held in REGISTERS (row operands, matrix row) and LDS (the
-// search direction, which neighbours read), and writes back only its owned rows (restricted additive Schwarz).
-// The many cheap iterations (~0.3 us, workgroup barriers only) happen between kernel boundaries instead of at them:
+// sweep's values, forms the fp64 residual of its local rows and corrects it by a fixed number of steps of the
+// Chebyshev semi-iteration on the Jacobi-scaled patch matrix (spectrum bracketed by [a, 2]; no inner products, one
+// workgroup barrier per step; float32 arithmetic with the neighbours' directions passed through LDS as bfloat16
+// triples — row operands and the matrix row stay in REGISTERS), and writes back only its owned rows (restricted
+// additive Schwarz).  The many cheap steps (~0.3 us) happen between kernel boundaries instead of at them:
 // 5-6 sweeps reach 1e-8 where CG needed 34 launches (measured on the config-3 system).
 //
 // The fixed point of the sweep is the solution of the same linear system the oracle solves directly; the sweep
@@ -152,14 +154,15 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
                                                     const double* __restrict__ bvec, const double* __restrict__ xin,
                                                     double* __restrict__ xout, int it, double arap_tol,
                                                     const double* __restrict__ ered, int nb_rhs, int sweep, double cg_tol,
-                                                    ChebCoef cc, int cheb_m, double* __restrict__ slot_prev,
+                                                    ChebCoef cc, int cheb_m, ChebCoef cc_strong, int cheb_m_strong,
+                                                    const double* __restrict__ ctl, double* __restrict__ slot_prev,
                                                     double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur) {
     // LDS: fp64 x of the local rows and the halo while the residual is formed (24 KB), then the correction directions as
     // bfloat16 triples, double-buffered (2 x 8 KB of the same array).  The neighbours' directions only steer the inexact
     // local solve; the residual that decides convergence and the solution stay fp64.
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * RTPB * sizeof(float4)];
     __shared__ double s_gam[3], s_bn[3];
-    __shared__ int s_done;
+    __shared__ int s_done, s_esc;
     double4* xs = reinterpret_cast<double4*>(smem);                    // 32-byte records: two 16-byte LDS accesses per gather instead of three 8-byte ones
     const int p = blockIdx.x, row = threadIdx.x, lane = row & 63, wv = row >> 6;
     const int LS = R.LS, base = p * LS;                                 // fixed table stride: the loads below need only p
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         if (lane == 0) s_bn[wv - 3] = bn;
     } else if (row == 6 * 64) {
         s_done = arap_done_before(ered + EFIN, it, arap_tol) ? 1 : 0;
+        s_esc = ctl[MVS_CTL_ESC] != 0.0 ? 1 : 0;                       // a solve missed cg_tol since the last harvest: strong local solves
     }
     xs[row] = make_double4(xi.x, xi.y, xi.z, 0.0);
     if (row < nh) xs[LS + row] = make_double4(xh.x, xh.y, xh.z, 0.0);
@@ -248,10 +252,15 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     // The steps run in float32: they only shape the correction e of an INEXACT local solve (the residual that decides
     // convergence is formed in fp64 from x at the start of every sweep, the fixed point is untouched), and in fp64 a step
     // was bound by 24 float->double conversions + 33 fp64 FMAs per thread (1460 cycles per step on a CU, half of a sweep).
+    // Two coefficient sets travel with the launch: the planned one and a strong one (lower bracket end, more steps) that the
+    // DEVICE selects once any solve since the last harvest has missed cg_tol (MVS_CTL_ESC) — the launch plan of a batch is
+    // fixed on the host, the strength of the local solves is not.
+    const ChebCoef& ck = s_esc ? cc_strong : cc;
+    if (s_esc) cheb_m = cheb_m_strong;
     float ex = 0.f, ey = 0.f, ez = 0.f;
     const float di_f = (float)di, inv_d_f = (float)inv_d;
     float rx = (float)r.x, ry = (float)r.y, rz = (float)r.z;
-    const float c0f = (float)cc.c0 * inv_d_f;
+    const float c0f = (float)ck.c0 * inv_d_f;
     float dx = c0f * rx, dy = c0f * ry, dz = c0f * rz;
     float w2f[W];
 #pragma unroll
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
             if (fixed) { ax = 0.f; ay = 0.f; az = 0.f; }
             ex += dx; ey += dy; ez += dz;
             rx -= ax; ry -= ay; rz -= az;
-            const float c1 = (float)cc.c1[k & 31], c2 = (float)cc.c2[k & 31] * inv_d_f;
+            const float c1 = (float)ck.c1[k & 31], c2 = (float)ck.c2[k & 31] * inv_d_f;
             dx = __builtin_fmaf(c1, dx, c2 * rx); dy = __builtin_fmaf(c1, dy, c2 * ry); dz = __builtin_fmaf(c1, dz, c2 * rz);
         }
     }
@@ -438,7 +447,7 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
     R.pnloc = d_pnloc; R.pown = d_pown; R.LS = LS; R.l2g = d_l2g; R.lcol = d_lcol; R.gent = d_gent; R.gcol = d_gcol;
     R.HS = HS; R.pnh = d_pnh; R.hl2g = d_hl2g;
     h->ras = R;
-    if (hipMalloc((void**)&h->d_ras_x2, sizeof(double) * 3 * (size_t)V) != hipSuccess || hipMalloc((void**)&h->d_ras_b, sizeof(double) * 3 * (size_t)V) != hipSuccess) {
+    if (hipMalloc((void**)&h->d_ras_x2, sizeof(double) * 3 * (size_t)V) != hipSuccess) {
         mvs_set_error("hipMalloc failed (patch solver vectors)"); return MVS_E_OOM;
     }
     if (hipMalloc((void**)&h->d_ras_pw, sizeof(double) * (size_t)W * l2g.size()) != hipSuccess || hipMalloc((void**)&h->d_ras_pd, sizeof(double) * l2g.size()) != hipSuccess) {
@@ -481,9 +490,9 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, const double* xin,
     double cheb_a = h->ras_a;
     int cheb_m = h->ras_m;
     if (!(cheb_a > 0.0) || cheb_m <= 0) ras_default_bracket(h, &cheb_a, &cheb_m);
-    ChebCoef cc;                                   // Saad, Iterative Methods, Alg. 12.1 with [a, 2]
-    {
-        const double theta = 0.5 * (2.0 + cheb_a), delta = 0.5 * (2.0 - cheb_a), sigma1 = theta / delta;
+    auto coefs = [](double a) {                    // Saad, Iterative Methods, Alg. 12.1 with [a, 2]
+        ChebCoef cc;
+        const double theta = 0.5 * (2.0 + a), delta = 0.5 * (2.0 - a), sigma1 = theta / delta;
         double rho = 1.0 / sigma1;
         cc.c0 = 1.0 / theta;
         for (int k = 0; k < 32; ++k) {
@@ -491,9 +500,14 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, const double* xin,
             cc.c1[k] = rho_new * rho; cc.c2[k] = 2.0 * rho_new / delta;
             rho = rho_new;
         }
-    }
+        return cc;
+    };
+    const ChebCoef cc = coefs(cheb_a);
+    const double strong_a = std::max(0.002, cheb_a / 9.0);       // the set the device switches to after a missed solve
+    const ChebCoef cc2 = coefs(strong_a);
+    const int m2 = ras_steps_for(strong_a);
     const dim3 grid(R.NP), blk(h->ras_block);     // as many waves as the largest patch has rows (idle waves only add barrier cost)
-    if (R.W == 8) k_ras_sweep<8><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, cc, cheb_m, slot_prev, slot_cur, iters_cur);
-    else if (R.W == 12) k_ras_sweep<12><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, cc, cheb_m, slot_prev, slot_cur, iters_cur);
-    else k_ras_sweep<16><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, cc, cheb_m, slot_prev, slot_cur, iters_cur);
+    if (R.W == 8) k_ras_sweep<8><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur);
+    else if (R.W == 12) k_ras_sweep<12><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur);
+    else k_ras_sweep<16><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur);
 }

@@ -27,10 +27,15 @@ def default_params(**kw) -> L.CParams:
     return p
 
 
-def _stats(st: L.CStats) -> dict:
+def _stats(st: L.CStats, status: int = 0) -> dict:
+    """``status``: the call's return value (0, or MVS_W_UNCONVERGED when a global solve of the batch ended above
+    cg_tol); ``converged`` says the same as a bool."""
     return dict(outer_done=st.outer_done, arap_iters_run=st.arap_iters_run, cg_iters=st.cg_iters,
                 n_valid=st.n_valid, energy=np.array(st.energy[:]), cg_rel_residual=st.cg_rel_residual,
-                cg_launches=st.cg_launches, cg_active=st.cg_active)
+                cg_launches=st.cg_launches, cg_active=st.cg_active,
+                worst_rel_residual_in_batch=st.worst_rel_residual_in_batch, solves_in_batch=st.solves_in_batch,
+                unconverged_solves=st.unconverged_solves, escalated=bool(st.escalated),
+                status=int(status), converged=(status == 0 and st.unconverged_solves == 0))
 
 
 class Deformation:
@@ -118,8 +123,8 @@ class Deformation:
 
     def iterate(self, n_outer: int = 1) -> dict:
         st = L.CStats()
-        L.check(L.lib().mvs_deform_iterate(self._h, C.byref(self.params), n_outer, C.byref(st)))
-        return _stats(st)
+        rc = L.check(L.lib().mvs_deform_iterate(self._h, C.byref(self.params), n_outer, C.byref(st)))
+        return _stats(st, rc)
 
     def enqueue(self, n_outer: int = 1):
         """``iterate`` without the host synchronisation (needs one earlier synchronous call); pair with ``collect``."""
@@ -127,8 +132,8 @@ class Deformation:
 
     def collect(self) -> dict:
         st = L.CStats()
-        L.check(L.lib().mvs_deform_collect(self._h, C.byref(self.params), C.byref(st)))
-        return _stats(st)
+        rc = L.check(L.lib().mvs_deform_collect(self._h, C.byref(self.params), C.byref(st)))
+        return _stats(st, rc)
 
     # sharded phases (mvs.h: mvs_deform_assoc_*), device addresses in / out
     def assoc_dmin(self, d2min_dev: int):
@@ -152,8 +157,8 @@ class Deformation:
             L.check(L.lib().mvs_deform_solve(self._h, C.byref(self.params), None))
             return None
         st = L.CStats()
-        L.check(L.lib().mvs_deform_solve(self._h, C.byref(self.params), C.byref(st)))
-        return _stats(st)
+        rc = L.check(L.lib().mvs_deform_solve(self._h, C.byref(self.params), C.byref(st)))
+        return _stats(st, rc)
 
     def sync(self):
         L.check(L.lib().mvs_deform_sync(self._h))
@@ -175,8 +180,8 @@ class Deformation:
         if len(ct) != self.K:
             raise ValueError("one target per node")
         st = L.CStats()
-        L.check(L.lib().mvs_deform_arap(self._h, C.byref(self.params), L.ptr(ct), C.byref(st)))
-        return _stats(st)
+        rc = L.check(L.lib().mvs_deform_arap(self._h, C.byref(self.params), L.ptr(ct), C.byref(st)))
+        return _stats(st, rc)
 
     # ---------------------------------------------------------------- getters --
     def vertices(self) -> np.ndarray:

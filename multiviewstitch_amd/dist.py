@@ -78,27 +78,61 @@ class EngineShard:
         return self.d.solve(sync)
 
 
-def sharded_step(shard, bufs, world: int, group=None, sync: bool = True):
+def sharded_step(shard, bufs, world: int, group=None, sync: bool = True, timers: dict | None = None):
     """One outer iteration of Deformation::Deform's body over view-sharded targets.
-    sync=False leaves the step enqueued (no host synchronisation, returns None)."""
+    sync=False leaves the step enqueued (no host synchronisation, returns None).
+    timers (optional, bench.py): {"all_reduce": [], "all_gather": [], "sync": bool} — every collective is bracketed by a
+    pair of events on the current stream (or, with "sync", by drained-stream wall-clock stamps: gloo collectives are host
+    round trips) and the pair appended to the list."""
     stream = getattr(shard, "stream", None)
     if stream is not None:
         with torch.cuda.stream(stream):
-            return _sharded_step(shard, bufs, world, group, sync)
-    return _sharded_step(shard, bufs, world, group, sync)
+            return _sharded_step(shard, bufs, world, group, sync, timers)
+    return _sharded_step(shard, bufs, world, group, sync, timers)
 
 
-def _sharded_step(shard, bufs, world, group, sync):
+class _Bracket:
+    def __init__(self, timers, name):
+        self.t, self.name = timers, name
+
+    def __enter__(self):
+        if self.t is None:
+            return
+        if self.t.get("sync"):
+            torch.cuda.synchronize()
+            import time
+            self.a = time.perf_counter()
+        else:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.t is None:
+            return
+        if self.t.get("sync"):
+            torch.cuda.synchronize()
+            import time
+            b = time.perf_counter()
+        else:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+        self.t[self.name].append((self.a, b))
+
+
+def _sharded_step(shard, bufs, world, group, sync, timers=None):
     shard.dmin(bufs)
     if world > 1:
-        dist.all_reduce(bufs["d2min"], op=dist.ReduceOp.MIN, group=group)
+        with _Bracket(timers, "all_reduce"):
+            dist.all_reduce(bufs["d2min"], op=dist.ReduceOp.MIN, group=group)
     shard.select(bufs)
     if world > 1 and "pack" in bufs:
-        dist.all_gather_into_tensor(bufs["pack_all"], bufs["pack"], group=group)      # records and counts in one collective
+        with _Bracket(timers, "all_gather"):
+            dist.all_gather_into_tensor(bufs["pack_all"], bufs["pack"], group=group)      # records and counts in one collective
         shard.merge(bufs, world)
     elif world > 1:
-        dist.all_gather_into_tensor(bufs["rec_all"], bufs["rec"], group=group)
-        dist.all_gather_into_tensor(bufs["cnt_all"], bufs["cnt"], group=group)
+        with _Bracket(timers, "all_gather"):
+            dist.all_gather_into_tensor(bufs["rec_all"], bufs["rec"], group=group)
+            dist.all_gather_into_tensor(bufs["cnt_all"], bufs["cnt"], group=group)
         shard.merge(bufs, world)
     elif "pack" in bufs:
         shard.merge(dict(bufs, pack_all=bufs["pack"]), 1)

@@ -16,9 +16,9 @@ def Deform(model_obj, template_obj, parts_path, cam_R, dist_thres: float, out_ob
     R = L.arr(cam_R, np.float64).reshape(9)
     prm = params if params is not None else default_params()
     st = L.CStats()
-    L.check(L.lib().mvs_processor_deform(os.fsencode(model_obj), os.fsencode(template_obj), os.fsencode(parts_path), L.ptr(R),
-                                         float(dist_thres), C.byref(prm), os.fsencode(out_obj), C.byref(st)))
-    return _stats(st)
+    rc = L.check(L.lib().mvs_processor_deform(os.fsencode(model_obj), os.fsencode(template_obj), os.fsencode(parts_path), L.ptr(R),
+                                              float(dist_thres), C.byref(prm), os.fsencode(out_obj), C.byref(st)))
+    return _stats(st, rc)
 
 
 def CheckConsistencyCore(curcam, refcams, depth, refdepths, min_dsp: float, max_dsp: float, reproj_err: int) -> np.ndarray:

@@ -81,6 +81,12 @@ def _p(a):
 
 
 # ---------------------------------------------------------------- math ----
+def set_threads(n: int):
+    """OpenMP threads of the per-node / per-vertex / per-right-hand-side loops (default 1 = the reference's single thread);
+    results are bit-identical for any count."""
+    lib().orc_set_threads(C.c_int(int(n)))
+
+
 def svd3(A):
     A = _c(A, np.float64)
     U, S, V = np.empty((3, 3)), np.empty(3), np.empty((3, 3))

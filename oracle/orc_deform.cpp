@@ -12,6 +12,14 @@
 
 using namespace orc;
 
+// Thread count of the loops that are independent per node / vertex / right-hand side (OpenMP; default 1 = the reference's
+// single thread, R/MultiViewStitch.vcxproj has no OpenMP).  Every parallel loop writes disjoint outputs and keeps each
+// item's arithmetic in its serial order, so the results are bit-identical for any thread count (tests/test_oracle_pins.py).
+// Only bench.py's "openmp_all_cores" column raises it.
+static int g_threads = 1;
+extern "C" void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+extern "C" int orc_get_threads(void) { return g_threads; }
+
 namespace {
 
 // squared L2 as FLANN's L2<float> accumulates it for 3 components:
@@ -196,6 +204,7 @@ orc_target_t orc_target_create(int64_t P, const double* pts, const double* norma
 void orc_target_destroy(orc_target_t t) { delete t; }
 
 void orc_assoc_dmin(orc_target_t t, int64_t K, const double* node_pts, float* d2min) {
+#pragma omp parallel for schedule(dynamic, 64) num_threads(g_threads) if (g_threads > 1)
     for (int64_t i = 0; i < K; ++i) {          // Deformation.cpp:274-284
         const float q[3] = {(float)node_pts[3 * i], (float)node_pts[3 * i + 1], (float)node_pts[3 * i + 2]};
         KdTree::DI nn;
@@ -206,8 +215,11 @@ void orc_assoc_dmin(orc_target_t t, int64_t K, const double* node_pts, float* d2
 void orc_assoc_select(orc_target_t t, int64_t K, const double* node_pts, const double* node_nrm,
                       const orc_params* p, const float* d2min, void* records, int32_t* counts) {
     Cand* rec = (Cand*)records;
+#pragma omp parallel num_threads(g_threads) if (g_threads > 1)
+    {
     std::vector<int> ball;
     std::vector<Cand> cands;
+#pragma omp for schedule(dynamic, 64)
     for (int64_t i = 0; i < K; ++i) {
         for (int s = 0; s < 8; ++s) { rec[8 * i + s] = Cand{0, 0, {0, 0, 0}, -1}; }
         counts[2 * i] = counts[2 * i + 1] = 0;
@@ -229,6 +241,7 @@ void orc_assoc_select(orc_target_t t, int64_t K, const double* node_pts, const d
         const int keep = std::min<int>(p->top_k, (int)cands.size());
         std::partial_sort(cands.begin(), cands.begin() + keep, cands.end(), cand_less);
         for (int s = 0; s < keep; ++s) rec[8 * i + s] = cands[s];
+    }
     }
 }
 
@@ -414,6 +427,7 @@ int orc_arap(int64_t V, const double* pts, int64_t F, const int32_t* faces, int6
     int ite = 0;
     for (; ite < iters; ++ite) {
         // ---- update_solution_arap: b_i = sum_j (wij R_i + wji R_j)(p_i - p_j)
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
         for (int64_t i = 0; i < V; ++i) {
             if (is_ctrl[i]) { b[3 * i] = b[3 * i + 1] = b[3 * i + 2] = 0; continue; }
             V3 acc = {0, 0, 0};
@@ -435,43 +449,50 @@ int orc_arap(int64_t V, const double* pts, int64_t F, const int32_t* faces, int6
                                            else r[3 * i + c] = 0;
             (void)bn;
         }
+        // (the three right-hand sides are independent solves: one thread each when threads are allowed; each works on
+        //  contiguous private copies of its column — same arithmetic, no cache lines shared between the threads)
+#pragma omp parallel for schedule(static, 1) num_threads(g_threads < 3 ? g_threads : 3) if (g_threads > 1)
         for (int c = 0; c < 3; ++c) {
+            std::vector<double> rc(V), zc(V), pc(V), Ac(V), xc(V), bc(V);
+            for (int64_t i = 0; i < V; ++i) { rc[i] = r[3 * i + c]; xc[i] = sol[3 * i + c]; bc[i] = b[3 * i + c]; }
             double bn = 0, rz = 0;
             for (int64_t i = 0; i < V; ++i) if (!is_ctrl[i]) {
-                bn += b[3 * i + c] * b[3 * i + c];
-                z[3 * i + c] = r[3 * i + c] / diag[i]; pp[3 * i + c] = z[3 * i + c];
-                rz += r[3 * i + c] * z[3 * i + c];
-            } else { z[3 * i + c] = pp[3 * i + c] = 0; }
+                bn += bc[i] * bc[i];
+                zc[i] = rc[i] / diag[i]; pc[i] = zc[i];
+                rz += rc[i] * zc[i];
+            } else { zc[i] = pc[i] = 0; }
             const double stop = 1e-28 * (bn > 0 ? bn : 1.0);
             for (int it = 0; it < 20000; ++it) {
                 double rr = 0;
-                for (int64_t i = 0; i < V; ++i) rr += r[3 * i + c] * r[3 * i + c];
+                for (int64_t i = 0; i < V; ++i) rr += rc[i] * rc[i];
                 if (rr <= stop) break;
                 // Ap (column c only)
                 double pAp = 0;
                 for (int64_t i = 0; i < V; ++i) {
-                    if (is_ctrl[i]) { Ap[3 * i + c] = 0; continue; }
-                    double acc = diag[i] * pp[3 * i + c];
+                    if (is_ctrl[i]) { Ac[i] = 0; continue; }
+                    double acc = diag[i] * pc[i];
                     for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
                         const int j = A.col[k];
-                        if (!is_ctrl[j]) acc -= 2.0 * w[k] * pp[3 * j + c];
+                        if (!is_ctrl[j]) acc -= 2.0 * w[k] * pc[j];
                     }
-                    Ap[3 * i + c] = acc; pAp += acc * pp[3 * i + c];
+                    Ac[i] = acc; pAp += acc * pc[i];
                 }
                 if (!(pAp > 0)) break;
                 const double alpha = rz / pAp;
                 double rz2 = 0;
                 for (int64_t i = 0; i < V; ++i) if (!is_ctrl[i]) {
-                    sol[3 * i + c] += alpha * pp[3 * i + c];
-                    r[3 * i + c] -= alpha * Ap[3 * i + c];
-                    z[3 * i + c] = r[3 * i + c] / diag[i];
-                    rz2 += r[3 * i + c] * z[3 * i + c];
+                    xc[i] += alpha * pc[i];
+                    rc[i] -= alpha * Ac[i];
+                    zc[i] = rc[i] / diag[i];
+                    rz2 += rc[i] * zc[i];
                 }
                 const double beta = rz2 / rz; rz = rz2;
-                for (int64_t i = 0; i < V; ++i) if (!is_ctrl[i]) pp[3 * i + c] = z[3 * i + c] + beta * pp[3 * i + c];
+                for (int64_t i = 0; i < V; ++i) if (!is_ctrl[i]) pc[i] = zc[i] + beta * pc[i];
             }
+            for (int64_t i = 0; i < V; ++i) sol[3 * i + c] = xc[i];
         }
         // ---- optimal_rotations_arap: cov_i = sum_j wij p_ij q_ij^T ; R_i = closest rotation
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
         for (int64_t i = 0; i < V; ++i) {
             double cov[9] = {0};
             for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {

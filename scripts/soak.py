@@ -20,12 +20,12 @@ for k in range(16):
     t0 = time.perf_counter()
     st = d.iterate(25)
     dt = time.perf_counter() - t0
-    worst = max(worst, st["cg_rel_residual"])
-    reports.append(st["cg_rel_residual"])
+    # worst TRUE residual over EVERY solve of the 25 passes (each judged on the device), not only the last pass
+    worst = max(worst, st["worst_rel_residual_in_batch"])
+    reports.append(st["worst_rel_residual_in_batch"])
     print(f"outer {25 * (k + 1):4d}: {1e3 * dt / 25:.3f} ms/iter, arap_iters_run {st['arap_iters_run']}, sweeps {st['cg_launches']} (active {st['cg_active']}), "
-          f"rel residual {st['cg_rel_residual']:.2e}, valid nodes {st['n_valid']}, energy {st['energy'][0]:.4e} -> {st['energy'][st['arap_iters_run'] - 1]:.4e}")
-# a launch plan is fixed from the previous harvest: when the system's conditioning jumps (it does around outer 175 on this
-# workload) the steps until the next harvest are under-converged, then the plan and the Chebyshev bracket adapt
+          f"worst rel residual of the batch {st['worst_rel_residual_in_batch']:.2e} ({st['unconverged_solves']} of {st['solves_in_batch']} solves above cg_tol, "
+          f"status {st['status']}, escalated {st['escalated']}), valid nodes {st['n_valid']}, energy {st['energy'][0]:.4e} -> {st['energy'][st['arap_iters_run'] - 1]:.4e}", flush=True)
 ok = sum(r <= 1.5e-8 for r in reports)
-print(f"{ok} of {len(reports)} reports within 1.5 cg_tol, worst {worst:.2e}")
-assert ok >= 0.75 * len(reports) and worst < 1e-5
+print(f"{ok} of {len(reports)} batches within 1.5 cg_tol, worst {worst:.2e}")
+assert worst <= 1.5e-8, worst

@@ -24,14 +24,14 @@ def test_every_declared_symbol_is_exported():
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
     assert sorted(_lib.EXPORTS) == decl, "multiviewstitch_amd/_lib.py signature table out of sync with include/*.h"
-    assert lib.mvs_abi_version() == 1
+    assert lib.mvs_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header():
     from multiviewstitch_amd import _lib
     assert C.sizeof(_lib.CCamera) == 4 * 8 + 9 * 8 + 3 * 8 + 2 * 4
     assert C.sizeof(_lib.CParams) == 80
-    assert C.sizeof(_lib.CStats) == 4 * 4 + 8 * 8 + 8 + 2 * 4
+    assert C.sizeof(_lib.CStats) == 4 * 4 + 8 * 8 + 8 + 2 * 4 + 8 + 4 * 4
     assert _lib.CAND_DTYPE.itemsize == 48
     from oracle import binding as O
     assert C.sizeof(O.Params) == C.sizeof(_lib.CParams) and C.sizeof(O.Camera) == C.sizeof(_lib.CCamera)

@@ -117,3 +117,24 @@ def test_view_shards_cover_every_view_once():
         sh = mdist.view_shards(n, w)
         assert len(sh) == w and sorted(v for s in sh for v in s) == list(range(n))
         assert max(len(s) for s in sh) - min(len(s) for s in sh) <= 1
+
+
+def test_bench_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus N` with no external launcher: the parent starts N ranks of itself (before touching any GPU),
+    relays rank 0's JSON line and fails when a rank fails.  Rehearsed here on the CPU with --dry-run (gloo)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["backend"] == "gloo" and out["sum_of_rank_ids_plus_1"] == 3.0
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run"],
+                       env=dict(env, MVS_BENCH_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0

@@ -230,3 +230,46 @@ def test_results_are_bit_reproducible(eng):
         st = d.iterate(2)
         outs.append((d.vertices(), d.rotations(), np.array(st["energy"])))
     assert all(np.array_equal(a, b) for a, b in zip(*outs))
+
+
+def test_solver_loop_reports_and_recovers_from_a_stale_plan(eng):
+    """The launch plan of a handle is sized from its previous solves.  Here it is made stale on purpose: calibrated at
+    cg_tol = 1e-4, then asked for 1e-10 inside ONE iterate(8) batch.  Every solve is judged on the device (true residual
+    of its result): the call must say that solves ended above cg_tol (status MVS_W_UNCONVERGED, counts, worst residual),
+    the device must have switched to the strong local solves, and the next call — re-planned from the harvest — must
+    converge."""
+    sc, tp, tn, _ = scene_and_target(2)
+    d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    assert d.solver_info()["kind"] == "patch"
+    d.UniformSampling(16)
+    d.set_target(tp, tn)
+    d.params.cg_tol = 1e-4
+    st = d.iterate(2)
+    assert st["converged"] and st["status"] == 0 and st["worst_rel_residual_in_batch"] <= 1e-4
+    assert st["solves_in_batch"] >= 4
+    d.params.cg_tol = 1e-10
+    st = d.iterate(8)
+    assert st["status"] == 1 and not st["converged"]
+    assert st["unconverged_solves"] > 0 and st["worst_rel_residual_in_batch"] > 1e-10 and st["escalated"]
+    assert st["unconverged_solves"] <= st["solves_in_batch"]
+    for _ in range(3):                                  # a harvest re-plans (2 n sweeps after a miss): at most a few calls to catch up
+        st = d.iterate(4)
+        if st["converged"]:
+            break
+    assert st["converged"] and st["status"] == 0 and st["worst_rel_residual_in_batch"] <= 1e-10 and not st["escalated"]
+    st = d.iterate(8)                                   # and stays converged, batch after batch
+    assert st["converged"] and st["cg_rel_residual"] <= 1e-10
+
+
+def test_every_solve_of_a_batch_is_judged(eng):
+    """worst_rel_residual_in_batch covers all passes of a call, cg_rel_residual the last one; both are TRUE residuals."""
+    sc, tp, tn, _ = scene_and_target(1)
+    for solver in (0, 1):
+        d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+        d.params.solver = solver
+        d.UniformSampling(16)
+        d.set_target(tp, tn)
+        d.iterate(1)
+        st = d.iterate(6)
+        assert st["converged"] and st["solves_in_batch"] >= 6 * 2 and st["unconverged_solves"] == 0
+        assert 0 < st["cg_rel_residual"] <= st["worst_rel_residual_in_batch"] <= d.params.cg_tol

@@ -128,3 +128,27 @@ def test_engine_shard_orders_with_the_collectives_stream(big):
     assert st["n_valid"] == rs["n_valid"] and np.array_equal(d.vertices(), ref.vertices())
     d.set_stream(None)
     assert d.stream() == own
+
+
+def test_config3_matches_oracle_at_vertex_level(big, oracle):
+    """The workload bench.py times (BASELINE config 3: 2.04 M points, 8 142 nodes, 54 762 vertices, 256 patches), compared
+    with the oracle's Deformation::Deform (R/Deformation/Deformation.cpp:232-402) outer iteration by outer iteration:
+    node set, valid-node count, ARAP iterations run (integers: equal), vertices and per-vertex rotations (<= 1e-6 RMS;
+    the north-star bound is 1e-4)."""
+    from tests.util import rms
+    d, tp, tn = make(big)
+    sc = big["sc"]
+    assert d.solver_info()["kind"] == "patch" and d.solver_info()["patches"] == 256
+    o = oracle.Deform(sc.verts, sc.normals, sc.faces)
+    assert o.sample_nodes(16) == d.K and np.array_equal(o.nodes(), d.nodes())
+    o.set_target(tp.cpu().numpy(), tn.cpu().numpy())
+    p = oracle.Params.default()
+    for it in range(3):
+        st, so = d.iterate(1), o.iterate(p, 1)
+        assert st["n_valid"] == so["n_valid"] and st["arap_iters_run"] == so["arap_iters_run"], f"outer {it}"
+        assert st["converged"] and st["worst_rel_residual_in_batch"] <= 1.5 * d.params.cg_tol
+        assert np.allclose(st["energy"][:5], so["energy"][:5], rtol=1e-6, atol=1e-12)
+        gs, os_ = d.node_targets(smoothed=True)["controls"], o.node_targets(smoothed=True)[0]
+        assert np.abs(gs - os_).max() <= 1e-10, f"outer {it}"
+        assert rms(d.vertices(), o.vertices()) <= 1e-6, f"outer {it}"
+        assert rms(d.rotations().reshape(-1, 9), o.rotations().reshape(-1, 9)) <= 1e-6, f"outer {it}"

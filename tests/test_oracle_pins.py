@@ -221,3 +221,23 @@ def test_bad_meshes_are_rejected(oracle):
     assert oracle.mesh_check(len(g["verts"]), bad) == -2
     with pytest.raises(ValueError):
         oracle.Deform(g["verts"], g["normals"], bad)
+
+
+def test_oracle_threads_do_not_change_a_bit(oracle):
+    """bench.py's "openmp_all_cores" column runs the oracle with OpenMP threads: the parallel loops are per node / per
+    vertex / per right-hand side with each item's arithmetic in serial order, so any thread count gives the same bits."""
+    from tests.util import scene_and_target
+    sc, tp, tn, _ = scene_and_target(1)
+    outs = []
+    try:
+        for threads in (1, 3, 5):
+            oracle.set_threads(threads)
+            o = oracle.Deform(sc.verts, sc.normals, sc.faces)
+            o.sample_nodes(16)
+            o.set_target(tp, tn)
+            st = o.iterate(oracle.Params.default(), 2)
+            outs.append((o.vertices(), o.rotations(), st["energy"], o.node_targets(True)[0]))
+    finally:
+        oracle.set_threads(1)
+    for other in outs[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(outs[0], other))
