@@ -229,7 +229,7 @@ class Target:
                                                     C.c_int64(index_base)))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:      # (module globals may be gone at interpreter exit)
             lib().orc_target_destroy(self.h)
             self.h = None
 
@@ -309,7 +309,8 @@ class Deform:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_deform_destroy(self.h)
+            if lib is not None:                                # (module globals may be gone at interpreter exit)
+                lib().orc_deform_destroy(self.h)
             self.h = None
 
     def sample_nodes(self, knn=16):
@@ -402,6 +403,14 @@ def part_recog(tmpl, tmpl_labels, pts):
     t, tl, p = _c(tmpl, np.float64), _c(tmpl_labels, np.int32), _c(pts, np.float64)
     out = np.empty(len(p), np.int32)
     lib().orc_part_recog(_p(t), _p(tl), C.c_int64(len(t)), _p(p), C.c_int64(len(p)), _p(out))
+    return out
+
+
+def part_recog_brute(tmpl, tmpl_labels, pts):
+    """the literal all-pairs scan (small inputs only): what part_recog's kd-tree must reproduce"""
+    t, tl, p = _c(tmpl, np.float64), _c(tmpl_labels, np.int32), _c(pts, np.float64)
+    out = np.empty(len(p), np.int32)
+    lib().orc_part_recog_brute(_p(t), _p(tl), C.c_int64(len(t)), _p(p), C.c_int64(len(p)), _p(out))
     return out
 
 

@@ -132,6 +132,10 @@ int  orc_remove_ground(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t
 int  orc_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray,
                         const double* view_ray, double* R, double* t, double* scale);
 void orc_part_recog(const double* tmpl, const int32_t* tmpl_labels, int64_t V, const double* pts, int64_t P, int32_t* out);
+void orc_part_recog_brute(const double* tmpl, const int32_t* tmpl_labels, int64_t V, const double* pts, int64_t P, int32_t* out);
+void orc_nearest_index(const double* base, int64_t V, const double* pts, int64_t P, int32_t* out_idx);
+void orc_set_threads(int n);
+int  orc_get_threads(void);
 int  orc_local_alignment_core(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels,
                               int64_t nt, uint32_t group_mask, int label, double* R, double* t, double* scale);
 int  orc_align(double* src, double* s_nrm, int64_t ns, const int32_t* s_labels, double* tgt, double* t_nrm, int64_t* nt,

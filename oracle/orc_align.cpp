@@ -266,7 +266,8 @@ int orc_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t
 }
 
 // PartRecognition::PartRecog (PartRecognition.cpp:50-77): label of the nearest template vertex
-void orc_part_recog(const double* tmpl, const int32_t* tmpl_labels, int64_t V, const double* pts, int64_t P, int32_t* out) {
+// brute-force form (every template vertex scanned per point): the literal restatement; kept for the pin test
+void orc_part_recog_brute(const double* tmpl, const int32_t* tmpl_labels, int64_t V, const double* pts, int64_t P, int32_t* out) {
     std::vector<float> tf((size_t)V * 3);
     for (size_t i = 0; i < (size_t)V * 3; ++i) tf[i] = (float)tmpl[i];
     for (int64_t i = 0; i < P; ++i) {
@@ -275,6 +276,15 @@ void orc_part_recog(const double* tmpl, const int32_t* tmpl_labels, int64_t V, c
         for (int64_t j = 0; j < V; ++j) { const float d = d2f32(q, &tf[3 * j]); if (d < best) { best = d; arg = j; } }
         out[i] = tmpl_labels[arg];
     }
+}
+// the same labels through the exact kd-tree 1-NN of orc_deform.cpp (O(P log V): BASELINE config 5 asks 2 M points
+// against 216 K template vertices)
+void orc_nearest_index(const double* base, int64_t V, const double* pts, int64_t P, int32_t* out_idx);
+void orc_part_recog(const double* tmpl, const int32_t* tmpl_labels, int64_t V, const double* pts, int64_t P, int32_t* out) {
+    if (V <= 0) { for (int64_t i = 0; i < P; ++i) out[i] = 0; return; }
+    std::vector<int32_t> idx((size_t)P);
+    orc_nearest_index(tmpl, V, pts, P, idx.data());
+    for (int64_t i = 0; i < P; ++i) out[i] = tmpl_labels[idx[i]];
 }
 
 // Alignment::LocalAlignmentCore (Alignment.cpp:423-546) on the points of src/tgt selected by group_mask;

@@ -193,6 +193,20 @@ void orc_knn_points(const double* pts, int64_t n, int k, int32_t* out_idx) {
     }
 }
 
+// exact nearest point of `base` (float32 coordinates, FLANN's accumulation order, ties -> lower index) for every query:
+// the kd-tree form of the 1-NN that PartRecog needs (orc_align.cpp); identical to a brute-force scan by construction of
+// KdTree::knn's (distance, index) order — checked against one in tests/test_oracle_pins.py
+void orc_nearest_index(const double* base, int64_t V, const double* pts, int64_t P, int32_t* out_idx) {
+    KdTree kd;
+    kd.build(base, V);
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(g_threads) if (g_threads > 1)
+    for (int64_t i = 0; i < P; ++i) {
+        const float q[3] = {(float)pts[3 * i], (float)pts[3 * i + 1], (float)pts[3 * i + 2]};
+        KdTree::DI nn;
+        out_idx[i] = kd.knn(q, 1, &nn) ? nn.i : 0;
+    }
+}
+
 orc_target_t orc_target_create(int64_t P, const double* pts, const double* normals, int64_t index_base) {
     orc_target_s* t = new orc_target_s;
     t->P = P; t->base = index_base;

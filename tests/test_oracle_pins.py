@@ -241,3 +241,17 @@ def test_oracle_threads_do_not_change_a_bit(oracle):
         oracle.set_threads(1)
     for other in outs[1:]:
         assert all(np.array_equal(a, b) for a, b in zip(outs[0], other))
+
+
+def test_part_recog_kdtree_equals_the_all_pairs_scan(oracle):
+    """PartRecog's 1-NN (R/PartRecognition/PartRecognition.cpp:50-77) through the oracle's kd-tree == the literal scan,
+    including exact duplicates of template vertices (tie -> lower index) and queries far outside the template."""
+    rng = np.random.default_rng(21)
+    tmpl = rng.normal(size=(700, 3))
+    tmpl[100] = tmpl[40]                                   # duplicate vertices with different labels
+    tmpl[650] = tmpl[40]
+    labels = rng.integers(0, 16, len(tmpl)).astype(np.int32)
+    labels[40], labels[100], labels[650] = 3, 9, 12
+    pts = np.concatenate([rng.normal(size=(4000, 3)) * 1.5, tmpl[[40, 100, 650]], tmpl[:50] + 1e-9, rng.normal(size=(20, 3)) * 50])
+    a, b = oracle.part_recog(tmpl, labels, pts), oracle.part_recog_brute(tmpl, labels, pts)
+    assert np.array_equal(a, b) and a[4000] == a[4001] == a[4002] == 3
