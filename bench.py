@@ -447,7 +447,8 @@ def main():
                                   f"kd-tree build {t_build:.2f}s excluded)"}
         # second column: the same code with OpenMP on every host core — per-node / per-vertex loops on all
         # threads, the global solve on 3 (one per right-hand side); bit-identical results
-        threads = max(1, len(os.sched_getaffinity(0)))
+        # (one thread per core up to 32: beyond that the 8 K-node / 55 K-vertex loops are too short to amortise the fork-join)
+        threads = int(os.environ.get("MVS_BENCH_OMP_THREADS", "0")) or max(1, min(32, len(os.sched_getaffinity(0))))
         O.set_threads(threads)
         n2, t2 = 0, 0.0
         while n2 < args.steps and t2 < 8.0:

@@ -166,11 +166,22 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
                                                   int it, double tol, double* __restrict__ ered,
                                                   double* __restrict__ rws, double* __restrict__ p,
                                                   double* __restrict__ bout, double cg_tol, double* __restrict__ ctl,
-                                                  int ring_slot) {
+                                                  int ring_slot, const double* __restrict__ prev_scal, unsigned* __restrict__ bar,
+                                                  double* __restrict__ bpure) {
     double* efin = ered + EFIN;
     __shared__ int s_done;
-    // block 0 judges the global solve of the previous ARAP iteration (true residual measured by its local step)
-    if (blockIdx.x == 0 && it >= 1 && ctl) judge_solve(ered, it - 1, gridDim.x, cg_tol, ctl, ring_slot, !arap_done_before(efin, it - 1, tol));
+    // The LAST block of the grid does no rows when there is a solve to judge (it >= 1): it folds the true-residual partials the
+    // previous ARAP iteration's local step left, writes the verdict into the control block (MVS_CTL_*), resets the barrier
+    // words of the coming solve's tail loop — concurrently with the row work of the others instead of in front of it.
+    const bool judge_block = ctl && it >= 1 && gridDim.x >= 2;
+    const int nbw = judge_block ? (int)gridDim.x - 1 : (int)gridDim.x;          // blocks that work on rows
+    if (bar && blockIdx.x == gridDim.x - 1 && threadIdx.x < 2) bar[threadIdx.x] = 0u;
+    if (judge_block && blockIdx.x == nbw) {
+        judge_solve(ered, it - 1, gridDim.x, cg_tol, ctl, ring_slot, !arap_done_before(efin, it - 1, tol), prev_scal);
+        if (threadIdx.x < 3) ered[it * EIT + (1 + threadIdx.x) * NBMAX + blockIdx.x] = 0.0;      // its slot of the bnorm partials
+        return;
+    }
+    if (!judge_block && blockIdx.x == 0 && it >= 1 && ctl) judge_solve(ered, it - 1, gridDim.x, cg_tol, ctl, ring_slot, !arap_done_before(efin, it - 1, tol), prev_scal);
     if (threadIdx.x < 64) {                      // wave 0 decides
         bool done = arap_done_before(efin, it - 1, tol);
         if (it >= 1) {
@@ -184,10 +195,10 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
     __syncthreads();
     if (s_done) return;
     double bn_acc = 0.0;
-    FOR_ROW_GROUPS(m, g) {
+    for (int g = blockIdx.x * NW + (threadIdx.x >> 6); g < m.nslices; g += nbw * NW) {
         const RowCtx r = row_ctx(m, g);
         const bool freerow = r.live && !m.is_ctrl[r.row];
-        d3 bb = mk3(0, 0, 0), ax = mk3(0, 0, 0);
+        d3 bb = mk3(0, 0, 0), ax = mk3(0, 0, 0), bd = mk3(0, 0, 0);      // bd: the Dirichlet columns' share of b
         if (freerow) {
             const d3 pi = ld3(pts + 3 * r.row);
             const double* Ri = rot + 9 * (int64_t)r.row;
@@ -202,14 +213,18 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
                 for (int c = 0; c < 9; ++c) M[c] = w * Ri[c] + w * Rj[c];
                 const d3 xj = ld3(sol + 3 * j);
                 bb = bb + mulMv(M, pi - ld3(pts + 3 * j));
-                if (m.is_ctrl[j]) bb = bb + (2.0 * w) * xj;      // Dirichlet column moved to the rhs
+                if (m.is_ctrl[j]) { bb = bb + (2.0 * w) * xj; bd = bd + (2.0 * w) * xj; }      // Dirichlet column moved to the rhs
                 else ax = ax - (2.0 * w) * xj;
             }
         }
         bb = mk3(red8(bb.x), red8(bb.y), red8(bb.z));
         ax = mk3(red8(ax.x), red8(ax.y), red8(ax.z));
+        if (bpure) bd = mk3(red8(bd.x), red8(bd.y), red8(bd.z));
         if (r.live && r.l < 3) {
             double res = 0.0;
+            // b without its Dirichlet share, NaN-free marker for control rows: what the local step needs to form the true
+            // residual of the solve from the edge differences it already holds (r_i = bpure_i - sum_j 2 w_ij (x_i - x_j))
+            if (bpure) bpure[3 * r.row + r.l] = freerow ? (r.l == 0 ? bb.x - bd.x : (r.l == 1 ? bb.y - bd.y : bb.z - bd.z)) : 0.0;
             if (freerow) {
                 const double di = m.diag[r.row];
                 const double b_c = r.l == 0 ? bb.x : (r.l == 1 ? bb.y : bb.z);
@@ -445,16 +460,15 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
         // the first eight edges (all of them when the degree is <= 8) stay in registers for the energy term
         double w0[8];
         d3 pp0[8], qq0[8];
-        int cj0[8];
         const bool judge = bvec != nullptr && m.is_ctrl[i] == 0;
-        // r_i = b_i - (d_i x_i - sum_{free j} 2 w_ij x_j) = b_i - sum_j 2 w_ij (x_i - x_j) - sum_{ctrl j} 2 w_ij x_j
+        // r_i = b_i - (d_i x_i - sum_{free j} 2 w_ij x_j) = (b_i - sum_{ctrl j} 2 w_ij x_j) - sum_j 2 w_ij (x_i - x_j): the first
+        // bracket is the `bpure` the rhs kernel wrote (bvec), the edge differences are the ones of the covariance
         d3 ax = mk3(0, 0, 0);
 #pragma unroll
         for (int l = 0; l < 8; ++l) {
             const int e = off + r * 8 + l;
             w0[l] = m.w[e];
             const int j = w0[l] == 0.0 ? i : m.col[e];
-            cj0[l] = judge ? m.is_ctrl[j] : 0;
             pp0[l] = pi - ld3(pts + 3 * j); qq0[l] = qi - ld3(sol + 3 * j);
         }
 #pragma unroll
@@ -462,7 +476,7 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
             if (w0[l] == 0.0) continue;
             const double w = w0[l];
             const d3 pp = pp0[l], qq = qq0[l];
-            if (judge) ax = ax + (2.0 * w) * (cj0[l] ? qi : qq);            // ctrl column: (x_i - x_j) + x_j
+            if (judge) ax = ax + (2.0 * w) * qq;
             c[0] += w * (pp.x * qq.x); c[1] += w * (pp.x * qq.y); c[2] += w * (pp.x * qq.z);
             c[3] += w * (pp.y * qq.x); c[4] += w * (pp.y * qq.y); c[5] += w * (pp.y * qq.z);
             c[6] += w * (pp.z * qq.x); c[7] += w * (pp.z * qq.y); c[8] += w * (pp.z * qq.z);
@@ -475,7 +489,7 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
                 if (w == 0.0) continue;
                 const int j = m.col[e];
                 const d3 pp = pi - ld3(pts + 3 * j), qq = qi - ld3(sol + 3 * j);
-                if (judge) ax = ax + (2.0 * w) * (m.is_ctrl[j] ? qi : qq);
+                if (judge) ax = ax + (2.0 * w) * qq;
                 c[0] += w * (pp.x * qq.x); c[1] += w * (pp.x * qq.y); c[2] += w * (pp.x * qq.z);
                 c[3] += w * (pp.y * qq.x); c[4] += w * (pp.y * qq.y); c[5] += w * (pp.y * qq.z);
                 c[6] += w * (pp.z * qq.x); c[7] += w * (pp.z * qq.y); c[8] += w * (pp.z * qq.z);
@@ -518,13 +532,14 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
 __global__ void k_arap_finalize(SellDev m, int iters, double tol, int nb, double* __restrict__ ered,
                                 const double* __restrict__ sol, double* __restrict__ pts, int32_t* __restrict__ info,
                                 const double* __restrict__ nrm, double* __restrict__ node_pts, double* __restrict__ node_nrm,
-                                double cg_tol, double* __restrict__ ctl, int ring_slot, double* __restrict__ host_ctl) {
+                                double cg_tol, double* __restrict__ ctl, int ring_slot, double* __restrict__ host_ctl,
+                                const double* __restrict__ last_scal) {
     // assign_solution + overwrite_initial_geometry (Deformation.cpp:398-400)
     double* efin = ered + EFIN;
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == gridDim.x - 1) {           // the extra block: stop-rule bookkeeping, the last solve's verdict, the host mirror
         // the last iteration's energy is only meaningful if that iteration ran (its kernels exit once the rule fired)
         const bool done = arap_done_before(efin, iters - 1, tol);
-        if (ctl) judge_solve(ered, iters - 1, nb, cg_tol, ctl, ring_slot, !done);       // (contains the block's barrier)
+        if (ctl) judge_solve(ered, iters - 1, nb, cg_tol, ctl, ring_slot, !done, last_scal);       // (contains the block's barrier)
         if (threadIdx.x < 64) {
             const double e_last = fold_partials(ered + (iters - 1) * EIT, nb);
             if (threadIdx.x == 0) {
@@ -540,11 +555,13 @@ __global__ void k_arap_finalize(SellDev m, int iters, double tol, int nb, double
                     // close this outer iteration's ring row and publish the control block to the host mirror (pinned,
                     // host-coherent): the host follows the solves without synchronising the stream
                     double* row = ctl + MVS_CTL_RING + ring_slot * 8;
-                    for (int t = run; t < 8; ++t) row[t] = -1.0;
+                    double* used = ctl + MVS_CTL_USED + ring_slot * 8;
+                    for (int t = run; t < 8; ++t) { row[t] = -1.0; used[t] = 0.0; }
                     ctl[MVS_CTL_SEQ] += 1.0;
                     if (host_ctl) {
                         double* hrow = host_ctl + MVS_CTL_RING + ring_slot * 8;
-                        for (int t = 0; t < 8; ++t) hrow[t] = row[t];
+                        double* hused = host_ctl + MVS_CTL_USED + ring_slot * 8;
+                        for (int t = 0; t < 8; ++t) { hrow[t] = row[t]; hused[t] = used[t]; }
                         for (int t = 0; t < MVS_CTL_SEQ; ++t) host_ctl[t] = ctl[t];
                         __threadfence_system();
                         host_ctl[MVS_CTL_SEQ] = ctl[MVS_CTL_SEQ];                 // last: a row is complete when its sequence number shows
@@ -553,6 +570,7 @@ __global__ void k_arap_finalize(SellDev m, int iters, double tol, int nb, double
                 }
             }
         }
+        return;
     }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m.V) {
@@ -604,8 +622,9 @@ void launch_cot_weights(const SellDev& m, const double* pts, double* coef, const
     if (coef) k_cg_coef<<<g, dim3(TPB), 0, s>>>(m, coef);      // CG only (the patch solver builds its own matrix)
 }
 void launch_arap_rhs(const SellDev& m, const double* pts, const double* sol, const double* rot, int it, double tol,
-                     double* ered, double* rws, double* p, double* bout, double cg_tol, double* ctl, int ring_slot, hipStream_t s) {
-    k_arap_rhs<<<dim3(arap_grid_blocks(m)), dim3(TPB), 0, s>>>(m, pts, sol, rot, it, tol, ered, rws, p, bout, cg_tol, ctl, ring_slot);
+                     double* ered, double* rws, double* p, double* bout, double cg_tol, double* ctl, int ring_slot,
+                     const double* prev_solve_scalars, unsigned* bar, double* bpure, hipStream_t s) {
+    k_arap_rhs<<<dim3(arap_grid_blocks(m)), dim3(TPB), 0, s>>>(m, pts, sol, rot, it, tol, ered, rws, p, bout, cg_tol, ctl, ring_slot, prev_solve_scalars, bar, bpure);
 }
 void launch_cg_w0(const SellDev& m, const double* coef, int it, double tol, const double* ered, double* rws,
                   double* slot0, hipStream_t s) {
@@ -625,9 +644,9 @@ void launch_arap_local(const SellDev& m, const double* pts, const double* sol, i
 // node_pts != NULL: also gathers the nodes' new positions and (unchanged) normals, as k_gather_nodes would
 void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered, const double* sol,
                           double* pts, int32_t* info, const double* nrm, double* node_pts, double* node_nrm,
-                          double cg_tol, double* ctl, int ring_slot, double* host_ctl, hipStream_t s) {
-    k_arap_finalize<<<dim3((m.V + 255) / 256), dim3(256), 0, s>>>(m, iters, tol, arap_grid_blocks(m), ered, sol, pts, info, nrm, node_pts, node_nrm,
-                                                                  cg_tol, ctl, ring_slot, host_ctl);
+                          double cg_tol, double* ctl, int ring_slot, double* host_ctl, const double* last_solve_scalars, hipStream_t s) {
+    k_arap_finalize<<<dim3((m.V + 255) / 256 + 1), dim3(256), 0, s>>>(m, iters, tol, arap_grid_blocks(m), ered, sol, pts, info, nrm, node_pts, node_nrm,
+                                                                  cg_tol, ctl, ring_slot, host_ctl, last_solve_scalars);
 }
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf, int V,
                            double* out, hipStream_t s) {

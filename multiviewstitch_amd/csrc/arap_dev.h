@@ -139,7 +139,7 @@ __device__ inline bool arap_done_before(const double* __restrict__ efin, int it,
 // right-hand side c; thread 0 writes rel^2 = max_c gamma_c / bnorm_c into the ring row and keeps the control block's
 // sticky summary (MVS_CTL_*, engine.h).  `ran` (thread 0's value counts): the iteration ran at all.
 __device__ inline void judge_solve(const double* __restrict__ ered, int it, int nb, double cg_tol, double* __restrict__ ctl,
-                                   int ring_slot, bool ran) {
+                                   int ring_slot, bool ran, const double* __restrict__ scal = nullptr) {
     __shared__ double s_rel[3];
     const int wv = threadIdx.x >> 6;
     if (wv >= 1 && wv <= 3) {
@@ -151,7 +151,11 @@ __device__ inline void judge_solve(const double* __restrict__ ered, int it, int 
     __syncthreads();
     if (threadIdx.x == 0) {
         double* row = ctl + MVS_CTL_RING + ring_slot * 8;
-        if (!ran) { row[it] = -1.0; return; }
+        double* used = ctl + MVS_CTL_USED + ring_slot * 8;
+        if (!ran) { row[it] = -1.0; used[it] = 0.0; return; }
+        // patch solver: how many of the planned sweeps did work (scal = the 8 scalars of the solve's last sweep slot:
+        // [6] some sweep found the solve finished, [7] sweeps that ran) — negative when no spare was left
+        used[it] = scal ? (scal[6] != 0.0 ? scal[7] : -scal[7]) : 0.0;
         double rel2 = fmax(s_rel[0], fmax(s_rel[1], s_rel[2]));
         if (!(rel2 == rel2)) rel2 = INFINITY;                             // a NaN residual is a miss
         row[it] = rel2;

@@ -75,7 +75,9 @@ struct RasDev {                // patches of the restricted additive Schwarz sol
 #define MVS_CTL_SEQ    4     /* outer iterations finalized since the handle was created                            */
 #define MVS_CTL_RING   8     /* [MVS_RING][8]: rel^2 of solve `it` of outer slot (seq % MVS_RING); -1 = did not run */
 #define MVS_RING       32
-#define MVS_CTL_SIZE   (MVS_CTL_RING + MVS_RING * 8)
+#define MVS_CTL_USED   (MVS_CTL_RING + MVS_RING * 8)   /* [MVS_RING][8]: sweeps solve `it` of that pass actually ran (patch solver);
+                                                          negative: it ran every planned sweep (no spare was left); 0: unknown */
+#define MVS_CTL_SIZE   (MVS_CTL_USED + MVS_RING * 8)
 
 struct PhaseTimer {
     double total_ms = 0; int64_t launches = 0;
@@ -139,12 +141,17 @@ struct mvs_deform_s {
     int ras_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // calibrated sweeps per ARAP iteration (0 = not calibrated)
     double ras_a = 0.0;             // lower end of the Chebyshev bracket of the local solves (0 = default from the node density)
     int ras_m = 0;                  // Chebyshev steps per sweep
-    int ras_bump[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // > 0: this solve showed a thin margin lately -> one more sweep than first + 1
     // closed loop (see MVS_CTL_*): device control block, its pinned host mirror, enqueue counters
     double* d_ctl = nullptr;
+    unsigned* d_bar = nullptr;      // [2] arrival counter + give-up flag of the tail loop's device-wide barrier (reset by k_arap_rhs before every solve)
+    double* d_bpure = nullptr;      // [V*3] right-hand side without its Dirichlet share (k_arap_rhs -> k_arap_local's true residual)
+    double* d_ras_tail = nullptr;   // [8][RAS_TAIL_MAX] sweep slots of the in-kernel sweeps of TAIL launches
     volatile double* h_ctl = nullptr;
     uint64_t seq_enqueued = 0;      // outer iterations enqueued since creation (the device counts the finalized ones in MVS_CTL_SEQ)
     uint64_t seq_peeked = 0;        // ... whose ring row the host has already looked at
+    uint64_t seq_harvested = 0;     // ... covered by the last harvest
+    int ras_seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sweeps solve `it` ran in the pass peek_ring looked at last, and how much
+    int ras_rise[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // that was above the pass before (trend-aware provisioning)
     uint64_t bump_seq[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // first pass enqueued with the last in-batch correction of solve `it`
     // timing
     int timing = 0;                 // 0 off, 1 all phases, 2 "cg" groups only
@@ -195,19 +202,22 @@ void launch_cot_weights(const SellDev& m, const double* pts, double* coef, const
 // rws / p != NULL: also the CG start state.  ctl / ring_row: the solver control block and this outer iteration's ring row
 // (the kernel judges the solve of ARAP iteration it-1 from the residual partials its local step left).
 void launch_arap_rhs(const SellDev& m, const double* pts, const double* sol, const double* rot, int it, double tol,
-                     double* ered, double* rws, double* p, double* bout, double cg_tol, double* ctl, int ring_slot, hipStream_t s);
+                     double* ered, double* rws, double* p, double* bout, double cg_tol, double* ctl, int ring_slot,
+                     const double* prev_solve_scalars /*8 scalars of the last sweep slot of solve it-1, or NULL*/,
+                     unsigned* bar /*tail-loop barrier words to reset, or NULL*/,
+                     double* bpure /*V*3: b without the Dirichlet columns' share (what the local step judges the solve against)*/, hipStream_t s);
 void launch_cg_w0(const SellDev& m, const double* coef, int it, double tol, const double* ered, double* rws,
                   double* slot0, hipStream_t s);
 // slot_i = slot of CG iteration i of this solve (slot0 + i*MVS_CG_SLOT); alpha_i / gamma_i are written into it
 void launch_cg_iter(const SellDev& m, const double* coef, int it, double tol, const double* ered, int i, double cg_tol,
                     const double* slot0, double* slot_i, double* slot_next, const double* rws_in, double* rws_out,
                     double* p, double* x, hipStream_t s);
-// b != NULL: also the residual partials of the solve whose result `sol` is (ered + it*EIT + 4*NBMAX)
+// b != NULL (the `bpure` of launch_arap_rhs): also the residual partials of the solve whose result `sol` is (ered + it*EIT + 4*NBMAX)
 void launch_arap_local(const SellDev& m, const double* pts, const double* sol, int it, double tol, double* ered,
                        double* rot, const double* b, hipStream_t s);
 void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered, const double* sol,
                           double* pts, int32_t* info, const double* nrm, double* node_pts, double* node_nrm,
-                          double cg_tol, double* ctl, int ring_slot, double* host_ctl, hipStream_t s);
+                          double cg_tol, double* ctl, int ring_slot, double* host_ctl, const double* last_solve_scalars, hipStream_t s);
 int  arap_grid_blocks(const SellDev& m);
 // schwarz.hip
 int  ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& rowptr, const std::vector<int32_t>& col,
@@ -222,8 +232,9 @@ struct RasSmooth { const double* orig; const int32_t* nbr; int nn; double* out; 
 void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s, const double* init_ctrl = nullptr, const RasSmooth& sm = RasSmooth{nullptr, nullptr, 0, nullptr});
 void ras_default_bracket(const mvs_deform_s* h, double* a, int* m);
 int  ras_steps_for(double a);
-void launch_ras_sweep(const mvs_deform_s* h, const double* b, const double* xin, double* xout, int it, double arap_tol, int sweep,
-                      double cg_tol, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s);
+#define RAS_TAIL_MAX 32      /* in-kernel sweeps a TAIL launch may add to a solve whose plan was too short */
+void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, double* xout, int it, double arap_tol, int sweep,
+                      double cg_tol, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots = nullptr);
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf,
                            int V, double* out, hipStream_t s);
 

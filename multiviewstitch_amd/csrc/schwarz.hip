@@ -96,7 +96,7 @@ __device__ inline double fold_n(const double* __restrict__ part, int n) {
     return wave_total(v);
 }
 
-// slot of one sweep: part[3][NPpad] | gamma[3] bn[3] pad.  Partials: one per (patch, wave 0..3) — the owned rows of a
+// slot of one sweep: part[3][NPpad] | gamma[3] bn[3] idle-flag active-count.  Partials: one per (patch, wave 0..3) — the owned rows of a
 // patch (<= 256) sit in its first four waves, so no workgroup-level reduction is needed for the residual norm.
 __host__ __device__ inline int ras_slot_doubles(int NPpad) { return 3 * NPpad + 8; }
 
@@ -149,25 +149,68 @@ __global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, doubl
     }
 }
 
-template <int W>
+// ---- device-wide barrier of the tail loop (bounded spin: tools/gridbar.hip measured 10-24 us per barrier at 256 workgroups —
+// far more than a kernel boundary, which is why the PLANNED sweeps are separate launches; the tail runs only when a solve
+// needs more sweeps than its plan holds).  bar[0] counts arrivals (k_arap_rhs resets it before every solve), bar[1] != 0: a
+// workgroup gave up waiting (not every workgroup of the launch was resident, e.g. many handles sweeping at once) — every
+// later barrier then falls through and the solve is reported as it stands.
+constexpr int TAIL_MAXSPIN = 1 << 16;
+__device__ inline bool tail_barrier(unsigned* bar, unsigned arrivals_wanted) {
+    __shared__ int s_ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ok = 0;
+        else {
+            __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            int spin = 0;
+            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrivals_wanted) {
+                if (++spin > TAIL_MAXSPIN || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+struct RasTail {              // TAIL launches only (the last planned sweep of a solve)
+    unsigned* bar;            // [2] arrival counter, give-up flag
+    double* slots;            // max_extra further sweep slots (partials of the in-kernel sweeps)
+    int max_extra;            // in-kernel sweeps after this launch's own one
+};
+
+template <int W, bool TAIL>
 __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __restrict__ pw, const double* __restrict__ pd,
-                                                    const double* __restrict__ bvec, const double* __restrict__ xin,
-                                                    double* __restrict__ xout, int it, double arap_tol,
-                                                    const double* __restrict__ ered, int nb_rhs, int sweep, double cg_tol,
+                                                    const double* __restrict__ bvec, double* xa, double* xb, int it, double arap_tol,
+                                                    const double* __restrict__ ered, int nb_rhs, int sweep, double cg_tol, double slow2,
                                                     ChebCoef cc, int cheb_m, ChebCoef cc_strong, int cheb_m_strong,
                                                     const double* __restrict__ ctl, double* __restrict__ slot_prev,
-                                                    double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur) {
+                                                    double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur, RasTail tail) {
     // LDS: fp64 x of the local rows and the halo while the residual is formed (24 KB), then the correction directions as
     // bfloat16 triples, double-buffered (2 x 8 KB of the same array).  The neighbours' directions only steer the inexact
     // local solve; the residual that decides convergence and the solution stay fp64.
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * RTPB * sizeof(float4)];
     __shared__ double s_gam[3], s_bn[3];
-    __shared__ int s_done, s_esc;
+    __shared__ int s_done, s_esc, s_slow[3];
     double4* xs = reinterpret_cast<double4*>(smem);                    // 32-byte records: two 16-byte LDS accesses per gather instead of three 8-byte ones
     const int p = blockIdx.x, row = threadIdx.x, lane = row & 63, wv = row >> 6;
     const int LS = R.LS, base = p * LS;                                 // fixed table stride: the loads below need only p
-    const int nloc = R.pnloc[p], nown = R.pown[p];
     const int NPpad = R.NPpad;
+    // ---- fast skip: an earlier sweep of this solve found it converged (and left the result in BOTH solution buffers): the
+    //      launch plan holds a spare sweep per solve — the DEVICE decides how many of the planned sweeps run
+    if (sweep > 0 && slot_prev[3 * NPpad + 6] != 0.0) {
+        if (p == 0 && row == 0) { slot_cur[3 * NPpad + 6] = 1.0; slot_cur[3 * NPpad + 7] = slot_prev[3 * NPpad + 7]; }
+        if (row == 0) iters_cur[p] = 0;
+        return;
+    }
+    const int nloc = R.pnloc[p], nown = R.pown[p];
     RSTAMP(0);
     // ---- operand loads, issued before the convergence scalars are known (a frozen sweep wastes them, a planned one
     //      overlaps them with the fold of the previous sweep's partials): tables, then this row's x, b, diagonal
@@ -188,15 +231,21 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
             if (lc[e] < 0) { lc[e] = row; w2[e] = 0.0; }              // padding entries
         }
     }
-    const d3 xi = ld3(xin + 3 * (int64_t)g);
-    const d3 xh = ld3(xin + 3 * (int64_t)gh);                          // frozen at the previous sweep's value for this sweep
+    const double* xin = xa;
+    double* xout = xb;
+    d3 xi = ld3(xin + 3 * (int64_t)g);
+    d3 xh = ld3(xin + 3 * (int64_t)gh);                                // frozen at the previous sweep's value for this sweep
     const double dd = pd[base + row];
     const bool fixed = dd == 0.0;
     const d3 rhs = ld3(bvec + 3 * (int64_t)g);                         // (b is 0 on control rows; padding rows are fixed)
     // ---- preamble: waves 0..2 fold the residual partials of the previous sweep, waves 3..5 the bnorm partials of the rhs kernel
     if (wv < 3) {
         const double gam = sweep > 0 ? fold_n(slot_prev + wv * NPpad, R.NP * 4) : INFINITY;
-        if (lane == 0) s_gam[wv] = gam;
+        // in-solve adaptation: the sweep before the previous one left the residual of ITS input in its slot (reduced by the
+        // previous sweep); when the previous sweep cut the residual by less than SLOW, a mode sits below the bracket of the
+        // local solves (the mesh deforms, the weights move) — this sweep then takes the strong coefficient set
+        const double gam2 = sweep > 1 ? (slot_prev - ras_slot_doubles(NPpad))[3 * NPpad + wv] : INFINITY;
+        if (lane == 0) { s_gam[wv] = gam; s_slow[wv] = (sweep > 1 && gam > slow2 * gam2) ? 1 : 0; }
     } else if (wv < 6) {
         const double bn = fold_partials(ered + it * EIT + (1 + (wv - 3)) * NBMAX, nb_rhs);
         if (lane == 0) s_bn[wv - 3] = bn;
@@ -214,6 +263,12 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     for (int c = 0; c < 3; ++c) if (s_gam[c] > 0.0 && s_gam[c] > cg_tol * cg_tol * bn[c]) frozen = false;
     if (p == 0 && row < 3 && sweep > 0) { slot_prev[3 * NPpad + row] = s_gam[row]; slot_prev[3 * NPpad + 3 + row] = bn[row]; }
     if (p == 0 && row < 3) { slot_cur[3 * NPpad + row] = 0.0; slot_cur[3 * NPpad + 3 + row] = bn[row]; }
+    const double ran_before = sweep > 0 ? slot_prev[3 * NPpad + 7] : 0.0;
+    if (p == 0 && row == 3) {        // [6]: this sweep found the solve finished; [7]: sweeps of this solve that did work so far
+        const bool idle = s_done || frozen;
+        slot_cur[3 * NPpad + 6] = idle ? 1.0 : 0.0;
+        slot_cur[3 * NPpad + 7] = idle ? ran_before : ran_before + 1.0;
+    }
     if (s_done || frozen) {
         // nothing to solve: keep the ping-pong buffers consistent, carry the converged partials forward
         if (row < nown) st3(xout + 3 * (int64_t)g, xi);
@@ -221,82 +276,131 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         if (row == 0) iters_cur[p] = 0;
         return;
     }
-    // ---- residual of the input on the local rows: r = b + (outside columns) - (d x_i - sum_inside 2 w_ij x_j)
     const double di = fixed ? 1.0 : dd;
-    d3 r = mk3(0, 0, 0);
-    {
-        d3 acc = mk3(0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < W; ++e)
-        {
-            const double4 t = xs[lc[e]];
-            acc = mk3(__builtin_fma(w2[e], t.x, acc.x), __builtin_fma(w2[e], t.y, acc.y), __builtin_fma(w2[e], t.z, acc.z));
-        }
-        if (!fixed) r = rhs - (mk3(di * xi.x, di * xi.y, di * xi.z) - acc);
-    }
-    RSTAMP(2);
     const double inv_d = 1.0 / di;
     const int nw = (nloc + 63) >> 6;                                   // waves that hold rows
-    if (wv < 4) {   // owned rows only -> the global residual norm of the input (every vertex is owned by exactly one patch)
-        const bool own = row < nown;
-        const double o0 = wave_sum_u(own ? r.x * r.x * inv_d : 0.0), o1 = wave_sum_u(own ? r.y * r.y * inv_d : 0.0),
-                     o2 = wave_sum_u(own ? r.z * r.z * inv_d : 0.0);
-        if (lane < 3) slot_cur[lane * NPpad + 4 * p + wv] = lane == 0 ? o0 : (lane == 1 ? o1 : o2);
-    }
-    RSTAMP(3);
-    // Local solve: `cheb_m` steps of the Chebyshev semi-iteration on D^-1 A_loc e = D^-1 r with the spectrum of the
-    // Jacobi-scaled patch matrix bracketed by [a, 2] (2 is the Gershgorin bound of a weakly diagonally dominant
-    // M-matrix; the lower end is a parameter — measured 0.12..0.16 on the bench mesh — and an estimate above the true
-    // value only slows the smooth modes down, it cannot diverge).  No inner products: one workgroup barrier per step;
-    // the step coefficients come precomputed from the host.
-    // The steps run in float32: they only shape the correction e of an INEXACT local solve (the residual that decides
-    // convergence is formed in fp64 from x at the start of every sweep, the fixed point is untouched), and in fp64 a step
-    // was bound by 24 float->double conversions + 33 fp64 FMAs per thread (1460 cycles per step on a CU, half of a sweep).
-    // Two coefficient sets travel with the launch: the planned one and a strong one (lower bracket end, more steps) that the
-    // DEVICE selects once any solve since the last harvest has missed cg_tol (MVS_CTL_ESC) — the launch plan of a batch is
-    // fixed on the host, the strength of the local solves is not.
-    const ChebCoef& ck = s_esc ? cc_strong : cc;
-    if (s_esc) cheb_m = cheb_m_strong;
-    float ex = 0.f, ey = 0.f, ez = 0.f;
     const float di_f = (float)di, inv_d_f = (float)inv_d;
-    float rx = (float)r.x, ry = (float)r.y, rz = (float)r.z;
-    const float c0f = (float)ck.c0 * inv_d_f;
-    float dx = c0f * rx, dy = c0f * ry, dz = c0f * rz;
     float w2f[W];
 #pragma unroll
     for (int q = 0; q < W; ++q) w2f[q] = (float)w2[q];
-    __syncthreads();                                                   // xs has been read by everyone: the buffer turns into dbuf
-    // The neighbours' directions travel through LDS as bfloat16 triples (8 bytes per row, one ds_read_b64 per matrix
-    // entry): the step is bound by the bank conflicts of these random gathers, not by arithmetic, and a 0.4 % error in
-    // what a NEIGHBOUR contributes to an inexact local solve costs no sweep (own direction, residual and correction stay
-    // float32; the residual that decides convergence is fp64).
     uint2* hb = reinterpret_cast<uint2*>(smem);
     auto to_bf16 = [](float v) -> unsigned { const unsigned u = __float_as_uint(v); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
-    if (row < nh) { hb[LS + row] = make_uint2(0u, 0u); hb[RTPB + LS + row] = make_uint2(0u, 0u); }
-    for (int k = 0; k < cheb_m; ++k) {
-        uint2* buf = hb + (k & 1) * RTPB;
-        buf[row] = make_uint2(to_bf16(dx) | (to_bf16(dy) << 16), to_bf16(dz));
-        __syncthreads();
-        if (wv < nw) {
-            float ax = di_f * dx, ay = di_f * dy, az = di_f * dz;
+    bool strong = s_esc || s_slow[0] || s_slow[1] || s_slow[2];
+
+    // One sweep of this patch: xs holds x of the local rows and the halo (fp64); residual of that input on the local rows, its
+    // owned part into `slot`, the Chebyshev correction, new x of the owned rows into `xo`.
+    auto sweep_body = [&](double* __restrict__ slot, double* __restrict__ xo) {
+        // ---- residual of the input on the local rows: r = b + (outside columns) - (d x_i - sum_inside 2 w_ij x_j)
+        d3 r = mk3(0, 0, 0);
+        {
+            d3 acc = mk3(0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < W; ++q) {
-                const uint2 t = buf[lc[q]];
-                const float tx = __uint_as_float(t.x << 16), ty = __uint_as_float(t.x & 0xffff0000u), tz = __uint_as_float(t.y << 16);
-                ax = __builtin_fmaf(-w2f[q], tx, ax); ay = __builtin_fmaf(-w2f[q], ty, ay); az = __builtin_fmaf(-w2f[q], tz, az);
+            for (int e = 0; e < W; ++e)
+            {
+                const double4 t = xs[lc[e]];
+                acc = mk3(__builtin_fma(w2[e], t.x, acc.x), __builtin_fma(w2[e], t.y, acc.y), __builtin_fma(w2[e], t.z, acc.z));
             }
-            if (fixed) { ax = 0.f; ay = 0.f; az = 0.f; }
-            ex += dx; ey += dy; ez += dz;
-            rx -= ax; ry -= ay; rz -= az;
-            const float c1 = (float)ck.c1[k & 31], c2 = (float)ck.c2[k & 31] * inv_d_f;
-            dx = __builtin_fmaf(c1, dx, c2 * rx); dy = __builtin_fmaf(c1, dy, c2 * ry); dz = __builtin_fmaf(c1, dz, c2 * rz);
+            if (!fixed) r = rhs - (mk3(di * xi.x, di * xi.y, di * xi.z) - acc);
         }
-    }
-    const d3 e = mk3((double)ex, (double)ey, (double)ez);
-    RSTAMP(4);
-    if (row < nown) st3(xout + 3 * (int64_t)g, xi + e);
-    if (row == 0) iters_cur[p] = cheb_m;
+        RSTAMP(2);
+        if (wv < 4) {   // owned rows only -> the global residual norm of the input (every vertex is owned by exactly one patch)
+            const bool own = row < nown;
+            const double o0 = wave_sum_u(own ? r.x * r.x * inv_d : 0.0), o1 = wave_sum_u(own ? r.y * r.y * inv_d : 0.0),
+                         o2 = wave_sum_u(own ? r.z * r.z * inv_d : 0.0);
+            if (lane < 3) slot[lane * NPpad + 4 * p + wv] = lane == 0 ? o0 : (lane == 1 ? o1 : o2);
+        }
+        RSTAMP(3);
+        // Local solve: `m` steps of the Chebyshev semi-iteration on D^-1 A_loc e = D^-1 r with the spectrum of the
+        // Jacobi-scaled patch matrix bracketed by [a, 2] (2 is the Gershgorin bound of a weakly diagonally dominant
+        // M-matrix; the lower end is a parameter and an estimate above the true value only slows the smooth modes down,
+        // it cannot diverge).  No inner products: one workgroup barrier per step; the step coefficients come
+        // precomputed from the host.
+        // The steps run in float32: they only shape the correction e of an INEXACT local solve (the residual that decides
+        // convergence is formed in fp64 from x at the start of every sweep, the fixed point is untouched), and in fp64 a step
+        // was bound by 24 float->double conversions + 33 fp64 FMAs per thread (1460 cycles per step on a CU, half of a sweep).
+        // Two coefficient sets travel with the launch: the planned one and a strong one (lower bracket end, more steps) that the
+        // DEVICE selects when the previous sweep of the solve converged slowly, or once any solve since the last harvest has
+        // missed cg_tol (MVS_CTL_ESC) — the launch plan of a batch is fixed on the host, the strength of the local solves is not.
+        const ChebCoef& ck = strong ? cc_strong : cc;
+        const int m = strong ? cheb_m_strong : cheb_m;
+        float ex = 0.f, ey = 0.f, ez = 0.f;
+        float rx = (float)r.x, ry = (float)r.y, rz = (float)r.z;
+        const float c0f = (float)ck.c0 * inv_d_f;
+        float dx = c0f * rx, dy = c0f * ry, dz = c0f * rz;
+        __syncthreads();                                               // xs has been read by everyone: the buffer turns into dbuf
+        // The neighbours' directions travel through LDS as bfloat16 triples (8 bytes per row, one ds_read_b64 per matrix
+        // entry): the step is bound by the bank conflicts of these random gathers, not by arithmetic, and a 0.4 % error in
+        // what a NEIGHBOUR contributes to an inexact local solve costs no sweep (own direction, residual and correction stay
+        // float32; the residual that decides convergence is fp64).
+        if (row < nh) { hb[LS + row] = make_uint2(0u, 0u); hb[RTPB + LS + row] = make_uint2(0u, 0u); }
+        for (int k = 0; k < m; ++k) {
+            uint2* buf = hb + (k & 1) * RTPB;
+            buf[row] = make_uint2(to_bf16(dx) | (to_bf16(dy) << 16), to_bf16(dz));
+            __syncthreads();
+            if (wv < nw) {
+                float ax = di_f * dx, ay = di_f * dy, az = di_f * dz;
+#pragma unroll
+                for (int q = 0; q < W; ++q) {
+                    const uint2 t = buf[lc[q]];
+                    const float tx = __uint_as_float(t.x << 16), ty = __uint_as_float(t.x & 0xffff0000u), tz = __uint_as_float(t.y << 16);
+                    ax = __builtin_fmaf(-w2f[q], tx, ax); ay = __builtin_fmaf(-w2f[q], ty, ay); az = __builtin_fmaf(-w2f[q], tz, az);
+                }
+                if (fixed) { ax = 0.f; ay = 0.f; az = 0.f; }
+                ex += dx; ey += dy; ez += dz;
+                rx -= ax; ry -= ay; rz -= az;
+                const float c1 = (float)ck.c1[k & 31], c2 = (float)ck.c2[k & 31] * inv_d_f;
+                dx = __builtin_fmaf(c1, dx, c2 * rx); dy = __builtin_fmaf(c1, dy, c2 * ry); dz = __builtin_fmaf(c1, dz, c2 * rz);
+            }
+        }
+        RSTAMP(4);
+        xi = xi + mk3((double)ex, (double)ey, (double)ez);
+        if (row < nown) st3(xo + 3 * (int64_t)g, xi);
+        return m;
+    };
+    int steps = sweep_body(slot_cur, xout);
     RSTAMP(5);
+    if (!TAIL) { if (row == 0) iters_cur[p] = steps; return; }
+
+    // ---- TAIL: this is the last planned sweep of the solve and its input had not converged.  Whether its result has is
+    //      known only after a device-wide reduction: instead of leaving the solve short, the launch keeps sweeping — barrier,
+    //      fold the partials of the sweep just done (residual of ITS input), stop when that input was converged (the sweep
+    //      that followed it is the confirming one, as in the planned sequence), else one more sweep from the other buffer.
+    //      On every way out both solution buffers hold the result on this patch's owned rows.
+    int extra = 0;
+    bool finished = false;
+    double* slot_k = slot_cur;                                         // partials of the sweep done last
+    for (;;) {
+        if (!tail_barrier(tail.bar, (unsigned)gridDim.x * (unsigned)(extra + 1))) break;     // not every workgroup is there: report as it stands
+        if (wv < 3) {
+            const double gam = fold_n(slot_k + wv * NPpad, R.NP * 4);
+            if (lane == 0) s_gam[wv] = gam;
+        }
+        __syncthreads();
+        bool conv = true;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) if (s_gam[c] > 0.0 && s_gam[c] > cg_tol * cg_tol * bn[c]) conv = false;
+        if (conv) { finished = true; break; }
+        if (extra >= tail.max_extra) break;
+        // one more sweep: the buffers swap roles; x of the halo comes from what the other patches just wrote
+        { const double* t = xin; xin = xout; xout = const_cast<double*>(t); }
+        xh = ld3(xin + 3 * (int64_t)gh);
+        __syncthreads();                                               // the direction buffers of the last sweep have been read
+        xs[row] = make_double4(xi.x, xi.y, xi.z, 0.0);                 // (own row: the value this thread wrote, or — overlap rows — must be re-read)
+        if (row >= nown) { const d3 t = ld3(xin + 3 * (int64_t)g); xi = t; xs[row] = make_double4(t.x, t.y, t.z, 0.0); }
+        if (row < nh) xs[LS + row] = make_double4(xh.x, xh.y, xh.z, 0.0);
+        __syncthreads();
+        strong = true;                                                 // a solve that overran its plan: no half measures
+        slot_k = tail.slots + (size_t)extra * ras_slot_doubles(NPpad);
+        steps += sweep_body(slot_k, xout);
+        ++extra;
+    }
+    // both buffers equal on the owned rows (xi is this thread's latest value of its row — for an owned row the value it wrote)
+    if (row < nown) { st3(xa + 3 * (int64_t)g, xi); st3(xb + 3 * (int64_t)g, xi); }
+    if (p == 0 && row == 3) {
+        slot_cur[3 * NPpad + 6] = finished ? 1.0 : 0.0;
+        slot_cur[3 * NPpad + 7] = ran_before + 1.0 + (double)extra;
+    }
+    if (row == 0) iters_cur[p] = steps;
 }
 
 template <class T> int up(T** d, const std::vector<T>& h) {
@@ -471,22 +575,33 @@ void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s, const double* init
     else k_ras_prepare<16><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
 }
 
-// a = 0.67 K/V (capped at 0.1), steps ~ 2.6 / sqrt(a): 8 steps at the density the reference's 16-NN sampling produces
+// a = 0.4 K/V (capped at 0.06), steps ~ 2.6 / sqrt(a): 11 steps at the density the reference's 16-NN sampling produces.
+// (Round 1 ran a = 0.1 with 8 steps: 8 % faster per sweep, but the bracket then sits right at the lowest mode of the
+// patches of the bench mesh — 21 % residual per sweep instead of 6-9 %, and every so often, as the template deforms, a mode
+// slips below it and a solve stalls at 40 % per sweep: scripts/pass_trace.py, pass 18.  Measured, scripts/bracket_sweep.py.)
+constexpr double RAS_SLOW = 0.15;     // a sweep that leaves more than this fraction of the residual calls for the strong set
 void ras_default_bracket(const mvs_deform_s* h, double* a, int* m) {
     const double dens = h->V > 0 ? (double)h->K / (double)h->V : 0.15;
-    *a = std::min(0.1, std::max(0.002, 0.67 * dens));
+    *a = std::min(0.06, std::max(0.005, 0.4 * dens));
+    if (const char* e = getenv("MVS_RAS_A")) { const double v = atof(e); if (v > 0.0) *a = v; }      // experiments (scripts/bracket_sweep.py)
     *m = ras_steps_for(*a);
 }
-int ras_steps_for(double a) { return std::min(32, std::max(6, (int)std::lround(2.6 / std::sqrt(a)))); }   // (2.6 re-measured with the bfloat16 steps: 1.6 / 2.0 / 2.6 / 3.2 / 4.0 -> 0.62 / 0.58 / 0.56 / 0.57 / 0.58 ms per outer iteration)
+int ras_steps_for(double a) {
+    double c = 2.6;
+    if (const char* e = getenv("MVS_RAS_C")) { const double v = atof(e); if (v > 0.0) c = v; }
+    return std::min(32, std::max(6, (int)std::lround(c / std::sqrt(a))));
+}   // (2.6 re-measured with the bfloat16 steps: 1.6 / 2.0 / 2.6 / 3.2 / 4.0 -> 0.62 / 0.58 / 0.56 / 0.57 / 0.58 ms per outer iteration)
 
-// one sweep of ARAP iteration `it`: slot_prev / slot_cur are the slots of sweeps (sweep-1) / sweep
-void launch_ras_sweep(const mvs_deform_s* h, const double* b, const double* xin, double* xout, int it, double arap_tol, int sweep,
-                      double cg_tol, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s) {
+// one sweep of ARAP iteration `it`: slot_prev / slot_cur are the slots of sweeps (sweep-1) / sweep.  tail_slots != NULL: this
+// is the last planned sweep of the solve — the launch keeps sweeping (device-wide barrier between sweeps, at most
+// RAS_TAIL_MAX more) until the solve has converged, should the plan have been too short.
+void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, double* xout, int it, double arap_tol, int sweep,
+                      double cg_tol, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots) {
     const RasDev& R = h->ras;
     const int nb = arap_grid_blocks(h->sell);
     // Chebyshev parameters: the bracket's lower end `a` and the step count live in the handle — initialised from the density
     // of the Dirichlet nodes (ras_default_bracket), then adapted by harvest_ras to the convergence it observes (the
-    // spectrum moves as the mesh deforms: 0.12..0.16 on the rest pose of the bench mesh, ~0.01 after 200 outer iterations)
+    // spectrum moves as the mesh deforms)
     double cheb_a = h->ras_a;
     int cheb_m = h->ras_m;
     if (!(cheb_a > 0.0) || cheb_m <= 0) ras_default_bracket(h, &cheb_a, &cheb_m);
@@ -503,11 +618,14 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, const double* xin,
         return cc;
     };
     const ChebCoef cc = coefs(cheb_a);
-    const double strong_a = std::max(0.002, cheb_a / 9.0);       // the set the device switches to after a missed solve
+    const double strong_a = std::max(0.005, cheb_a / 6.0);       // the set the device switches to (slow sweep / missed solve / tail)
     const ChebCoef cc2 = coefs(strong_a);
     const int m2 = ras_steps_for(strong_a);
     const dim3 grid(R.NP), blk(h->ras_block);     // as many waves as the largest patch has rows (idle waves only add barrier cost)
-    if (R.W == 8) k_ras_sweep<8><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur);
-    else if (R.W == 12) k_ras_sweep<12><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur);
-    else k_ras_sweep<16><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur);
+    const RasTail tail{h->d_bar, tail_slots, RAS_TAIL_MAX};
+#define MVS_SWEEP(W, T) k_ras_sweep<W, T><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, \
+                                                              RAS_SLOW * RAS_SLOW, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur, tail)
+    if (tail_slots) { if (R.W == 8) MVS_SWEEP(8, true); else if (R.W == 12) MVS_SWEEP(12, true); else MVS_SWEEP(16, true); }
+    else            { if (R.W == 8) MVS_SWEEP(8, false); else if (R.W == 12) MVS_SWEEP(12, false); else MVS_SWEEP(16, false); }
+#undef MVS_SWEEP
 }

@@ -11,6 +11,8 @@ import bench
 dev = torch.device("cuda", 0)
 sc = S.make_scene(3, device=dev)
 d = deformation.Deformation(sc.verts, sc.normals, sc.faces)
+if len(sys.argv) > 1 and sys.argv[1] == "cg":
+    d.params.solver = 1          # the one-kernel-per-iteration CG instead of the patch sweeps
 d.UniformSampling(16)
 tp, tn = bench.build_target(torch, srt_mod, S, sc, range(8), dev)
 d.set_target_dev(tp.data_ptr(), tn.data_ptr(), tp.shape[0], 0)

@@ -232,12 +232,12 @@ def test_results_are_bit_reproducible(eng):
     assert all(np.array_equal(a, b) for a, b in zip(*outs))
 
 
-def test_solver_loop_reports_and_recovers_from_a_stale_plan(eng):
-    """The launch plan of a handle is sized from its previous solves.  Here it is made stale on purpose: calibrated at
-    cg_tol = 1e-4, then asked for 1e-10 inside ONE iterate(8) batch.  Every solve is judged on the device (true residual
-    of its result): the call must say that solves ended above cg_tol (status MVS_W_UNCONVERGED, counts, worst residual),
-    the device must have switched to the strong local solves, and the next call — re-planned from the harvest — must
-    converge."""
+def test_solver_loop_finishes_solves_whose_plan_is_stale(eng):
+    """The launch plan of a handle is provisioned from its previous solves.  Here it is made stale on purpose: calibrated at
+    cg_tol = 1e-4, then asked for 1e-10 inside ONE iterate(8) batch.  The DEVICE decides how many sweeps a solve runs: the
+    last planned sweep of a solve keeps sweeping in the kernel (device-wide barrier between sweeps) until the solve has
+    converged, and every solve's result is judged by its true residual — so the stale batch converges all the same, and
+    the host (following the residual ring while it enqueues) restores the plan within a few passes."""
     sc, tp, tn, _ = scene_and_target(2)
     d = eng.Deformation(sc.verts, sc.normals, sc.faces)
     assert d.solver_info()["kind"] == "patch"
@@ -247,18 +247,37 @@ def test_solver_loop_reports_and_recovers_from_a_stale_plan(eng):
     st = d.iterate(2)
     assert st["converged"] and st["status"] == 0 and st["worst_rel_residual_in_batch"] <= 1e-4
     assert st["solves_in_batch"] >= 4
+    short = st["cg_launches"]
     d.params.cg_tol = 1e-10
     st = d.iterate(8)
-    assert st["status"] == 1 and not st["converged"]
-    assert st["unconverged_solves"] > 0 and st["worst_rel_residual_in_batch"] > 1e-10 and st["escalated"]
-    assert st["unconverged_solves"] <= st["solves_in_batch"]
-    for _ in range(3):                                  # a harvest re-plans (2 n sweeps after a miss): at most a few calls to catch up
-        st = d.iterate(4)
-        if st["converged"]:
-            break
-    assert st["converged"] and st["status"] == 0 and st["worst_rel_residual_in_batch"] <= 1e-10 and not st["escalated"]
-    st = d.iterate(8)                                   # and stays converged, batch after batch
+    assert st["converged"] and st["status"] == 0 and st["unconverged_solves"] == 0
+    assert st["worst_rel_residual_in_batch"] <= 1e-10 and st["solves_in_batch"] >= 16
+    assert st["cg_launches"] > short                     # by the end of the batch the plan has caught up
+    st = d.iterate(8)
     assert st["converged"] and st["cg_rel_residual"] <= 1e-10
+
+
+def test_solver_loop_reports_a_tolerance_it_cannot_reach(eng):
+    """cg_tol far below what fp64 residuals of this system can reach: the in-kernel loop gives up after its budget of extra
+    sweeps, the solves are judged above cg_tol and the call says so — status MVS_W_UNCONVERGED, counts, worst residual, the
+    device-side escalation — instead of returning MVS_OK as round 1 did."""
+    sc, tp, tn, _ = scene_and_target(2)
+    d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    d.UniformSampling(16)
+    d.set_target(tp, tn)
+    st = d.iterate(1)
+    assert st["converged"]
+    v_ok = d.vertices()
+    d.params.cg_tol = 1e-17
+    st = d.iterate(2)
+    assert st["status"] == 1 and not st["converged"]
+    assert st["unconverged_solves"] > 0 and st["unconverged_solves"] <= st["solves_in_batch"]
+    assert st["worst_rel_residual_in_batch"] > 1e-17 and st["escalated"]
+    assert st["worst_rel_residual_in_batch"] < 1e-10                           # the solves are as good as fp64 gets, just not 1e-17
+    assert np.isfinite(d.vertices()).all() and np.abs(d.vertices() - v_ok).max() < 0.1
+    d.params.cg_tol = 1e-8
+    st = d.iterate(2)
+    assert st["converged"] and st["status"] == 0 and not st["escalated"]
 
 
 def test_every_solve_of_a_batch_is_judged(eng):
