@@ -201,6 +201,25 @@ int mvs_srt_remove_outliers(const double* matches, int64_t n,
                             uint32_t* rand_state,
                             uint8_t* keep, int64_t* n_keep, double* err);
 
+/* Key-frame pair selection of Processor::AlignmentSeq (R/Processor/Processor.cpp:746-765) between the n1 frames of one
+ * sequence and the n2 frames of the next: RemoveOutliers runs on every frame pair (i, j) holding >= min_match_count
+ * matches — in the reference's loop order (i outer, j inner), one rand() stream through all of them — and the pair with
+ * the strictly smallest residual whose filtered list still holds >= min_match_count matches is selected.
+ *   cams1[n1], cams2[n2]      : the frames' cameras;
+ *   match_offsets[n1*n2 + 1]  : pair k = i*n2 + j owns matches [match_offsets[k], match_offsets[k+1]) (ascending from 0);
+ *   matches                   : lifted 3-D matches {p.xyz, q.xyz} of all pairs, back to back;
+ *   rand_state                : srand seed / LCG state in, advanced state out;
+ *   frm_idx1, frm_idx2, err   : the selection (-1, -1, HUGE_VAL and MVS_E_DEGENERATE when no pair qualifies — the
+ *                               reference prints "No Enough Sift Feature Matches" and exits, :794-800);
+ *   keep (optional, total)    : surviving mask of EVERY pair (the reference filters all the lists in place);
+ *   n_keep, pair_err (optional, n1*n2): survivors and residual per pair (HUGE_VAL for a pair that was skipped).
+ * All hypotheses of a RANSAC round of all pairs run as one launch set. */
+int mvs_select_keyframe_pair(int32_t n1, int32_t n2, const mvs_camera* cams1, const mvs_camera* cams2,
+                             const int64_t* match_offsets, const double* matches, int32_t min_match_count, int iters,
+                             double pixel_err, double adapt_ratio, uint32_t* rand_state,
+                             int32_t* frm_idx1, int32_t* frm_idx2, double* err,
+                             uint8_t* keep, int64_t* n_keep, double* pair_err);
+
 /* Fill triples with the reference's generator: MSVC rand() LCG driving
  * Shuffle(idx, n, 3) (R/Common/Utils.h:25-34).  state in/out. */
 int mvs_srt_make_triples(int64_t n, int iters, uint32_t* state, int32_t* triples);

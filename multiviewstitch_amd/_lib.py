@@ -92,6 +92,7 @@ _SIGS = {
     "mvs_srt_residual": (C.c_int, [_VP, _I64, _VP, _VP, _D, _VP, _VP, _VP, _VP]),
     "mvs_srt_remove_outliers": (C.c_int, [_VP, _I64, _VP, _VP, _I32, _D, _D, _VP, _VP, _VP, _VP]),
     "mvs_srt_make_triples": (C.c_int, [_I64, _I32, _VP, _VP]),
+    "mvs_select_keyframe_pair": (C.c_int, [_I32, _I32, _VP, _VP, _VP, _VP, _I32, _I32, _D, _D, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "mvs_srt_compose": (C.c_int, [_D, _VP, _VP, _VP, _VP, _VP]),
     "mvs_srt_relative": (C.c_int, [_D, _VP, _VP, _D, _VP, _VP, _VP, _VP, _VP]),
     "mvs_srt_apply": (C.c_int, [_VP, _VP, _I64, _D, _VP, _VP, _I32, _VP, _VP]),

@@ -215,6 +215,139 @@ int mvs_srt_remove_outliers(const double* matches, int64_t n, const mvs_camera* 
     return MVS_OK;
 }
 
+// Key-frame pair selection, Processor::AlignmentSeq (R/Processor/Processor.cpp:746-765): RemoveOutliers on EVERY frame pair
+// (i of sequence k, j of sequence k+1) that holds >= min_match_count matches, in the reference's loop order (i outer, j
+// inner, one rand() stream running through all of them); the pair with the strictly smallest residual whose filtered list
+// still holds >= min_match_count matches wins.
+// The pairs are independent except for the random stream, and a round of RemoveOutliers draws a fixed number of values
+// (iters x 3), so the stream position of (pair e, round r) is known in advance as long as every earlier pair runs all three
+// rounds: round r of ALL pairs goes out as one set of launches (every RANSAC hypothesis of every pair in one grid).  A pair
+// that stops early (fewer than 3 survivors) shifts the stream for the pairs after it: those are then redone one by one.
+int mvs_select_keyframe_pair(int32_t n1, int32_t n2, const mvs_camera* cams1, const mvs_camera* cams2, const int64_t* match_offsets,
+                             const double* matches, int32_t min_match_count, int iters, double pixel_err, double adapt_ratio,
+                             uint32_t* rand_state, int32_t* frm_idx1, int32_t* frm_idx2, double* err_out, uint8_t* keep,
+                             int64_t* n_keep, double* pair_err) {
+    if (n1 < 1 || n2 < 1 || !cams1 || !cams2 || !match_offsets || !rand_state || !frm_idx1 || !frm_idx2 || !err_out || iters < 1 ||
+        (int64_t)n1 * n2 > 1000000) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    const int np = n1 * n2;
+    const int64_t total = match_offsets[np];
+    for (int k = 0; k < np; ++k) if (match_offsets[k + 1] < match_offsets[k] || match_offsets[0] != 0) { mvs_set_error("match_offsets must ascend from 0"); return MVS_E_INVALID_ARG; }
+    if (total > 0 && !matches) { mvs_set_error("matches is NULL"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    struct Pair { int k; int64_t size, n0; std::vector<double> cur; std::vector<int64_t> id; double ratio = 1.0, err = HUGE_VAL; int rounds = 0; bool running = true; };
+    std::vector<Pair> el;                                       // eligible pairs in loop order (:750)
+    for (int k = 0; k < np; ++k) {
+        const int64_t n = match_offsets[k + 1] - match_offsets[k];
+        if (n < min_match_count) continue;
+        Pair p; p.k = k; p.size = p.n0 = n;
+        p.cur.assign(matches + 6 * match_offsets[k], matches + 6 * match_offsets[k + 1]);
+        p.id.resize(n);
+        for (int64_t i = 0; i < n; ++i) p.id[i] = i;
+        el.push_back(std::move(p));
+    }
+    const uint32_t start = *rand_state;
+    auto advance = [&](uint32_t st, int64_t draws) { for (int64_t d = 0; d < draws; ++d) (void)msvc_rand(&st); return st; };
+    const int64_t per_round = (int64_t)iters * 3;
+    // one filter step of RemoveOutliers on the host (:207-258) from the per-match pixel errors of the round
+    auto filter = [&](Pair& p, const double* pm) {
+        double err_all = 0.0;
+        int64_t newSize = 0;
+        for (int64_t i = 0; i < p.size; ++i) {
+            const double e1 = pm[2 * i], e2 = pm[2 * i + 1];
+            err_all += (e1 + e2) * 0.5;
+            if (e1 <= pixel_err * p.ratio && e2 <= pixel_err * p.ratio) {
+                for (int c = 0; c < 6; ++c) p.cur[6 * newSize + c] = p.cur[6 * i + c];
+                p.id[newSize++] = p.id[i];
+            }
+        }
+        p.ratio *= adapt_ratio;
+        p.err = err_all / (double)p.size;
+        p.size = newSize;
+        p.rounds++;
+        if (newSize < 3) p.running = false;
+    };
+    int first_short = -1;                                       // first pair (index into el) that did not run all three rounds
+    for (int r = 0; r < 3 && !el.empty(); ++r) {
+        std::vector<int> act;
+        for (int e = 0; e < (int)el.size(); ++e) if (el[e].running && el[e].size >= 3) act.push_back(e); else if (el[e].running) el[e].running = false;
+        if (act.empty()) break;
+        std::vector<int64_t> off(act.size() + 1, 0);
+        for (size_t a = 0; a < act.size(); ++a) off[a + 1] = off[a] + el[act[a]].size;
+        const int64_t tot = off.back();
+        std::vector<double> m_all((size_t)tot * 6);
+        std::vector<int32_t> set_of(tot), tri((size_t)act.size() * iters * 3);
+        std::vector<CamDev> c1(act.size()), c2(act.size());
+        for (size_t a = 0; a < act.size(); ++a) {
+            Pair& p = el[act[a]];
+            std::memcpy(m_all.data() + 6 * off[a], p.cur.data(), sizeof(double) * 6 * p.size);
+            for (int64_t i = off[a]; i < off[a + 1]; ++i) set_of[i] = (int32_t)a;
+            c1[a] = make_camdev(&cams1[p.k / n2]); c2[a] = make_camdev(&cams2[p.k % n2]);
+            uint32_t st = advance(start, ((int64_t)3 * act[a] + r) * per_round);       // (assumes 3 rounds for every earlier pair)
+            if ((rc = mvs_srt_make_triples(p.size, iters, &st, tri.data() + (size_t)a * iters * 3))) return rc;
+        }
+        DevBuf dm, doff, dset, dc1, dc2, dtri, dstats, dhyp, dout, dpm;
+        if ((rc = dm.alloc(m_all.size() * 8)) || (rc = doff.alloc(off.size() * 8)) || (rc = dset.alloc(set_of.size() * 4)) ||
+            (rc = dc1.alloc(c1.size() * sizeof(CamDev))) || (rc = dc2.alloc(c2.size() * sizeof(CamDev))) || (rc = dtri.alloc(tri.size() * 4)) ||
+            (rc = dstats.alloc(act.size() * 16 * 8)) || (rc = dhyp.alloc(act.size() * (size_t)iters * 13 * 8)) || (rc = dout.alloc(act.size() * 13 * 8)) ||
+            (rc = dpm.alloc((size_t)tot * 16))) return rc;
+        HIPCHK(hipMemcpy(dm.p, m_all.data(), m_all.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(doff.p, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dset.p, set_of.data(), set_of.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dc1.p, c1.data(), c1.size() * sizeof(CamDev), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dc2.p, c2.data(), c2.size() * sizeof(CamDev), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dtri.p, tri.data(), tri.size() * 4, hipMemcpyHostToDevice));
+        if ((rc = srt_ransac_round_batched(dm.as<double>(), doff.as<int64_t>(), (int)act.size(), tot, dset.as<int32_t>(), dc1.as<CamDev>(), dc2.as<CamDev>(),
+                                           dtri.as<int32_t>(), iters, dstats.as<double>(), dhyp.as<double>(), dout.as<double>(), dpm.as<double>(), nullptr))) return rc;
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<double> pm((size_t)tot * 2);
+        HIPCHK(hipMemcpy(pm.data(), dpm.p, pm.size() * 8, hipMemcpyDeviceToHost));
+        for (size_t a = 0; a < act.size(); ++a) filter(el[act[a]], pm.data() + 2 * off[a]);
+    }
+    for (int e = 0; e < (int)el.size(); ++e) if (el[e].rounds < 3) { first_short = e; break; }
+    uint32_t st_end = advance(start, (int64_t)3 * el.size() * per_round);
+    if (first_short >= 0) {
+        // the pairs after the first short one saw a shifted stream: redo them one after the other from the true position
+        int64_t draws = 0;
+        for (int e = 0; e <= first_short; ++e) draws += el[e].rounds * per_round;
+        uint32_t st = advance(start, draws);
+        for (int e = first_short + 1; e < (int)el.size(); ++e) {
+            Pair& p = el[e];
+            std::vector<uint8_t> kp(p.n0);
+            int64_t nk = 0;
+            double er = HUGE_VAL;
+            const double* m0 = matches + 6 * match_offsets[p.k];
+            if ((rc = mvs_srt_remove_outliers(m0, p.n0, &cams1[p.k / n2], &cams2[p.k % n2], iters, pixel_err, adapt_ratio, &st, kp.data(), &nk, &er))) return rc;
+            p.size = nk; p.err = er; p.id.clear();
+            for (int64_t i = 0; i < p.n0; ++i) if (kp[i]) p.id.push_back(i);
+        }
+        st_end = st;
+    }
+    *rand_state = st_end;
+    // the selection (:757-763), strict <
+    double err = HUGE_VAL;
+    int64_t maxMatchCount = 0;
+    int f1 = -1, f2 = -1;
+    if (keep) std::memset(keep, 1, (size_t)total);              // pairs that were skipped keep their lists as they are
+    if (n_keep) for (int k = 0; k < np; ++k) n_keep[k] = match_offsets[k + 1] - match_offsets[k];
+    if (pair_err) for (int k = 0; k < np; ++k) pair_err[k] = HUGE_VAL;
+    for (const Pair& p : el) {
+        if (keep) {
+            std::memset(keep + match_offsets[p.k], 0, (size_t)p.n0);
+            for (int64_t i = 0; i < p.size; ++i) keep[match_offsets[p.k] + p.id[i]] = 1;
+        }
+        if (n_keep) n_keep[p.k] = p.size;
+        if (pair_err) pair_err[p.k] = p.err;
+        if (p.err < err && p.size >= min_match_count) { maxMatchCount = p.size; err = p.err; f1 = p.k / n2; f2 = p.k % n2; }
+    }
+    *frm_idx1 = f1; *frm_idx2 = f2; *err_out = err;
+    if (maxMatchCount < min_match_count) {                      // :794-800: the reference exits here
+        mvs_set_error("no frame pair keeps >= %d matches after RemoveOutliers (best %lld)", (int)min_match_count, (long long)maxMatchCount);
+        return MVS_E_DEGENERATE;
+    }
+    return MVS_OK;
+}
+
 // 3x3 glue on the host: a handful of flops per sequence pair.
 static void mul33(const double* A, const double* B, double* C) {
     double T[9];

@@ -25,4 +25,8 @@ int srt_fit_dev(const double* matches_dev, int64_t n, const mvs_camera* c1, cons
 // Rt_dev: 12 device doubles = R row-major, t
 void launch_srt_residual(const double* matches_dev, int64_t n, const CamDev& c1, const CamDev& c2, double scale,
                          const double* Rt_dev, double* per_match_dev, hipStream_t s);
+// one RemoveOutliers round over `sets` independent match sets at once (all device buffers; see srt.hip)
+int srt_ransac_round_batched(const double* m_all, const int64_t* off, int sets, int64_t total, const int32_t* set_of, const CamDev* c1,
+                             const CamDev* c2, const int32_t* triples, int iters, double* stats, double* hyp, double* out, double* per_match,
+                             hipStream_t s);
 #endif

@@ -174,7 +174,110 @@ __global__ void k_srt_residual_out(const double* __restrict__ m, int64_t n, CamD
     out[13] = err / (double)n;
 }
 
+// ------------------------------------------------------------------ batched ----
+// The same four steps over MANY independent match sets at once (every frame pair of two sequences:
+// Processor::AlignmentSeq's key-frame selection, R/Processor/Processor.cpp:746-765, runs RemoveOutliers on each):
+// set k owns matches [off[k], off[k+1]) of one concatenated array and its own pair of cameras.
+__global__ __launch_bounds__(256) void k_srt_stats_b(const double* __restrict__ m_all, const int64_t* __restrict__ off, double* __restrict__ stats_all) {
+    __shared__ double sm[4 * 9];
+    const int k = blockIdx.x;
+    const double* m = m_all + 6 * off[k];
+    const int64_t n = off[k + 1] - off[k];
+    double* stats = stats_all + 16 * (int64_t)k;
+    if (n < 1) return;                           // (uniform per block)
+    double v[9];
+    for (int q = 0; q < 9; ++q) v[q] = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 256)
+        for (int q = 0; q < 6; ++q) v[q] += m[6 * i + q];
+    block_sum_arr<6>(v, sm);
+    const d3 b1 = mk3(v[0] / (double)n, v[1] / (double)n, v[2] / (double)n);
+    const d3 b2 = mk3(v[3] / (double)n, v[4] / (double)n, v[5] / (double)n);
+    double sc[1] = {0};
+    for (int64_t i = threadIdx.x; i < n; i += 256) sc[0] += norm3(ld3(m + 6 * i + 3) - b2) / norm3(ld3(m + 6 * i) - b1);
+    block_sum_arr<1>(sc, sm);
+    if (threadIdx.x == 0) { st3(stats, b1); st3(stats + 3, b2); stats[6] = sc[0] / (double)n; }
+}
+
+__global__ void k_srt_ransac_b(const double* __restrict__ m_all, const int64_t* __restrict__ off, const CamDev* __restrict__ c1,
+                               const CamDev* __restrict__ c2, const double* __restrict__ stats_all, const int32_t* __restrict__ triples,
+                               int iters, double* __restrict__ hyp /* sets * iters * 13 */) {
+    const int k = blockIdx.y, h = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = off[k + 1] - off[k];
+    if (h >= iters || n < 3) return;
+    const double* m = m_all + 6 * off[k];
+    const double* stats = stats_all + 16 * (int64_t)k;
+    const d3 b1 = ld3(stats), b2 = ld3(stats + 3);
+    const double scale = stats[6];
+    const int32_t* tri = triples + 3 * ((int64_t)k * iters + h);
+    double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < 3; ++j) {                          // SRTSolver.cpp:153-163
+        const int64_t i = tri[j];
+        const d3 d = ld3(m + 6 * i) - b1;
+        const d3 X = mk3(d.x * scale, d.y * scale, d.z * scale), Y = ld3(m + 6 * i + 3) - b2;
+        S[0] += X.x * Y.x; S[1] += X.x * Y.y; S[2] += X.x * Y.z;
+        S[3] += X.y * Y.x; S[4] += X.y * Y.y; S[5] += X.y * Y.z;
+        S[6] += X.z * Y.x; S[7] += X.z * Y.y; S[8] += X.z * Y.z;
+    }
+    double R[9], t[3];
+    rt_from_S(S, scale, b1, b2, R, t);
+    const Xf x = make_xf(scale, R, t);
+    const CamDev ca = c1[k], cb = c2[k];
+    double err = 0.0;
+    for (int64_t i = 0; i < n; ++i) {                      // ResidualError, :8-26 (match order)
+        double e1, e2;
+        match_err(ca, cb, x, m + 6 * i, &e1, &e2);
+        err = err + (e1 + e2) * 0.5;
+    }
+    err /= (double)n;
+    double* o = hyp + 13 * ((int64_t)k * iters + h);
+    for (int i = 0; i < 9; ++i) o[i] = R[i];
+    for (int i = 0; i < 3; ++i) o[9 + i] = t[i];
+    o[12] = err;
+}
+
+// first strict minimum per set (:178), then the per-match pixel errors of the picked transform (what RemoveOutliers thresholds)
+__global__ void k_srt_pick_b(const double* __restrict__ hyp, int iters, const double* __restrict__ stats_all, const int64_t* __restrict__ off,
+                             double* __restrict__ out_all /* sets * 13: scale, R, t */) {
+    const int k = blockIdx.x;
+    if (threadIdx.x != 0 || off[k + 1] - off[k] < 3) return;
+    const double* H = hyp + 13 * (int64_t)k * iters;
+    double best = INFINITY;
+    int arg = -1;
+    for (int h = 0; h < iters; ++h)
+        if (H[13 * (int64_t)h + 12] < best) { best = H[13 * (int64_t)h + 12]; arg = h; }
+    double* out = out_all + 13 * (int64_t)k;
+    out[0] = stats_all[16 * (int64_t)k + 6];
+    if (arg < 0) {
+        for (int i = 0; i < 9; ++i) out[1 + i] = (i % 4 == 0) ? 1.0 : 0.0;
+        for (int i = 0; i < 3; ++i) out[10 + i] = 0.0;
+    } else {
+        for (int i = 0; i < 12; ++i) out[1 + i] = H[13 * (int64_t)arg + i];
+    }
+}
+__global__ void k_srt_residual_b(const double* __restrict__ m_all, int64_t total, const int32_t* __restrict__ set_of, const CamDev* __restrict__ c1,
+                                 const CamDev* __restrict__ c2, const double* __restrict__ out_all, double* __restrict__ per_match) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = set_of[i];
+    const double* out = out_all + 13 * (int64_t)k;
+    const Xf x = make_xf(out[0], out + 1, out + 10);
+    match_err(c1[k], c2[k], x, m_all + 6 * i, &per_match[2 * i], &per_match[2 * i + 1]);
+}
+
 }  // namespace
+
+// One RemoveOutliers round for `sets` independent match sets (device buffers; sets with fewer than 3 matches are skipped):
+// stats -> every hypothesis of every set in ONE launch -> pick -> per-match pixel errors of the picked transforms.
+int srt_ransac_round_batched(const double* m_all, const int64_t* off, int sets, int64_t total, const int32_t* set_of, const CamDev* c1,
+                             const CamDev* c2, const int32_t* triples, int iters, double* stats, double* hyp, double* out, double* per_match,
+                             hipStream_t s) {
+    if (sets <= 0 || total <= 0) return MVS_OK;
+    k_srt_stats_b<<<dim3(sets), dim3(256), 0, s>>>(m_all, off, stats);
+    k_srt_ransac_b<<<dim3((iters + 63) / 64, sets), dim3(64), 0, s>>>(m_all, off, c1, c2, stats, triples, iters, hyp);
+    k_srt_pick_b<<<dim3(sets), dim3(64), 0, s>>>(hyp, iters, stats, off, out);
+    k_srt_residual_b<<<dim3((unsigned)((total + 127) / 128)), dim3(128), 0, s>>>(m_all, total, set_of, c1, c2, out, per_match);
+    return mvs_check_hip(hipGetLastError(), "srt_ransac_round_batched");
+}
 
 int srt_fit_dev(const double* matches_dev, int64_t n, const mvs_camera* c1, const mvs_camera* c2, int mode,
                 const int32_t* triples_dev, int iters, double* out_dev, hipStream_t s) {

@@ -88,6 +88,29 @@ def remove_outliers(matches, cam1, cam2, iters: int = 200, pixel_err: float = 60
     return keep, nk.value, err.value, st.value
 
 
+def select_keyframe_pair(cams1, cams2, matches, min_match_count: int = 7, iters: int = 200, pixel_err: float = 60.0,
+                         adapt_ratio: float = 0.75, state: int = 1):
+    """Key-frame pair selection of Processor::AlignmentSeq (R/Processor/Processor.cpp:746-765).
+    ``matches[i][j]`` = (n_ij, 6) lifted 3-D matches between frame i of one sequence and frame j of the next.
+    -> dict(frm_idx1, frm_idx2, err, keep = per-pair boolean masks, n_keep, pair_err, state); raises MvsError
+    (MVS_E_DEGENERATE) when no pair qualifies, as the reference exits."""
+    n1, n2 = len(cams1), len(cams2)
+    flat = [L.arr(matches[i][j], np.float64).reshape(-1, 6) for i in range(n1) for j in range(n2)]
+    off = np.zeros(n1 * n2 + 1, np.int64)
+    off[1:] = np.cumsum([len(m) for m in flat])
+    allm = np.ascontiguousarray(np.concatenate(flat)) if off[-1] else np.zeros((0, 6))
+    c1 = (L.CCamera * n1)(*[L.CCamera.of(c) for c in cams1])
+    c2 = (L.CCamera * n2)(*[L.CCamera.of(c) for c in cams2])
+    st, f1, f2, err = C.c_uint32(state), C.c_int32(), C.c_int32(), C.c_double()
+    keep = np.zeros(int(off[-1]), np.uint8)
+    nk, perr = np.zeros(n1 * n2, np.int64), np.zeros(n1 * n2)
+    L.check(L.lib().mvs_select_keyframe_pair(n1, n2, C.cast(c1, C.c_void_p), C.cast(c2, C.c_void_p), L.ptr(off), L.ptr(allm), min_match_count,
+                                             iters, pixel_err, adapt_ratio, C.cast(C.byref(st), C.c_void_p), C.cast(C.byref(f1), C.c_void_p),
+                                             C.cast(C.byref(f2), C.c_void_p), C.cast(C.byref(err), C.c_void_p), L.ptr(keep), L.ptr(nk), L.ptr(perr)))
+    masks = [[keep[off[i * n2 + j]:off[i * n2 + j + 1]].astype(bool) for j in range(n2)] for i in range(n1)]
+    return dict(frm_idx1=f1.value, frm_idx2=f2.value, err=err.value, keep=masks, n_keep=nk.reshape(n1, n2), pair_err=perr.reshape(n1, n2), state=st.value)
+
+
 def compose(sk, Rk, tk, s0, R0, t0):
     """Chain composition (Processor.cpp:819-823): returns the updated (s0, R0, t0)."""
     Rk, tk = L.arr(Rk, np.float64), L.arr(tk, np.float64)

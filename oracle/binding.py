@@ -175,6 +175,25 @@ def srt_remove_outliers(matches, cam1, cam2, iters, pixel_err, adapt_ratio, stat
     return keep, nk.value, err.value, st.value
 
 
+def select_keyframe_pair(cams1, cams2, matches, min_match_count=7, iters=200, pixel_err=60.0, adapt_ratio=0.75, state=1):
+    """matches[i][j] = (n_ij, 6); -> dict like multiviewstitch_amd.srt.select_keyframe_pair, plus rc (0 or -9)."""
+    n1, n2 = len(cams1), len(cams2)
+    flat = [_c(matches[i][j], np.float64).reshape(-1, 6) for i in range(n1) for j in range(n2)]
+    off = np.zeros(n1 * n2 + 1, np.int64)
+    off[1:] = np.cumsum([len(m) for m in flat])
+    allm = np.ascontiguousarray(np.concatenate(flat)) if off[-1] else np.zeros((0, 6))
+    c1 = (Camera * n1)(*[Camera.of(c) for c in cams1])
+    c2 = (Camera * n2)(*[Camera.of(c) for c in cams2])
+    st, f1, f2, err = C.c_uint32(state), C.c_int32(), C.c_int32(), C.c_double()
+    keep = np.zeros(int(off[-1]), np.uint8)
+    nk, perr = np.zeros(n1 * n2, np.int64), np.zeros(n1 * n2)
+    rc = lib().orc_select_keyframe_pair(C.c_int32(n1), C.c_int32(n2), c1, c2, _p(off), _p(allm), C.c_int32(min_match_count), C.c_int(iters),
+                                        C.c_double(pixel_err), C.c_double(adapt_ratio), C.byref(st), C.byref(f1), C.byref(f2), C.byref(err),
+                                        _p(keep), _p(nk), _p(perr))
+    masks = [[keep[off[i * n2 + j]:off[i * n2 + j + 1]].astype(bool) for j in range(n2)] for i in range(n1)]
+    return dict(rc=rc, frm_idx1=f1.value, frm_idx2=f2.value, err=err.value, keep=masks, n_keep=nk.reshape(n1, n2), pair_err=perr.reshape(n1, n2), state=st.value)
+
+
 def srt_compose(sk, Rk, tk, s0, R0, t0):
     Rk, tk = _c(Rk, np.float64), _c(tk, np.float64)
     R0, t0 = _c(R0, np.float64).copy(), _c(t0, np.float64).copy()

@@ -75,6 +75,10 @@ double orc_srt_residual(const double* matches, int64_t n, const orc_camera* c1, 
 int    orc_srt_remove_outliers(const double* matches, int64_t n, const orc_camera* c1,
                                const orc_camera* c2, int iters, double pixel_err, double adapt_ratio,
                                uint32_t* rand_state, uint8_t* keep, int64_t* n_keep, double* err);
+int orc_select_keyframe_pair(int32_t n1, int32_t n2, const orc_camera* cams1, const orc_camera* cams2, const int64_t* off,
+                             const double* matches, int32_t min_match_count, int iters, double pixel_err, double adapt_ratio,
+                             uint32_t* state, int32_t* frm1, int32_t* frm2, double* err_out, uint8_t* keep, int64_t* n_keep,
+                             double* pair_err);
 void   orc_srt_make_triples(int64_t n, int iters, uint32_t* state, int32_t* triples);
 void   orc_srt_compose(double sk, const double* Rk, const double* tk, double* s0, double* R0, double* t0);
 void   orc_srt_relative(double s_k0, const double* R_k0, const double* t_k0, double s_k,

@@ -515,6 +515,38 @@ extern "C" int orc_srt_remove_outliers(const double* matches, int64_t n, const o
     return 0;
 }
 
+// Key-frame pair selection, Processor::AlignmentSeq (R/Processor/Processor.cpp:746-765): the double loop over the frames of
+// two sequences, RemoveOutliers on every pair with >= min_match_count matches (one rand() stream through all of them, in
+// loop order), strict `res_err < err` selection among the pairs that still hold >= min_match_count matches afterwards.
+// Returns 0, or -9 when no pair qualifies (the reference prints "No Enough Sift Feature Matches" and exits, :794-800).
+extern "C" int orc_select_keyframe_pair(int32_t n1, int32_t n2, const orc_camera* cams1, const orc_camera* cams2,
+                                        const int64_t* off, const double* matches, int32_t min_match_count, int iters,
+                                        double pixel_err, double adapt_ratio, uint32_t* state, int32_t* frm1, int32_t* frm2,
+                                        double* err_out, uint8_t* keep, int64_t* n_keep, double* pair_err) {
+    double err = HUGE_VAL;
+    int64_t maxMatchCount = 0;
+    *frm1 = -1; *frm2 = -1;
+    for (int i = 0; i < n1; ++i)
+        for (int j = 0; j < n2; ++j) {
+            const int k = i * n2 + j;
+            const int64_t n = off[k + 1] - off[k];
+            if (n_keep) n_keep[k] = n;
+            if (pair_err) pair_err[k] = HUGE_VAL;
+            if (keep) std::memset(keep + off[k], 1, (size_t)n);
+            if (n < min_match_count) continue;                               // :750
+            std::vector<uint8_t> kp((size_t)n);
+            int64_t nk = 0;
+            double res_err = HUGE_VAL;
+            orc_srt_remove_outliers(matches + 6 * off[k], n, &cams1[i], &cams2[j], iters, pixel_err, adapt_ratio, state, kp.data(), &nk, &res_err);   // :754
+            if (keep) std::memcpy(keep + off[k], kp.data(), (size_t)n);
+            if (n_keep) n_keep[k] = nk;
+            if (pair_err) pair_err[k] = res_err;
+            if (res_err < err && nk >= min_match_count) { maxMatchCount = nk; err = res_err; *frm1 = i; *frm2 = j; }   // :755-762
+        }
+    *err_out = err;
+    return maxMatchCount < min_match_count ? -9 : 0;
+}
+
 extern "C" {
 
 void orc_srt_compose(double sk, const double* Rk, const double* tk, double* s0, double* R0, double* t0) {
