@@ -421,6 +421,25 @@ void* mvs_deform_stream(mvs_deform_t h);        /* hipStream_t of the handle    
  * be selected: create a stream.  The handle's stream is drained first. */
 int mvs_deform_set_stream(mvs_deform_t h, void* hip_stream);
 
+/* ---- multi-GPU: one process (or thread) per GPU, RCCL over xGMI (SURVEY.md §8b "Threading", §8e) ----
+ * The view-sharded body above, driven from C: every rank holds the target points of its views (mvs_deform_set_target
+ * with the global index_base of its first point), the template and the node set are the same everywhere.  RCCL is
+ * bound at run time (dlopen): a host that never calls these entries does not need it.
+ *   mvs_comm_unique_id : rank 0 makes the 128-byte id and hands it to the other ranks by its own means (file, socket,
+ *                        MPI, torch.distributed broadcast ...);
+ *   mvs_comm_init      : collective over all ranks; uses the CURRENT HIP device (mvs_set_device / hipSetDevice first);
+ *   mvs_deform_iterate_sharded : n_outer passes; per pass one ncclAllReduce(min) of K floats and one ncclAllGather of
+ *                        K * 392 bytes per rank, both on the handle's stream (no host synchronisation between engine
+ *                        kernels and collectives); merge and solve replicated — the replicas stay bit-identical.
+ *                        Statistics / status as mvs_deform_iterate (read back every 32nd pass and at the end). */
+#define MVS_COMM_ID_BYTES 128
+typedef struct mvs_comm_s* mvs_comm_t;
+int mvs_comm_unique_id(uint8_t* id /*MVS_COMM_ID_BYTES*/);
+int mvs_comm_init(int rank, int nranks, const uint8_t* id /*MVS_COMM_ID_BYTES*/, mvs_comm_t* out);
+int mvs_comm_destroy(mvs_comm_t c);
+int mvs_comm_info(mvs_comm_t c, int* rank, int* nranks);
+int mvs_deform_iterate_sharded(mvs_deform_t h, mvs_comm_t c, const mvs_deform_params* p, int n_outer, mvs_deform_stats* stats);
+
 /* Read-back (host buffers). */
 int mvs_deform_get_vertices(mvs_deform_t h, double* pts /*V*3*/);
 int mvs_deform_get_normals(mvs_deform_t h, double* normals /*V*3*/);

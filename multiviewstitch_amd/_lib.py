@@ -120,6 +120,11 @@ _SIGS = {
     "mvs_deform_assoc_merge": (C.c_int, [_VP, _VP, _VP, _VP, _I32]),
     "mvs_deform_assoc_merge_packed": (C.c_int, [_VP, _VP, _VP, _I32]),
     "mvs_deform_solve": (C.c_int, [_VP, _VP, _VP]),
+    "mvs_comm_unique_id": (C.c_int, [_VP]),
+    "mvs_comm_init": (C.c_int, [_I32, _I32, _VP, _VP]),
+    "mvs_comm_destroy": (C.c_int, [_VP]),
+    "mvs_comm_info": (C.c_int, [_VP, _VP, _VP]),
+    "mvs_deform_iterate_sharded": (C.c_int, [_VP, _VP, _VP, _I32, _VP]),
     "mvs_deform_sync": (C.c_int, [_VP]),
     "mvs_deform_stream": (C.c_void_p, [_VP]),
     "mvs_deform_set_stream": (C.c_int, [_VP, _VP]),

@@ -820,6 +820,7 @@ int mvs_deform_destroy(mvs_deform_t h) {
     dfree(h->d_spos); dfree(h->d_tpos); dfree(h->d_tnrm); dfree(h->d_cell_start); dfree(h->d_coarse_cnt);
     for (int k = 0; k < 2; ++k) dfree(h->d_rws[k]);
     dfree(h->d_p); dfree(h->d_coef); dfree(h->d_slots); dfree(h->d_energy); dfree(h->d_info); dfree(h->d_ctl); dfree(h->d_bar); dfree(h->d_ras_tail); dfree(h->d_bpure);
+    if (h->d_sh) { (void)hipFree(h->d_sh); h->d_sh = nullptr; }
     if (h->h_ctl) { (void)hipHostFree((void*)h->h_ctl); h->h_ctl = nullptr; }
     ras_free(h);
     for (auto& pr : h->pending) { (void)hipEventDestroy(pr.second.first); (void)hipEventDestroy(pr.second.second); }
@@ -1064,6 +1065,10 @@ int mvs_deform_assoc_merge_packed(mvs_deform_t h, const mvs_deform_params* p, co
 int mvs_deform_solve(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stats* stats) {
     int rc = ready(h, p, false);
     if (rc) return rc;
+    if (h->cg_iters > 0) {              // calibrated: stay at most THROTTLE_LAG passes ahead of the device and follow the residual ring
+        if ((rc = throttle(h))) return rc;
+        peek_ring(h, *p, use_ras(h, *p));
+    }
     const CgPlan cg = probe_cg(h, *p);
     rc = enqueue_solve(h, *p, h->d_ctrl_raw, true, cg);
     if (rc) return rc;

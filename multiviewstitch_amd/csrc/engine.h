@@ -144,6 +144,9 @@ struct mvs_deform_s {
     // closed loop (see MVS_CTL_*): device control block, its pinned host mirror, enqueue counters
     double* d_ctl = nullptr;
     unsigned* d_bar = nullptr;      // [2] arrival counter + give-up flag of the tail loop's device-wide barrier (reset by k_arap_rhs before every solve)
+    // exchange buffers of mvs_deform_iterate_sharded (comm.cpp): d2min | this rank's packed block | every rank's block
+    void* d_sh = nullptr;
+    int64_t sh_K = 0; int sh_nranks = 0; size_t sh_off_pack = 0, sh_off_all = 0;
     double* d_bpure = nullptr;      // [V*3] right-hand side without its Dirichlet share (k_arap_rhs -> k_arap_local's true residual)
     double* d_ras_tail = nullptr;   // [8][RAS_TAIL_MAX] sweep slots of the in-kernel sweeps of TAIL launches
     volatile double* h_ctl = nullptr;

@@ -369,6 +369,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     int extra = 0;
     bool finished = false;
     double* slot_k = slot_cur;                                         // partials of the sweep done last
+    double g_before[3] = {s_gam[0], s_gam[1], s_gam[2]};               // residual of the input of the sweep BEFORE the one done last
     for (;;) {
         if (!tail_barrier(tail.bar, (unsigned)gridDim.x * (unsigned)(extra + 1))) break;     // not every workgroup is there: report as it stands
         if (wv < 3) {
@@ -376,9 +377,13 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
             if (lane == 0) s_gam[wv] = gam;
         }
         __syncthreads();
-        bool conv = true;
+        bool conv = true, slow = false;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) if (s_gam[c] > 0.0 && s_gam[c] > cg_tol * cg_tol * bn[c]) conv = false;
+        for (int c = 0; c < 3; ++c) {
+            if (s_gam[c] > 0.0 && s_gam[c] > cg_tol * cg_tol * bn[c]) conv = false;
+            if (s_gam[c] > slow2 * g_before[c]) slow = true;           // the same rule a planned sweep applies in its preamble:
+            g_before[c] = s_gam[c];                                    // what a sweep computes does not depend on where the plan ended
+        }
         if (conv) { finished = true; break; }
         if (extra >= tail.max_extra) break;
         // one more sweep: the buffers swap roles; x of the halo comes from what the other patches just wrote
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         if (row >= nown) { const d3 t = ld3(xin + 3 * (int64_t)g); xi = t; xs[row] = make_double4(t.x, t.y, t.z, 0.0); }
         if (row < nh) xs[LS + row] = make_double4(xh.x, xh.y, xh.z, 0.0);
         __syncthreads();
-        strong = true;                                                 // a solve that overran its plan: no half measures
+        strong = s_esc || slow;
         slot_k = tail.slots + (size_t)extra * ras_slot_doubles(NPpad);
         steps += sweep_body(slot_k, xout);
         ++extra;

@@ -160,6 +160,12 @@ class Deformation:
         rc = L.check(L.lib().mvs_deform_solve(self._h, C.byref(self.params), C.byref(st)))
         return _stats(st, rc)
 
+    def iterate_sharded(self, comm: "Comm", n_outer: int = 1) -> dict:
+        """``mvs_deform_iterate_sharded``: the view-sharded passes with the collectives issued by the library itself (RCCL)."""
+        st = L.CStats()
+        rc = L.check(L.lib().mvs_deform_iterate_sharded(self._h, comm._c, C.byref(self.params), n_outer, C.byref(st)))
+        return _stats(st, rc)
+
     def sync(self):
         L.check(L.lib().mvs_deform_sync(self._h))
 
@@ -234,6 +240,34 @@ class Deformation:
         ms, n = C.c_double(), C.c_int64()
         L.check(L.lib().mvs_deform_kernel_time(self._h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class Comm:
+    """``mvs_comm_t``: the library's own RCCL communicator (one rank per GPU).  ``Comm.unique_id()`` on rank 0, share the
+    bytes with the other ranks, then ``Comm(rank, nranks, id)`` everywhere (a collective)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        L.check(L.lib().mvs_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def __init__(self, rank: int, nranks: int, uid: bytes):
+        self._c = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        L.check(L.lib().mvs_comm_init(rank, nranks, C.cast(buf, C.c_void_p), C.cast(C.byref(self._c), C.c_void_p)))
+        self.rank, self.nranks = rank, nranks
+
+    def close(self):
+        if getattr(self, "_c", None):
+            L.lib().mvs_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def knn_points(pts, k: int) -> np.ndarray:

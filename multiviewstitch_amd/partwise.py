@@ -104,24 +104,45 @@ def split_parts(faces, labels, n_parts: int | None = None):
     return out
 
 
+def assign_parts(sizes, world: int) -> list[int]:
+    """Owner rank of every part: largest part first onto the least loaded rank (ties: lower rank, lower part index) —
+    deterministic, so every rank computes the same map without talking."""
+    load = [0] * world
+    owner = [0] * len(sizes)
+    for k in sorted(range(len(sizes)), key=lambda q: (-int(sizes[q]), q)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[k] = r
+        load[r] += int(sizes[k])
+    return owner
+
+
 class PartwiseDeformation:
     """One ``Deformation`` per part label; same call sequence as ``Deformation`` (UniformSampling -> set_target ->
-    iterate -> vertices)."""
+    iterate -> vertices).
 
-    def __init__(self, points, normals, facets, labels, n_parts: int | None = None, device: int | None = None):
+    ``world > 1`` (one process per GPU, torch.distributed initialised): the parts are INDEPENDENT fits, so they shard
+    naturally — every rank owns the handles of its parts only (``assign_parts``: balanced by vertex count), takes the scan
+    points of those parts, iterates them without any communication, and the one collective of the whole fit is the
+    all-gather of the part vertices in ``vertices()`` (padded to the largest rank's share; ``group`` = process group)."""
+
+    def __init__(self, points, normals, facets, labels, n_parts: int | None = None, device: int | None = None,
+                 rank: int = 0, world: int = 1, group=None, handle_factory=None):
         self.points = np.array(points, np.float64).reshape(-1, 3)
         self.normals = np.array(normals, np.float64).reshape(-1, 3)
         self.labels = np.asarray(labels, np.int32).reshape(-1)
         if len(self.labels) != len(self.points):
             raise ValueError("one label per vertex")
         self.parts = split_parts(facets, self.labels, n_parts)
+        self.rank, self.world, self.group = int(rank), int(world), group
+        self.owner = assign_parts([len(p["vid"]) for p in self.parts], self.world)
+        make = handle_factory if handle_factory is not None else (lambda pts, nrm, fcs: Deformation(pts, nrm, fcs, device))
         self.handles: list[Deformation | None] = []
-        for part in self.parts:
-            if len(part["faces"]) == 0:
+        for k, part in enumerate(self.parts):
+            if len(part["faces"]) == 0 or self.owner[k] != self.rank:
                 self.handles.append(None)
                 continue
             vid = part["vid"]
-            self.handles.append(Deformation(self.points[vid], self.normals[vid], part["faces"], device))
+            self.handles.append(make(self.points[vid], self.normals[vid], part["faces"]))
         self._calibrated = False
         self._pool = None
         self.host_threads = 8
@@ -149,6 +170,7 @@ class PartwiseDeformation:
 
     @property
     def K(self) -> int:
+        """nodes of the parts this rank owns (all parts when world == 1)"""
         return sum(h.K for _, h in self.live)
 
     def set_target(self, tpts, tnormals, tlabels):
@@ -180,9 +202,33 @@ class PartwiseDeformation:
         list(self._pool.map(lambda kh: kh[1].enqueue(n_outer), self.live))
         return [h.collect() for _, h in self.live]
 
-    def vertices(self) -> np.ndarray:
-        """[V,3]: each part's vertices at their place; vertices of no sub-mesh (isolated by the split) stay at rest."""
+    def vertices(self, comm_device=None) -> np.ndarray:
+        """[V,3]: each part's vertices at their place; vertices of no sub-mesh (isolated by the split) stay at rest.
+        world > 1: every rank contributes the vertices of the parts it owns to ONE all-gather (comm_device: the torch
+        device the collective runs on — the rank's GPU under nccl = RCCL, None = CPU tensors for gloo)."""
         out = self.points.copy()
         for k, h in self.live:
             out[self.parts[k]["vid"]] = h.vertices()
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            mine = [k for k in range(len(self.parts)) if self.owner[k] == self.rank and len(self.parts[k]["faces"])]
+            share = [sum(len(self.parts[k]["vid"]) for k in range(len(self.parts)) if self.owner[k] == r and len(self.parts[k]["faces"]))
+                     for r in range(self.world)]
+            width = max(max(share), 1) * 3
+            send = torch.zeros(width, dtype=torch.float64, device=comm_device)
+            if mine:
+                flat = np.concatenate([out[self.parts[k]["vid"]].reshape(-1) for k in mine])
+                send[:len(flat)] = torch.from_numpy(flat).to(send.device)
+            recv = torch.empty(self.world * width, dtype=torch.float64, device=comm_device)
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+            recv = recv.cpu().numpy().reshape(self.world, width)
+            for r in range(self.world):
+                o = 0
+                for k in range(len(self.parts)):
+                    if self.owner[k] != r or len(self.parts[k]["faces"]) == 0:
+                        continue
+                    n = len(self.parts[k]["vid"]) * 3
+                    out[self.parts[k]["vid"]] = recv[r, o:o + n].reshape(-1, 3)
+                    o += n
         return out

@@ -138,3 +138,85 @@ def test_bench_launcher_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run"],
                        env=dict(env, MVS_BENCH_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+# ---------------------------------------------------------------- parts over ranks (BASELINE config 5) ----
+class _OraclePart:
+    """The handle protocol PartwiseDeformation drives, on top of oracle/ (the product handle needs a GPU)."""
+
+    def __init__(self, pts, nrm, faces):
+        from oracle import binding as O
+        self.O, self.o = O, O.Deform(pts, nrm, faces)
+        self.params = O.Params.default()
+
+    def UniformSampling(self, knn=16):
+        self.K = self.o.sample_nodes(knn)
+        return self.K
+
+    def set_target(self, tp, tn):
+        self.o.set_target(tp, tn)
+
+    def iterate(self, n=1):
+        return self.o.iterate(self.params, n)
+
+    def enqueue(self, n=1):
+        self._st = self.o.iterate(self.params, n)
+
+    def collect(self):
+        return self._st
+
+    def vertices(self):
+        return self.o.vertices()
+
+    def close(self):
+        pass
+
+
+def _parts_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multiviewstitch_amd import partwise as PW
+    from tests.util import scene_and_target
+    sc, tp, tn, _ = scene_and_target(0)
+    labels, tl = PW.sector_labels(sc.verts, 5), PW.sector_labels(tp, 5)
+    pd = PW.PartwiseDeformation(sc.verts, sc.normals, sc.faces, labels, 5, rank=rank, world=world, handle_factory=_OraclePart)
+    pd.UniformSampling(16)
+    pd.set_target(tp, tn, tl)
+    pd.iterate(1)
+    pd.iterate(1)
+    q.put((rank, pd.vertices(), [k for k, _ in pd.live], pd.owner))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_parts_shard_over_ranks_with_one_all_gather():
+    """config 5's per-part graphs are independent fits: two ranks each own some parts, iterate them without talking, and
+    the all-gather in vertices() gives every rank the mesh a single process computes."""
+    from multiviewstitch_amd import partwise as PW
+    from tests.util import scene_and_target
+    assert PW.assign_parts([5, 9, 9, 1], 2) == [0, 0, 1, 1]          # largest first onto the least loaded rank, ties -> lower rank
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_parts_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sc, tp, tn, _ = scene_and_target(0)
+    labels, tl = PW.sector_labels(sc.verts, 5), PW.sector_labels(tp, 5)
+    ref = PW.PartwiseDeformation(sc.verts, sc.normals, sc.faces, labels, 5, handle_factory=_OraclePart)
+    ref.UniformSampling(16)
+    ref.set_target(tp, tn, tl)
+    ref.iterate(1)
+    ref.iterate(1)
+    want = ref.vertices()
+    assert np.abs(want - sc.verts).max() > 1e-4                        # the fit moved something
+    assert sorted(got[0][2] + got[1][2]) == [k for k, _ in ref.live] and not set(got[0][2]) & set(got[1][2])
+    assert got[0][3] == got[1][3]
+    for _, v, _, _ in got:
+        assert np.array_equal(v, want)

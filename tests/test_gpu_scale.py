@@ -152,3 +152,23 @@ def test_config3_matches_oracle_at_vertex_level(big, oracle):
         assert np.abs(gs - os_).max() <= 1e-10, f"outer {it}"
         assert rms(d.vertices(), o.vertices()) <= 1e-6, f"outer {it}"
         assert rms(d.rotations().reshape(-1, 9), o.rotations().reshape(-1, 9)) <= 1e-6, f"outer {it}"
+
+
+def test_library_owned_rccl_communicator_drives_the_sharded_passes(big):
+    """mvs_comm_* + mvs_deform_iterate_sharded: the C-ABI's own multi-GPU entry (RCCL bound at run time).  One rank is all a
+    one-GPU box can hold, but it goes through the real thing: ncclCommInitRank, the sharded kernels (dmin / select / merge
+    split at the exchange points) and the replicated solve — and must give the bits of the fused single-GPU iteration."""
+    from multiviewstitch_amd.deformation import Comm
+    d, _, _ = make(big)
+    ref, _, _ = make(big)
+    uid = Comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = Comm(0, 1, uid)
+    st = d.iterate_sharded(comm, 3)
+    rs = ref.iterate(3)
+    assert st["outer_done"] == 3 and st["converged"] and st["n_valid"] == rs["n_valid"]
+    assert np.array_equal(d.vertices(), ref.vertices())
+    st = d.iterate_sharded(comm, 2)                      # and again on the calibrated handle (enqueue-only passes inside)
+    ref.iterate(2)
+    assert st["converged"] and np.array_equal(d.vertices(), ref.vertices())
+    comm.close()
