@@ -90,28 +90,6 @@ __device__ inline float box_lb2(const QCell& c, float x0, float x1, float y0, fl
     return (ex * ex + ey * ey) + ez * ez;
 }
 
-// decode the t-th cell of the cubic shell of radius S >= 1 (n = 2S+1): two z faces, two y faces, two x faces.
-// No integer divisions (each is a ~40-instruction sequence on this hardware and the shell walk of a far node decodes
-// hundreds of cells per lane — they were most of its cycles, scripts/dmin_shells.py): which of the two faces is a
-// comparison, the row inside a face one float multiply, exact for the sizes that occur (t < 2^20, n <= 257: the
-// quotient is taken at t + 0.5, at least 0.5/n away from an integer, against a float error below 1e-5).
-__device__ inline int div_small(int t, int d, float inv_d) { (void)d; return (int)(((float)t + 0.5f) * inv_d); }
-__device__ inline void shell_cell(int t, int S, int* dx, int* dy, int* dz) {
-    const int n = 2 * S + 1, m = n - 2;
-    const int nzf = n * n, nyf = n * m;
-    const float inv_n = 1.0f / (float)n, inv_m = 1.0f / (float)m;      // (wave-uniform: scalar work)
-    if (t < 2 * nzf) {
-        const int f = t >= nzf, r = t - f * nzf, q = div_small(r, n, inv_n);
-        *dz = f ? S : -S; *dy = q - S; *dx = r - q * n - S;
-    } else if (t < 2 * nzf + 2 * nyf) {
-        const int t1 = t - 2 * nzf, f = t1 >= nyf, r = t1 - f * nyf, q = div_small(r, n, inv_n);
-        *dy = f ? S : -S; *dz = q - (S - 1); *dx = r - q * n - S;
-    } else {
-        const int t2 = t - 2 * nzf - 2 * nyf, f = t2 >= m * m, r = t2 - f * m * m, q = div_small(r, m, inv_m);
-        *dx = f ? S : -S; *dz = q - (S - 1); *dy = r - q * m - (S - 1);
-    }
-}
-
 // ------------------------------------------------------------------ dmin ----
 // exact squared distance (float32) of one node to its nearest target point, by one wave; every lane gets the result
 // limit2: an UPPER bound on the squared distance of the node to the nearest point of the WHOLE target (all ranks), or

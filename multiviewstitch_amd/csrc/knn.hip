@@ -434,12 +434,10 @@ void launch_knn_grid(const double* pts, int n, int k, int32_t* out, void* ws, hi
 // vertex (float32 distances, ties -> lower vertex index) for every query point.
 //   pass 1 (k_label_nn):  one thread per query walks the cubic shells 0..NEAR_SHELLS of the template's point grid;
 //                         a query whose search is not closed by then is appended to the far list
-//   pass 2 (k_label_far): far queries against ALL template vertices, tiles staged through LDS and broadcast to the
-//                         256 queries of a workgroup (V = 10 K template vertices are 160 KB as float4)
-// so the cost of a query is bounded by V distance evaluations however far it lies from the template.
+//   pass 2 (k_label_far): a wave per far query: the shell walk continued 64 cells at a time, all V vertices only for a
+//                         query far outside the template's box
 namespace {
 constexpr int NEAR_SHELLS = 3;
-constexpr int FAR_TILE = 2048;
 
 __global__ __launch_bounds__(256) void k_label_nn(const NgGeom* __restrict__ geo, const int* __restrict__ cs,
                                                   const float4* __restrict__ sorted, const int32_t* __restrict__ labels,
@@ -506,33 +504,65 @@ __global__ __launch_bounds__(256) void k_label_nn(const NgGeom* __restrict__ geo
     }
 }
 
-__global__ __launch_bounds__(256) void k_label_far(const double* __restrict__ tmpl, int V, const int32_t* __restrict__ labels,
-                                                   const double* __restrict__ pts, const int32_t* __restrict__ far,
-                                                   int32_t* __restrict__ out) {
+// far queries, ONE WAVE each: the shell walk goes on with 64 cells per step (shell s holds ~24 s^2 cells, each a 2-load
+// range look-up and a handful of points), closed by the same bound as pass 1; a query still open after FAR_SHELLS shells
+// (far outside the template's bounding box) scans all V template vertices with its 64 lanes.  Either way a far query
+// costs its own wave a few microseconds — round 1 gave every 256 far queries a workgroup that walked all V vertices
+// through LDS whatever their number (2.5 ms for a 216 K-vertex template, even for a single far query).
+constexpr int FAR_SHELLS = 12;
+__global__ __launch_bounds__(256) void k_label_far(const NgGeom* __restrict__ geo, const int* __restrict__ cs, const float4* __restrict__ sorted,
+                                                   int V, const int32_t* __restrict__ labels, const double* __restrict__ pts,
+                                                   const int32_t* __restrict__ far, int32_t* __restrict__ out) {
     const int count = far[0];
-    if ((int64_t)blockIdx.x * 256 >= count) return;
-    __shared__ float4 tile[FAR_TILE];
-    const int slot = blockIdx.x * 256 + threadIdx.x;
-    const bool live = slot < count;
-    const int64_t q = live ? far[1 + slot] : far[1];
+    const int lane = threadIdx.x & 63;
+    const NgGeom g = *geo;
+    const int sall = max(g.nx, max(g.ny, g.nz));
+    for (int slot = blockIdx.x * 4 + (threadIdx.x >> 6); slot < count; slot += gridDim.x * 4) {      // (wave-uniform)
+    const int64_t q = far[1 + slot];
     const float qx = (float)pts[3 * q], qy = (float)pts[3 * q + 1], qz = (float)pts[3 * q + 2];
     float best = INFINITY;
-    int arg = 0;
-    for (int base = 0; base < V; base += FAR_TILE) {
-        const int cnt = min(FAR_TILE, V - base);
-        __syncthreads();
-        for (int k = threadIdx.x; k < cnt; k += 256) {
-            const double* t = tmpl + 3 * (int64_t)(base + k);
-            tile[k] = make_float4((float)t[0], (float)t[1], (float)t[2], 0.0f);
+    int arg = 0x7fffffff;
+    auto take = [&](const float4& p) {
+        const float d = d2f(qx, qy, qz, p.x, p.y, p.z);
+        const int j = __float_as_int(p.w);
+        if (d < best || (d == best && j < arg)) { best = d; arg = j; }
+    };
+    auto wave_best = [&]() {                                              // (distance, index) minimum over the wave, in every lane
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float d = __shfl_xor(best, o, 64);
+            const int j = __shfl_xor(arg, o, 64);
+            if (d < best || (d == best && j < arg)) { best = d; arg = j; }
         }
-        __syncthreads();
-        for (int k = 0; k < cnt; ++k) {                       // ascending vertex index: a strict < keeps the lowest on ties
-            const float4 p = tile[k];
-            const float d = d2f(qx, qy, qz, p.x, p.y, p.z);
-            if (d < best) { best = d; arg = base + k; }
+    };
+    const float fx = (qx - g.minx) * g.inv_h, fy = (qy - g.miny) * g.inv_h, fz = (qz - g.minz) * g.inv_h;
+    const int cx = ng_axis(qx, g.minx, g.inv_h, g.nx), cy = ng_axis(qy, g.miny, g.inv_h, g.ny), cz = ng_axis(qz, g.minz, g.inv_h, g.nz);
+    float m = fminf(fminf(fminf(fx - cx, cx + 1 - fx), fminf(fy - cy, cy + 1 - fy)), fminf(fz - cz, cz + 1 - fz));
+    m = fmaxf(m, 0.0f);
+    bool open = true;
+    for (int s = 0; s <= min(FAR_SHELLS, sall) && open; ++s) {
+        const int n = 2 * s + 1, total = s == 0 ? 1 : 6 * n * n - 12 * n + 8;
+        for (int base = 0; base < total; base += 64) {
+            const int t = base + lane;
+            int a = 0, b = 0;
+            if (t < total) {
+                int dx = 0, dy = 0, dz = 0;
+                if (s > 0) shell_cell(t, s, &dx, &dy, &dz);
+                const int x = cx + dx, y = cy + dy, z = cz + dz;
+                if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) { const int c = (z * g.ny + y) * g.nx + x; a = cs[c]; b = cs[c + 1]; }
+            }
+            for (int k = a; k < b; ++k) take(sorted[k]);
         }
+        wave_best();
+        const float bound = ((float)s + m - 0.01f) * g.h;
+        if ((bound > 0.0f && best <= bound * bound) || s >= sall) open = false;
     }
-    if (live) out[q] = labels[arg];
+    if (open) {                                                           // every template vertex, 64 at a time (sorted order: any order, the
+        for (int k = lane; k < V; k += 64) take(sorted[k]);               //  (distance, index) minimum does not depend on it)
+        wave_best();
+    }
+    if (lane == 0) out[q] = labels[arg];
+    }
 }
 }  // namespace
 
@@ -547,5 +577,5 @@ void launch_label_nn(const double* tmpl, int V, const int32_t* tmpl_labels, void
     (void)hipMemsetAsync(far_list, 0, sizeof(int32_t), s);
     const unsigned nb = (unsigned)((P + 255) / 256);
     k_label_nn<<<dim3(nb), dim3(256), 0, s>>>(w.geo, w.start, w.sorted, tmpl_labels, pts, P, out, far_list);
-    k_label_far<<<dim3(nb), dim3(256), 0, s>>>(tmpl, V, tmpl_labels, pts, far_list, out);
+    k_label_far<<<dim3((unsigned)std::min<int64_t>((P + 3) / 4, 8192)), dim3(256), 0, s>>>(w.geo, w.start, w.sorted, V, tmpl_labels, pts, far_list, out);   // waves stride over the far list
 }

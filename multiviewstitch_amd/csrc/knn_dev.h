@@ -16,6 +16,28 @@ __device__ inline int ng_axis(float x, float mn, float inv_h, int n) {
     return (int)f;
 }
 
+// decode the t-th cell of the cubic shell of radius S >= 1 (n = 2S+1): two z faces, two y faces, two x faces.
+// No integer divisions (each is a ~40-instruction sequence on this hardware and the shell walk of a far node decodes
+// hundreds of cells per lane — they were most of its cycles, scripts/dmin_shells.py): which of the two faces is a
+// comparison, the row inside a face one float multiply, exact for the sizes that occur (t < 2^20, n <= 257: the
+// quotient is taken at t + 0.5, at least 0.5/n away from an integer, against a float error below 1e-5).
+__device__ inline int div_small(int t, int d, float inv_d) { (void)d; return (int)(((float)t + 0.5f) * inv_d); }
+__device__ inline void shell_cell(int t, int S, int* dx, int* dy, int* dz) {
+    const int n = 2 * S + 1, m = n - 2;
+    const int nzf = n * n, nyf = n * m;
+    const float inv_n = 1.0f / (float)n, inv_m = 1.0f / (float)m;      // (wave-uniform: scalar work)
+    if (t < 2 * nzf) {
+        const int f = t >= nzf, r = t - f * nzf, q = div_small(r, n, inv_n);
+        *dz = f ? S : -S; *dy = q - S; *dx = r - q * n - S;
+    } else if (t < 2 * nzf + 2 * nyf) {
+        const int t1 = t - 2 * nzf, f = t1 >= nyf, r = t1 - f * nyf, q = div_small(r, n, inv_n);
+        *dy = f ? S : -S; *dz = q - (S - 1); *dx = r - q * n - S;
+    } else {
+        const int t2 = t - 2 * nzf - 2 * nyf, f = t2 >= m * m, r = t2 - f * m * m, q = div_small(r, m, inv_m);
+        *dx = f ? S : -S; *dz = q - (S - 1); *dy = r - q * m - (S - 1);
+    }
+}
+
 // query q (one wave; every lane passes the same q): its k nearest points of the grid (geo, cs, sorted) -> out[q*k..];
 // sm_out != NULL: also the first Jacobi sweep of the node-target smoothing for q
 __device__ inline void ng_knn_query(int q, const double* __restrict__ pts, int n, int k, const NgGeom* __restrict__ geo,

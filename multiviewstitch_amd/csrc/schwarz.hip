@@ -441,7 +441,9 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
     if (V < 2048) return MVS_OK;                      // small meshes: a handful of CG launches is already cheap
     int maxdeg = 0;
     for (int i = 0; i < V; ++i) maxdeg = std::max(maxdeg, rowptr[i + 1] - rowptr[i]);
-    const int W = maxdeg <= 8 ? 8 : (maxdeg <= 12 ? 12 : 16);
+    // entries stored per patch-local row: the smallest of 6 / 8 / 12 / 16 that holds the mesh's largest vertex degree (a closed
+    // triangulated surface averages 6; every stored entry is an LDS gather + 3 FMAs per Chebyshev step and 10 bytes of table)
+    const int W = maxdeg <= 6 ? 6 : (maxdeg <= 8 ? 8 : (maxdeg <= 12 ? 12 : 16));
     if (maxdeg > 16) return MVS_OK;
     // patches: a whole number of "rounds" of one patch per CU (a 257th patch would cost a second round of the whole chip),
     // at most ~240 owned rows each so that three rings of overlap stay well inside the 1024-row limit
@@ -575,7 +577,8 @@ int ras_slot_size(const mvs_deform_s* h) { return ras_slot_doubles(h->ras.NPpad)
 void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s, const double* init_ctrl, const RasSmooth& sm) {
     const RasDev& R = h->ras;
     const dim3 grid(R.NP), blk(h->ras_block);
-    if (R.W == 8) k_ras_prepare<8><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
+    if (R.W == 6) k_ras_prepare<6><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
+    else if (R.W == 8) k_ras_prepare<8><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
     else if (R.W == 12) k_ras_prepare<12><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
     else k_ras_prepare<16><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
 }
@@ -630,7 +633,7 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, doubl
     const RasTail tail{h->d_bar, tail_slots, RAS_TAIL_MAX};
 #define MVS_SWEEP(W, T) k_ras_sweep<W, T><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, \
                                                               RAS_SLOW * RAS_SLOW, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur, tail)
-    if (tail_slots) { if (R.W == 8) MVS_SWEEP(8, true); else if (R.W == 12) MVS_SWEEP(12, true); else MVS_SWEEP(16, true); }
-    else            { if (R.W == 8) MVS_SWEEP(8, false); else if (R.W == 12) MVS_SWEEP(12, false); else MVS_SWEEP(16, false); }
+    if (tail_slots) { if (R.W == 6) MVS_SWEEP(6, true); else if (R.W == 8) MVS_SWEEP(8, true); else if (R.W == 12) MVS_SWEEP(12, true); else MVS_SWEEP(16, true); }
+    else            { if (R.W == 6) MVS_SWEEP(6, false); else if (R.W == 8) MVS_SWEEP(8, false); else if (R.W == 12) MVS_SWEEP(12, false); else MVS_SWEEP(16, false); }
 #undef MVS_SWEEP
 }
