@@ -316,7 +316,8 @@ def main():
                     "share_of_step": round(cg_ms / (1e3 * elapsed), 3)}
         if info["kind"] == "patch":
             roofline["note"] = ("LDS-resident local iterations: the launch is bound by its dependent load chain and workgroup "
-                                "barriers, not by HBM bytes; local Chebyshev steps per launch = 8")
+                                "barriers, not by HBM bytes; local Chebyshev steps per active launch = "
+                                f"{st['cg_iters'] / max(1, st['cg_active']):.1f}; idle launches (solve finished) return after one scalar load")
         # the whole iteration against the HBM roof, B_iter = 24 P + 328 K + 264 V + n_cg * 108 V (its fp32 /
         # int32 storage model) with the solver passes actually run per step
         b_iter = 24 * P_total + 328 * int(K) + 264 * V + int(active_per_step) * 108 * V
