@@ -248,8 +248,8 @@ def main():
         log(f"[bench r{rank}] warmup done: solver iterations={st['cg_iters']} arap_iters_run={st['arap_iters_run']} "
             f"n_valid={st['n_valid']} worst rel residual of the warm-up batch={st['worst_rel_residual_in_batch']:.2e}")
     worst.update(rel=0.0, missed=0, solves=0, status=0)
-    d.enable_timing(2)                      # HIP events around the CG groups only (2 per solve)
-    fence()
+    d.enable_timing(3)                      # HIP events around the global-solve launch groups of every 4th pass (+1 % on the step;
+    fence()                                 # around every solve they cost 5 %: scripts/timing_overhead.py)
     tb = time.perf_counter()
     st = run(args.steps)
     fence()
@@ -312,8 +312,8 @@ def main():
                     "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": solve_bytes,
                     "avg_launch_us": round(1e6 * avg_s, 3), "launches": int(cg_launches), "active_fraction": round(active_frac, 3),
-                    "launches_per_step": round(cg_launches / args.steps, 2),
-                    "share_of_step": round(cg_ms / (1e3 * elapsed), 3)}
+                    "launches_per_step": int(st["cg_launches"]), "timed_sample": "the solver launches of every 4th outer iteration of the timed region",
+                    "share_of_step": round(1e3 * avg_s * st["cg_launches"] / ms_per_step, 3)}
         if info["kind"] == "patch":
             roofline["note"] = ("LDS-resident local iterations: the launch is bound by its dependent load chain and workgroup "
                                 "barriers, not by HBM bytes; local Chebyshev steps per active launch = "

@@ -472,7 +472,7 @@ int mvs_deform_arap(mvs_deform_t h, const mvs_deform_params* p,
  * hipEvents on the handle's stream (bench.py's roofline object).  names:
  * "assoc", "graph", "smooth", "weights", "rhs", "cg", "local", "finalize". */
 int mvs_deform_kernel_time(mvs_deform_t h, const char* name, double* total_ms, int64_t* launches);
-/* on: 0 off, 1 every phase, 2 only the "cg" groups (two events per global solve). */
+/* on: 0 off, 1 every phase, 2 only the "cg" groups (two events per global solve), 3 the "cg" groups of every fourth pass. */
 int mvs_deform_enable_timing(mvs_deform_t h, int on);
 
 #ifdef __cplusplus

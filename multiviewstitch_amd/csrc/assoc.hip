@@ -96,7 +96,10 @@ __device__ inline float box_lb2(const QCell& c, float x0, float x1, float y0, fl
 // INFINITY.  A rank whose own points all lie beyond it cannot hold that nearest point: the search stops as soon as it has
 // covered the bound and returns what it has (>= the true global minimum, which the all-reduce(MIN) takes from the rank
 // that does hold the point — that rank's search is not cut short, its best is inside the bound).
-__device__ inline float dmin_node(const GridDev& g, const double* __restrict__ node_pts, int node, float limit2 = INFINITY) {
+// deferred != NULL: a search that the fine shells and the first two coarse shells do not close is NOT continued by this wave —
+// *deferred is set and the best distance seen so far returned (a valid upper bound): the caller hands the node to a 16-wave
+// workgroup (dmin_coarse_wg), which walks the coarse shells with all its waves.
+__device__ inline float dmin_node(const GridDev& g, const double* __restrict__ node_pts, int node, float limit2 = INFINITY, bool* deferred = nullptr) {
     ASTAMP_BEGIN;
     const int lane = threadIdx.x & 63;
     const float qx = (float)node_pts[3 * node], qy = (float)node_pts[3 * node + 1], qz = (float)node_pts[3 * node + 2];
@@ -188,6 +191,9 @@ __device__ inline float dmin_node(const GridDev& g, const double* __restrict__ n
             Mc = fmaxf(Mc, 0.0f);                                // fine-cell units
             const int SmaxC = max(g.NX, max(g.NY, g.NZ));
             for (int S = 0; S <= SmaxC; ++S) {                   // bounded: at S == SmaxC every coarse cell was visited
+                // still open after the node's own coarse cell and its 26 neighbours: a FAR node (hundreds of coarse cells to
+                // look up from here on) — left to a whole workgroup when the caller can defer it
+                if (S == 2 && deferred) { *deferred = true; return wave_min_f(best); }
                 const int n = 2 * S + 1;
                 const int total = S == 0 ? 1 : 6 * n * n - 12 * n + 8;
                 // SB groups of 64 cells of the shell go through the two dependent look-ups (occupancy, then the cell's point
@@ -285,7 +291,76 @@ constexpr int HEAVY_RANGES = 2048;
 constexpr int HEAVY_ROWS = 25;                              // rows of the ball's bounding box above which a node is deferred
 struct HeavyLds { double pd[HEAVY_WAVES][8], pl[HEAVY_WAVES][8], x[HEAVY_WAVES][8], y[HEAVY_WAVES][8], z[HEAVY_WAVES][8];
                   long long idx[HEAVY_WAVES][8]; int nb[HEAVY_WAVES], np[HEAVY_WAVES];
-                  int nr, ra[HEAVY_RANGES], rb[HEAVY_RANGES]; };      // occupied coarse cells of the ball, found by all waves
+                  int nr, ra[HEAVY_RANGES], rb[HEAVY_RANGES];         // occupied coarse cells of the ball, found by all waves
+                  float fmin[HEAVY_WAVES];                            // per-wave nearest distances of dmin_coarse_wg
+                  int ball; };                                        // ball members counted so far by all waves (full-result cut-off)
+constexpr int HEAVY_SPLIT = 1;                              // workgroups that share one heavy node in the fused launch (> 1: their lists are joined by
+                                                            // k_assoc_merge_heavy.  Measured at 8 with the ~225 heavy nodes of the metric workload: 114 us instead of
+                                                            // 64 — every sharer pays the fixed costs of a node, the 16-list merge above all; kept for meshes with few heavy nodes)
+constexpr int HEAVY_SPLIT_CAP = 1024;                       // heavy nodes the split scratch holds; the (never seen) rest is done whole
+constexpr int HEAVY_DMIN_FLAG = 0x40000000;                 // heavy-list entry: the node's nearest distance is still open (coarse walk deferred)
+
+// The coarse-shell walk of dmin_node (stage B) by ALL waves of a workgroup: a far node (it faces a hole of the scan, its
+// nearest point lies 4-5 coarse cells away) looks ~1300 coarse cells up, which took one wave 16 of the 21 us it spent on
+// such a node — and ~30 of them set the duration of k_assoc_local.  Groups of 64 cells go round-robin over the waves; the
+// shells are taken in batches (0-3, 4-5, then one by one) with the waves' minima joined through LDS after each batch.
+// `best` = distance to a point already seen (stage A), INFINITY if none.  The result is the exact nearest distance: which
+// cells are skipped depends on the order of the search, the minimum does not.
+__device__ inline float dmin_coarse_wg(const GridDev& g, const double* __restrict__ node_pts, int node, float best, HeavyLds* lds) {
+    const int lane = threadIdx.x & 63, part = (int)(threadIdx.x >> 6);
+    const float qx = (float)node_pts[3 * node], qy = (float)node_pts[3 * node + 1], qz = (float)node_pts[3 * node + 2];
+    const QCell c = query_cell(g, qx, qy, qz);
+    const int CX = c.cx >> 3, CY = c.cy >> 3, CZ = c.cz >> 3;
+    const float ih2 = g.inv_h * g.inv_h;
+    float Mc = fminf(fminf(fminf(c.fx - 8.f * CX, 8.f * CX + 8.f - c.fx), fminf(c.fy - 8.f * CY, 8.f * CY + 8.f - c.fy)),
+                     fminf(c.fz - 8.f * CZ, 8.f * CZ + 8.f - c.fz));
+    Mc = fmaxf(Mc, 0.0f);
+    const int SmaxC = max(g.NX, max(g.NY, g.NZ));
+    for (int s_lo = 0; s_lo <= SmaxC;) {
+        const int s_hi = s_lo == 0 ? min(3, SmaxC) : (s_lo == 4 ? min(5, SmaxC) : s_lo);
+        int grp = 0;
+        for (int S = s_lo; S <= s_hi; ++S) {
+            const int n = 2 * S + 1, total = S == 0 ? 1 : 6 * n * n - 12 * n + 8;
+            for (int base = 0; base < total; base += 64, ++grp) {
+                if ((grp % HEAVY_WAVES) != part) continue;            // (wave-uniform)
+                const int t = base + lane;
+                int a = 0, b = 0;
+                float lb2 = INFINITY;
+                if (t < total) {
+                    int dx = 0, dy = 0, dz = 0;
+                    if (S > 0) shell_cell(t, S, &dx, &dy, &dz);
+                    const int X = CX + dx, Y = CY + dy, Z = CZ + dz;
+                    if (X >= 0 && X < g.NX && Y >= 0 && Y < g.NY && Z >= 0 && Z < g.NZ) {
+                        const int64_t C = grid_coarse(g.NX, g.NY, X, Y, Z);
+                        const int a0 = g.coarse_start[C], b0 = g.coarse_start[C + 1];
+                        lb2 = box_lb2(c, 8.f * X, 8.f * X + 8.f, 8.f * Y, 8.f * Y + 8.f, 8.f * Z, 8.f * Z + 8.f);
+                        if (b0 > a0 && lb2 <= best * ih2) { a = a0; b = b0; }
+                    }
+                }
+                unsigned long long cmask = __ballot(b > a);
+                while (cmask) {
+                    const int l = __ffsll((long long)cmask) - 1;
+                    cmask &= cmask - 1;
+                    if (__int_as_float(rl_i(__float_as_int(lb2), l)) > best * ih2) continue;      // a closer point turned up meanwhile
+                    const int A = rl_i(a, l), B = rl_i(b, l);
+                    for (int i = A + lane; i < B; i += 64) {
+                        const float4 p = g.spos[i];
+                        best = fminf(best, d2f(qx, qy, qz, p.x, p.y, p.z));
+                    }
+                    best = wave_min_f(best);
+                }
+            }
+        }
+        if (lane == 0) lds->fmin[part] = best;
+        __syncthreads();
+        best = wave_min_f(lds->fmin[lane % HEAVY_WAVES]);
+        __syncthreads();
+        const float bound = (((float)s_hi) * 8.f + Mc - 0.08f) * g.h;
+        if (bound > 0.0f && best <= bound * bound) break;
+        s_lo = s_hi + 1;
+    }
+    return best;
+}
 
 // single-rank mode: what k_assoc_merge would compute from this node's (only) list, written straight from the wave
 struct LocalMerge {
@@ -294,13 +369,18 @@ struct LocalMerge {
     int max_result;
 };
 
+// (sub, nsub): PARTS > 1 only — this workgroup is number `sub` of `nsub` that share the node: it lists every occupied coarse
+// cell of the ball like the others but scans only its share of them; its list and counts are partial (merged by
+// k_assoc_merge_heavy) and go to slot `out` of rec / counts instead of the node's.
 template <int PARTS>
 __device__ inline void select_node(const GridDev& g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm,
                                    int node, int top_k, float dm, mvs_cand* __restrict__ rec,
                                    int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap, HeavyLds* lds,
-                                   const LocalMerge& lm) {
+                                   const LocalMerge& lm, int sub = 0, int nsub = 1, int64_t out = -1) {
     ASTAMP_BEGIN;
-    const int lane = threadIdx.x & 63, part = PARTS > 1 ? (int)(threadIdx.x >> 6) : 0;
+    if (out < 0) out = node;
+    const int lane = threadIdx.x & 63, part = (PARTS > 1 ? (int)(threadIdx.x >> 6) : 0) + sub * PARTS;
+    const int nparts = PARTS * nsub;                         // shares the node's ranges are dealt into
     int k_occ = 0;                                           // running index of the occupied rows (PARTS > 1)
     const d3 orig = ld3(node_pts + 3 * node), nn = ld3(node_nrm + 3 * node);
     const float qx = (float)orig.x, qy = (float)orig.y, qz = (float)orig.z;
@@ -315,6 +395,12 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
     if (g.P > 0 && dm < INFINITY) {
         const float r2 = dm * 2.0f;                          // radiusSearch(..., minDist * 2.0f, ...)  :288
         const double nlen = norm3(nn);
+        // A ball with >= max_result members drops the node (the reference's radiusSearch returns at most max_result = 10000
+        // neighbours and an exactly-full result is discarded, Deformation.cpp:286-297): once the workgroup has counted that
+        // many, nothing else about the node matters — the waves stop scanning.  The far nodes (their balls hold 50-100 K
+        // points: the rim of the hole they face) were 10-29 us of scanning each; the count they report is then a lower
+        // bound >= max_result, not the ball's size.
+        const int full = (PARTS > 1 && lm.max_result > 0) ? lm.max_result : 0x7fffffff;
         const QCell c = query_cell(g, qx, qy, qz);
         const int32_t* __restrict__ cs = g.cell_start;
 
@@ -399,7 +485,7 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
                     while (mask) {
                         const int l = __ffsll((long long)mask) - 1;
                         mask &= mask - 1;
-                        if (PARTS == 1 || (k_occ++ % PARTS) == part) scan(rl_i(a, l), rl_i(b, l));
+                        if (PARTS == 1 || (k_occ++ % nparts) == part) scan(rl_i(a, l), rl_i(b, l));
                     }
                 }
             } else {
@@ -411,11 +497,12 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
                 const int nX = X1 - X0 + 1, nY = Y1 - Y0 + 1, ncc = nX * nY * (Z1 - Z0 + 1);
                 // (split mode: wave `part` looks up every PARTS-th group of 64 coarse cells and appends the occupied ones to
                 //  a workgroup list; the list is then scanned round-robin, so both the look-ups and the points are shared)
-                if (PARTS > 1) { if (threadIdx.x == 0) lds->nr = 0; __syncthreads(); }
-                for (int base = 64 * part; base < ncc; base += 64 * PARTS) {
+                if (PARTS > 1) { if (threadIdx.x == 0) { lds->nr = 0; lds->ball = 0; } __syncthreads(); }
+                const int lpart = PARTS > 1 ? (int)(threadIdx.x >> 6) : 0;        // the LOOK-UPS are shared by this workgroup's waves only
+                for (int base = 64 * lpart; base < ncc; base += 64 * PARTS) {
                     const int t = base + lane;
                     int a = 0, b = 0;
-                    if (t < ncc) {
+                    if (t < ncc && (nsub == 1 || (t % nsub) == sub)) {    // (a sharing workgroup looks only ITS cells up: every nsub-th of the box)
                         const int X = X0 + t % nX, Y = Y0 + (t / nX) % nY, Z = Z0 + t / (nX * nY);
                         const int64_t C = grid_coarse(g.NX, g.NY, X, Y, Z);
                         const int a0 = g.coarse_start[C], b0 = g.coarse_start[C + 1];
@@ -439,7 +526,14 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
                     unsigned long long tA_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tA_) :: "memory");
 #endif
                     const int nr = min(lds->nr, HEAVY_RANGES);
-                    for (int r = part; r < nr; r += PARTS) scan(lds->ra[r], lds->rb[r]);
+                    int told = 0;                                    // ball members this wave has already added to the workgroup's count
+                    for (int r = lpart; r < nr; r += PARTS) {            // (the list holds this workgroup's cells only)
+                        if (lds->ball >= full) break;                    // (wave-uniform: one LDS word)
+                        scan(lds->ra[r], lds->rb[r]);
+                        const int mine = wave_sum_i(n_ball);
+                        if (lane == 0 && mine > told) atomicAdd(&lds->ball, mine - told);
+                        told = mine;
+                    }
 #ifdef MVS_STAMPS   // (scripts/heavy_stats.py: list built / this wave done scanning / all waves done, in 16-cycle units, + ranges)
                     unsigned long long tB_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tB_) :: "memory");
                     __syncthreads();
@@ -454,25 +548,25 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
     n_ball = wave_sum_i(n_ball);
     n_pass = wave_sum_i(n_pass);
     if (PARTS > 1) {
-        // merge the waves' lists: wave 0 re-inserts the <= PARTS * 8 survivors into a fresh list (same total order)
-        if (lane < 8) {
-            const bool live = lane < len;
-            lds->pd[part][lane] = L_pd; lds->pl[part][lane] = L_pl; lds->x[part][lane] = L_x; lds->y[part][lane] = L_y; lds->z[part][lane] = L_z;
-            lds->idx[part][lane] = live ? L_idx : -1;
-        }
+        // merge the waves' lists by a TREE: in round `stride` wave w < stride takes the <= 8 survivors of wave w + stride into its
+        // own list (same insertion, same total order); log2(PARTS) rounds of <= 8 insertions instead of one wave re-inserting
+        // all PARTS * 8 candidates one after the other (that was 20-30 K cycles at the end of every heavy node's chain)
+        const int part = (int)(threadIdx.x >> 6);            // (local wave index from here on)
         if (lane == 0) { lds->nb[part] = n_ball; lds->np[part] = n_pass; }
-        __syncthreads();
-        if (part == 0) {
-            len = 0; L_idx = -1;
-            n_ball = 0; n_pass = 0;
-            for (int w = 0; w < PARTS; ++w) { n_ball += lds->nb[w]; n_pass += lds->np[w]; }
-            for (int base = 0; base < PARTS * 8; base += 64) {
-                const int q = base + lane, w = q >> 3, k = q & 7;
-                const bool has0 = q < PARTS * 8 && lds->idx[w][k] >= 0;
+        for (int stride = PARTS / 2; stride >= 1; stride >>= 1) {
+            if (part >= stride && part < 2 * stride && lane < 8) {       // the giving half publishes its list
+                const bool live = lane < len;
+                lds->pd[part][lane] = L_pd; lds->pl[part][lane] = L_pl; lds->x[part][lane] = L_x; lds->y[part][lane] = L_y; lds->z[part][lane] = L_z;
+                lds->idx[part][lane] = live ? L_idx : -1;
+            }
+            __syncthreads();
+            if (part < stride) {
+                const int w = part + stride;
+                const bool has0 = lane < 8 && lds->idx[w][lane & 7] >= 0;
                 bool has = has0;
-                const double pd = has0 ? lds->pd[w][k] : 0.0, pl = has0 ? lds->pl[w][k] : 0.0;
-                const d3 tp = has0 ? mk3(lds->x[w][k], lds->y[w][k], lds->z[w][k]) : mk3(0, 0, 0);
-                const long long gi = has0 ? lds->idx[w][k] : 0;
+                const double pd = has0 ? lds->pd[w][lane] : 0.0, pl = has0 ? lds->pl[w][lane] : 0.0;
+                const d3 tp = has0 ? mk3(lds->x[w][lane], lds->y[w][lane], lds->z[w][lane]) : mk3(0, 0, 0);
+                const long long gi = has0 ? lds->idx[w][lane] : 0;
                 const double apl = fabs(pl);
                 unsigned long long pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
                 while (pend) {
@@ -498,18 +592,23 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
                     pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
                 }
             }
+            __syncthreads();                                 // (the publishing slots are reused by the next round)
+        }
+        if (part == 0) {
+            n_ball = 0; n_pass = 0;
+            for (int w = 0; w < PARTS; ++w) { n_ball += lds->nb[w]; n_pass += lds->np[w]; }
         }
         if (part != 0) return;
     }
     if (lane < 8) {
-        mvs_cand* o = rec + (int64_t)node * 8 + lane;
+        mvs_cand* o = rec + out * 8 + lane;
         const bool live = lane < len;
         o->proj_dist = live ? L_pd : 0.0;
         o->proj_len = live ? L_pl : 0.0;
         o->pos[0] = live ? L_x : 0.0; o->pos[1] = live ? L_y : 0.0; o->pos[2] = live ? L_z : 0.0;
         o->index = live ? L_idx : -1;
     }
-    if (lane == 0) { counts[2 * node] = n_ball; counts[2 * node + 1] = n_pass; }
+    if (lane == 0) { counts[2 * out] = n_ball; counts[2 * out + 1] = n_pass; }
     if (lm.controls) {
         // means over the list, best first (Deformation.cpp:338-349), and the rejection tests (:286-297, :350-353) —
         // the same operations in the same order as k_assoc_merge with one rank
@@ -563,23 +662,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     if (blockIdx.x == 0 && threadIdx.x == 0) heavy_next[0] = 0;       // the list of the NEXT outer iteration (they alternate): no memset launch
     const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (node >= K) return;
-    const float best = dmin_node(g, node_pts, node);
-    if ((threadIdx.x & 63) == 0) d2min[node] = best;
+    bool deferred = false;
+    const float best = dmin_node(g, node_pts, node, INFINITY, heavy ? &deferred : nullptr);
+    if ((threadIdx.x & 63) == 0) d2min[node] = best;         // (deferred: the best of the fine shells, an upper bound)
+    if (deferred) {
+        // a far node: its coarse walk AND its (wide) ball query go to the workgroup-per-node pass
+        int slot = 0;
+        if ((threadIdx.x & 63) == 0) slot = atomicAdd(&heavy[0], 1);
+        slot = rl_i(slot, 0);
+        if (slot < heavy_cap) { if ((threadIdx.x & 63) == 0) heavy[1 + slot] = node | HEAVY_DMIN_FLAG; return; }
+        const float full = dmin_node(g, node_pts, node);     // (list full: cannot happen with heavy_cap = K)
+        if ((threadIdx.x & 63) == 0) d2min[node] = full;
+        select_node<1>(g, node_pts, node_nrm, node, top_k, full, rec, counts, nullptr, 0, nullptr, lm);
+        return;
+    }
     select_node<1>(g, node_pts, node_nrm, node, top_k, best, rec, counts, heavy, heavy_cap, nullptr, lm);
+}
+
+// one heavy-list entry by one 16-wave workgroup (share `sub` of `nsub`): the deferred coarse walk first when the entry asks
+// for it (every sharing workgroup repeats it: they all need the distance), then the ball query
+__device__ inline void heavy_entry(const GridDev& g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm, int entry,
+                                   int top_k, float* __restrict__ d2min, mvs_cand* __restrict__ rec, int32_t* __restrict__ counts,
+                                   HeavyLds* lds, const LocalMerge& lm, int sub, int nsub, int64_t out) {
+    const int node = entry & ~HEAVY_DMIN_FLAG;
+    float dm = d2min[node];
+    if (entry & HEAVY_DMIN_FLAG) {
+        dm = dmin_coarse_wg(g, node_pts, node, dm, lds);
+        __syncthreads();                                     // (every wave has read d2min[node] before it is replaced)
+        if (sub == 0 && threadIdx.x == 0) d2min[node] = dm;
+    }
+    select_node<HEAVY_WAVES>(g, node_pts, node_nrm, node, top_k, dm, rec, counts, nullptr, 0, lds, lm, sub, nsub, out);
 }
 
 // the deferred nodes: one 16-wave workgroup per node (a far node's ball covers thousands of points; left to one
 // wave, eight such nodes set the duration of the whole association: 300 K cycles against a median of 12 K)
 __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_select_heavy(GridDev g, const double* __restrict__ node_pts,
                                                                          const double* __restrict__ node_nrm, int top_k,
-                                                                         const float* __restrict__ d2min, mvs_cand* __restrict__ rec,
+                                                                         float* __restrict__ d2min, mvs_cand* __restrict__ rec,
                                                                          int32_t* __restrict__ counts, const int32_t* __restrict__ heavy,
                                                                          int heavy_cap, LocalMerge lm) {
     __shared__ HeavyLds lds;
     const int n = min(heavy[0], heavy_cap);
     for (int h = blockIdx.x; h < n; h += gridDim.x) {
-        const int node = heavy[1 + h];
-        select_node<HEAVY_WAVES>(g, node_pts, node_nrm, node, top_k, d2min[node], rec, counts, nullptr, 0, &lds, lm);
+        heavy_entry(g, node_pts, node_nrm, heavy[1 + h], top_k, d2min, rec, counts, &lds, lm, 0, 1, -1);
         __syncthreads();                                     // the LDS lists are reused by the next node
     }
 }
@@ -590,20 +715,29 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_select_heavy(GridDev
 // heavy nodes, the next `knn_blocks` one graph query per wave, the rest (cot_blocks >= 0) the weight rows.
 __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_heavy_knn(GridDev g, const double* __restrict__ node_pts,
                                                                       const double* __restrict__ node_nrm, int top_k,
-                                                                      const float* __restrict__ d2min, mvs_cand* __restrict__ rec,
+                                                                      float* __restrict__ d2min, mvs_cand* __restrict__ rec,
                                                                       int32_t* __restrict__ counts, const int32_t* __restrict__ heavy,
                                                                       int heavy_cap, LocalMerge lm, int heavy_blocks,
+                                                                      mvs_cand* __restrict__ part_rec, int32_t* __restrict__ part_cnt,
                                                                       int K, int nn, const NgGeom* __restrict__ geo,
                                                                       const int* __restrict__ cs, const float4* __restrict__ sorted,
                                                                       int32_t* __restrict__ nbr, int knn_blocks, SellDev m,
                                                                       const double* __restrict__ mesh_pts) {
     __shared__ HeavyLds lds;
     if ((int)blockIdx.x < heavy_blocks) {
-        const int n = min(heavy[0], heavy_cap);
-        for (int h = blockIdx.x; h < n; h += heavy_blocks) {
-            const int node = heavy[1 + h];
-            select_node<HEAVY_WAVES>(g, node_pts, node_nrm, node, top_k, d2min[node], rec, counts, nullptr, 0, &lds, lm);
+        // HEAVY_SPLIT workgroups share a heavy node (its ~30 are few against 256 CUs, and each is a 40-50 us chain when one
+        // workgroup does it all): every sharer lists the ball's occupied coarse cells, scans its share of them and leaves a
+        // partial top-k list + counts in the split scratch; k_assoc_merge_heavy (next launch) joins them.
+        const int n = min(heavy[0], heavy_cap), ns = HEAVY_SPLIT > 1 ? min(n, HEAVY_SPLIT_CAP) : 0;
+        const LocalMerge none{};
+        for (int v = blockIdx.x; v < ns * HEAVY_SPLIT; v += heavy_blocks) {
+            const int h = v / HEAVY_SPLIT, sub = v % HEAVY_SPLIT;
+            heavy_entry(g, node_pts, node_nrm, heavy[1 + h], top_k, d2min, part_rec, part_cnt, &lds, none, sub, HEAVY_SPLIT, (int64_t)v);
             __syncthreads();                                 // the LDS lists are reused by the next node
+        }
+        for (int h = ns + blockIdx.x; h < n; h += heavy_blocks) {      // not shared (or beyond the scratch): whole nodes, final results
+            heavy_entry(g, node_pts, node_nrm, heavy[1 + h], top_k, d2min, rec, counts, &lds, lm, 0, 1, -1);
+            __syncthreads();
         }
         return;
     }
@@ -697,6 +831,91 @@ __global__ __launch_bounds__(256) void k_assoc_merge(const double* __restrict__ 
     if (lane == 0) { valid[node] = ok ? 1 : 0; st3(controls + 3 * node, mp); }   // :355-356 (controls stay at orig otherwise, :271-272)
 }
 
+// The HEAVY_SPLIT partial lists of a heavy node (k_assoc_heavy_knn) -> its list, counts and — single-rank runs — its target:
+// one wave per node, the insertion and the target rule are k_assoc_merge's (a partial list is the top-k of its share of
+// the ball, so the top-k of their union is the node's).
+__global__ __launch_bounds__(256) void k_assoc_merge_heavy(const double* __restrict__ node_pts, const double* __restrict__ node_nrm,
+                                                           const int32_t* __restrict__ heavy, int heavy_cap, int top_k,
+                                                           const mvs_cand* __restrict__ part_rec, const int32_t* __restrict__ part_cnt,
+                                                           mvs_cand* __restrict__ rec, int32_t* __restrict__ counts, LocalMerge lm) {
+    const int n = HEAVY_SPLIT > 1 ? min(min(heavy[0], heavy_cap), HEAVY_SPLIT_CAP) : 0;
+    const int h = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (h >= n) return;                                       // wave-uniform
+    const int node = heavy[1 + h] & ~HEAVY_DMIN_FLAG;
+    const d3 orig = ld3(node_pts + 3 * node), nn = ld3(node_nrm + 3 * node);
+    double L_pd = 0, L_pl = 0, L_x = 0, L_y = 0, L_z = 0;
+    long long L_idx = -1;
+    int len = 0;
+    double t_pd = 0, t_apl = 0; long long t_idx = 0;
+    static_assert(HEAVY_SPLIT * 8 <= 64, "one pass of the wave takes every partial record");
+    const int r = lane >> 3, sl = lane & 7;
+    int n_ball = 0, n_pass = 0;
+    bool has = false;
+    double pd = 0, pl = 0; d3 tp = mk3(0, 0, 0); long long gi = 0;
+    if (r < HEAVY_SPLIT) {
+        const int64_t v = (int64_t)h * HEAVY_SPLIT + r;
+        if (sl == 0) { n_ball = part_cnt[2 * v]; n_pass = part_cnt[2 * v + 1]; }
+        const mvs_cand c = part_rec[v * 8 + sl];
+        if (c.index >= 0) { has = true; pd = c.proj_dist; pl = c.proj_len; tp = mk3(c.pos[0], c.pos[1], c.pos[2]); gi = c.index; }
+    }
+    n_ball = wave_sum_i(n_ball); n_pass = wave_sum_i(n_pass);
+    const double apl = fabs(pl);
+    unsigned long long pend = __ballot(has);
+    while (pend) {
+        const int src = __ffsll((long long)pend) - 1;
+        const double c_pd = rl_d(pd, src), c_pl = rl_d(pl, src);
+        const double c_x = rl_d(tp.x, src), c_y = rl_d(tp.y, src), c_z = rl_d(tp.z, src);
+        const long long c_i = rl_ll(gi, src);
+        const bool less = lane < len && key_less(L_pd, fabs(L_pl), L_idx, c_pd, fabs(c_pl), c_i);
+        const int pos = __popcll(__ballot(less));
+        const double u_pd = shfl_up_d(L_pd), u_pl = shfl_up_d(L_pl);
+        const double u_x = shfl_up_d(L_x), u_y = shfl_up_d(L_y), u_z = shfl_up_d(L_z);
+        const long long u_i = shfl_up_ll(L_idx);
+        if (lane > pos && lane <= len && lane < top_k) {
+            L_pd = u_pd; L_pl = u_pl; L_x = u_x; L_y = u_y; L_z = u_z; L_idx = u_i;
+        } else if (lane == pos) {
+            L_pd = c_pd; L_pl = c_pl; L_x = c_x; L_y = c_y; L_z = c_z; L_idx = c_i;
+        }
+        len = min(len + 1, top_k);
+        if (len == top_k) {
+            t_pd = rl_d(L_pd, top_k - 1); t_apl = fabs(rl_d(L_pl, top_k - 1)); t_idx = rl_ll(L_idx, top_k - 1);
+        }
+        if (lane == src) has = false;
+        pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
+    }
+    if (lane < 8) {
+        mvs_cand* o = rec + (int64_t)node * 8 + lane;
+        const bool live = lane < len;
+        o->proj_dist = live ? L_pd : 0.0;
+        o->proj_len = live ? L_pl : 0.0;
+        o->pos[0] = live ? L_x : 0.0; o->pos[1] = live ? L_y : 0.0; o->pos[2] = live ? L_z : 0.0;
+        o->index = live ? L_idx : -1;
+    }
+    if (lane == 0) { counts[2 * node] = n_ball; counts[2 * node + 1] = n_pass; }
+    if (lm.controls) {                                        // the tail of select_node: means best first, rejection tests
+        bool ok = n_ball < lm.max_result && len > 0;
+        d3 mp = orig;
+        double m_pl = 0, m_pd = 0;
+        d3 acc = mk3(0, 0, 0);
+        for (int sidx = 0; sidx < len; ++sidx) {
+            m_pl += rl_d(L_pl, sidx); m_pd += rl_d(L_pd, sidx);
+            acc = acc + mk3(rl_d(L_x, sidx), rl_d(L_y, sidx), rl_d(L_z, sidx));
+        }
+        if (ok) {
+            const double dn = (double)len;
+            m_pl /= dn; m_pd /= dn; acc = acc / dn;
+            if (m_pl >= lm.proj_len_err || m_pd >= lm.proj_dist_err) ok = false;
+            if (ok) {
+                const d3 dir = acc - orig;
+                if (fabs(dot3(dir, nn) / (norm3(dir) * norm3(nn))) < lm.min_cos) ok = false;
+            }
+            if (ok) mp = acc;
+        }
+        if (lm.top_idx && lane < 8) lm.top_idx[(int64_t)node * 8 + lane] = (n_ball < lm.max_result && len > 0 && lane < len) ? L_idx : -1;
+        if (lane == 0) { lm.valid[node] = ok ? 1 : 0; st3(lm.controls + 3 * node, mp); }
+    }
+}
+
 }  // namespace
 
 #ifdef MVS_STAMPS
@@ -714,7 +933,7 @@ void launch_assoc_dmin(const GridDev& g, const double* node_pts, int K, float* d
     k_assoc_dmin<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, K, d2min, prev_d2, prev_node);
 }
 void launch_assoc_select(const GridDev& g, const double* node_pts, const double* node_nrm, int K, int top_k,
-                         const float* d2min, mvs_cand* rec, int32_t* counts, int32_t* heavy, int heavy_cap, hipStream_t s, bool defer_heavy,
+                         float* d2min, mvs_cand* rec, int32_t* counts, int32_t* heavy, int heavy_cap, hipStream_t s, bool defer_heavy,
                          float* prev_d2, double* prev_node) {
     if (K <= 0) return;
     if (heavy) (void)hipMemsetAsync(heavy, 0, sizeof(int32_t), s);
@@ -734,10 +953,14 @@ void launch_assoc_local(const GridDev& g, const double* node_pts, const double* 
 }
 // the deferred heavy-node pass of launch_assoc_local together with the node graph (grid already built in ws by
 // knn_grid_build on the same node positions): nbr[K * nn] = each node's nn nearest nodes, itself included
+size_t assoc_split_scratch_bytes(int K) {                  // [records | counts] of the partial lists of the split heavy nodes
+    const size_t n = (size_t)std::min(K, HEAVY_SPLIT_CAP) * HEAVY_SPLIT;
+    return n * 8 * sizeof(mvs_cand) + n * 2 * sizeof(int32_t);
+}
 void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
-                            const float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, int heavy_cap,
+                            float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, int heavy_cap,
                             double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s,
-                            const SellDev* mesh, const double* mesh_pts, int cot_blocks) {
+                            const SellDev* mesh, const double* mesh_pts, int cot_blocks, void* split_scratch) {
     if (K <= 0) return;
     const LocalMerge lm{controls, valid, top_idx, p.proj_len_err, p.proj_dist_err, p.min_cos, p.max_result};
     const void *geo, *sorted;
@@ -745,9 +968,15 @@ void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const doub
     knn_grid_views(knn_ws, K, &geo, &cs, &sorted);
     const int heavy_blocks = std::min(heavy_cap, 256), knn_blocks = (K + HEAVY_WAVES - 1) / HEAVY_WAVES;
     const int cot = mesh ? cot_blocks : 0;
+    mvs_cand* part_rec = (mvs_cand*)split_scratch;
+    int32_t* part_cnt = (int32_t*)((char*)split_scratch + (size_t)std::min(K, HEAVY_SPLIT_CAP) * HEAVY_SPLIT * 8 * sizeof(mvs_cand));
     k_assoc_heavy_knn<<<dim3(heavy_blocks + knn_blocks + cot), dim3(64 * HEAVY_WAVES), 0, s>>>(
-        g, node_pts, node_nrm, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm, heavy_blocks, K, nn, (const NgGeom*)geo, cs,
+        g, node_pts, node_nrm, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm, heavy_blocks, part_rec, part_cnt, K, nn, (const NgGeom*)geo, cs,
         (const float4*)sorted, nbr, knn_blocks, mesh ? *mesh : SellDev{}, mesh_pts);
+    // the split nodes' partial lists -> lists, counts, targets (a wave per node; the list is short: waves beyond it leave)
+    if (HEAVY_SPLIT > 1)
+        k_assoc_merge_heavy<<<dim3((std::min(heavy_cap, HEAVY_SPLIT_CAP) + 3) / 4), dim3(256), 0, s>>>(
+            node_pts, node_nrm, heavy, heavy_cap, p.top_k, part_rec, part_cnt, rec, counts, lm);
 }
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks, double* controls,

@@ -108,6 +108,7 @@ struct mvs_deform_s {
     mvs_cand *d_records = nullptr;
     int64_t *d_top_idx = nullptr;
     int32_t *d_heavy = nullptr;       // [1 + K]: nodes deferred to the workgroup-per-node association kernel
+    void *d_heavy_split = nullptr;    // partial lists of the heavy nodes that several workgroups share (assoc_split_scratch_bytes)
     int32_t *d_heavy2 = nullptr;      // second list: single-rank iterations alternate (each resets the other's counter)
     float* d_prev_d2 = nullptr;        // sharded step: global nearest distance of every node at the previous association ...
     double* d_prev_node = nullptr;     // ... and where the node stood (bound for the next nearest-distance search)
@@ -173,16 +174,17 @@ int scan_exclusive_i32(const int32_t* in, int64_t n, int32_t* out, hipStream_t s
 void launch_assoc_dmin(const GridDev& g, const double* node_pts, int K, float* d2min, hipStream_t s, const float* prev_d2 = nullptr,
                        const double* prev_node = nullptr);
 void launch_assoc_select(const GridDev& g, const double* node_pts, const double* node_nrm, int K, int top_k,
-                         const float* d2min, mvs_cand* rec, int32_t* counts, int32_t* heavy /*[1 + cap] or NULL*/, int heavy_cap,
+                         float* d2min, mvs_cand* rec, int32_t* counts, int32_t* heavy /*[1 + cap] or NULL*/, int heavy_cap,
                          hipStream_t s, bool defer_heavy = false /*the caller launches launch_assoc_heavy_knn*/,
                          float* prev_d2 = nullptr, double* prev_node = nullptr /*out: what the next launch_assoc_dmin may use*/);
 void launch_assoc_local(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, float* d2min,
                         mvs_cand* rec, int32_t* counts, int32_t* heavy /*counter already 0*/, int32_t* heavy_next /*reset for the next call*/,
                         int heavy_cap, double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s, bool defer_heavy = false);
+size_t assoc_split_scratch_bytes(int K);
 void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
-                            const float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, int heavy_cap,
+                            float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, int heavy_cap,
                             double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s,
-                            const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks);
+                            const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks, void* split_scratch);
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks,
                         double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s,
@@ -237,7 +239,7 @@ void ras_default_bracket(const mvs_deform_s* h, double* a, int* m);
 int  ras_steps_for(double a);
 #define RAS_TAIL_MAX 32      /* in-kernel sweeps a TAIL launch may add to a solve whose plan was too short */
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, double* xout, int it, double arap_tol, int sweep,
-                      double cg_tol, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots = nullptr);
+                      double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots = nullptr);
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf,
                            int V, double* out, hipStream_t s);
 

@@ -189,7 +189,7 @@ struct RasTail {              // TAIL launches only (the last planned sweep of a
 template <int W, bool TAIL>
 __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __restrict__ pw, const double* __restrict__ pd,
                                                     const double* __restrict__ bvec, double* xa, double* xb, int it, double arap_tol,
-                                                    const double* __restrict__ ered, int nb_rhs, int sweep, double cg_tol, double slow2,
+                                                    const double* __restrict__ ered, int nb_rhs, int sweep, double cg_tol, double stop_margin, double slow2,
                                                     ChebCoef cc, int cheb_m, ChebCoef cc_strong, int cheb_m_strong,
                                                     const double* __restrict__ ctl, double* __restrict__ slot_prev,
                                                     double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur, RasTail tail) {
@@ -245,7 +245,8 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         // previous sweep); when the previous sweep cut the residual by less than SLOW, a mode sits below the bracket of the
         // local solves (the mesh deforms, the weights move) — this sweep then takes the strong coefficient set
         const double gam2 = sweep > 1 ? (slot_prev - ras_slot_doubles(NPpad))[3 * NPpad + wv] : INFINITY;
-        if (lane == 0) { s_gam[wv] = gam; s_slow[wv] = (sweep > 1 && gam > slow2 * gam2) ? 1 : 0; }
+        // s_slow: 1 = the previous sweep converged slowly (strong coefficient set), 2 = its rate is not known yet (sweeps 0, 1)
+        if (lane == 0) { s_gam[wv] = gam; s_slow[wv] = sweep > 1 ? ((gam > slow2 * gam2) ? 1 : 0) : 2; }
     } else if (wv < 6) {
         const double bn = fold_partials(ered + it * EIT + (1 + (wv - 3)) * NBMAX, nb_rhs);
         if (lane == 0) s_bn[wv - 3] = bn;
@@ -258,9 +259,15 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     __syncthreads();
     RSTAMP(1);
     const double bn[3] = {s_bn[0], s_bn[1], s_bn[2]};
+    // The solve stops when a sweep finds its input at cg_tol — the sweep that follows such an input (this one's predecessor:
+    // it could not know) has improved it by another 7x at least when the sweeps converge healthily (rate below RAS_SLOW) — and
+    // at stop_margin * cg_tol (0.5) when they do not or the rate is not known yet: near convergence of an ill-conditioned
+    // system the f32 / bf16 local corrections make the residual history noisy and a sweep may give some of it back.
+    const bool healthy = s_slow[0] == 0 && s_slow[1] == 0 && s_slow[2] == 0;
+    const double stop = healthy ? cg_tol : stop_margin * cg_tol;
     bool frozen = sweep > 0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) if (s_gam[c] > 0.0 && s_gam[c] > cg_tol * cg_tol * bn[c]) frozen = false;
+    for (int c = 0; c < 3; ++c) if (s_gam[c] > 0.0 && s_gam[c] > stop * stop * bn[c]) frozen = false;
     if (p == 0 && row < 3 && sweep > 0) { slot_prev[3 * NPpad + row] = s_gam[row]; slot_prev[3 * NPpad + 3 + row] = bn[row]; }
     if (p == 0 && row < 3) { slot_cur[3 * NPpad + row] = 0.0; slot_cur[3 * NPpad + 3 + row] = bn[row]; }
     const double ran_before = sweep > 0 ? slot_prev[3 * NPpad + 7] : 0.0;
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     for (int q = 0; q < W; ++q) w2f[q] = (float)w2[q];
     uint2* hb = reinterpret_cast<uint2*>(smem);
     auto to_bf16 = [](float v) -> unsigned { const unsigned u = __float_as_uint(v); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
-    bool strong = s_esc || s_slow[0] || s_slow[1] || s_slow[2];
+    bool strong = s_esc || s_slow[0] == 1 || s_slow[1] == 1 || s_slow[2] == 1;
 
     // One sweep of this patch: xs holds x of the local rows and the halo (fp64); residual of that input on the local rows, its
     // owned part into `slot`, the Chebyshev correction, new x of the owned rows into `xo`.
@@ -378,11 +385,14 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         }
         __syncthreads();
         bool conv = true, slow = false;
+        const bool known = g_before[0] < INFINITY;                     // (the rate of the sweep before the one just done)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            if (s_gam[c] > 0.0 && s_gam[c] > cg_tol * cg_tol * bn[c]) conv = false;
-            if (s_gam[c] > slow2 * g_before[c]) slow = true;           // the same rule a planned sweep applies in its preamble:
-            g_before[c] = s_gam[c];                                    // what a sweep computes does not depend on where the plan ended
+        for (int c = 0; c < 3; ++c) if (s_gam[c] > slow2 * g_before[c]) slow = true;      // the same rules a planned sweep applies in its
+        const double stop_k = (known && !slow) ? cg_tol : stop_margin * cg_tol;           // preamble: what a sweep computes does not depend
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {                                                      // on where the plan ended
+            if (s_gam[c] > 0.0 && s_gam[c] > stop_k * stop_k * bn[c]) conv = false;
+            g_before[c] = s_gam[c];
         }
         if (conv) { finished = true; break; }
         if (extra >= tail.max_extra) break;
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         if (row >= nown) { const d3 t = ld3(xin + 3 * (int64_t)g); xi = t; xs[row] = make_double4(t.x, t.y, t.z, 0.0); }
         if (row < nh) xs[LS + row] = make_double4(xh.x, xh.y, xh.z, 0.0);
         __syncthreads();
-        strong = s_esc || slow;
+        strong = s_esc || (known && slow);
         slot_k = tail.slots + (size_t)extra * ras_slot_doubles(NPpad);
         steps += sweep_body(slot_k, xout);
         ++extra;
@@ -604,7 +614,7 @@ int ras_steps_for(double a) {
 // is the last planned sweep of the solve — the launch keeps sweeping (device-wide barrier between sweeps, at most
 // RAS_TAIL_MAX more) until the solve has converged, should the plan have been too short.
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, double* xout, int it, double arap_tol, int sweep,
-                      double cg_tol, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots) {
+                      double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots) {
     const RasDev& R = h->ras;
     const int nb = arap_grid_blocks(h->sell);
     // Chebyshev parameters: the bracket's lower end `a` and the step count live in the handle — initialised from the density
@@ -631,7 +641,7 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, doubl
     const int m2 = ras_steps_for(strong_a);
     const dim3 grid(R.NP), blk(h->ras_block);     // as many waves as the largest patch has rows (idle waves only add barrier cost)
     const RasTail tail{h->d_bar, tail_slots, RAS_TAIL_MAX};
-#define MVS_SWEEP(W, T) k_ras_sweep<W, T><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, \
+#define MVS_SWEEP(W, T) k_ras_sweep<W, T><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, stop_margin, \
                                                               RAS_SLOW * RAS_SLOW, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur, tail)
     if (tail_slots) { if (R.W == 6) MVS_SWEEP(6, true); else if (R.W == 8) MVS_SWEEP(8, true); else if (R.W == 12) MVS_SWEEP(12, true); else MVS_SWEEP(16, true); }
     else            { if (R.W == 6) MVS_SWEEP(6, false); else if (R.W == 8) MVS_SWEEP(8, false); else if (R.W == 12) MVS_SWEEP(12, false); else MVS_SWEEP(16, false); }

@@ -233,7 +233,7 @@ class Deformation:
         return {"kind": "patch" if kind.value else "cg", "patches": patches.value, "local_rows": rows.value, "width": width.value}
 
     def enable_timing(self, on: int = 1):
-        """0 off, 1 every phase, 2 only the "cg" groups (mvs_deform_enable_timing)."""
+        """0 off, 1 every phase, 2 only the "cg" groups, 3 the "cg" groups of every fourth pass (mvs_deform_enable_timing)."""
         L.check(L.lib().mvs_deform_enable_timing(self._h, int(on)))
 
     def kernel_time(self, name: str):

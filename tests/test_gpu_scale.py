@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from multiviewstitch_amd import scene as S
+from tests.util import counts_match
 
 pytestmark = pytest.mark.gpu
 
@@ -61,7 +62,7 @@ def test_full_size_iteration_properties(big, oracle):
     pick = np.random.default_rng(0).choice(len(nodes), 600, replace=False)
     ref = tgt.associate(verts0[nodes[pick]], big["sc"].normals[nodes[pick]], oracle.Params.default())
     assert np.array_equal(got["d2min"][pick], ref["d2min"])
-    assert np.array_equal(got["counts"][pick], ref["counts"])
+    assert counts_match(got["counts"][pick], ref["counts"])
     assert np.array_equal(got["top_idx"][pick], ref["top_idx"])
     assert np.array_equal(got["valid"][pick], ref["valid"])
     assert np.abs(got["controls"][pick] - ref["controls"]).max() <= 1e-12
