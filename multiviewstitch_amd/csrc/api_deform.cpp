@@ -308,12 +308,17 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     double* x_cur = h->d_sol;            // the patch solver ping-pongs between d_sol and d_ras_x2
     int64_t ras_slot = 0;
     const double* prev_scal = nullptr;   // the 8 scalars of the last sweep slot of the previous solve (idle flag, sweeps that ran)
+    // fused mode (RasDev::fuse): the local step of iteration k and the right-hand side of k+1 are ONE patch kernel; only
+    // iteration 0's right-hand side (R = I) is a launch of its own, and the first sweep of a solve closes the previous
+    // iteration's stop-rule bookkeeping (what k_arap_rhs did)
+    const bool fuse = ras && h->ras.fuse != 0;
     for (int it = 0; ras && it < p.arap_iters; ++it) {
-        {
+        if (it == 0 || !fuse) {
             Tic t = tic(h, "rhs");
             launch_arap_rhs(h->sell, h->d_pts, x_cur, h->d_rot, it, p.arap_tol, h->d_energy, nullptr, nullptr, h->d_ras_b, p.cg_tol, h->d_ctl, slot, prev_scal, h->d_bar, h->d_bpure, s);
             toc(t, 1);
         }
+        const double* before_scal = prev_scal;               // (fused mode: the solve the fused kernel's extra block judges)
         {
             Tic t = tic(h, "cg");
             const int ss = ras_slot_size(h);
@@ -323,7 +328,8 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
                 // the last planned sweep of a solve is a TAIL launch: should the plan turn out too short it keeps sweeping in
                 // the kernel (its extra sweeps' partial sums go to the solve's tail slots)
                 launch_ras_sweep(h, h->d_ras_b, x_cur, x_next, it, p.arap_tol, i, p.cg_tol, STOP_AT, i > 0 ? cur - ss : nullptr, cur,
-                                 h->d_ras_iters + (size_t)ras_slot * h->ras.NP, s, last ? h->d_ras_tail + (size_t)it * RAS_TAIL_MAX * ss : nullptr);
+                                 h->d_ras_iters + (size_t)ras_slot * h->ras.NP, s, last ? h->d_ras_tail + (size_t)it * RAS_TAIL_MAX * ss : nullptr,
+                                 fuse && i == 0 && it >= 1);
                 x_cur = x_next;
                 ++ras_slot;
             };
@@ -355,7 +361,12 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
             toc(t, launched);
             prev_scal = h->d_ras_slots + (size_t)(ras_slot - 1) * ss + 3 * (size_t)h->ras.NPpad;
         }
-        { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, x_cur, it, p.arap_tol, h->d_energy, h->d_rot, h->d_bpure, s); toc(t, 1); }
+        {
+            Tic t = tic(h, "local");
+            if (fuse) launch_ras_local_rhs(h, x_cur, it, p.arap_iters, p.arap_tol, p.cg_tol, slot, before_scal, s);
+            else launch_arap_local(h->sell, h->d_pts, x_cur, it, p.arap_tol, h->d_energy, h->d_rot, h->d_bpure, s);
+            toc(t, 1);
+        }
     }
     for (int it = 0; !ras && it < p.arap_iters; ++it) {                                           // deform(5, 1e-4), :398
         double* slots = h->d_slots + plan.offset(it);

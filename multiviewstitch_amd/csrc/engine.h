@@ -51,6 +51,11 @@ struct RasDev {                // patches of the restricted additive Schwarz sol
                                // for a vertex outside the patch, LS + its place in the patch's halo list; -1 padding
     const int32_t* gent;       // same layout: entry id in the ELL-8 adjacency (addresses SellDev::w), -1 padding
     const int32_t* gcol;       // same layout: vertex of the column, -1 padding (k_ras_prepare only)
+    const int32_t* pn1;        // NP: owned rows + first overlap ring (the rows whose rotation the fused local+rhs kernel needs)
+    int32_t fuse;              // 1: every neighbour of an owned row lies within the first ring of its patch and NP <= MVS_NBMAX:
+                               //    local step of ARAP iteration k and right-hand side of k+1 run as ONE patch kernel (k_ras_local_rhs)
+    int32_t stage_slots;       // x / rest-position staging slots the fused kernel needs (LS + largest halo)
+    int32_t n1max;             // largest pn1
     int32_t HS;                // halo slots per patch (stride of hl2g)
     const int32_t* pnh;        // NP: halo vertices of each patch (columns outside the patch, each listed once)
     const int32_t* hl2g;       // [NP][HS] halo slot -> vertex
@@ -137,6 +142,7 @@ struct mvs_deform_s {
     int64_t ras_rows = 0;
     int ras_block = 1024;           // workgroup size of the sweep kernel
     double *d_ras_x2 = nullptr, *d_ras_b = nullptr, *d_ras_slots = nullptr, *d_ras_pw = nullptr, *d_ras_pd = nullptr;
+    double *d_ras_pwr = nullptr;     // raw cotangent weights in the patch-table layout (fused local+rhs kernel)
     int32_t *d_ras_iters = nullptr;
     int64_t ras_slots_cap = 0;
     int ras_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // calibrated sweeps per ARAP iteration (0 = not calibrated)
@@ -239,7 +245,12 @@ void ras_default_bracket(const mvs_deform_s* h, double* a, int* m);
 int  ras_steps_for(double a);
 #define RAS_TAIL_MAX 32      /* in-kernel sweeps a TAIL launch may add to a solve whose plan was too short */
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, double* xout, int it, double arap_tol, int sweep,
-                      double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots = nullptr);
+                      double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots = nullptr,
+                      bool fold_energy = false /*fused mode, sweep 0 of it >= 1: closes ARAP iteration it-1 (energy, stop rule) as k_arap_rhs does*/);
+// local step of ARAP iteration `it` (rotations, energy, true residual of the solve whose result `x` is) and, when do_rhs, the
+// right-hand side of iteration it+1 — one patch kernel; its extra block judges solve it-1 and resets the tail barrier
+void launch_ras_local_rhs(const mvs_deform_s* h, const double* x, int it, int iters, double arap_tol, double cg_tol, int ring_slot,
+                          const double* prev_solve_scalars, hipStream_t s);
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf,
                            int V, double* out, hipStream_t s);
 

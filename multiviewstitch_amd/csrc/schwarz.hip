@@ -25,6 +25,7 @@
 #include "engine.h"
 #include "dev_common.h"
 #include "arap_dev.h"
+#include "svd3_dev.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -108,7 +109,8 @@ struct ChebCoef { double c0, c1[32], c2[32]; };      // d_0 = c0 D^-1 r ;  d_{k+
 template <int W>
 __global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, double* __restrict__ pw, double* __restrict__ pd,
                                                       const double* __restrict__ ctrl, const double* __restrict__ pts,
-                                                      double* __restrict__ sol, double* __restrict__ rot, RasSmooth sm) {
+                                                      double* __restrict__ sol, double* __restrict__ rot, RasSmooth sm,
+                                                      double* __restrict__ pwr) {
     const int p = blockIdx.x, row = threadIdx.x;
     const int LS = R.LS, base = p * LS, nloc = R.pnloc[p];
     const bool live = row < nloc;                                      // rows nloc..LS-1 are padding: inert (pd = 0, pw = 0)
@@ -145,7 +147,9 @@ __global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, doubl
 #pragma unroll
     for (int e = 0; e < W; ++e) {
         const int ge = gent[e * LS + row], gc = gcol[e * LS + row];
-        o[e * LS + row] = (ge >= 0 && !fixed && !m.is_ctrl[gc]) ? 2.0 * m.w[ge] : 0.0;
+        const double w = ge >= 0 ? m.w[ge] : 0.0;
+        o[e * LS + row] = (ge >= 0 && !fixed && !m.is_ctrl[gc]) ? 2.0 * w : 0.0;
+        if (pwr) pwr[(int64_t)base * W + e * LS + row] = live ? w : 0.0;      // raw weights: covariance, right-hand side (k_ras_local_rhs)
     }
 }
 
@@ -189,10 +193,10 @@ struct RasTail {              // TAIL launches only (the last planned sweep of a
 template <int W, bool TAIL>
 __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __restrict__ pw, const double* __restrict__ pd,
                                                     const double* __restrict__ bvec, double* xa, double* xb, int it, double arap_tol,
-                                                    const double* __restrict__ ered, int nb_rhs, int sweep, double cg_tol, double stop_margin, double slow2,
+                                                    double* __restrict__ ered, int nb_rhs, int sweep, double cg_tol, double stop_margin, double slow2,
                                                     ChebCoef cc, int cheb_m, ChebCoef cc_strong, int cheb_m_strong,
                                                     const double* __restrict__ ctl, double* __restrict__ slot_prev,
-                                                    double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur, RasTail tail) {
+                                                    double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur, RasTail tail, int fold_energy) {
     // LDS: fp64 x of the local rows and the halo while the residual is formed (24 KB), then the correction directions as
     // bfloat16 triples, double-buffered (2 x 8 KB of the same array).  The neighbours' directions only steer the inexact
     // local solve; the residual that decides convergence and the solution stay fp64.
@@ -250,9 +254,21 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     } else if (wv < 6) {
         const double bn = fold_partials(ered + it * EIT + (1 + (wv - 3)) * NBMAX, nb_rhs);
         if (lane == 0) s_bn[wv - 3] = bn;
-    } else if (row == 6 * 64) {
-        s_done = arap_done_before(ered + EFIN, it, arap_tol) ? 1 : 0;
-        s_esc = ctl[MVS_CTL_ESC] != 0.0 ? 1 : 0;                       // a solve missed cg_tol since the last harvest: strong local solves
+    } else if (wv == 6) {
+        bool done;
+        if (fold_energy) {
+            // fused mode, first sweep of ARAP iteration it >= 1: nobody has closed iteration it-1 yet (the fused local + rhs kernel
+            // left its energy partials) — k_arap_rhs's bookkeeping, by every workgroup for itself and by workgroup 0 for the record
+            double* efin = ered + EFIN;
+            done = arap_done_before(efin, it - 1, arap_tol);
+            const double e_prev = done ? 0.0 : fold_partials(ered + (it - 1) * EIT, nb_rhs);   // (did not run: its partials are stale)
+            if (p == 0 && lane == 0) efin[it - 1] = e_prev;
+            if (!done && arap_tol > 0.0 && it >= 2 && fabs((efin[it - 2] - e_prev) / e_prev) < arap_tol) done = true;
+        } else done = arap_done_before(ered + EFIN, it, arap_tol);
+        if (lane == 0) {
+            s_done = done ? 1 : 0;
+            s_esc = ctl[MVS_CTL_ESC] != 0.0 ? 1 : 0;                   // a solve missed cg_tol since the last harvest: strong local solves
+        }
     }
     xs[row] = make_double4(xi.x, xi.y, xi.z, 0.0);
     if (row < nh) xs[LS + row] = make_double4(xh.x, xh.y, xh.z, 0.0);
@@ -418,6 +434,153 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     if (row == 0) iters_cur[p] = steps;
 }
 
+// ---- local step of ARAP iteration `it` and right-hand side of iteration it+1 as ONE patch kernel ------------------------------
+// Round 1 ran them as two row kernels (k_arap_local: a thread per vertex, k_arap_rhs: 8 lanes per vertex) whose neighbour
+// gathers — positions, solution, 72-byte rotations — came from L2: 78 MB of gathers per ARAP iteration for 5 MB of distinct
+// data, and a kernel boundary between them only because a row's right-hand side needs its NEIGHBOURS' new rotations.
+// Here a workgroup stages x and the rest positions of its patch (local rows + halo) in LDS once, computes the rotations
+// of its owned rows AND their first ring (1.3x the rotations, all from LDS), keeps them in LDS, and assembles b for its
+// owned rows from there.  Same operations in the same order per row as the two kernels (k_arap_local, k_arap_rhs): the
+// rotations and b are bit-identical; the energy and residual sums are folded patch by patch instead of block by block.
+//   it, iters : this ARAP iteration, the schedule's length (do_rhs = it + 1 < iters)
+//   grid      : NP + 1 — the extra block judges the solve of iteration it-1 (ring, control block), resets the tail barrier of the
+//               coming solve and zero-fills the partial slots the row kernels' fold count expects beyond NP
+template <int W>
+__global__ __launch_bounds__(RTPB) void k_ras_local_rhs(SellDev m, RasDev R, const double* __restrict__ pw, const double* __restrict__ pwr,
+                                                        const double* __restrict__ pd, const double* __restrict__ pts,
+                                                        const double* __restrict__ x, double* __restrict__ rot,
+                                                        const double* bpure_in /*may alias bpure_out*/, double* __restrict__ bout, double* bpure_out,
+                                                        int it, int iters, double arap_tol, double* __restrict__ ered, int nb,
+                                                        double cg_tol, double* __restrict__ ctl, int ring_slot,
+                                                        const double* __restrict__ prev_scal, unsigned* __restrict__ bar) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    __shared__ double s_red[16][8];
+    __shared__ int s_flag;
+    double* efin = ered + EFIN;
+    const int p = blockIdx.x, row = threadIdx.x, lane = row & 63, wv = row >> 6;
+    if (p == R.NP) {                                               // ---- the extra block
+        if (bar && row < 2) bar[row] = 0u;
+        // (the row kernels and the sweeps fold `nb` partials per sum: the slots NP .. nb-1 of what the patches write hold zeros)
+        for (int q = R.NP + row; q < nb; q += blockDim.x) {
+            ered[it * EIT + q] = 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { ered[it * EIT + (4 + c) * NBMAX + q] = 0.0; if (it + 1 < iters) ered[(it + 1) * EIT + (1 + c) * NBMAX + q] = 0.0; }
+        }
+        if (ctl && it >= 1) judge_solve(ered, it - 1, nb, cg_tol, ctl, ring_slot, !arap_done_before(efin, it - 1, arap_tol), prev_scal);
+        return;
+    }
+    if (row == 0) s_flag = arap_done_before(efin, it, arap_tol) ? 1 : 0;
+    __syncthreads();
+    if (s_flag) return;                                            // the reference's energy stop rule fired before this iteration
+    const int LS = R.LS, base = p * LS;
+    const int nloc = R.pnloc[p], nown = R.pown[p], n1 = R.pn1[p], nh = R.pnh[p];
+    double* xs = reinterpret_cast<double*>(dyn);                   // [stage_slots][3] x of the local rows, then of the halo
+    double* ps = xs + 3 * (size_t)R.stage_slots;                   // [stage_slots][3] rest positions, same slots
+    double* Rs = ps + 3 * (size_t)R.stage_slots;                   // [n1max][9] rotations of the owned rows and the first ring
+    const int g = R.l2g[base + row], gh = R.hl2g[base + row];
+    int lc[W];
+    double wr[W], w2[W];
+    {
+        const int16_t* lcol = R.lcol + (int64_t)base * W;
+        const double* pwp = pw + (int64_t)base * W;
+        const double* prp = pwr + (int64_t)base * W;
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            lc[e] = (int)lcol[e * LS + row];
+            wr[e] = prp[e * LS + row];
+            w2[e] = pwp[e * LS + row];
+            if (lc[e] < 0) { lc[e] = row; wr[e] = 0.0; w2[e] = 0.0; }
+        }
+    }
+    const d3 xi = ld3(x + 3 * (int64_t)g), pi = ld3(pts + 3 * (int64_t)g);
+    const double dd = pd[base + row];                              // 0: control vertex or padding row
+    st3(xs + 3 * row, xi); st3(ps + 3 * row, pi);
+    if (row < nh) { st3(xs + 3 * (LS + row), ld3(x + 3 * (int64_t)gh)); st3(ps + 3 * (LS + row), ld3(pts + 3 * (int64_t)gh)); }
+    __syncthreads();
+    // ---- phase 1: rotation of every row up to the first ring; energy and true residual on the owned rows
+    double e_acc = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+    const bool live = row < nloc;
+    if (live && row < n1) {
+        double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        d3 pp0[W], qq0[W];
+        d3 ax = mk3(0, 0, 0);
+        const bool judge = row < nown && dd != 0.0;
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            const int j = wr[e] == 0.0 ? row : lc[e];
+            pp0[e] = pi - ld3(ps + 3 * j); qq0[e] = xi - ld3(xs + 3 * j);
+        }
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            if (wr[e] == 0.0) continue;
+            const double w = wr[e];
+            const d3 pp = pp0[e], qq = qq0[e];
+            if (judge) ax = ax + (2.0 * w) * qq;
+            c[0] += w * (pp.x * qq.x); c[1] += w * (pp.x * qq.y); c[2] += w * (pp.x * qq.z);
+            c[3] += w * (pp.y * qq.x); c[4] += w * (pp.y * qq.y); c[5] += w * (pp.y * qq.z);
+            c[6] += w * (pp.z * qq.x); c[7] += w * (pp.z * qq.y); c[8] += w * (pp.z * qq.z);
+        }
+        double Rm[9];
+        closest_rotation(c, Rm);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rs[9 * row + k] = Rm[k];
+        if (row < nown) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) rot[9 * (int64_t)g + k] = Rm[k];
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                if (wr[e] == 0.0) continue;
+                e_acc += wr[e] * sqn3(qq0[e] - mulMv(Rm, pp0[e]));
+            }
+            if (judge) {
+                const d3 res = ld3(bpure_in + 3 * (int64_t)g) - ax;
+                const double inv_d = 1.0 / dd;
+                g0 = res.x * res.x * inv_d; g1 = res.y * res.y * inv_d; g2 = res.z * res.z * inv_d;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: right-hand side of iteration it+1 on the owned rows (k_arap_rhs's row, the neighbours' rotations from LDS)
+    double bn0 = 0.0, bn1 = 0.0, bn2 = 0.0;
+    if (it + 1 < iters && row < nown) {
+        d3 bb = mk3(0, 0, 0), bd = mk3(0, 0, 0);
+        const bool freerow = dd != 0.0;
+        if (freerow) {
+            const double* Ri = Rs + 9 * row;
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const double w = wr[e];
+                if (w == 0.0) continue;
+                const int j = lc[e];
+                const double* Rj = Rs + 9 * j;
+                double M[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) M[k] = w * Ri[k] + w * Rj[k];
+                bb = bb + mulMv(M, pi - ld3(ps + 3 * j));
+                if (w2[e] == 0.0) { const d3 xj = ld3(xs + 3 * j); bb = bb + (2.0 * w) * xj; bd = bd + (2.0 * w) * xj; }   // Dirichlet column (free row, masked entry)
+            }
+            bn0 = bb.x * bb.x / dd; bn1 = bb.y * bb.y / dd; bn2 = bb.z * bb.z / dd;
+        }
+        st3(bout + 3 * (int64_t)g, freerow ? bb : mk3(0, 0, 0));
+        st3(bpure_out + 3 * (int64_t)g, freerow ? bb - bd : mk3(0, 0, 0));
+    }
+    // ---- the patch's seven sums -> its slots of the partial arrays (fixed order: waves by DPP, then wave 0 over the waves)
+    {
+        double v[7] = {e_acc, g0, g1, g2, bn0, bn1, bn2};
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { const double t = wave_sum_u(v[k]); if (lane == 0) s_red[wv][k] = t; }
+        __syncthreads();
+        if (row < 7) {
+            double t = 0.0;
+            const int nwv = (int)(blockDim.x >> 6);
+            for (int w = 0; w < nwv; ++w) t += s_red[w][row];
+            if (row == 0) ered[it * EIT + p] = t;
+            else if (row < 4) ered[it * EIT + (3 + row) * NBMAX + p] = t;
+            else if (it + 1 < iters) ered[(it + 1) * EIT + (row - 3) * NBMAX + p] = t;
+        }
+    }
+}
+
 template <class T> int up(T** d, const std::vector<T>& h) {
     *d = nullptr;
     if (hipMalloc((void**)d, std::max<size_t>(1, h.size()) * sizeof(T)) != hipSuccess) { mvs_set_error("hipMalloc failed (patch tables)"); return MVS_E_OOM; }
@@ -436,8 +599,8 @@ extern "C" int mvs_debug_ras_stamps(unsigned long long* out, int n) {
 void ras_free(mvs_deform_s* h) {
     auto fr = [](const void* p) { if (p) (void)hipFree(const_cast<void*>(p)); };
     fr(h->ras.pnloc); fr(h->ras.pown); fr(h->ras.l2g); fr(h->ras.lcol); fr(h->ras.gent); fr(h->ras.gcol); fr(h->ras.pnh); fr(h->ras.hl2g);
-    fr(h->d_ras_x2); fr(h->d_ras_b); fr(h->d_ras_pw); fr(h->d_ras_pd); fr(h->d_ras_slots); fr(h->d_ras_iters);
-    h->ras = RasDev{}; h->d_ras_x2 = h->d_ras_b = h->d_ras_slots = h->d_ras_pw = h->d_ras_pd = nullptr; h->d_ras_iters = nullptr;
+    fr(h->d_ras_x2); fr(h->d_ras_b); fr(h->d_ras_pw); fr(h->d_ras_pd); fr(h->d_ras_slots); fr(h->d_ras_iters); fr(h->ras.pn1); fr(h->d_ras_pwr);
+    h->ras = RasDev{}; h->d_ras_x2 = h->d_ras_b = h->d_ras_slots = h->d_ras_pw = h->d_ras_pd = h->d_ras_pwr = nullptr; h->d_ras_iters = nullptr;
     h->has_ras = false; h->ras_slots_cap = 0;
 }
 
@@ -492,7 +655,7 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
     }
     // pass 1: the rows of every patch (owned rows, then the overlap ring by ring)
     std::vector<std::vector<int32_t>> prows(NP);
-    std::vector<int32_t> pnloc(NP), pown(NP);
+    std::vector<int32_t> pnloc(NP), pown(NP), pn1(NP);
     std::vector<int32_t> mark(V, -1), lidx(V, -1);
     int max_nloc = 0;
     int64_t total_rows = 0;
@@ -513,7 +676,9 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
             std::sort(next.begin(), next.end());
             rows.insert(rows.end(), next.begin(), next.end());
             level_begin = level_end;
+            if (ring == 0) pn1[p] = (int)rows.size();
         }
+        if (pn1[p] == 0) pn1[p] = nown;                                   // (no ring fitted: the fusion check below will fail)
         if ((int)rows.size() > RTPB || nown > 256) return MVS_OK;     // cannot happen (<= 240 owned rows, rings cut at RTPB)
         pown[p] = nown;
         pnloc[p] = (int)rows.size();
@@ -531,7 +696,8 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
     // vertex-of-the-column table at all
     std::vector<std::vector<int32_t>> phalo(NP);
     std::vector<int32_t> pnh(NP, 0);
-    int max_nh = 0;
+    int max_nh = 0, n1max = 0;
+    bool fuse_ok = NP <= MVS_NBMAX;
     for (int p = 0; p < NP; ++p) {
         const std::vector<int32_t>& rows = prows[p];
         const int nloc = pnloc[p];
@@ -549,6 +715,12 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
                 gcolv[e0 + (size_t)k * LS + q] = j;
             }
         }
+        // fused local + rhs: the right-hand side of an owned row reads the rotations of its neighbours from the workgroup's
+        // LDS, where the rotations of the owned rows and the first ring live
+        for (int q = 0; q < pown[p] && fuse_ok; ++q)
+            for (int e = rowptr[rows[q]]; e < rowptr[rows[q] + 1]; ++e)
+                if (lidx[col[e]] < 0 || lidx[col[e]] >= pn1[p]) { fuse_ok = false; break; }
+        n1max = std::max(n1max, pn1[p]);
         for (int v : rows) lidx[v] = -1;
         for (int v : halo) lidx[v] = -1;
         pnh[p] = (int)halo.size();
@@ -561,23 +733,33 @@ int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& ro
     RasDev R{};
     R.NP = NP; R.NPpad = (4 * NP + 63) / 64 * 64; R.W = W;
     int rc;
-    int32_t *d_pnloc, *d_pown, *d_l2g, *d_gent, *d_gcol, *d_pnh, *d_hl2g;
+    int32_t *d_pnloc, *d_pown, *d_l2g, *d_gent, *d_gcol, *d_pnh, *d_hl2g, *d_pn1;
     int16_t* d_lcol;
     if ((rc = up(&d_pnloc, pnloc)) || (rc = up(&d_pown, pown)) || (rc = up(&d_l2g, l2g)) || (rc = up(&d_lcol, lcol)) || (rc = up(&d_gent, gent)) || (rc = up(&d_gcol, gcolv)) ||
         (rc = up(&d_pnh, pnh)) || (rc = up(&d_hl2g, hl2g))) return rc;
+    if ((rc = up(&d_pn1, pn1))) return rc;
+    // Measured on the metric workload (scripts/fuse_compare.py): the fused kernel takes 23.1 us against 13.3 + 12.1 us of the two
+    // row kernels it replaces — it moves a quarter of their bytes, but the rotations' Jacobi chains set its duration just as
+    // they set k_arap_local's, the first ring's rotations are computed twice, and half of its threads idle through phase 1 —
+    // and a step comes out 0.591 ms against 0.581.  It stays an option (MVS_FUSE=1; parity-tested like the default path).
+    if (!getenv("MVS_FUSE") || getenv("MVS_FUSE")[0] != '1') fuse_ok = false;
+    const int stage_slots = (LS + max_nh + 63) / 64 * 64;
+    if (sizeof(double) * (6 * (size_t)stage_slots + 9 * (size_t)n1max) > 60 * 1024) fuse_ok = false;     // the fused kernel's LDS staging (dynamic, default limit 64 KB)
+    R.pn1 = d_pn1; R.fuse = fuse_ok ? 1 : 0; R.n1max = n1max; R.stage_slots = stage_slots;
     R.pnloc = d_pnloc; R.pown = d_pown; R.LS = LS; R.l2g = d_l2g; R.lcol = d_lcol; R.gent = d_gent; R.gcol = d_gcol;
     R.HS = HS; R.pnh = d_pnh; R.hl2g = d_hl2g;
     h->ras = R;
     if (hipMalloc((void**)&h->d_ras_x2, sizeof(double) * 3 * (size_t)V) != hipSuccess) {
         mvs_set_error("hipMalloc failed (patch solver vectors)"); return MVS_E_OOM;
     }
+    if (fuse_ok && hipMalloc((void**)&h->d_ras_pwr, sizeof(double) * (size_t)W * l2g.size()) != hipSuccess) { mvs_set_error("hipMalloc failed (patch matrix)"); return MVS_E_OOM; }
     if (hipMalloc((void**)&h->d_ras_pw, sizeof(double) * (size_t)W * l2g.size()) != hipSuccess || hipMalloc((void**)&h->d_ras_pd, sizeof(double) * l2g.size()) != hipSuccess) {
         mvs_set_error("hipMalloc failed (patch matrix)"); return MVS_E_OOM;
     }
     h->ras_rows = total_rows;
     h->ras_block = LS;
     h->has_ras = true;
-    if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] patch solver: %d patches, %lld local rows for %d vertices, workgroup %d threads, %d entries per row\n", NP, (long long)h->ras_rows, V, h->ras_block, W);
+    if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] patch solver: %d patches, %lld local rows for %d vertices, workgroup %d threads, %d entries per row, fused local+rhs %s\n", NP, (long long)h->ras_rows, V, h->ras_block, W, fuse_ok ? "on" : "off");
     return MVS_OK;
 }
 
@@ -587,10 +769,10 @@ int ras_slot_size(const mvs_deform_s* h) { return ras_slot_doubles(h->ras.NPpad)
 void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s, const double* init_ctrl, const RasSmooth& sm) {
     const RasDev& R = h->ras;
     const dim3 grid(R.NP), blk(h->ras_block);
-    if (R.W == 6) k_ras_prepare<6><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
-    else if (R.W == 8) k_ras_prepare<8><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
-    else if (R.W == 12) k_ras_prepare<12><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
-    else k_ras_prepare<16><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
+    if (R.W == 6) k_ras_prepare<6><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm, R.fuse ? h->d_ras_pwr : nullptr);
+    else if (R.W == 8) k_ras_prepare<8><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm, R.fuse ? h->d_ras_pwr : nullptr);
+    else if (R.W == 12) k_ras_prepare<12><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm, R.fuse ? h->d_ras_pwr : nullptr);
+    else k_ras_prepare<16><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm, R.fuse ? h->d_ras_pwr : nullptr);
 }
 
 // a = 0.4 K/V (capped at 0.06), steps ~ 2.6 / sqrt(a): 11 steps at the density the reference's 16-NN sampling produces.
@@ -614,7 +796,8 @@ int ras_steps_for(double a) {
 // is the last planned sweep of the solve — the launch keeps sweeping (device-wide barrier between sweeps, at most
 // RAS_TAIL_MAX more) until the solve has converged, should the plan have been too short.
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, double* xout, int it, double arap_tol, int sweep,
-                      double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots) {
+                      double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots,
+                      bool fold_energy) {
     const RasDev& R = h->ras;
     const int nb = arap_grid_blocks(h->sell);
     // Chebyshev parameters: the bracket's lower end `a` and the step count live in the handle — initialised from the density
@@ -642,8 +825,20 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, doubl
     const dim3 grid(R.NP), blk(h->ras_block);     // as many waves as the largest patch has rows (idle waves only add barrier cost)
     const RasTail tail{h->d_bar, tail_slots, RAS_TAIL_MAX};
 #define MVS_SWEEP(W, T) k_ras_sweep<W, T><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, stop_margin, \
-                                                              RAS_SLOW * RAS_SLOW, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur, tail)
+                                                              RAS_SLOW * RAS_SLOW, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur, tail, fold_energy ? 1 : 0)
     if (tail_slots) { if (R.W == 6) MVS_SWEEP(6, true); else if (R.W == 8) MVS_SWEEP(8, true); else if (R.W == 12) MVS_SWEEP(12, true); else MVS_SWEEP(16, true); }
     else            { if (R.W == 6) MVS_SWEEP(6, false); else if (R.W == 8) MVS_SWEEP(8, false); else if (R.W == 12) MVS_SWEEP(12, false); else MVS_SWEEP(16, false); }
 #undef MVS_SWEEP
+}
+
+void launch_ras_local_rhs(const mvs_deform_s* h, const double* x, int it, int iters, double arap_tol, double cg_tol, int ring_slot,
+                          const double* prev_solve_scalars, hipStream_t s) {
+    const RasDev& R = h->ras;
+    const dim3 grid(R.NP + 1), blk(h->ras_block);
+    const size_t lds = sizeof(double) * (6 * (size_t)R.stage_slots + 9 * (size_t)R.n1max);
+    const int nb = arap_grid_blocks(h->sell);
+#define MVS_LR(W) k_ras_local_rhs<W><<<grid, blk, lds, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pwr, h->d_ras_pd, h->d_pts, x, h->d_rot, h->d_bpure, h->d_ras_b, \
+                                                           h->d_bpure, it, iters, arap_tol, h->d_energy, nb, cg_tol, h->d_ctl, ring_slot, prev_solve_scalars, h->d_bar)
+    if (R.W == 6) MVS_LR(6); else if (R.W == 8) MVS_LR(8); else if (R.W == 12) MVS_LR(12); else MVS_LR(16);
+#undef MVS_LR
 }

@@ -292,3 +292,29 @@ def test_every_solve_of_a_batch_is_judged(eng):
         st = d.iterate(6)
         assert st["converged"] and st["solves_in_batch"] >= 6 * 2 and st["unconverged_solves"] == 0
         assert 0 < st["cg_rel_residual"] <= st["worst_rel_residual_in_batch"] <= d.params.cg_tol
+
+
+def test_fused_local_rhs_kernel_matches_the_two_row_kernels(eng, oracle, monkeypatch):
+    """MVS_FUSE=1: local step of ARAP iteration k and right-hand side of k+1 as one patch kernel (schwarz.hip,
+    k_ras_local_rhs).  Per row it performs the operations of k_arap_local and k_arap_rhs in their order — rotations are
+    bit-identical — only the energy / residual sums are folded in another order: same oracle parity, and against the
+    default path the vertices agree to the solves' tolerance."""
+    sc, tp, tn, _ = scene_and_target(2)
+    outs = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("MVS_FUSE", fuse)
+        d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+        d.UniformSampling(16)
+        d.set_target(tp, tn)
+        st = [d.iterate(1) for _ in range(3)]
+        assert all(s_["converged"] for s_ in st)
+        outs.append((d.vertices(), d.rotations(), [s_["energy"] for s_ in st], [s_["arap_iters_run"] for s_ in st]))
+    monkeypatch.delenv("MVS_FUSE")
+    assert outs[0][3] == outs[1][3]
+    assert np.allclose(outs[0][2], outs[1][2], rtol=1e-9)
+    assert rms(outs[0][0], outs[1][0]) <= 1e-8 and rms(outs[0][1].reshape(-1, 9), outs[1][1].reshape(-1, 9)) <= 1e-7
+    o = oracle.Deform(sc.verts, sc.normals, sc.faces)
+    o.sample_nodes(16)
+    o.set_target(tp, tn)
+    o.iterate(oracle.Params.default(), 3)
+    assert rms(outs[1][0], o.vertices()) <= 1e-6
