@@ -46,6 +46,8 @@ def parse_args(argv=None):
     ap.add_argument("--config", type=int, default=3, help="scene config (multiviewstitch_amd/scene.py); 3 = metric workload")
     ap.add_argument("--phases", action="store_true", help="extra instrumented pass: per-phase HIP-event times to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "all_gather", "owner"],
+                    help="N > 1: how the ranks' best-8 records meet (auto: owner-merges from 4 ranks on, DESIGN.md §6)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                                                       "the N > 1 code path with several ranks sharing one GPU)")
     ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal without a GPU: every rank joins the process group "
@@ -216,9 +218,42 @@ def main():
             worst["status"] = max(worst["status"], st["status"])
         return st
 
+    exchange = None
     if world > 1:
         shard = mdist.EngineShard(d, device)
         bufs = shard.buffers(K, world)
+        exchange = "all_gather"
+        want = args.exchange if args.exchange != "auto" else ("owner" if world >= 4 else "all_gather")
+        if want == "owner":
+            # owner-merges exchange: checked once, before anything is timed, against the all-gather exchange on the
+            # same records — identical node targets on this rank, and every rank must agree — else the all-gather form runs
+            ok, why = 1, ""
+            try:
+                obufs = shard.buffers_owner(K, world, rank)
+                with torch.cuda.stream(shard.stream):
+                    shard.dmin(obufs)
+                    dist.all_reduce(obufs["d2min"], op=dist.ReduceOp.MIN)
+                    shard.select(obufs)
+                    bufs["rec"].copy_(obufs["rec"]); bufs["cnt"].copy_(obufs["cnt"])
+                    dist.all_gather_into_tensor(bufs["pack_all"], bufs["pack"])
+                    shard.merge(bufs, world)
+                torch.cuda.synchronize(device)
+                a = d.node_targets()
+                with torch.cuda.stream(shard.stream):
+                    mdist._sharded_exchange_owner(shard, obufs, world, None, None)
+                torch.cuda.synchronize(device)
+                b = d.node_targets()
+                if not (np.array_equal(a["controls"], b["controls"]) and np.array_equal(a["valid"], b["valid"])):
+                    ok, why = 0, "targets differ from the all-gather exchange"
+            except Exception as e:                          # noqa: BLE001  (a collective the backend lacks, ...)
+                ok, why = 0, f"{type(e).__name__}: {e}"
+            agree = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if int(agree.item()) == 1:
+                bufs, exchange = obufs, "owner_merges"
+            else:
+                log(f"[bench r{rank}] owner-merges exchange not used ({why or 'another rank declined'}): all-gather exchange")
+                exchange = "all_gather (owner-merges check failed)"
 
         def run(n, timers=None):
             st = None
@@ -394,7 +429,12 @@ def main():
             ms = [a.elapsed_time(b) if hasattr(a, "elapsed_time") else 1e3 * (b - a) for a, b in timers[name]]
             collectives[name + "_ms_per_step"] = round(float(np.mean(ms)), 4) if ms else None
         collectives["bytes_all_reduce"] = int(K) * 4
-        collectives["bytes_all_gather_in_per_rank"] = int(K) * 392 * world
+        collectives["exchange"] = exchange
+        if exchange == "owner_merges":          # "all_gather" timer = all-to-all (records, counts) + block merge + all-gather of the targets
+            collectives["bytes_all_to_all_in_per_rank"] = int(K) * 392
+            collectives["bytes_all_gather_in_per_rank"] = int(bufs["owner"]["stride"]) * world
+        else:
+            collectives["bytes_all_gather_in_per_rank"] = int(K) * 392 * world
 
     if args.phases:
         d.enable_timing(1)

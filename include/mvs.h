@@ -410,6 +410,19 @@ int mvs_deform_assoc_merge(mvs_deform_t h, const mvs_deform_params* p,
  * (K*392 bytes each) — what a single all-gather of each rank's packed [records | counts] buffer produces (one collective
  * per outer iteration less than gathering the two arrays separately). */
 int mvs_deform_assoc_merge_packed(mvs_deform_t h, const mvs_deform_params* p, const void* packed_all_dev, int nranks);
+/* Owner-merges form of step 3 for many ranks.  The all-gather of every rank's records delivers nranks * K * 392 bytes INTO
+ * every rank; with an owner per node block an all-to-all moves K * 392 bytes into a rank and the merged targets come back
+ * in an all-gather of K * 25 bytes.  Blocks: block_nodes = ceil(K / nranks), rank r owns [r * block_nodes, min(K, (r+1) *
+ * block_nodes)).  Rank r receives every rank's records / counts OF ITS BLOCK — rank s's at records_blk_dev + s * (k1-k0) * 8
+ * records, counts_blk_dev + s * (k1-k0) * 2 — and merges them into block_dev = [block_nodes * 3 doubles (targets) |
+ * block_nodes bytes (valid)]; after the all-gather of the blocks every rank installs all K targets with
+ * _set_node_targets_dev (block b at blocks_dev + b * block_stride_bytes) and calls _solve.  Same merge, same total order:
+ * the same targets as _assoc_merge, bit for bit (the best-8 index lists stay with the owners: mvs_deform_top_idx gives -1). */
+int mvs_deform_assoc_merge_block(mvs_deform_t h, const mvs_deform_params* p, const mvs_cand* records_blk_dev,
+                                 const int32_t* counts_blk_dev, int nranks, int64_t k0, int64_t k1, int64_t block_nodes,
+                                 void* block_dev);
+int mvs_deform_set_node_targets_dev(mvs_deform_t h, const void* blocks_dev, int nblocks, int64_t block_nodes,
+                                    int64_t block_stride_bytes);
 /* stats == NULL (after the first, calibrating call): enqueue only, no host synchronisation. */
 int mvs_deform_solve(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stats* stats);
 int mvs_deform_sync(mvs_deform_t h);            /* wait for the handle's stream */

@@ -1082,6 +1082,33 @@ int mvs_deform_assoc_merge_packed(mvs_deform_t h, const mvs_deform_params* p, co
     toc(t, 1);
     return mvs_check_hip(hipGetLastError(), "assoc_merge");
 }
+// owner-merges exchange (N >= 4 ranks): a rank merges only the node block [k0, k1) it owns, into ONE block buffer
+// [block_nodes * 3 doubles | block_nodes bytes] (block_nodes >= k1 - k0: the padded size every rank all-gathers) ...
+int mvs_deform_assoc_merge_block(mvs_deform_t h, const mvs_deform_params* p, const mvs_cand* records_blk_dev, const int32_t* counts_blk_dev,
+                                 int nranks, int64_t k0, int64_t k1, int64_t block_nodes, void* block_dev) {
+    int rc = ready(h, p, false);
+    if (rc) return rc;
+    if (!records_blk_dev || !counts_blk_dev || !block_dev || nranks < 1 || k0 < 0 || k1 < k0 || k1 > h->K || block_nodes < k1 - k0) {
+        mvs_set_error("bad arguments (0 <= k0 <= k1 <= K, block_nodes >= k1 - k0)"); return MVS_E_INVALID_ARG;
+    }
+    Tic t = tic(h, "assoc");
+    launch_assoc_merge(h->d_node_pts, h->d_node_nrm, (int)(k1 - k0), *p, records_blk_dev, counts_blk_dev, nranks, (double*)block_dev,
+                       (uint8_t*)block_dev + sizeof(double) * 3 * (size_t)block_nodes, nullptr, h->stream, 0, 0, (int)k0);
+    toc(t, 1);
+    return mvs_check_hip(hipGetLastError(), "assoc_merge_block");
+}
+// ... and every rank installs the all-gathered blocks (what mvs_deform_assoc_merge would have left) before _solve: node k
+// is entry k % block_nodes of block k / block_nodes
+int mvs_deform_set_node_targets_dev(mvs_deform_t h, const void* blocks_dev, int nblocks, int64_t block_nodes, int64_t block_stride_bytes) {
+    if (!h || !blocks_dev || nblocks < 1 || block_nodes < 1) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    if (h->K == 0) { mvs_set_error("no nodes"); return MVS_E_STATE; }
+    if ((int64_t)nblocks * block_nodes < h->K || block_stride_bytes < block_nodes * 25) {
+        mvs_set_error("the blocks do not cover the %lld nodes", (long long)h->K); return MVS_E_INVALID_ARG;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    launch_install_targets(blocks_dev, (int)h->K, (int)block_nodes, block_stride_bytes, h->d_ctrl_raw, h->d_valid, h->d_top_idx, h->stream);
+    return mvs_check_hip(hipGetLastError(), "set_node_targets");
+}
 int mvs_deform_solve(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stats* stats) {
     int rc = ready(h, p, false);
     if (rc) return rc;

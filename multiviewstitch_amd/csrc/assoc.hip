@@ -757,13 +757,16 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_heavy_knn(GridDev g,
 __global__ __launch_bounds__(256) void k_assoc_merge(const double* __restrict__ node_pts, const double* __restrict__ node_nrm, int K,
                               mvs_deform_params p, const mvs_cand* __restrict__ rec_all,
                               const int32_t* __restrict__ counts_all, int nranks, double* __restrict__ controls,
-                              uint8_t* __restrict__ valid, int64_t* __restrict__ top_idx, int64_t rec_stride, int64_t cnt_stride) {
+                              uint8_t* __restrict__ valid, int64_t* __restrict__ top_idx, int64_t rec_stride, int64_t cnt_stride, int node0) {
     // rank r's records start rec_stride BYTES after rank r-1's, its counts cnt_stride bytes (dense arrays: K*8*48 and K*2*4;
     // one packed buffer per rank [records | counts]: both = the packed size)
-    const int node = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    if (node >= K) return;                                    // wave-uniform
+    // node0 > 0 (owner-merges exchange): the K nodes of this launch are the block node0 .. node0 + K - 1 of the handle's nodes;
+    // records, counts and the outputs are indexed inside the block, the node positions / normals by the node itself
+    const int q = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (q >= K) return;                                       // wave-uniform
     const int lane = threadIdx.x & 63;
-    const d3 orig = ld3(node_pts + 3 * node), nn = ld3(node_nrm + 3 * node);
+    const d3 orig = ld3(node_pts + 3 * (int64_t)(node0 + q)), nn = ld3(node_nrm + 3 * (int64_t)(node0 + q));
+    const int node = q;                                       // (index into the record / count / output arrays)
     const int top_k = p.top_k;
     double L_pd = 0, L_pl = 0, L_x = 0, L_y = 0, L_z = 0;
     long long L_idx = -1;
@@ -978,12 +981,31 @@ void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const doub
         k_assoc_merge_heavy<<<dim3((std::min(heavy_cap, HEAVY_SPLIT_CAP) + 3) / 4), dim3(256), 0, s>>>(
             node_pts, node_nrm, heavy, heavy_cap, p.top_k, part_rec, part_cnt, rec, counts, lm);
 }
+// owner-merges exchange: scatter the all-gathered per-owner blocks [block_nodes*3 doubles | block_nodes bytes] into the handle's
+// dense node targets (the owners keep the index lists: -1 here)
+__global__ void k_install_targets(const uint8_t* __restrict__ blocks, int K, int block_nodes, int64_t stride, double* __restrict__ controls,
+                                  uint8_t* __restrict__ valid, int64_t* __restrict__ top_idx) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const int r = k / block_nodes, q = k - r * block_nodes;
+    const uint8_t* blk = blocks + (int64_t)r * stride;
+    const double* c = (const double*)blk + 3 * (int64_t)q;
+    controls[3 * (int64_t)k] = c[0]; controls[3 * (int64_t)k + 1] = c[1]; controls[3 * (int64_t)k + 2] = c[2];
+    valid[k] = blk[sizeof(double) * 3 * (int64_t)block_nodes + q];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) top_idx[8 * (int64_t)k + j] = -1;
+}
+void launch_install_targets(const void* blocks, int K, int block_nodes, int64_t stride_bytes, double* controls, uint8_t* valid, int64_t* top_idx,
+                            hipStream_t s) {
+    if (K <= 0) return;
+    k_install_targets<<<dim3((K + 255) / 256), dim3(256), 0, s>>>((const uint8_t*)blocks, K, block_nodes, stride_bytes, controls, valid, top_idx);
+}
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks, double* controls,
-                        uint8_t* valid, int64_t* top_idx, hipStream_t s, int64_t rec_stride, int64_t cnt_stride) {
+                        uint8_t* valid, int64_t* top_idx, hipStream_t s, int64_t rec_stride, int64_t cnt_stride, int node0) {
     if (K <= 0) return;
     if (rec_stride == 0) rec_stride = (int64_t)K * 8 * sizeof(mvs_cand);
     if (cnt_stride == 0) cnt_stride = (int64_t)K * 2 * sizeof(int32_t);
     k_assoc_merge<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(node_pts, node_nrm, K, p, rec_all, counts_all, nranks,
-                                                             controls, valid, top_idx, rec_stride, cnt_stride);
+                                                             controls, valid, top_idx, rec_stride, cnt_stride, node0);
 }

@@ -191,10 +191,13 @@ void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const doub
                             float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, int heavy_cap,
                             double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s,
                             const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks, void* split_scratch);
+void launch_install_targets(const void* blocks, int K, int block_nodes, int64_t stride_bytes, double* controls, uint8_t* valid, int64_t* top_idx,
+                            hipStream_t s);
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                         const mvs_cand* rec_all, const int32_t* counts_all, int nranks,
                         double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s,
-                        int64_t rec_stride_bytes = 0, int64_t cnt_stride_bytes = 0 /*0 = dense arrays*/);
+                        int64_t rec_stride_bytes = 0, int64_t cnt_stride_bytes = 0 /*0 = dense arrays*/,
+                        int node0 = 0 /*> 0: the K nodes are the block node0.. of the handle's nodes (owner-merges exchange)*/);
 // knn.hip
 void launch_knn(const double* pts, int n, int k, int32_t* out, hipStream_t s);                 // brute force, LDS tiles
 size_t knn_grid_ws_bytes(int n);

@@ -151,6 +151,15 @@ class Deformation:
         """rank r's block of ``packed_all``: [K*8 records (48 B)][K*2 int32 counts] — one all-gather instead of two."""
         L.check(L.lib().mvs_deform_assoc_merge_packed(self._h, C.byref(self.params), L.ptr(int(packed_all_dev)), nranks))
 
+    def assoc_merge_block(self, records_blk_dev: int, counts_blk_dev: int, nranks: int, k0: int, k1: int, block_nodes: int, block_dev: int):
+        """owner-merges exchange: merge the node block [k0, k1) from every rank's records of that block into
+        block_dev = [block_nodes*3 doubles | block_nodes bytes]"""
+        L.check(L.lib().mvs_deform_assoc_merge_block(self._h, C.byref(self.params), L.ptr(int(records_blk_dev)), L.ptr(int(counts_blk_dev)), nranks,
+                                                     k0, k1, block_nodes, L.ptr(int(block_dev))))
+
+    def set_node_targets_dev(self, blocks_dev: int, nblocks: int, block_nodes: int, block_stride_bytes: int):
+        L.check(L.lib().mvs_deform_set_node_targets_dev(self._h, L.ptr(int(blocks_dev)), nblocks, block_nodes, block_stride_bytes))
+
     def solve(self, sync: bool = True):
         """sync=False: enqueue only (no host synchronisation, no stats) — for back-to-back sharded steps."""
         if not sync:

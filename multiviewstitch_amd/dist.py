@@ -9,6 +9,8 @@ Per outer iteration the ranks exchange, over ``torch.distributed`` (backend
   3. every rank merges the N record sets with the same total order -> identical
      node targets everywhere; smoothing + ARAP run replicated, so the meshes
      never diverge and nothing else is communicated.
+  2'/3'. (owner-merges, for N >= 4: ``buffers_owner``) all-to-all of the records / counts by node block, each rank merges the block
+     it owns, all-gather of the merged targets (25 B per node) — K * 392 B into a rank instead of N * K * 392 B, 1/N of the merge.
 
 The exchange is written against a small "shard" protocol so the same code
 drives the HIP engine (``EngineShard``) and, in the CPU tests, a checker shard
@@ -61,6 +63,32 @@ class EngineShard:
                     cnt=torch.empty(K * 2, dtype=torch.int32, device=dev),
                     rec_all=torch.empty(world * K * 8 * REC_BYTES, dtype=torch.uint8, device=dev),
                     cnt_all=torch.empty(world * K * 2, dtype=torch.int32, device=dev))
+
+    @staticmethod
+    def _buffers_owner(K, world, rank, dev):
+        bn, blocks = node_blocks(K, world)
+        mine = blocks[rank][1] - blocks[rank][0]
+        stride = (bn * 25 + 31) // 32 * 32
+        return dict(d2min=torch.empty(K, dtype=torch.float32, device=dev),
+                    rec=torch.empty(K * 8 * REC_BYTES, dtype=torch.uint8, device=dev), cnt=torch.empty(K * 2, dtype=torch.int32, device=dev),
+                    rec_in=torch.empty(max(1, world * mine * 8 * REC_BYTES), dtype=torch.uint8, device=dev),
+                    cnt_in=torch.empty(max(1, world * mine * 2), dtype=torch.int32, device=dev),
+                    blk=torch.zeros(stride, dtype=torch.uint8, device=dev), blk_all=torch.empty(world * stride, dtype=torch.uint8, device=dev),
+                    owner=dict(rank=rank, bn=bn, blocks=blocks, stride=stride))
+
+    def buffers_owner(self, K, world, rank):
+        with torch.cuda.stream(self.stream):
+            return self._buffers_owner(K, world, rank, self.device)
+
+    def merge_block(self, b, world):
+        o = b["owner"]
+        k0, k1 = o["blocks"][o["rank"]]
+        if k1 > k0:
+            self.d.assoc_merge_block(b["rec_in"].data_ptr(), b["cnt_in"].data_ptr(), world, k0, k1, o["bn"], b["blk"].data_ptr())
+
+    def install(self, b, world):
+        o = b["owner"]
+        self.d.set_node_targets_dev(b["blk_all"].data_ptr(), world, o["bn"], o["stride"])
 
     def dmin(self, b):
         self.d.assoc_dmin(b["d2min"].data_ptr())
@@ -119,13 +147,37 @@ class _Bracket:
         self.t[self.name].append((self.a, b))
 
 
+def _sharded_exchange_owner(shard, bufs, world, group, timers):
+    """owner-merges exchange (N >= 4): every rank receives the records of ITS node block only (K * 392 B in, not N * K * 392 B),
+    merges that block, and the blocks' targets (25 B per node) are all-gathered and installed"""
+    o = bufs["owner"]
+    sizes = [b[1] - b[0] for b in o["blocks"]]
+    mine = sizes[o["rank"]]
+    with _Bracket(timers, "all_gather"):
+        if world > 1:
+            dist.all_to_all_single(bufs["rec_in"][:world * mine * 8 * REC_BYTES], bufs["rec"], [mine * 8 * REC_BYTES] * world,
+                                   [n * 8 * REC_BYTES for n in sizes], group=group)
+            dist.all_to_all_single(bufs["cnt_in"][:world * mine * 2], bufs["cnt"], [mine * 2] * world, [n * 2 for n in sizes], group=group)
+        else:
+            bufs["rec_in"].copy_(bufs["rec"])
+            bufs["cnt_in"].copy_(bufs["cnt"])
+        shard.merge_block(bufs, world)
+        if world > 1:
+            dist.all_gather_into_tensor(bufs["blk_all"], bufs["blk"], group=group)
+        else:
+            bufs["blk_all"].copy_(bufs["blk"])
+    shard.install(bufs, world)
+
+
 def _sharded_step(shard, bufs, world, group, sync, timers=None):
     shard.dmin(bufs)
     if world > 1:
         with _Bracket(timers, "all_reduce"):
             dist.all_reduce(bufs["d2min"], op=dist.ReduceOp.MIN, group=group)
     shard.select(bufs)
-    if world > 1 and "pack" in bufs:
+    if "owner" in bufs:
+        _sharded_exchange_owner(shard, bufs, world, group, timers)
+    elif world > 1 and "pack" in bufs:
         with _Bracket(timers, "all_gather"):
             dist.all_gather_into_tensor(bufs["pack_all"], bufs["pack"], group=group)      # records and counts in one collective
         shard.merge(bufs, world)
@@ -139,6 +191,12 @@ def _sharded_step(shard, bufs, world, group, sync, timers=None):
     else:
         shard.merge(dict(bufs, rec_all=bufs["rec"], cnt_all=bufs["cnt"]), 1)
     return shard.solve(sync) if not sync else shard.solve()
+
+
+def node_blocks(K: int, world: int):
+    """owner-merges exchange: (block_nodes, [(k0, k1) per rank]) — block_nodes = ceil(K / world), the layout mvs.h fixes"""
+    bn = max(1, -(-K // world))
+    return bn, [(min(K, r * bn), min(K, (r + 1) * bn)) for r in range(world)]
 
 
 def view_shards(n_views: int, world: int):

@@ -54,6 +54,33 @@ class OracleShard:
             cnt = b["cnt_all"].numpy().reshape(world, K, 2)
         self.merged = self.O.assoc_merge(self.pts[self.nodes], self.nrm[self.nodes], self.p, rec, cnt)
 
+    # owner-merges exchange (dist.py, N >= 4 on the GPU): same protocol, checker side
+    def buffers_owner(self, K, world, rank):
+        from multiviewstitch_amd.dist import EngineShard
+        return EngineShard._buffers_owner(K, world, rank, torch.device("cpu"))
+
+    def merge_block(self, b, world):
+        o = b["owner"]
+        k0, k1 = o["blocks"][o["rank"]]
+        n, bn = k1 - k0, o["bn"]
+        if n == 0:
+            return
+        rec = b["rec_in"].numpy()[:world * n * 8 * 48].view(self.O.CAND_DTYPE).reshape(world, n, 8)
+        cnt = b["cnt_in"].numpy()[:world * n * 2].reshape(world, n, 2)
+        nodes = self.nodes[k0:k1]
+        m = self.O.assoc_merge(self.pts[nodes], self.nrm[nodes], self.p, rec, cnt)
+        blk = b["blk"].numpy()
+        blk[:bn * 24].view(np.float64).reshape(bn, 3)[:n] = m["controls"]
+        blk[bn * 24:bn * 24 + n] = m["valid"].astype(np.uint8)
+
+    def install(self, b, world):
+        o = b["owner"]
+        K, bn = len(self.nodes), o["bn"]
+        allb = b["blk_all"].numpy().reshape(world, o["stride"])
+        ctrl = np.concatenate([allb[r, :bn * 24].view(np.float64).reshape(bn, 3) for r in range(world)])[:K]
+        valid = np.concatenate([allb[r, bn * 24:bn * 25] for r in range(world)])[:K]
+        self.merged = dict(controls=ctrl.copy(), valid=valid.astype(bool))
+
     def solve(self, sync=True):
         O = self.O
         npts = self.pts[self.nodes]
@@ -76,7 +103,7 @@ def _worker(rank, world, port, q, packed=True):
     assert offs[rank] == cuts[rank] and counts.sum() == P
     shard = OracleShard(O, g, cuts[rank], cuts[rank + 1])
     shard.packed = packed
-    bufs = shard.buffers(len(g["nodes"]), world)
+    bufs = shard.buffers_owner(len(g["nodes"]), world, rank) if packed == "owner" else shard.buffers(len(g["nodes"]), world)
     for _ in range(2):
         mdist.sharded_step(shard, bufs, world)
     q.put((rank, shard.pts, shard.merged["valid"]))
@@ -87,7 +114,8 @@ def _worker(rank, world, port, q, packed=True):
 import pytest
 
 
-@pytest.mark.parametrize("packed", [True, False])           # one all-gather of [records | counts], or the two arrays separately
+# one all-gather of [records | counts]; the two arrays separately; owner-merges (all-to-all by node block, all-gather of the targets)
+@pytest.mark.parametrize("packed", [True, False, "owner"])
 def test_sharded_step_world2_matches_single_rank(packed):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

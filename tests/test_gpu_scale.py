@@ -224,3 +224,55 @@ def test_sharded_bound_holds_for_nearly_converged_nodes():
             assert np.array_equal(ga["top_idx"], gr["top_idx"]) and np.array_equal(ga["valid"], gr["valid"]), f"outer {it}"
             assert np.array_equal(d.vertices(), ref.vertices()), f"outer {it}"
     assert float(np.sqrt(gr["d2min"]).max()) < 5e-3 and float(np.median(np.sqrt(gr["d2min"]))) < 1e-4      # the nodes do sit on the scan
+
+
+@pytest.mark.gpu
+def test_owner_merges_exchange_gives_the_all_gather_targets(big):
+    """Owner-merges exchange (mvs.h: mvs_deform_assoc_merge_block / _set_node_targets_dev; dist.py for N >= 4), four shards
+    emulated on one GPU with the all-to-all written as slices: every rank merges only its node block, the gathered blocks are
+    installed everywhere, and targets, validity and the mesh after the solve equal the single handle's, bit for bit."""
+    import torch
+    from multiviewstitch_amd import _lib
+    from multiviewstitch_amd import dist as mdist
+    if _lib.device_count() == 0:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box")
+    dev = torch.device("cuda", 0)
+    world = 4
+    ref, _, _ = make(big)
+    keep = [make(big, v) for v in mdist.view_shards(len(big["tp"]), world)]       # (device arrays stay referenced)
+    shards = [k[0] for k in keep]
+    K = ref.K
+    bn, blocks = mdist.node_blocks(K, world)
+    assert blocks[-1][1] == K and K % world != 0            # ragged last block
+    stride = (bn * 25 + 31) // 32 * 32
+    d2 = [torch.empty(K, dtype=torch.float32, device=dev) for _ in shards]
+    rec = torch.empty((world, K * 8 * 48), dtype=torch.uint8, device=dev)
+    cnt = torch.empty((world, K * 2), dtype=torch.int32, device=dev)
+    blk_all = torch.zeros(world * stride, dtype=torch.uint8, device=dev)
+    for it in range(2):
+        ref.iterate(1)
+        for d, b in zip(shards, d2):
+            d.assoc_dmin(b.data_ptr())
+            d.sync()
+        dmin = torch.stack(d2).min(dim=0).values.contiguous()
+        for r, d in enumerate(shards):
+            d.assoc_select(dmin.data_ptr(), rec[r].data_ptr(), cnt[r].data_ptr())
+            d.sync()
+        for r, d in enumerate(shards):                      # owner r: the records of its block from every rank ("all-to-all")
+            k0, k1 = blocks[r]
+            rin = torch.cat([rec[s, k0 * 384:k1 * 384] for s in range(world)]).contiguous()
+            cin = torch.cat([cnt[s, k0 * 2:k1 * 2] for s in range(world)]).contiguous()
+            torch.cuda.synchronize()
+            d.assoc_merge_block(rin.data_ptr(), cin.data_ptr(), world, k0, k1, bn, blk_all[r * stride:].data_ptr())
+            d.sync()
+        for d in shards:                                    # "all-gather" done: install everywhere, solve replicated
+            d.set_node_targets_dev(blk_all.data_ptr(), world, bn, stride)
+            d.solve()
+        gr = ref.node_targets()
+        for d in shards:
+            ga = d.node_targets()
+            assert np.array_equal(ga["valid"], gr["valid"]) and np.array_equal(ga["controls"], gr["controls"]), f"outer {it}"
+            assert np.all(ga["top_idx"] == -1)
+            assert np.array_equal(d.vertices(), ref.vertices()), f"outer {it}"
+    with pytest.raises(RuntimeError):
+        shards[0].set_node_targets_dev(blk_all.data_ptr(), 1, bn, stride)         # blocks that do not cover the nodes
