@@ -267,6 +267,17 @@ int mvs_remove_ground(int64_t* V, double* pts, double* normals, int64_t* F, int3
 int mvs_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t nt,
                        const double* ground_ray, const double* view_ray, double* R /*9*/, double* t /*3*/, double* scale);
 
+/* InitAlignment with the scan sharded over ranks by view: `tgt_local` holds this rank's share (may be empty), the
+ * template `src` is replicated.  The scan's count / sums, bounding box, centred second moments (PointSetUtils.cpp:9-39) and its
+ * extent along the first pivot (Alignment.cpp:281-296) are reduced over the ranks through the caller's all-reduce — four calls
+ * of at most 6 doubles — so every rank returns the same R, t, scale; they equal mvs_init_alignment on the whole scan up to the
+ * order of the floating-point sums.  `reduce(ctx, v, n, op)` all-reduces the n HOST doubles v in place, op 0 = sum, 1 = min,
+ * and returns 0 on success; mvs_comm_reduce (ctx = an mvs_comm_t) is a ready one over RCCL. */
+typedef int (*mvs_reduce_fn)(void* ctx, double* v, int n, int op);
+int mvs_init_alignment_sharded(const double* src, int64_t ns, const double* tgt_local, int64_t nt_local,
+                               const double* ground_ray, const double* view_ray, mvs_reduce_fn reduce, void* reduce_ctx,
+                               double* R /*9*/, double* t /*3*/, double* scale);
+
 /* PartRecognition::PartRecog (R/PartRecognition/PartRecognition.cpp:50-77): label of the nearest template vertex. */
 int mvs_part_recog(const double* tmpl_pts, const int32_t* tmpl_labels, int64_t V,
                    const double* pts, int64_t P, int32_t* out_labels);
@@ -450,6 +461,8 @@ typedef struct mvs_comm_s* mvs_comm_t;
 int mvs_comm_unique_id(uint8_t* id /*MVS_COMM_ID_BYTES*/);
 int mvs_comm_init(int rank, int nranks, const uint8_t* id /*MVS_COMM_ID_BYTES*/, mvs_comm_t* out);
 int mvs_comm_destroy(mvs_comm_t c);
+/* an mvs_reduce_fn over a communicator (ctx = the mvs_comm_t): n <= 16 host doubles, op 0 = sum, 1 = min */
+int mvs_comm_reduce(void* comm, double* v, int n, int op);
 int mvs_comm_info(mvs_comm_t c, int* rank, int* nranks);
 int mvs_deform_iterate_sharded(mvs_deform_t h, mvs_comm_t c, const mvs_deform_params* p, int n_outer, mvs_deform_stats* stats);
 

@@ -75,6 +75,16 @@ class Alignment:
         L.check(L.lib().mvs_init_alignment(L.ptr(s), len(s), L.ptr(t), len(t), L.ptr(g), L.ptr(v), L.ptr(R), L.ptr(tr), C.byref(sc)))
         return R, tr, sc.value
 
+    def InitAlignmentSharded(self, src, tgt_local, groundRay, viewRay, reducer):
+        """InitAlignment with the scan sharded over ranks by view: tgt_local = this rank's share (may be empty), reducer = the
+        all-reduce callback (multiviewstitch_amd.dist.host_reducer); every rank returns the same (R, t, scale)."""
+        s, t = L.arr(src, np.float64).reshape(-1, 3), L.arr(tgt_local, np.float64).reshape(-1, 3)
+        g, v = L.arr(groundRay, np.float64), L.arr(viewRay, np.float64)
+        R, tr, sc = np.empty((3, 3)), np.empty(3), C.c_double()
+        L.check(L.lib().mvs_init_alignment_sharded(L.ptr(s), len(s), L.ptr(t) if len(t) else None, len(t), L.ptr(g), L.ptr(v),
+                                                   C.cast(reducer, C.c_void_p), None, L.ptr(R), L.ptr(tr), C.byref(sc)))
+        return R, tr, sc.value
+
     def LocalAlignmentCore(self, src, s_labels, tgt, t_labels, group_mask: int, label: int):
         s, t = L.arr(src, np.float64).reshape(-1, 3), L.arr(tgt, np.float64).reshape(-1, 3)
         sl, tl = L.arr(s_labels, np.int32), L.arr(t_labels, np.int32)

@@ -365,8 +365,18 @@ struct Work {                 // per-call reduction scratch (device + pinned-siz
     int fetch(size_t n) { return mvs_check_hip(hipMemcpy(h.data(), part.p, sizeof(double) * n, hipMemcpyDeviceToHost), "memcpy"); }
 };
 
+// view-sharded form (mvs_init_alignment_sharded): the caller's all-reduce over the ranks on small host vectors, op 0 = sum, 1 = min
+struct Reducer {
+    mvs_reduce_fn fn = nullptr; void* ctx = nullptr;
+    int run(double* v, int n, int op) const {
+        if (!fn) return MVS_OK;
+        if (fn(ctx, v, n, op) != 0) { mvs_set_error("the caller's all-reduce failed"); return MVS_E_STATE; }
+        return MVS_OK;
+    }
+};
+
 // PointSetUtils::SetInput + CalcPivots on the selected device points
-int pca_dev(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, Work& w, Pca* out) {
+int pca_dev(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, Work& w, Pca* out, const Reducer& red = Reducer()) {
     k_moments1<<<dim3(NBLK), dim3(TPB)>>>(pts, n, labels, mask, w.part.as<double>());
     int rc = w.fetch((size_t)NBLK * 11);
     if (rc) return rc;
@@ -379,6 +389,13 @@ int pca_dev(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, 
         for (int c = 0; c < 3; ++c) { out->lo[c] = std::min(out->lo[c], p[4 + c]); out->hi[c] = std::max(out->hi[c], p[7 + c]); }
         present |= (uint32_t)p[10];
     }
+    if (red.fn) {                                  // counts, sums and the box over ALL ranks (a rank may hold no point: 0 / +-inf)
+        double a[4] = {cnt, s[0], s[1], s[2]};
+        double b[6] = {out->lo[0], out->lo[1], out->lo[2], -out->hi[0], -out->hi[1], -out->hi[2]};
+        if ((rc = red.run(a, 4, 0)) || (rc = red.run(b, 6, 1))) return rc;
+        cnt = a[0]; s[0] = a[1]; s[1] = a[2]; s[2] = a[3];
+        for (int c = 0; c < 3; ++c) { out->lo[c] = b[c]; out->hi[c] = -b[3 + c]; }
+    }
     out->cnt = cnt; out->present = present;
     if (cnt < 2) { mvs_set_error("PCA needs at least 2 points (got %.0f)", cnt); return MVS_E_DEGENERATE; }
     for (int c = 0; c < 3; ++c) out->bary[c] = s[c] / cnt;                    // PointSetUtils.cpp:43-47
@@ -386,6 +403,7 @@ int pca_dev(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, 
     if ((rc = w.fetch((size_t)NBLK * 6))) return rc;
     double m[6] = {0, 0, 0, 0, 0, 0};
     for (int b = 0; b < NBLK; ++b) for (int k = 0; k < 6; ++k) m[k] += w.h[(size_t)b * 6 + k];
+    if ((rc = red.run(m, 6, 0))) return rc;
     double C[9] = {m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5]};
     for (int k = 0; k < 9; ++k) C[k] /= (cnt - 1.0);                          // :26
     double val[3], vec[9];
@@ -523,15 +541,20 @@ int remove_ground_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int6
 }
 
 int init_alignment_dev(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray, const double* view_ray,
-                       Work& w, double* R, double* t, double* scale) {
+                       Work& w, double* R, double* t, double* scale, const Reducer& red = Reducer()) {
     Pca ps, pt;
     int rc;
-    if ((rc = pca_dev(src, ns, nullptr, 0, w, &ps)) || (rc = pca_dev(tgt, nt, nullptr, 0, w, &pt))) return rc;
+    if ((rc = pca_dev(src, ns, nullptr, 0, w, &ps)) || (rc = pca_dev(tgt, nt, nullptr, 0, w, &pt, red))) return rc;
     if (dotp(ground_ray, pt.axis[0]) < 0) for (int c = 0; c < 3; ++c) pt.axis[0][c] = -pt.axis[0][c];   // :255
     if (dotp(view_ray, pt.axis[2]) < 0) for (int c = 0; c < 3; ++c) pt.axis[2][c] = -pt.axis[2][c];     // :256
     Range r1, r2;
     if ((rc = range_dev(src, ns, nullptr, 0, ps.axis[0], ps.bary, nullptr, w, &r1)) ||
         (rc = range_dev(tgt, nt, nullptr, 0, pt.axis[0], pt.bary, nullptr, w, &r2))) return rc;
+    if (red.fn) {                                  // the scan's extent along its first pivot over all ranks (start values DBL_MAX / DBL_MIN included)
+        double e[2] = {r2.lo, -r2.hi};
+        if ((rc = red.run(e, 2, 1))) return rc;
+        r2.lo = e[0]; r2.hi = -e[1];
+    }
     *scale = (r2.hi - r2.lo) / (r1.hi - r1.lo);                                  // :297
     double S[9], T[9], Si[9];
     for (int i = 0; i < 3; ++i) for (int r = 0; r < 3; ++r) { S[3 * r + i] = ps.axis[i][r]; T[3 * r + i] = pt.axis[i][r]; }   // pivots as columns
@@ -671,6 +694,20 @@ int mvs_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t
     Dev ds, dt; Work w;
     if ((rc = up(ds, src, (size_t)ns * 3)) || (rc = up(dt, tgt, (size_t)nt * 3)) || (rc = w.init())) return rc;
     return init_alignment_dev(ds.as<double>(), ns, dt.as<double>(), nt, ground_ray, view_ray, w, R, t, scale);
+}
+
+int mvs_init_alignment_sharded(const double* src, int64_t ns, const double* tgt_local, int64_t nt_local, const double* ground_ray,
+                               const double* view_ray, mvs_reduce_fn reduce, void* reduce_ctx, double* R, double* t, double* scale) {
+    if (!src || ns < 2 || nt_local < 0 || (nt_local > 0 && !tgt_local) || !ground_ray || !view_ray || !reduce || !R || !t || !scale) {
+        mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG;
+    }
+    int rc = need_device();
+    if (rc) return rc;
+    Dev ds, dt; Work w;
+    if ((rc = up(ds, src, (size_t)ns * 3)) || (rc = up(dt, tgt_local, (size_t)nt_local * 3, 3)) || (rc = w.init())) return rc;
+    Reducer red;
+    red.fn = reduce; red.ctx = reduce_ctx;
+    return init_alignment_dev(ds.as<double>(), ns, dt.as<double>(), nt_local, ground_ray, view_ray, w, R, t, scale, red);
 }
 
 int mvs_part_recog(const double* tmpl_pts, const int32_t* tmpl_labels, int64_t V, const double* pts, int64_t P, int32_t* out_labels) {

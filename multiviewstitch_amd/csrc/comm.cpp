@@ -56,6 +56,7 @@ int check_nccl(ncclResult_t e, const char* what) {
 struct mvs_comm_s {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1, device = 0;
+    double* scratch = nullptr;               // 16 doubles on the device (mvs_comm_reduce)
 };
 
 extern "C" {
@@ -92,8 +93,23 @@ int mvs_comm_destroy(mvs_comm_t c) {
     if (!c) return MVS_OK;
     int rc = MVS_OK;
     if (c->comm && g_rccl.CommDestroy) rc = check_nccl(g_rccl.CommDestroy(c->comm), "ncclCommDestroy");
+    if (c->scratch) (void)hipFree(c->scratch);
     delete c;
     return rc;
+}
+
+int mvs_comm_reduce(void* ctx, double* v, int n, int op) {
+    mvs_comm_t c = (mvs_comm_t)ctx;
+    if (!c || !v || n < 1 || n > 16 || (op != 0 && op != 1)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    if (c->nranks == 1) return MVS_OK;
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->scratch) HIPCHK(hipMalloc(&c->scratch, sizeof(double) * 16));
+    HIPCHK(hipMemcpy(c->scratch, v, sizeof(double) * n, hipMemcpyHostToDevice));
+    int rc = check_nccl(g_rccl.AllReduce(c->scratch, c->scratch, (size_t)n, ncclFloat64, op == 0 ? ncclSum : ncclMin, c->comm, nullptr), "ncclAllReduce");
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(hipMemcpy(v, c->scratch, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return MVS_OK;
 }
 
 int mvs_comm_info(mvs_comm_t c, int* rank, int* nranks) {

@@ -193,6 +193,36 @@ def _sharded_step(shard, bufs, world, group, sync, timers=None):
     return shard.solve(sync) if not sync else shard.solve()
 
 
+_REDUCE_FN = None
+
+
+def host_reducer(group=None, device=None):
+    """The all-reduce the view-sharded Alignment entries call back (mvs.h: mvs_reduce_fn — small HOST vectors of doubles,
+    op 0 = sum, 1 = min), over ``torch.distributed``: on the CPU for gloo, through a device tensor for nccl (RCCL).
+    Returns a ctypes function pointer; keep it referenced while the call runs."""
+    import ctypes as C
+    global _REDUCE_FN
+    if _REDUCE_FN is None:
+        _REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+
+    def reduce(_ctx, v, n, op):
+        try:
+            if not dist.is_initialized() or dist.get_world_size(group) == 1:
+                return 0
+            a = np.ctypeslib.as_array(v, shape=(n,))
+            t = torch.from_numpy(a.copy())
+            if device is not None:
+                t = t.to(device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MIN, group=group)
+            a[:] = t.cpu().numpy()
+            return 0
+        except Exception:                       # noqa: BLE001  (an exception must not unwind through the C frame: reported as an error code)
+            import traceback
+            traceback.print_exc()
+            return 1
+    return _REDUCE_FN(reduce)
+
+
 def node_blocks(K: int, world: int):
     """owner-merges exchange: (block_nodes, [(k0, k1) per rank]) — block_nodes = ceil(K / world), the layout mvs.h fixes"""
     bn = max(1, -(-K // world))

@@ -408,6 +408,21 @@ def remove_ground(pts, nrm, faces, dist_thres=0.81):
     return gr, p[:V.value], (n[:V.value] if n is not None else None), f[:F.value]
 
 
+def init_alignment_sharded(src, tgt_local, ground_ray, view_ray, reducer):
+    """reducer: a ctypes callback int(void* ctx, double* v, int n, int op) (multiviewstitch_amd.dist.host_reducer)"""
+    s, t = _c(src, np.float64), _c(np.asarray(tgt_local, np.float64).reshape(-1, 3), np.float64)
+    g, v = _c(ground_ray, np.float64), _c(view_ray, np.float64)
+    R, tr, sc = np.empty((3, 3)), np.empty(3), C.c_double()
+    f = lib().orc_init_alignment_sharded
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = f(s.ctypes.data, len(s), t.ctypes.data, len(t), g.ctypes.data, v.ctypes.data, C.cast(reducer, C.c_void_p), None,
+           R.ctypes.data, tr.ctypes.data, C.addressof(sc))
+    if rc:
+        raise RuntimeError(f"orc_init_alignment_sharded -> {rc}")
+    return R, tr, sc.value
+
+
 def init_alignment(src, tgt, ground_ray, view_ray):
     s, t = _c(src, np.float64), _c(tgt, np.float64)
     g, v = _c(ground_ray, np.float64), _c(view_ray, np.float64)

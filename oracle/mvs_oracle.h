@@ -133,6 +133,11 @@ int  orc_pca(const double* pts, int64_t n, const int32_t* labels, uint32_t mask,
              double* axes /*9: row i = i-th pivot*/, double* evals);
 void orc_retain_connect_region(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t* faces);
 int  orc_remove_ground(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t* faces, double dist_thres, double* ground_ray);
+/* view-sharded InitAlignment (checker of mvs_init_alignment_sharded): tgt = this rank's share; reduce(ctx, v, n, op) all-reduces
+ * n host doubles in place over the ranks, op 0 = sum, 1 = min; returns 0 on success */
+typedef int (*orc_reduce_fn)(void* ctx, double* v, int n, int op);
+int  orc_init_alignment_sharded(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray,
+                                const double* view_ray, orc_reduce_fn reduce, void* ctx, double* R, double* t, double* scale);
 int  orc_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray,
                         const double* view_ray, double* R, double* t, double* scale);
 void orc_part_recog(const double* tmpl, const int32_t* tmpl_labels, int64_t V, const double* pts, int64_t P, int32_t* out);

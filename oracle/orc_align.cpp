@@ -62,12 +62,20 @@ void eig3(const double* C, double* val, double* vec) {
 
 struct Pca { V3 bary; double lo[3], hi[3]; V3 axis[3]; double eval[3]; };
 
+// view-sharded form: the caller's all-reduce over the ranks (op 0 = sum, 1 = min) on small host vectors
+struct Reducer {
+    orc_reduce_fn fn = nullptr; void* ctx = nullptr;
+    bool on() const { return fn != nullptr; }
+    bool run(double* v, int n, int op) const { return !fn || fn(ctx, v, n, op) == 0; }
+};
+
 // PointSetUtils::SetInput + CalcPivots (PointSetUtils.cpp:3-61) over the points selected by `mask`
 // (bit l set = label l accepted; labels == nullptr -> every point)
-bool pca(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, Pca* out) {
+bool pca(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, Pca* out, const Reducer& red = Reducer()) {
     V3 sum = {0, 0, 0};
     int64_t cnt = 0;
     bool first = true;
+    if (red.on()) for (int c = 0; c < 3; ++c) { out->lo[c] = INFINITY; out->hi[c] = -INFINITY; }   // (a rank may hold no point)
     for (int64_t i = 0; i < n; ++i) {
         if (labels && !((mask >> labels[i]) & 1u)) continue;
         const V3 p = v3(pts + 3 * i);
@@ -79,6 +87,13 @@ bool pca(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, Pca
         }
         first = false;
     }
+    if (red.on()) {                                                          // counts, sums and the box over ALL ranks
+        double a[4] = {(double)cnt, sum.x, sum.y, sum.z};
+        double b[6] = {out->lo[0], out->lo[1], out->lo[2], -out->hi[0], -out->hi[1], -out->hi[2]};
+        if (!red.run(a, 4, 0) || !red.run(b, 6, 1)) return false;
+        cnt = (int64_t)a[0]; sum = {a[1], a[2], a[3]};
+        for (int c = 0; c < 3; ++c) { out->lo[c] = b[c]; out->hi[c] = -b[3 + c]; }
+    }
     if (cnt < 2) return false;
     out->bary = sum / (double)cnt;
     double C[9] = {0};
@@ -88,6 +103,7 @@ bool pca(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, Pca
         const double a[3] = {d.x, d.y, d.z};
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) C[3 * r + c] += a[r] * a[c];
     }
+    if (red.on() && !red.run(C, 9, 0)) return false;
     for (int k = 0; k < 9; ++k) C[k] /= (double)(cnt - 1);                  // PointSetUtils.cpp:26
     double val[3], vec[9];
     eig3(C, val, vec);
@@ -246,13 +262,22 @@ int orc_remove_ground(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t*
 }
 
 // Alignment::InitAlignment (Alignment.cpp:235-314): R (row-major), t, scale
-int orc_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray,
-                       const double* view_ray, double* R, double* t, double* scale) {
+// reduce != nullptr: tgt holds only this rank's share of the scan (sharded by view); its sums, box and extent are reduced over the ranks
+int orc_init_alignment_sharded(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray,
+                               const double* view_ray, orc_reduce_fn reduce, void* ctx, double* R, double* t, double* scale) {
     Pca ps, pt;
-    if (!pca(src, ns, nullptr, 0, &ps) || !pca(tgt, nt, nullptr, 0, &pt)) return -9;
+    Reducer red;
+    red.fn = reduce; red.ctx = ctx;
+    if (!pca(src, ns, nullptr, 0, &ps) || !pca(tgt, nt, nullptr, 0, &pt, red)) return -9;
     if (dot(v3(ground_ray), pt.axis[0]) < 0) pt.axis[0] = -1.0 * pt.axis[0];     // :255
     if (dot(v3(view_ray), pt.axis[2]) < 0) pt.axis[2] = -1.0 * pt.axis[2];       // :256
-    const Range r1 = range_along(src, ns, nullptr, 0, ps.axis[0], ps.bary), r2 = range_along(tgt, nt, nullptr, 0, pt.axis[0], pt.bary);
+    const Range r1 = range_along(src, ns, nullptr, 0, ps.axis[0], ps.bary);
+    Range r2 = range_along(tgt, nt, nullptr, 0, pt.axis[0], pt.bary);
+    if (red.on()) {
+        double e[2] = {r2.lo, -r2.hi};                                           // (the loops' start values DBL_MAX / DBL_MIN take part, as on one rank)
+        if (!red.run(e, 2, 1)) return -9;
+        r2.lo = e[0]; r2.hi = -e[1];
+    }
     *scale = (r2.hi - r2.lo) / (r1.hi - r1.lo);                                  // :297
     double S[9], T[9], Si[9];                                                     // pivots as COLUMNS
     for (int i = 0; i < 3; ++i) { S[i] = ps.axis[i].x; S[3 + i] = ps.axis[i].y; S[6 + i] = ps.axis[i].z;
@@ -263,6 +288,10 @@ int orc_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t
     for (int k = 0; k < 9; ++k) sR[k] = *scale * R[k];
     put(t, (r2.hi - r1.hi * *scale) * pt.axis[0] + pt.bary - mulMv(sR, ps.bary));  // :300
     return 0;
+}
+int orc_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray,
+                       const double* view_ray, double* R, double* t, double* scale) {
+    return orc_init_alignment_sharded(src, ns, tgt, nt, ground_ray, view_ray, nullptr, nullptr, R, t, scale);
 }
 
 // PartRecognition::PartRecog (PartRecognition.cpp:50-77): label of the nearest template vertex

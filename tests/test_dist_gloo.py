@@ -248,3 +248,64 @@ def test_parts_shard_over_ranks_with_one_all_gather():
     assert got[0][3] == got[1][3]
     for _, v, _, _ in got:
         assert np.array_equal(v, want)
+
+
+# ---------------------------------------------------------------- Alignment reductions by view ----
+def _align_worker(rank, world, port, q, engine):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import binding as O
+    from multiviewstitch_amd import dist as mdist
+    from tests.util import body_scene
+    sc = body_scene()
+    gr, p, _, _ = O.remove_ground(sc["tgt"], sc["t_nrm"], sc["t_faces"], 0.81)
+    cuts = [0, len(p) // 3, len(p)] if world == 2 else [0, len(p) // 3, len(p) // 3, len(p)]      # uneven; with 3 ranks one is empty
+    mine = p[cuts[rank]:cuts[rank + 1]]
+    red = mdist.host_reducer()
+    if engine:                                       # the product entry (GPU box): mvs_init_alignment_sharded
+        from multiviewstitch_amd import alignment
+        R, t, s = alignment.Alignment().InitAlignmentSharded(sc["src"], mine, gr, sc["view_ray"], red)
+    else:                                            # the checker, driven through the same reducer
+        R, t, s = O.init_alignment_sharded(sc["src"], mine, gr, sc["view_ray"], red)
+    q.put((rank, R, t, s))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_align(world, engine):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_align_worker, args=(r, world, port, q, engine)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, R, t, sc = q.get(timeout=180)
+        res[r] = (R, t, sc)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from oracle import binding as O
+    from tests.util import body_scene
+    b = body_scene()
+    gr, p, _, _ = O.remove_ground(b["tgt"], b["t_nrm"], b["t_faces"], 0.81)
+    want = O.init_alignment(b["src"], p, gr, b["view_ray"])
+    for r in range(1, world):                                                   # every rank holds the same similarity, bit for bit
+        assert all(np.array_equal(np.asarray(a), np.asarray(c)) for a, c in zip(res[0], res[r]))
+    # ... and it is the unsharded one up to the order of the sums (12 reduced moments / extents)
+    assert np.abs(res[0][0] - want[0]).max() < 1e-9 and np.abs(res[0][1] - want[1]).max() < 1e-9 and abs(res[0][2] - want[2]) < 1e-11
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_init_alignment_reductions_shard_by_view(world):
+    _run_align(world, engine=False)
+
+
+@pytest.mark.gpu
+def test_gpu_init_alignment_sharded_two_ranks_on_one_gpu():
+    """mvs_init_alignment_sharded in two processes sharing the box's GPU, reduced over gloo by dist.host_reducer."""
+    _run_align(2, engine=True)
