@@ -176,6 +176,9 @@ constexpr int RAS_MAX_SWEEPS = 128;
 RasPlan probe_ras(const mvs_deform_s* h) {
     RasPlan r;
     for (int i = 0; i < 8; ++i) r.n[i] = h->ras_plan[i] > 0 ? h->ras_plan[i] : RAS_FIRST_PLAN;
+    // experiment (scripts/host_bound.py): at most this many LAUNCHES per solve — the rest of the sweeps run inside the last one
+    static const int cap = getenv("MVS_RAS_PLAN_CAP") ? atoi(getenv("MVS_RAS_PLAN_CAP")) : 0;
+    if (cap > 0) for (int i = 0; i < 8; ++i) if (h->ras_plan[i] > 0) r.n[i] = std::min(r.n[i], cap);
     return r;
 }
 bool use_ras(const mvs_deform_s* h, const mvs_deform_params& p) { return h->has_ras && p.solver != MVS_SOLVER_CG; }
@@ -797,7 +800,7 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals, in
     TRY(dmalloc(&h->d_is_ctrl, (size_t)V));
     for (int k = 0; k < 2; ++k) TRY(dmalloc(&h->d_rws[k], (size_t)V * 9));
     TRY(dmalloc(&h->d_p, (size_t)V * 3)); TRY(dmalloc(&h->d_coef, (size_t)ne)); TRY(dmalloc(&h->d_energy, MVS_ERED_SIZE)); TRY(dmalloc(&h->d_info, 8));
-    TRY(dmalloc(&h->d_ras_b, (size_t)V * 3)); TRY(dmalloc(&h->d_ctl, MVS_CTL_SIZE)); TRY(dmalloc(&h->d_bar, 16)); TRY(dmalloc(&h->d_bpure, (size_t)V * 3));
+    TRY(dmalloc(&h->d_ras_b, (size_t)V * 3)); TRY(dmalloc(&h->d_ctl, MVS_CTL_SIZE)); TRY(dmalloc(&h->d_bar, (size_t)MVS_BAR_WORDS * MVS_BAR_STRIDE)); TRY(dmalloc(&h->d_bpure, (size_t)V * 3));
     {   // pinned, host-coherent mirror of the control block: the last kernel of every pass writes it, the host reads it
         // without synchronising (throttle / peek_ring)
         void* hp = nullptr;

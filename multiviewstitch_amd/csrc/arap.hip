@@ -175,7 +175,7 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
     // words of the coming solve's tail loop — concurrently with the row work of the others instead of in front of it.
     const bool judge_block = ctl && it >= 1 && gridDim.x >= 2;
     const int nbw = judge_block ? (int)gridDim.x - 1 : (int)gridDim.x;          // blocks that work on rows
-    if (bar && blockIdx.x == gridDim.x - 1 && threadIdx.x < 2) bar[threadIdx.x] = 0u;
+    if (bar && blockIdx.x == gridDim.x - 1 && threadIdx.x < MVS_BAR_WORDS) bar[threadIdx.x * MVS_BAR_STRIDE] = 0u;
     if (judge_block && blockIdx.x == nbw) {
         judge_solve(ered, it - 1, gridDim.x, cg_tol, ctl, ring_slot, !arap_done_before(efin, it - 1, tol), prev_scal);
         if (threadIdx.x < 3) ered[it * EIT + (1 + threadIdx.x) * NBMAX + blockIdx.x] = 0.0;      // its slot of the bnorm partials

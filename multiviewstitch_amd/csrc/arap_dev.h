@@ -162,6 +162,13 @@ __device__ inline void judge_solve(const double* __restrict__ ered, int it, int 
         ctl[MVS_CTL_WORST] = fmax(ctl[MVS_CTL_WORST], rel2);
         ctl[MVS_CTL_SOLVES] += 1.0;
         if (rel2 > cg_tol * cg_tol) { ctl[MVS_CTL_MISSED] += 1.0; ctl[MVS_CTL_ESC] = 1.0; }
+        // the solve was stopped on a PREDICTED residual (k_ras_sweep): how far off was the prediction?  The running maximum of
+        // true / predicted (decaying 6 % per predicted solve) is the safety factor of the next predictions
+        const double pr = ctl[MVS_CTL_PRED];
+        if (pr > 0.0) {
+            ctl[MVS_CTL_PSAFE] = fmax(rel2 / pr, 0.94 * ctl[MVS_CTL_PSAFE]);
+            ctl[MVS_CTL_PRED] = 0.0;
+        }
     }
 }
 

@@ -78,6 +78,14 @@ struct RasDev {                // patches of the restricted additive Schwarz sol
 #define MVS_CTL_MISSED 2     /* solves above cg_tol since the last harvest                                         */
 #define MVS_CTL_SOLVES 3     /* solves judged since the last harvest                                               */
 #define MVS_CTL_SEQ    4     /* outer iterations finalized since the handle was created                            */
+// barrier words of the tail loop (unsigned, one per 128 B line): root counter, give-up flag, 16 group counters, 16 group release words
+#define MVS_BAR_STRIDE 32
+#define MVS_BAR_GROUPS 16
+#define MVS_BAR_WORDS  (2 + 2 * MVS_BAR_GROUPS)
+#define MVS_CTL_PRED   5     /* patch solver: rel^2 PREDICTED for the solve in flight when its last sweep was stopped by
+                                prediction (0: it was not); the judge compares it with the true residual and clears it      */
+#define MVS_CTL_PSAFE  6     /* running max (slowly decaying) of (true / predicted) rel^2 over the predicted solves: the
+                                safety factor the next predictions carry (values below 1 count as 1)                       */
 #define MVS_CTL_RING   8     /* [MVS_RING][8]: rel^2 of solve `it` of outer slot (seq % MVS_RING); -1 = did not run */
 #define MVS_RING       32
 #define MVS_CTL_USED   (MVS_CTL_RING + MVS_RING * 8)   /* [MVS_RING][8]: sweeps solve `it` of that pass actually ran (patch solver);

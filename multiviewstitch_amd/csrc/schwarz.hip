@@ -39,7 +39,11 @@ namespace {
 __device__ unsigned long long g_ras_stamps[4096 * 8];
 #define RSTAMP(k) do { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
         if ((threadIdx.x & 63) == 0 && sweep == 1 && it == 0 && blockIdx.x < 256) g_ras_stamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } while (0)
+__device__ unsigned long long g_tail_stamps[256 * 8];
+#define TSTAMP(k) do { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        if (threadIdx.x == 0 && extra == 0 && it == 0 && blockIdx.x < 256) g_tail_stamps[blockIdx.x * 8 + (k)] = t_; } while (0)
 #else
+#define TSTAMP(k)
 #define RSTAMP(k)
 #endif
 constexpr int RTPB = 1024;          // threads per workgroup = max local rows of a patch
@@ -153,28 +157,41 @@ __global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, doubl
     }
 }
 
-// ---- device-wide barrier of the tail loop (bounded spin: tools/gridbar.hip measured 10-24 us per barrier at 256 workgroups —
-// far more than a kernel boundary, which is why the PLANNED sweeps are separate launches; the tail runs only when a solve
-// needs more sweeps than its plan holds).  bar[0] counts arrivals (k_arap_rhs resets it before every solve), bar[1] != 0: a
-// workgroup gave up waiting (not every workgroup of the launch was resident, e.g. many handles sweeping at once) — every
-// later barrier then falls through and the solve is reported as it stands.
+// ---- device-wide barrier of the tail loop (bounded spin).  A kernel boundary is the cheaper device-wide barrier — which is
+// why the PLANNED sweeps are separate launches; the tail runs only when a solve needs more sweeps than its plan holds.
+// One counter for all 256 workgroups cost 12 us per barrier (scripts/tail_stamps.py: 256 read-modify-writes of ONE address,
+// which agent scope sends to memory past the eight per-XCD L2s, one after the other): the arrivals are counted per group of
+// 16 workgroups (different lines: concurrent), the last of a group reports to the root counter, the last at the root writes
+// the generation into one release word per group, and a workgroup polls only its group's word.
+// Words (MVS_BAR_STRIDE apart, k_arap_rhs zeroes them before every solve): [0] root, [1] give-up flag != 0: a workgroup gave up
+// waiting (not every workgroup of the launch was resident, e.g. many handles sweeping at once) — every later barrier then
+// falls through and the solve is reported as it stands; [2 + g] arrivals of group g; [2 + GROUPS + g] release word of group g.
 constexpr int TAIL_MAXSPIN = 1 << 16;
-__device__ inline bool tail_barrier(unsigned* bar, unsigned arrivals_wanted) {
+__device__ inline bool tail_barrier(unsigned* bar, unsigned gen /* 1, 2, ... : the barrier's number within this solve */) {
     __shared__ int s_ok;
     __syncthreads();
     if (threadIdx.x == 0) {
         int ok = 1;
-        if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ok = 0;
+        unsigned* giveup = bar + MVS_BAR_STRIDE;
+        if (__hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ok = 0;
         else {
-            __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned nblk = gridDim.x, ng = nblk < (unsigned)MVS_BAR_GROUPS ? nblk : (unsigned)MVS_BAR_GROUPS;
+            const unsigned g = blockIdx.x % ng, gsize = (nblk - g + ng - 1) / ng;
+            unsigned* grp = bar + (2 + g) * MVS_BAR_STRIDE;
+            unsigned* rel = bar + (2 + MVS_BAR_GROUPS + g) * MVS_BAR_STRIDE;
+            if (__hip_atomic_fetch_add(grp, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gsize * gen) {
+                if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == ng * gen)
+                    for (unsigned j = 0; j < ng; ++j)
+                        __hip_atomic_store(bar + (2 + MVS_BAR_GROUPS + j) * MVS_BAR_STRIDE, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
             int spin = 0;
-            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrivals_wanted) {
-                if (++spin > TAIL_MAXSPIN || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
+                if (++spin > TAIL_MAXSPIN || __hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    __hip_atomic_store(giveup, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     ok = 0;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(4);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
@@ -185,7 +202,7 @@ __device__ inline bool tail_barrier(unsigned* bar, unsigned arrivals_wanted) {
 }
 
 struct RasTail {              // TAIL launches only (the last planned sweep of a solve)
-    unsigned* bar;            // [2] arrival counter, give-up flag
+    unsigned* bar;            // MVS_BAR_WORDS words, MVS_BAR_STRIDE apart (tail_barrier)
     double* slots;            // max_extra further sweep slots (partials of the in-kernel sweeps)
     int max_extra;            // in-kernel sweeps after this launch's own one
 };
@@ -194,14 +211,14 @@ template <int W, bool TAIL>
 __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __restrict__ pw, const double* __restrict__ pd,
                                                     const double* __restrict__ bvec, double* xa, double* xb, int it, double arap_tol,
                                                     double* __restrict__ ered, int nb_rhs, int sweep, double cg_tol, double stop_margin, double slow2,
-                                                    ChebCoef cc, int cheb_m, ChebCoef cc_strong, int cheb_m_strong,
-                                                    const double* __restrict__ ctl, double* __restrict__ slot_prev,
+                                                    double predict2, ChebCoef cc, int cheb_m, ChebCoef cc_strong, int cheb_m_strong,
+                                                    double* __restrict__ ctl, double* __restrict__ slot_prev,
                                                     double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur, RasTail tail, int fold_energy) {
     // LDS: fp64 x of the local rows and the halo while the residual is formed (24 KB), then the correction directions as
     // bfloat16 triples, double-buffered (2 x 8 KB of the same array).  The neighbours' directions only steer the inexact
     // local solve; the residual that decides convergence and the solution stay fp64.
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * RTPB * sizeof(float4)];
-    __shared__ double s_gam[3], s_bn[3];
+    __shared__ double s_gam[3], s_gam2[3], s_bn[3], s_psafe;
     __shared__ int s_done, s_esc, s_slow[3];
     double4* xs = reinterpret_cast<double4*>(smem);                    // 32-byte records: two 16-byte LDS accesses per gather instead of three 8-byte ones
     const int p = blockIdx.x, row = threadIdx.x, lane = row & 63, wv = row >> 6;
@@ -250,7 +267,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         // local solves (the mesh deforms, the weights move) — this sweep then takes the strong coefficient set
         const double gam2 = sweep > 1 ? (slot_prev - ras_slot_doubles(NPpad))[3 * NPpad + wv] : INFINITY;
         // s_slow: 1 = the previous sweep converged slowly (strong coefficient set), 2 = its rate is not known yet (sweeps 0, 1)
-        if (lane == 0) { s_gam[wv] = gam; s_slow[wv] = sweep > 1 ? ((gam > slow2 * gam2) ? 1 : 0) : 2; }
+        if (lane == 0) { s_gam[wv] = gam; s_gam2[wv] = gam2; s_slow[wv] = sweep > 1 ? ((gam > slow2 * gam2) ? 1 : 0) : 2; }
     } else if (wv < 6) {
         const double bn = fold_partials(ered + it * EIT + (1 + (wv - 3)) * NBMAX, nb_rhs);
         if (lane == 0) s_bn[wv - 3] = bn;
@@ -268,6 +285,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         if (lane == 0) {
             s_done = done ? 1 : 0;
             s_esc = ctl[MVS_CTL_ESC] != 0.0 ? 1 : 0;                   // a solve missed cg_tol since the last harvest: strong local solves
+            s_psafe = fmax(1.0, ctl[MVS_CTL_PSAFE]);                   // (true / predicted)^2 of the predicted stops so far
         }
     }
     xs[row] = make_double4(xi.x, xi.y, xi.z, 0.0);
@@ -284,6 +302,29 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     bool frozen = sweep > 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) if (s_gam[c] > 0.0 && s_gam[c] > stop * stop * bn[c]) frozen = false;
+    // Predicted stop.  What is known here is the residual of the PREVIOUS sweep's input (g1) and of the one before (g2): this
+    // sweep's own input is one sweep better than g1.  While the sweeps converge healthily (rate g1/g2 below RAS_SLOW, normal
+    // coefficient set) that input is predicted at g1 * (g1/g2); when the prediction, times the safety factor the judge keeps
+    // (MVS_CTL_PSAFE: how far above its prediction the true residual of a predicted solve has been lately), sits below
+    // predict * cg_tol, the input is taken as the solution and this sweep does not run.  Without it every solve ran one sweep
+    // more than its tolerance asked for (the sweep that FOUND its input converged had already improved it 20x).  Nothing is
+    // taken on trust: k_arap_local measures the true fp64 residual of what is kept, the judge block compares it with the
+    // prediction, and reports (and escalates on) a solve above cg_tol.
+    if (!frozen && healthy && predict2 > 0.0 && !s_esc) {
+        bool pred = true;
+        double prel2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (s_gam[c] > 0.0) {
+                const double pg = s_gam[c] * (s_gam[c] / s_gam2[c]);
+                if (!(pg * s_psafe <= predict2 * cg_tol * cg_tol * bn[c])) pred = false;
+                prel2 = fmax(prel2, pg / bn[c]);
+            }
+        if (pred) {
+            frozen = true;
+            if (p == 0 && row == 0) ctl[MVS_CTL_PRED] = prel2;
+        }
+    }
     if (p == 0 && row < 3 && sweep > 0) { slot_prev[3 * NPpad + row] = s_gam[row]; slot_prev[3 * NPpad + 3 + row] = bn[row]; }
     if (p == 0 && row < 3) { slot_cur[3 * NPpad + row] = 0.0; slot_cur[3 * NPpad + 3 + row] = bn[row]; }
     const double ran_before = sweep > 0 ? slot_prev[3 * NPpad + 7] : 0.0;
@@ -394,7 +435,9 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     double* slot_k = slot_cur;                                         // partials of the sweep done last
     double g_before[3] = {s_gam[0], s_gam[1], s_gam[2]};               // residual of the input of the sweep BEFORE the one done last
     for (;;) {
-        if (!tail_barrier(tail.bar, (unsigned)gridDim.x * (unsigned)(extra + 1))) break;     // not every workgroup is there: report as it stands
+        TSTAMP(0);
+        if (!tail_barrier(tail.bar, (unsigned)(extra + 1))) break;     // not every workgroup is there: report as it stands
+        TSTAMP(1);
         if (wv < 3) {
             const double gam = fold_n(slot_k + wv * NPpad, R.NP * 4);
             if (lane == 0) s_gam[wv] = gam;
@@ -406,12 +449,25 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         for (int c = 0; c < 3; ++c) if (s_gam[c] > slow2 * g_before[c]) slow = true;      // the same rules a planned sweep applies in its
         const double stop_k = (known && !slow) ? cg_tol : stop_margin * cg_tol;           // preamble: what a sweep computes does not depend
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {                                                      // on where the plan ended
+        for (int c = 0; c < 3; ++c)                                                        // on where the plan ended
             if (s_gam[c] > 0.0 && s_gam[c] > stop_k * stop_k * bn[c]) conv = false;
-            g_before[c] = s_gam[c];
+        if (!conv && known && !slow && predict2 > 0.0 && !s_esc) {                         // (predicted stop: the output just written)
+            conv = true;
+            double prel2 = 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (s_gam[c] > 0.0) {
+                    const double pg = s_gam[c] * (s_gam[c] / g_before[c]);
+                    if (!(pg * s_psafe <= predict2 * cg_tol * cg_tol * bn[c])) conv = false;
+                    prel2 = fmax(prel2, pg / bn[c]);
+                }
+            if (conv && p == 0 && row == 0) ctl[MVS_CTL_PRED] = prel2;
         }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g_before[c] = s_gam[c];
         if (conv) { finished = true; break; }
         if (extra >= tail.max_extra) break;
+        TSTAMP(2);
         // one more sweep: the buffers swap roles; x of the halo comes from what the other patches just wrote
         { const double* t = xin; xin = xout; xout = const_cast<double*>(t); }
         xh = ld3(xin + 3 * (int64_t)gh);
@@ -422,7 +478,9 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         __syncthreads();
         strong = s_esc || (known && slow);
         slot_k = tail.slots + (size_t)extra * ras_slot_doubles(NPpad);
+        TSTAMP(3);
         steps += sweep_body(slot_k, xout);
+        TSTAMP(4);
         ++extra;
     }
     // both buffers equal on the owned rows (xi is this thread's latest value of its row — for an owned row the value it wrote)
@@ -459,7 +517,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_local_rhs(SellDev m, RasDev R, con
     double* efin = ered + EFIN;
     const int p = blockIdx.x, row = threadIdx.x, lane = row & 63, wv = row >> 6;
     if (p == R.NP) {                                               // ---- the extra block
-        if (bar && row < 2) bar[row] = 0u;
+        if (bar && row < MVS_BAR_WORDS) bar[row * MVS_BAR_STRIDE] = 0u;
         // (the row kernels and the sweeps fold `nb` partials per sum: the slots NP .. nb-1 of what the patches write hold zeros)
         for (int q = R.NP + row; q < nb; q += blockDim.x) {
             ered[it * EIT + q] = 0.0;
@@ -591,6 +649,9 @@ template <class T> int up(T** d, const std::vector<T>& h) {
 }  // namespace
 
 #ifdef MVS_STAMPS
+extern "C" int mvs_debug_tail_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_stamps), sizeof(unsigned long long) * n);
+}
 extern "C" int mvs_debug_ras_stamps(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ras_stamps), sizeof(unsigned long long) * n);
 }
@@ -779,6 +840,8 @@ void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s, const double* init
 // (Round 1 ran a = 0.1 with 8 steps: 8 % faster per sweep, but the bracket then sits right at the lowest mode of the
 // patches of the bench mesh — 21 % residual per sweep instead of 6-9 %, and every so often, as the template deforms, a mode
 // slips below it and a solve stalls at 40 % per sweep: scripts/pass_trace.py, pass 18.  Measured, scripts/bracket_sweep.py.)
+// predicted stop (k_ras_sweep): margin on (predicted residual of a sweep's input) x (observed true / predicted), as a fraction of cg_tol; 0 = off
+const double RAS_PREDICT = getenv("MVS_PREDICT") ? atof(getenv("MVS_PREDICT")) : 0.33;
 constexpr double RAS_SLOW = 0.15;     // a sweep that leaves more than this fraction of the residual calls for the strong set
 void ras_default_bracket(const mvs_deform_s* h, double* a, int* m) {
     const double dens = h->V > 0 ? (double)h->K / (double)h->V : 0.15;
@@ -825,7 +888,7 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, doubl
     const dim3 grid(R.NP), blk(h->ras_block);     // as many waves as the largest patch has rows (idle waves only add barrier cost)
     const RasTail tail{h->d_bar, tail_slots, RAS_TAIL_MAX};
 #define MVS_SWEEP(W, T) k_ras_sweep<W, T><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, stop_margin, \
-                                                              RAS_SLOW * RAS_SLOW, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur, tail, fold_energy ? 1 : 0)
+                                                              RAS_SLOW * RAS_SLOW, RAS_PREDICT * RAS_PREDICT, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur, tail, fold_energy ? 1 : 0)
     if (tail_slots) { if (R.W == 6) MVS_SWEEP(6, true); else if (R.W == 8) MVS_SWEEP(8, true); else if (R.W == 12) MVS_SWEEP(12, true); else MVS_SWEEP(16, true); }
     else            { if (R.W == 6) MVS_SWEEP(6, false); else if (R.W == 8) MVS_SWEEP(8, false); else if (R.W == 12) MVS_SWEEP(12, false); else MVS_SWEEP(16, false); }
 #undef MVS_SWEEP
