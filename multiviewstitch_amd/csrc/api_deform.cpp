@@ -213,20 +213,6 @@ int ensure_slots(mvs_deform_s* h, int arap_iters, const CgPlan& cg) {
 }
 
 // association of the handle's nodes against the handle's (local) target, nranks = 1
-void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
-    Tic t = tic(h, "assoc");
-    const int K = (int)h->K;
-    int32_t* cur = h->heavy_flip ? h->d_heavy2 : h->d_heavy;
-    int32_t* nxt = h->heavy_flip ? h->d_heavy : h->d_heavy2;
-    h->heavy_flip ^= 1;
-    // the heavy-node pass shares a launch with the node-graph search of enqueue_solve when that search runs on the grid
-    const bool defer = h->d_knn_ws != nullptr && p.graph_k + 1 <= 64;
-    launch_assoc_local(h->grid, h->d_node_pts, h->d_node_nrm, K, p, h->d_d2min, h->d_records, h->d_counts, cur, nxt, K, h->d_ctrl_raw,
-                       h->d_valid, h->d_top_idx, h->stream, defer);
-    h->heavy_pending = defer ? cur : nullptr;
-    toc(t, defer ? 1 : 2);
-}
-
 static int ensure_nbr(mvs_deform_s* h, int nn) {
     if (nn == h->nbr_k) return MVS_OK;
     dfree(h->d_nbr);
@@ -236,6 +222,27 @@ static int ensure_nbr(mvs_deform_s* h, int nn) {
     h->nbr_k = nn;
     return MVS_OK;
 }
+
+void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
+    Tic t = tic(h, "assoc");
+    const int K = (int)h->K;
+    int32_t* cur = h->heavy_flip ? h->d_heavy2 : h->d_heavy;
+    int32_t* nxt = h->heavy_flip ? h->d_heavy : h->d_heavy2;
+    h->heavy_flip ^= 1;
+    // the heavy-node pass shares a launch with the node-graph search of enqueue_solve when that search runs on the grid
+    const bool defer = h->d_knn_ws != nullptr && p.graph_k + 1 <= 64;
+    // the 9-NN graph of the nodes needs only their positions: its grid is built first and the queries ride with the nodes' own
+    // searches (k_assoc_local); the heavy-node launch of enqueue_solve then carries the heavy nodes and the cotangent weights
+    const int nn = p.graph_k + 1;
+    const bool graph_here = defer && ensure_nbr(h, nn) == MVS_OK;
+    if (graph_here) knn_grid_build(h->d_node_pts, K, h->d_knn_ws, h->stream);
+    launch_assoc_local(h->grid, h->d_node_pts, h->d_node_nrm, K, p, h->d_d2min, h->d_records, h->d_counts, cur, nxt, K, h->d_ctrl_raw,
+                       h->d_valid, h->d_top_idx, h->stream, defer, nn, h->d_nbr, graph_here ? h->d_knn_ws : nullptr);
+    h->graph_in_local = graph_here;
+    h->heavy_pending = defer ? cur : nullptr;
+    toc(t, defer ? 1 : 2);
+}
+
 
 // graph smoothing (optional) + ARAP + geometry update.  ctrl_src: K*3 node targets.
 int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctrl_src, bool graph_smooth, const CgPlan& plan) {
@@ -260,14 +267,14 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
             } else if (h->d_knn_ws && h->heavy_pending) {
                 // single-rank iteration: the deferred heavy nodes of the association and the graph queries in one launch
                 // (the node targets are complete only after it: every smoothing sweep is a k_smooth launch)
-                knn_grid_build(h->d_node_pts, K, h->d_knn_ws, s);
+                if (!h->graph_in_local) knn_grid_build(h->d_node_pts, K, h->d_knn_ws, s);
                 // ... and, for the patch solver, the cotangent weights (they need the rest geometry only; the start of the
                 // solve, which needs the smoothed targets, moves into k_ras_prepare)
                 weights_done = use_ras(h, p);
                 launch_assoc_heavy_knn(h->grid, h->d_node_pts, h->d_node_nrm, K, p, h->d_d2min, h->d_records, h->d_counts, h->heavy_pending, K,
                                        h->d_ctrl_raw, h->d_valid, h->d_top_idx, nn, h->d_nbr, h->d_knn_ws, s,
-                                       weights_done ? &h->sell : nullptr, h->d_pts, arap_grid_blocks(h->sell), h->d_heavy_split);
-                h->heavy_pending = nullptr;
+                                       weights_done ? &h->sell : nullptr, h->d_pts, arap_grid_blocks(h->sell), h->d_heavy_split, !h->graph_in_local);
+                h->heavy_pending = nullptr; h->graph_in_local = false;
                 toc(t, knn_grid_launches(K));
             } else if (h->d_knn_ws) {
                 // the grid kNN also performs the first smoothing sweep (its wave holds the neighbour list)

@@ -288,11 +288,18 @@ __global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __r
 // A PARTS == 1 caller that passes a `heavy` list defers nodes whose ball spans more than 64 grid rows to it.
 constexpr int HEAVY_WAVES = 16;
 constexpr int HEAVY_RANGES = 2048;
+constexpr int HEAVY_CAND = 10240;                           // members of a ball the workgroup list holds (>= params.max_result = 10000)
+constexpr int HEAVY_PIECE = 256;                            // a listed cell is dealt out in pieces of this many points
 constexpr int HEAVY_ROWS = 25;                              // rows of the ball's bounding box above which a node is deferred
 struct HeavyLds { double pd[HEAVY_WAVES][8], pl[HEAVY_WAVES][8], x[HEAVY_WAVES][8], y[HEAVY_WAVES][8], z[HEAVY_WAVES][8];
                   long long idx[HEAVY_WAVES][8]; int nb[HEAVY_WAVES], np[HEAVY_WAVES];
                   int nr, ra[HEAVY_RANGES], rb[HEAVY_RANGES];         // occupied coarse cells of the ball, found by all waves
                   float fmin[HEAVY_WAVES];                            // per-wave nearest distances of dmin_coarse_wg
+                  int next;                                           // next piece of the range list nobody has taken yet
+                  int hist[256], sel_bin, sel_before, nwin, npass;    // radix select of the 8th smallest (float) projection distance
+                  int cand[HEAVY_CAND];                               // ball members (sorted-order indices) found by phase 1 of the listed pieces
+                  int len[HEAVY_WAVES];                               // live entries of each wave's list (rank merge)
+                  double r_pd[8], r_pl[8], r_x[8], r_y[8], r_z[8]; long long r_idx[8];   // the merged list, best first
                   int ball; };                                        // ball members counted so far by all waves (full-result cut-off)
 constexpr int HEAVY_SPLIT = 1;                              // workgroups that share one heavy node in the fused launch (> 1: their lists are joined by
                                                             // k_assoc_merge_heavy.  Measured at 8 with the ~225 heavy nodes of the metric workload: 114 us instead of
@@ -391,6 +398,7 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
     int len = 0;
     double t_pd = 0, t_apl = 0; long long t_idx = 0;       // key of the current top_k-th element
     int n_ball = 0, n_pass = 0;
+    bool slots_ready = false;          // PARTS > 1: the workgroup selection below has already put the node's candidates into the merge slots
 
     if (g.P > 0 && dm < INFINITY) {
         const float r2 = dm * 2.0f;                          // radiusSearch(..., minDist * 2.0f, ...)  :288
@@ -404,6 +412,47 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
         const QCell c = query_cell(g, qx, qy, qz);
         const int32_t* __restrict__ cs = g.cell_start;
 
+        // top-k insertion of the lanes' candidates (has: this lane holds one) into the wave-resident sorted list
+#ifdef MVS_STAMP_INSERT
+        unsigned long long ins_cycles = 0, ins_count = 0;
+#endif
+        auto insert = [&](bool has, double pd, double pl, d3 tp, long long gi) {
+#ifdef MVS_STAMP_INSERT
+            unsigned long long ti0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ti0_) :: "memory");
+#endif
+            const double apl = fabs(pl);
+            unsigned long long pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
+            while (pend) {
+                const int src = __ffsll((long long)pend) - 1;
+                const double c_pd = rl_d(pd, src), c_pl = rl_d(pl, src);
+                const double c_x = rl_d(tp.x, src), c_y = rl_d(tp.y, src), c_z = rl_d(tp.z, src);
+                const long long c_i = rl_ll(gi, src);
+                const bool less = lane < len && key_less(L_pd, fabs(L_pl), L_idx, c_pd, fabs(c_pl), c_i);
+                const int pos = __popcll(__ballot(less));
+                const double u_pd = shfl_up_d(L_pd), u_pl = shfl_up_d(L_pl);
+                const double u_x = shfl_up_d(L_x), u_y = shfl_up_d(L_y), u_z = shfl_up_d(L_z);
+                const long long u_i = shfl_up_ll(L_idx);
+                if (lane > pos && lane <= len && lane < top_k) {
+                    L_pd = u_pd; L_pl = u_pl; L_x = u_x; L_y = u_y; L_z = u_z; L_idx = u_i;
+                } else if (lane == pos) {
+                    L_pd = c_pd; L_pl = c_pl; L_x = c_x; L_y = c_y; L_z = c_z; L_idx = c_i;
+                }
+                len = min(len + 1, top_k);
+                if (len == top_k) {
+                    t_pd = rl_d(L_pd, top_k - 1); t_apl = fabs(rl_d(L_pl, top_k - 1)); t_idx = rl_ll(L_idx, top_k - 1);
+                }
+                if (lane == src) has = false;
+                pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
+#ifdef MVS_STAMP_INSERT
+                ++ins_count;
+#endif
+            }
+#ifdef MVS_STAMP_INSERT
+            unsigned long long ti1_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ti1_) :: "memory");
+            ins_cycles += ti1_ - ti0_;
+            if (PARTS == 1 && lane == 0 && node < 16384) g_assoc_cycles[2 * node] = ins_cycles | (ins_count << 32);
+#endif
+        };
         // all points of the sorted range [A, B): ball test, normal filter, keys, top-k insertion
         auto scan = [&](int A, int B) {
             for (int cb = A; cb < B; cb += 64) {             // wave-uniform trip count
@@ -427,30 +476,7 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
                         }
                     }
                 }
-                const double apl = fabs(pl);
-                unsigned long long pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
-                while (pend) {
-                    const int src = __ffsll((long long)pend) - 1;
-                    const double c_pd = rl_d(pd, src), c_pl = rl_d(pl, src);
-                    const double c_x = rl_d(tp.x, src), c_y = rl_d(tp.y, src), c_z = rl_d(tp.z, src);
-                    const long long c_i = rl_ll(gi, src);
-                    const bool less = lane < len && key_less(L_pd, fabs(L_pl), L_idx, c_pd, fabs(c_pl), c_i);
-                    const int pos = __popcll(__ballot(less));
-                    const double u_pd = shfl_up_d(L_pd), u_pl = shfl_up_d(L_pl);
-                    const double u_x = shfl_up_d(L_x), u_y = shfl_up_d(L_y), u_z = shfl_up_d(L_z);
-                    const long long u_i = shfl_up_ll(L_idx);
-                    if (lane > pos && lane <= len && lane < top_k) {
-                        L_pd = u_pd; L_pl = u_pl; L_x = u_x; L_y = u_y; L_z = u_z; L_idx = u_i;
-                    } else if (lane == pos) {
-                        L_pd = c_pd; L_pl = c_pl; L_x = c_x; L_y = c_y; L_z = c_z; L_idx = c_i;
-                    }
-                    len = min(len + 1, top_k);
-                    if (len == top_k) {
-                        t_pd = rl_d(L_pd, top_k - 1); t_apl = fabs(rl_d(L_pl, top_k - 1)); t_idx = rl_ll(L_idx, top_k - 1);
-                    }
-                    if (lane == src) has = false;
-                    pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
-                }
+                insert(has, pd, pl, tp, gi);
             }
         };
 
@@ -497,7 +523,7 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
                 const int nX = X1 - X0 + 1, nY = Y1 - Y0 + 1, ncc = nX * nY * (Z1 - Z0 + 1);
                 // (split mode: wave `part` looks up every PARTS-th group of 64 coarse cells and appends the occupied ones to
                 //  a workgroup list; the list is then scanned round-robin, so both the look-ups and the points are shared)
-                if (PARTS > 1) { if (threadIdx.x == 0) { lds->nr = 0; lds->ball = 0; } __syncthreads(); }
+                if (PARTS > 1) { if (threadIdx.x == 0) { lds->nr = 0; lds->ball = 0; lds->next = 0; } __syncthreads(); }
                 const int lpart = PARTS > 1 ? (int)(threadIdx.x >> 6) : 0;        // the LOOK-UPS are shared by this workgroup's waves only
                 for (int base = 64 * lpart; base < ncc; base += 64 * PARTS) {
                     const int t = base + lane;
@@ -508,10 +534,18 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
                         const int a0 = g.coarse_start[C], b0 = g.coarse_start[C + 1];
                         if (b0 > a0 && box_lb2(c, 8.f * X, 8.f * X + 8.f, 8.f * Y, 8.f * Y + 8.f, 8.f * Z, 8.f * Z + 8.f) <= lim) { a = a0; b = b0; }
                     }
-                    if (PARTS > 1) {
-                        int slot = HEAVY_RANGES;
-                        if (b > a) slot = atomicAdd(&lds->nr, 1);
-                        if (slot < HEAVY_RANGES) { lds->ra[slot] = a; lds->rb[slot] = b; b = a; }     // listed
+                    if (PARTS > 1 && b > a) {
+                        // listed in pieces of HEAVY_PIECE points: the waves take pieces as they become free (below) — a coarse cell
+                        // holds a few dozen to a few thousand points, and dealt out whole, cell by cell round-robin, the busiest
+                        // wave of a far node scanned twice as long as the first to finish (scripts/heavy_stats.py)
+                        const int np_ = (b - a + HEAVY_PIECE - 1) / HEAVY_PIECE;
+                        const int slot = atomicAdd(&lds->nr, np_);
+                        if (slot + np_ <= HEAVY_RANGES) {
+                            for (int k = 0; k < np_; ++k) { lds->ra[slot + k] = a + k * HEAVY_PIECE; lds->rb[slot + k] = min(b, a + (k + 1) * HEAVY_PIECE); }
+                            b = a;                                                                    // listed
+                        } else if (slot < HEAVY_RANGES) {
+                            for (int k = slot; k < HEAVY_RANGES; ++k) { lds->ra[k] = 0; lds->rb[k] = 0; }   // (its slots stay empty; scanned here)
+                        }
                     }
                     unsigned long long cmask = __ballot(b > a);                                     // (overflow of the list: scanned here)
                     while (cmask) {
@@ -526,13 +560,162 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
                     unsigned long long tA_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tA_) :: "memory");
 #endif
                     const int nr = min(lds->nr, HEAVY_RANGES);
-                    int told = 0;                                    // ball members this wave has already added to the workgroup's count
-                    for (int r = lpart; r < nr; r += PARTS) {            // (the list holds this workgroup's cells only)
-                        if (lds->ball >= full) break;                    // (wave-uniform: one LDS word)
-                        scan(lds->ra[r], lds->rb[r]);
-                        const int mine = wave_sum_i(n_ball);
-                        if (lane == 0 && mine > told) atomicAdd(&lds->ball, mine - told);
-                        told = mine;
+                    // Phase 1 — ball test only: the waves take pieces as they become free, stream their positions (four 64-point
+                    // groups in flight) and append the members of the ball to ONE workgroup list of sorted-order indices.  A far
+                    // node's pieces hold ~20 K points of which ~2 K are in the ball: testing, normal, position and insertion
+                    // group by group was three cold round trips per 64 points with a tenth of the lanes busy after the first
+                    // (12 K cycles per piece: scripts/heavy_stats.py).  Phase 2 goes through the list with every lane holding
+                    // a member.  The list has room for `full` members: a ball with more drops the node (see above).
+                    const bool listed = full <= HEAVY_CAND && lds->nr <= HEAVY_RANGES;   // (no result cap, a larger one, or cells that did not fit
+                                                                                          //  the piece list and were scanned on the spot: per-wave lists)
+                    for (;;) {                                           // (the list holds this workgroup's cells only)
+                        int r = 0;
+                        if (lane == 0) r = atomicAdd(&lds->next, 1);
+                        r = rl_i(r, 0);
+                        if (r >= nr || lds->ball >= full) break;         // (wave-uniform: one LDS word)
+                        const int A = lds->ra[r], B = lds->rb[r];
+                        if (!listed) {
+                            const int before = n_ball;
+                            scan(A, B);
+                            const int add = wave_sum_i(n_ball - before);
+                            if (lane == 0 && add) atomicAdd(&lds->ball, add);
+                            continue;
+                        }
+                        float4 p4[HEAVY_PIECE / 64];
+#pragma unroll
+                        for (int u = 0; u < HEAVY_PIECE / 64; ++u) { const int i = A + 64 * u + lane; p4[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (i < B) p4[u] = g.spos[i]; }
+#pragma unroll
+                        for (int u = 0; u < HEAVY_PIECE / 64; ++u) {
+                            const int i = A + 64 * u + lane;
+                            const bool in = i < B && d2f(qx, qy, qz, p4[u].x, p4[u].y, p4[u].z) <= r2;
+                            const unsigned long long m = __ballot(in);
+                            if (m) {
+                                int base = 0;
+                                if (lane == 0) base = atomicAdd(&lds->ball, __popcll(m));
+                                base = rl_i(base, 0);
+                                const int my = base + __popcll(m & ((1ull << lane) - 1ull));
+                                if (in) { ++n_ball; if (my < HEAVY_CAND) lds->cand[my] = i; }
+                            }
+                        }
+                    }
+                    if (listed) {
+                        __syncthreads();
+                        const int nc = lds->ball;
+                        if (nc < full) {                                 // (a full ball: the node is dropped, its list is never read)
+                            // Phase 2 — the top_k of the ball's members by (projection distance, |projection length|, index), WITHOUT a
+                            // sorted list per wave: keeping those cost 60 K of a far node's 100 K cycles (an insertion is ~100
+                            // instructions — ballot, twelve lane reads, six fp64 lane shifts — and each wave did ~30 of them, four
+                            // waves to a SIMD).  Every thread keeps the FLOAT projection distance of its members (rounding is
+                            // monotone: a member of the exact top_k has a float distance <= the top_k-th smallest float distance T);
+                            // a radix select over the workgroup finds T; the members at or below T — top_k of them plus float ties —
+                            // are recomputed in fp64 into the merge slots and ranked exactly by the merge stage below.
+                            constexpr int KMAX = HEAVY_CAND / (64 * PARTS);
+                            const int tid = (int)threadIdx.x, nk = (nc + 64 * PARTS - 1) / (64 * PARTS);
+                            unsigned ukey[KMAX];
+                            if (tid < PARTS * 8) lds->idx[tid >> 3][tid & 7] = -1;
+                            if (tid == 0) { lds->nwin = 0; lds->npass = 0; }
+#pragma unroll
+                            for (int k = 0; k < KMAX; ++k) {
+                                ukey[k] = 0xffffffffu;                   // not a member / not facing the node
+                                const int q = k * 64 * PARTS + tid;
+                                if (k < nk && q < nc) {
+                                    const int i = lds->cand[q];
+                                    const d3 tn = ld3(g.tnrm + 3 * (int64_t)i);
+                                    if (dot3(nn, tn) > 0) {                       // :307
+                                        ++n_pass;
+                                        const d3 tp = ld3(g.tpos + 3 * (int64_t)i);
+                                        const d3 dir = tp - orig;                 // :331
+                                        const double pl = dot3(dir, nn) / nlen;   // :332
+                                        const double x = sqn3(dir) - pl * pl;
+                                        const double pd = sqrt((0.0 < x) ? x : 0.0);
+                                        const float f = (float)pd;
+                                        ukey[k] = (f == f) ? __float_as_uint(f) : 0x7f800000u;      // (pd >= +0: the bit patterns order like the values)
+                                    }
+                                }
+                            }
+                            __syncthreads();
+                            {
+                                const int mine = wave_sum_i(n_pass);     // (this wave's members that face the node: all counted in this phase)
+                                if (lane == 0 && mine) atomicAdd(&lds->npass, mine);
+                            }
+                            __syncthreads();
+                            unsigned T = 0xfffffffeu;                    // fewer than top_k candidates: all of them
+                            if (lds->npass > top_k) {
+                                unsigned prefix = 0u, known = 0u;
+                                int want = top_k;
+                                for (int shift = 24; shift >= 0; shift -= 8) {
+                                    if (tid < 256) lds->hist[tid] = 0;
+                                    __syncthreads();
+#pragma unroll
+                                    for (int k = 0; k < KMAX; ++k)
+                                        if (ukey[k] != 0xffffffffu && (ukey[k] & known) == prefix) atomicAdd(&lds->hist[(ukey[k] >> shift) & 255u], 1);
+                                    __syncthreads();
+                                    if (tid < 64) {                      // bin of the want-th smallest: lane l owns bins 4l .. 4l+3
+                                        const int h0 = lds->hist[4 * lane], h1 = lds->hist[4 * lane + 1], h2 = lds->hist[4 * lane + 2], h3 = lds->hist[4 * lane + 3];
+                                        int incl = (h0 + h1) + (h2 + h3);
+                                        const int own = incl;
+                                        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+                                        const unsigned long long reach = __ballot(incl >= want);
+                                        const int L = __ffsll((long long)reach) - 1;         // (npass > top_k >= want: some lane reaches it)
+                                        if (lane == L) {
+                                            int before = incl - own, bin = 4 * lane;
+                                            if (before + h0 < want) { before += h0; ++bin; if (before + h1 < want) { before += h1; ++bin; if (before + h2 < want) { before += h2; ++bin; } } }
+                                            lds->sel_bin = bin; lds->sel_before = before;
+                                        }
+                                    }
+                                    __syncthreads();
+                                    prefix |= (unsigned)lds->sel_bin << shift;
+                                    known |= 255u << shift;
+                                    want -= lds->sel_before;
+                                }
+                                T = prefix;
+                            }
+                            // the members at or below T, exactly: into the merge slots
+#pragma unroll
+                            for (int k = 0; k < KMAX; ++k) {
+                                if (ukey[k] <= T && ukey[k] != 0xffffffffu) {
+                                    const int slot = atomicAdd(&lds->nwin, 1);
+                                    if (slot < PARTS * 8) {
+                                        const int i = lds->cand[k * 64 * PARTS + tid];
+                                        const d3 tp = ld3(g.tpos + 3 * (int64_t)i);
+                                        const d3 dir = tp - orig;                 // :331
+                                        const double pl = dot3(dir, nn) / nlen;   // :332
+                                        const double x = sqn3(dir) - pl * pl;
+                                        lds->pd[slot >> 3][slot & 7] = sqrt((0.0 < x) ? x : 0.0);     // :334, clamped (Appendix A.2)
+                                        lds->pl[slot >> 3][slot & 7] = pl;
+                                        lds->x[slot >> 3][slot & 7] = tp.x; lds->y[slot >> 3][slot & 7] = tp.y; lds->z[slot >> 3][slot & 7] = tp.z;
+                                        lds->idx[slot >> 3][slot & 7] = g.index_base + (long long)__float_as_int(g.spos[i].w);
+                                    }
+                                }
+                            }
+                            __syncthreads();
+                            if (lds->nwin <= PARTS * 8) slots_ready = true;
+                            else {
+                                // more float ties than merge slots (degenerate input: hundreds of members at one distance): the lists
+                                // per wave after all
+                                n_pass = 0;
+                                for (int cb = 64 * lpart; cb < nc; cb += 64 * PARTS) {
+                                    const int q = cb + lane;
+                                    bool has = false;
+                                    double pd = 0, pl = 0; d3 tp = mk3(0, 0, 0); long long gi = 0;
+                                    if (q < nc) {
+                                        const int i = lds->cand[q];
+                                        const d3 tn = ld3(g.tnrm + 3 * (int64_t)i);
+                                        if (dot3(nn, tn) > 0) {                       // :307
+                                            ++n_pass;
+                                            tp = ld3(g.tpos + 3 * (int64_t)i);
+                                            const d3 dir = tp - orig;                 // :331
+                                            pl = dot3(dir, nn) / nlen;                // :332
+                                            const double x = sqn3(dir) - pl * pl;
+                                            pd = sqrt((0.0 < x) ? x : 0.0);           // :334, clamped (Appendix A.2)
+                                            gi = g.index_base + (long long)__float_as_int(g.spos[i].w);
+                                            has = true;
+                                        }
+                                    }
+                                    insert(has, pd, pl, tp, gi);
+                                }
+                            }
+                        }
                     }
 #ifdef MVS_STAMPS   // (scripts/heavy_stats.py: list built / this wave done scanning / all waves done, in 16-cycle units, + ranges)
                     unsigned long long tB_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tB_) :: "memory");
@@ -548,51 +731,44 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
     n_ball = wave_sum_i(n_ball);
     n_pass = wave_sum_i(n_pass);
     if (PARTS > 1) {
-        // merge the waves' lists by a TREE: in round `stride` wave w < stride takes the <= 8 survivors of wave w + stride into its
-        // own list (same insertion, same total order); log2(PARTS) rounds of <= 8 insertions instead of one wave re-inserting
-        // all PARTS * 8 candidates one after the other (that was 20-30 K cycles at the end of every heavy node's chain)
+        // merge the waves' lists by RANK: the <= PARTS * 8 survivors are published, every candidate counts how many others
+        // precede it in the total order (8 lanes per candidate, PARTS * 8 / 8 comparisons each) and the ones with fewer than
+        // top_k predecessors ARE the node's list, at the position their count says.  (One wave re-inserting all candidates took
+        // 20-30 K cycles at the end of every heavy node's chain; a tree of pairwise insertions still 33 K: an insertion is a
+        // ballot, twelve lane reads and six fp64 shifts.)
         const int part = (int)(threadIdx.x >> 6);            // (local wave index from here on)
-        if (lane == 0) { lds->nb[part] = n_ball; lds->np[part] = n_pass; }
-        for (int stride = PARTS / 2; stride >= 1; stride >>= 1) {
-            if (part >= stride && part < 2 * stride && lane < 8) {       // the giving half publishes its list
-                const bool live = lane < len;
-                lds->pd[part][lane] = L_pd; lds->pl[part][lane] = L_pl; lds->x[part][lane] = L_x; lds->y[part][lane] = L_y; lds->z[part][lane] = L_z;
-                lds->idx[part][lane] = live ? L_idx : -1;
+        if (lane == 0) { lds->nb[part] = n_ball; lds->np[part] = n_pass; lds->len[part] = slots_ready ? 0 : len; }
+        if (lane < 8 && !slots_ready) {
+            const bool live = lane < len;
+            lds->pd[part][lane] = L_pd; lds->pl[part][lane] = L_pl; lds->x[part][lane] = L_x; lds->y[part][lane] = L_y; lds->z[part][lane] = L_z;
+            lds->idx[part][lane] = live ? L_idx : -1;
+        }
+        __syncthreads();
+        {
+            const int cand = (int)(threadIdx.x >> 3), chunk = (int)(threadIdx.x & 7);      // PARTS * 64 threads: PARTS * 8 candidates x 8 lanes
+            const int cw = cand >> 3, cl = cand & 7;
+            const long long my_i = lds->idx[cw][cl];
+            const double my_pd = lds->pd[cw][cl], my_apl = fabs(lds->pl[cw][cl]);
+            int before = 0;
+            constexpr int PER = PARTS;                                                       // PARTS * 8 candidates / 8 lanes
+            for (int k = 0; k < PER; ++k) {
+                const int j = chunk * PER + k, jw = j >> 3, jl = j & 7;
+                const long long o_i = lds->idx[jw][jl];
+                if (o_i >= 0 && key_less(lds->pd[jw][jl], fabs(lds->pl[jw][jl]), o_i, my_pd, my_apl, my_i)) ++before;
             }
-            __syncthreads();
-            if (part < stride) {
-                const int w = part + stride;
-                const bool has0 = lane < 8 && lds->idx[w][lane & 7] >= 0;
-                bool has = has0;
-                const double pd = has0 ? lds->pd[w][lane] : 0.0, pl = has0 ? lds->pl[w][lane] : 0.0;
-                const d3 tp = has0 ? mk3(lds->x[w][lane], lds->y[w][lane], lds->z[w][lane]) : mk3(0, 0, 0);
-                const long long gi = has0 ? lds->idx[w][lane] : 0;
-                const double apl = fabs(pl);
-                unsigned long long pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
-                while (pend) {
-                    const int src = __ffsll((long long)pend) - 1;
-                    const double c_pd = rl_d(pd, src), c_pl = rl_d(pl, src);
-                    const double c_x = rl_d(tp.x, src), c_y = rl_d(tp.y, src), c_z = rl_d(tp.z, src);
-                    const long long c_i = rl_ll(gi, src);
-                    const bool less = lane < len && key_less(L_pd, fabs(L_pl), L_idx, c_pd, fabs(c_pl), c_i);
-                    const int pos = __popcll(__ballot(less));
-                    const double u_pd = shfl_up_d(L_pd), u_pl = shfl_up_d(L_pl);
-                    const double u_x = shfl_up_d(L_x), u_y = shfl_up_d(L_y), u_z = shfl_up_d(L_z);
-                    const long long u_i = shfl_up_ll(L_idx);
-                    if (lane > pos && lane <= len && lane < top_k) {
-                        L_pd = u_pd; L_pl = u_pl; L_x = u_x; L_y = u_y; L_z = u_z; L_idx = u_i;
-                    } else if (lane == pos) {
-                        L_pd = c_pd; L_pl = c_pl; L_x = c_x; L_y = c_y; L_z = c_z; L_idx = c_i;
-                    }
-                    len = min(len + 1, top_k);
-                    if (len == top_k) {
-                        t_pd = rl_d(L_pd, top_k - 1); t_apl = fabs(rl_d(L_pl, top_k - 1)); t_idx = rl_ll(L_idx, top_k - 1);
-                    }
-                    if (lane == src) has = false;
-                    pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
-                }
+            before += __shfl_xor(before, 1, 64); before += __shfl_xor(before, 2, 64); before += __shfl_xor(before, 4, 64);
+            if (chunk == 0 && my_i >= 0 && before < top_k) {
+                lds->r_pd[before] = my_pd; lds->r_pl[before] = lds->pl[cw][cl];
+                lds->r_x[before] = lds->x[cw][cl]; lds->r_y[before] = lds->y[cw][cl]; lds->r_z[before] = lds->z[cw][cl];
+                lds->r_idx[before] = my_i;
             }
-            __syncthreads();                                 // (the publishing slots are reused by the next round)
+        }
+        __syncthreads();
+        if (part == 0) {
+            int tot = slots_ready ? lds->nwin : 0;
+            for (int w = 0; w < PARTS; ++w) tot += lds->len[w];
+            len = min(tot, top_k);
+            if (lane < len) { L_pd = lds->r_pd[lane]; L_pl = lds->r_pl[lane]; L_x = lds->r_x[lane]; L_y = lds->r_y[lane]; L_z = lds->r_z[lane]; L_idx = lds->r_idx[lane]; }
         }
         if (part == 0) {
             n_ball = 0; n_pass = 0;
@@ -658,8 +834,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                                                      const double* __restrict__ node_nrm, int K, int top_k,
                                                      float* __restrict__ d2min, mvs_cand* __restrict__ rec,
                                                      int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap, LocalMerge lm,
-                                                     int32_t* __restrict__ heavy_next) {
+                                                     int32_t* __restrict__ heavy_next, int assoc_blocks, int nn, const NgGeom* __restrict__ geo,
+                                                     const int* __restrict__ ng_cs, const float4* __restrict__ ng_sorted, int32_t* __restrict__ nbr) {
     if (blockIdx.x == 0 && threadIdx.x == 0) heavy_next[0] = 0;       // the list of the NEXT outer iteration (they alternate): no memset launch
+    if ((int)blockIdx.x >= assoc_blocks) {
+        // passengers: the 9-NN graph queries of the nodes (a wave each, like the nodes' own searches; the grid of the node
+        // positions was built by the launch before).  They used to ride with the heavy nodes — 1024-thread workgroups at 128
+        // registers, one per CU: 509 of them were two of that launch's four rounds — and fill the half-empty last round here
+        const int q = ((int)blockIdx.x - assoc_blocks) * 4 + (int)(threadIdx.x >> 6);
+        if (q < K) ng_knn_query(q, node_pts, K, nn, geo, ng_cs, ng_sorted, nbr, nullptr, nullptr);
+        return;
+    }
     const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (node >= K) return;
     bool deferred = false;
@@ -947,10 +1132,17 @@ void launch_assoc_select(const GridDev& g, const double* node_pts, const double*
 // ... and the merge: with one rank a node's list is final, its wave writes the node target itself
 void launch_assoc_local(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, float* d2min,
                         mvs_cand* rec, int32_t* counts, int32_t* heavy, int32_t* heavy_next, int heavy_cap, double* controls, uint8_t* valid,
-                        int64_t* top_idx, hipStream_t s, bool defer_heavy) {
+                        int64_t* top_idx, hipStream_t s, bool defer_heavy, int nn, int32_t* nbr, void* knn_ws) {
     if (K <= 0) return;
     const LocalMerge lm{controls, valid, top_idx, p.proj_len_err, p.proj_dist_err, p.min_cos, p.max_result};
-    k_assoc_local<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm, heavy_next);
+    // knn_ws != NULL: the grid of the node positions has been built in it (knn_grid_build, same stream): the node-graph queries
+    // share the launch, nbr[K * nn] = each node's nn nearest nodes, itself included
+    const void *geo = nullptr, *sorted = nullptr;
+    const int* cs = nullptr;
+    if (knn_ws) knn_grid_views(knn_ws, K, &geo, &cs, &sorted);
+    const int ab = (K + 3) / 4, kb = knn_ws ? (K + 3) / 4 : 0;
+    k_assoc_local<<<dim3(ab + kb), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm, heavy_next, ab, nn,
+                                                       (const NgGeom*)geo, cs, (const float4*)sorted, nbr);
     if (!defer_heavy)
         k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm);
 }
@@ -963,13 +1155,13 @@ size_t assoc_split_scratch_bytes(int K) {                  // [records | counts]
 void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                             float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, int heavy_cap,
                             double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s,
-                            const SellDev* mesh, const double* mesh_pts, int cot_blocks, void* split_scratch) {
+                            const SellDev* mesh, const double* mesh_pts, int cot_blocks, void* split_scratch, bool with_knn) {
     if (K <= 0) return;
     const LocalMerge lm{controls, valid, top_idx, p.proj_len_err, p.proj_dist_err, p.min_cos, p.max_result};
     const void *geo, *sorted;
     const int* cs;
     knn_grid_views(knn_ws, K, &geo, &cs, &sorted);
-    const int heavy_blocks = std::min(heavy_cap, 256), knn_blocks = (K + HEAVY_WAVES - 1) / HEAVY_WAVES;
+    const int heavy_blocks = std::min(heavy_cap, 256), knn_blocks = with_knn ? (K + HEAVY_WAVES - 1) / HEAVY_WAVES : 0;    // (!with_knn: the graph came with k_assoc_local)
     const int cot = mesh ? cot_blocks : 0;
     mvs_cand* part_rec = (mvs_cand*)split_scratch;
     int32_t* part_cnt = (int32_t*)((char*)split_scratch + (size_t)std::min(K, HEAVY_SPLIT_CAP) * HEAVY_SPLIT * 8 * sizeof(mvs_cand));

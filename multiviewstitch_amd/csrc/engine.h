@@ -165,6 +165,7 @@ struct mvs_deform_s {
     double* d_bpure = nullptr;      // [V*3] right-hand side without its Dirichlet share (k_arap_rhs -> k_arap_local's true residual)
     double* d_ras_tail = nullptr;   // [8][RAS_TAIL_MAX] sweep slots of the in-kernel sweeps of TAIL launches
     volatile double* h_ctl = nullptr;
+    bool graph_in_local = false;    // this pass's node graph was searched in the k_assoc_local launch (enqueue_assoc_local)
     uint64_t seq_enqueued = 0;      // outer iterations enqueued since creation (the device counts the finalized ones in MVS_CTL_SEQ)
     uint64_t seq_peeked = 0;        // ... whose ring row the host has already looked at
     uint64_t seq_harvested = 0;     // ... covered by the last harvest
@@ -193,12 +194,14 @@ void launch_assoc_select(const GridDev& g, const double* node_pts, const double*
                          float* prev_d2 = nullptr, double* prev_node = nullptr /*out: what the next launch_assoc_dmin may use*/);
 void launch_assoc_local(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, float* d2min,
                         mvs_cand* rec, int32_t* counts, int32_t* heavy /*counter already 0*/, int32_t* heavy_next /*reset for the next call*/,
-                        int heavy_cap, double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s, bool defer_heavy = false);
+                        int heavy_cap, double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s, bool defer_heavy = false,
+                        int nn = 0, int32_t* nbr = nullptr, void* knn_ws = nullptr /* != NULL: the node-graph queries share the launch (grid built in it) */);
 size_t assoc_split_scratch_bytes(int K);
 void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                             float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, int heavy_cap,
                             double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s,
-                            const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks, void* split_scratch);
+                            const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks, void* split_scratch,
+                            bool with_knn = true /*false: the graph came with launch_assoc_local*/);
 void launch_install_targets(const void* blocks, int K, int block_nodes, int64_t stride_bytes, double* controls, uint8_t* valid, int64_t* top_idx,
                             hipStream_t s);
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
