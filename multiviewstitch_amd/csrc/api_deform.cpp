@@ -441,8 +441,14 @@ int throttle(mvs_deform_s* h) {
 // (plan = sweeps it ran + RAS_SPARES) from the next pass enqueued on; CG: a solve that missed cg_tol gets a longer plan.
 void peek_ring(mvs_deform_s* h, const mvs_deform_params& p, bool ras) {
     if (!h->h_ctl) return;
-    const uint64_t done = (uint64_t)h->h_ctl[MVS_CTL_SEQ];
+    // Only the passes the throttle has just waited for are looked at — enqueued - THROTTLE_LAG of them — not whatever else the
+    // device has finished meanwhile: the plans are then a function of the call sequence, not of timing (every rank of a
+    // sharded run re-plans alike; a run's launch counts are reproducible).
+    uint64_t done = (uint64_t)h->h_ctl[MVS_CTL_SEQ];
+    const uint64_t due = h->seq_enqueued > (uint64_t)THROTTLE_LAG ? h->seq_enqueued - THROTTLE_LAG : 0;
+    if (done > due) done = due;
     uint64_t q = h->seq_peeked;
+    if (q >= done) return;
     if (done > MVS_RING && q < done - MVS_RING) q = done - MVS_RING;
     const double tol2 = PEEK_AT * PEEK_AT * p.cg_tol * p.cg_tol;
     for (; q < done; ++q) {
@@ -487,6 +493,7 @@ int read_judgement(mvs_deform_s* h, const mvs_deform_params& p, Judgement* j) {
     HIPCHK(hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     j->esc = ctl[MVS_CTL_ESC] != 0.0;
+    if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] predicted stops: true / predicted residual (running maximum) %.2f\n", std::sqrt(std::max(1.0, ctl[MVS_CTL_PSAFE])));
     j->worst2 = ctl[MVS_CTL_WORST];
     j->missed = (int)ctl[MVS_CTL_MISSED];
     j->solves = (int)ctl[MVS_CTL_SOLVES];
