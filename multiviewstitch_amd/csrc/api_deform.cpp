@@ -133,7 +133,7 @@ void free_nodes(mvs_deform_s* h) {
     dfree(h->d_nodes); dfree(h->d_nbr); dfree(h->d_node_pts); dfree(h->d_node_nrm); dfree(h->d_ctrl_raw);
     dfree(h->d_ctrl_a); dfree(h->d_ctrl_b); dfree(h->d_valid); dfree(h->d_d2min); dfree(h->d_counts);
     dfree(h->d_records); dfree(h->d_top_idx); dfree(h->d_heavy); dfree(h->d_heavy2);
-    if (h->d_heavy_split) { (void)hipFree(h->d_heavy_split); h->d_heavy_split = nullptr; } dfree(h->d_prev_d2); dfree(h->d_prev_node);
+    dfree(h->d_prev_d2); dfree(h->d_prev_node);
     h->prev_valid = false;
     if (h->d_knn_ws) { (void)hipFree(h->d_knn_ws); h->d_knn_ws = nullptr; }
     h->d_ctrl_final = nullptr; h->K = 0; h->nbr_k = 0; h->h_nodes.clear();
@@ -273,7 +273,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
                 weights_done = use_ras(h, p);
                 launch_assoc_heavy_knn(h->grid, h->d_node_pts, h->d_node_nrm, K, p, h->d_d2min, h->d_records, h->d_counts, h->heavy_pending, K,
                                        h->d_ctrl_raw, h->d_valid, h->d_top_idx, nn, h->d_nbr, h->d_knn_ws, s,
-                                       weights_done ? &h->sell : nullptr, h->d_pts, arap_grid_blocks(h->sell), h->d_heavy_split, !h->graph_in_local);
+                                       weights_done ? &h->sell : nullptr, h->d_pts, arap_grid_blocks(h->sell), !h->graph_in_local);
                 h->heavy_pending = nullptr; h->graph_in_local = false;
                 toc(t, knn_grid_launches(K));
             } else if (h->d_knn_ws) {
@@ -890,7 +890,6 @@ int mvs_deform_set_nodes(mvs_deform_t h, const int32_t* vertex_idx, int64_t K) {
     TRY(mvs_check_hip(hipMemsetAsync(h->d_heavy, 0, sizeof(int32_t), h->stream), "memset")); TRY(mvs_check_hip(hipMemsetAsync(h->d_heavy2, 0, sizeof(int32_t), h->stream), "memset"));
     h->heavy_flip = 0;
     if (K >= 1024) TRY(mvs_check_hip(hipMalloc(&h->d_knn_ws, knn_grid_ws_bytes((int)K)), "hipMalloc"));   // small graphs: brute force
-    if (K >= 1024) TRY(mvs_check_hip(hipMalloc(&h->d_heavy_split, assoc_split_scratch_bytes((int)K)), "hipMalloc"));
 #undef TRY
     HIPCHK(hipMemcpyAsync(h->d_is_ctrl, ctrl_id.data(), sizeof(int32_t) * h->V, hipMemcpyHostToDevice, h->stream));
     if (K) HIPCHK(hipMemcpyAsync(h->d_nodes, vertex_idx, sizeof(int32_t) * K, hipMemcpyHostToDevice, h->stream));
@@ -1070,7 +1069,7 @@ int mvs_deform_assoc_select(mvs_deform_t h, const mvs_deform_params* p, const fl
         knn_grid_build(h->d_node_pts, K, h->d_knn_ws, h->stream);
         launch_assoc_heavy_knn(h->grid, h->d_node_pts, h->d_node_nrm, K, *p, const_cast<float*>(d2min_dev), records_dev, counts_dev, h->d_heavy, K,
                                nullptr, nullptr, nullptr, nn, h->d_nbr, h->d_knn_ws, h->stream, w ? &h->sell : nullptr, h->d_pts,
-                               arap_grid_blocks(h->sell), h->d_heavy_split);
+                               arap_grid_blocks(h->sell));
         h->graph_ready_nn = nn; h->weights_ready = w;
     }
     toc(t, fuse ? 3 : 2);

@@ -301,10 +301,6 @@ struct HeavyLds { double pd[HEAVY_WAVES][8], pl[HEAVY_WAVES][8], x[HEAVY_WAVES][
                   int len[HEAVY_WAVES];                               // live entries of each wave's list (rank merge)
                   double r_pd[8], r_pl[8], r_x[8], r_y[8], r_z[8]; long long r_idx[8];   // the merged list, best first
                   int ball; };                                        // ball members counted so far by all waves (full-result cut-off)
-constexpr int HEAVY_SPLIT = 1;                              // workgroups that share one heavy node in the fused launch (> 1: their lists are joined by
-                                                            // k_assoc_merge_heavy.  Measured at 8 with the ~225 heavy nodes of the metric workload: 114 us instead of
-                                                            // 64 — every sharer pays the fixed costs of a node, the 16-list merge above all; kept for meshes with few heavy nodes)
-constexpr int HEAVY_SPLIT_CAP = 1024;                       // heavy nodes the split scratch holds; the (never seen) rest is done whole
 constexpr int HEAVY_DMIN_FLAG = 0x40000000;                 // heavy-list entry: the node's nearest distance is still open (coarse walk deferred)
 
 // The coarse-shell walk of dmin_node (stage B) by ALL waves of a workgroup: a far node (it faces a hole of the scan, its
@@ -376,18 +372,15 @@ struct LocalMerge {
     int max_result;
 };
 
-// (sub, nsub): PARTS > 1 only — this workgroup is number `sub` of `nsub` that share the node: it lists every occupied coarse
-// cell of the ball like the others but scans only its share of them; its list and counts are partial (merged by
-// k_assoc_merge_heavy) and go to slot `out` of rec / counts instead of the node's.
 template <int PARTS>
 __device__ inline void select_node(const GridDev& g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm,
                                    int node, int top_k, float dm, mvs_cand* __restrict__ rec,
                                    int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap, HeavyLds* lds,
-                                   const LocalMerge& lm, int sub = 0, int nsub = 1, int64_t out = -1) {
+                                   const LocalMerge& lm) {
     ASTAMP_BEGIN;
-    if (out < 0) out = node;
-    const int lane = threadIdx.x & 63, part = (PARTS > 1 ? (int)(threadIdx.x >> 6) : 0) + sub * PARTS;
-    const int nparts = PARTS * nsub;                         // shares the node's ranges are dealt into
+    const int64_t out = node;
+    const int lane = threadIdx.x & 63, part = PARTS > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const int nparts = PARTS;                                // shares the node's ranges are dealt into
     int k_occ = 0;                                           // running index of the occupied rows (PARTS > 1)
     const d3 orig = ld3(node_pts + 3 * node), nn = ld3(node_nrm + 3 * node);
     const float qx = (float)orig.x, qy = (float)orig.y, qz = (float)orig.z;
@@ -528,7 +521,7 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
                 for (int base = 64 * lpart; base < ncc; base += 64 * PARTS) {
                     const int t = base + lane;
                     int a = 0, b = 0;
-                    if (t < ncc && (nsub == 1 || (t % nsub) == sub)) {    // (a sharing workgroup looks only ITS cells up: every nsub-th of the box)
+                    if (t < ncc) {
                         const int X = X0 + t % nX, Y = Y0 + (t / nX) % nY, Z = Z0 + t / (nX * nY);
                         const int64_t C = grid_coarse(g.NX, g.NY, X, Y, Z);
                         const int a0 = g.coarse_start[C], b0 = g.coarse_start[C + 1];
@@ -864,19 +857,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     select_node<1>(g, node_pts, node_nrm, node, top_k, best, rec, counts, heavy, heavy_cap, nullptr, lm);
 }
 
-// one heavy-list entry by one 16-wave workgroup (share `sub` of `nsub`): the deferred coarse walk first when the entry asks
-// for it (every sharing workgroup repeats it: they all need the distance), then the ball query
+// one heavy-list entry by one 16-wave workgroup: the deferred coarse walk first when the entry asks for it, then the ball query
 __device__ inline void heavy_entry(const GridDev& g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm, int entry,
                                    int top_k, float* __restrict__ d2min, mvs_cand* __restrict__ rec, int32_t* __restrict__ counts,
-                                   HeavyLds* lds, const LocalMerge& lm, int sub, int nsub, int64_t out) {
+                                   HeavyLds* lds, const LocalMerge& lm) {
     const int node = entry & ~HEAVY_DMIN_FLAG;
     float dm = d2min[node];
     if (entry & HEAVY_DMIN_FLAG) {
         dm = dmin_coarse_wg(g, node_pts, node, dm, lds);
         __syncthreads();                                     // (every wave has read d2min[node] before it is replaced)
-        if (sub == 0 && threadIdx.x == 0) d2min[node] = dm;
+        if (threadIdx.x == 0) d2min[node] = dm;
     }
-    select_node<HEAVY_WAVES>(g, node_pts, node_nrm, node, top_k, dm, rec, counts, nullptr, 0, lds, lm, sub, nsub, out);
+    select_node<HEAVY_WAVES>(g, node_pts, node_nrm, node, top_k, dm, rec, counts, nullptr, 0, lds, lm);
 }
 
 // the deferred nodes: one 16-wave workgroup per node (a far node's ball covers thousands of points; left to one
@@ -889,7 +881,7 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_select_heavy(GridDev
     __shared__ HeavyLds lds;
     const int n = min(heavy[0], heavy_cap);
     for (int h = blockIdx.x; h < n; h += gridDim.x) {
-        heavy_entry(g, node_pts, node_nrm, heavy[1 + h], top_k, d2min, rec, counts, &lds, lm, 0, 1, -1);
+        heavy_entry(g, node_pts, node_nrm, heavy[1 + h], top_k, d2min, rec, counts, &lds, lm);
         __syncthreads();                                     // the LDS lists are reused by the next node
     }
 }
@@ -903,25 +895,15 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_heavy_knn(GridDev g,
                                                                       float* __restrict__ d2min, mvs_cand* __restrict__ rec,
                                                                       int32_t* __restrict__ counts, const int32_t* __restrict__ heavy,
                                                                       int heavy_cap, LocalMerge lm, int heavy_blocks,
-                                                                      mvs_cand* __restrict__ part_rec, int32_t* __restrict__ part_cnt,
                                                                       int K, int nn, const NgGeom* __restrict__ geo,
                                                                       const int* __restrict__ cs, const float4* __restrict__ sorted,
                                                                       int32_t* __restrict__ nbr, int knn_blocks, SellDev m,
                                                                       const double* __restrict__ mesh_pts) {
     __shared__ HeavyLds lds;
     if ((int)blockIdx.x < heavy_blocks) {
-        // HEAVY_SPLIT workgroups share a heavy node (its ~30 are few against 256 CUs, and each is a 40-50 us chain when one
-        // workgroup does it all): every sharer lists the ball's occupied coarse cells, scans its share of them and leaves a
-        // partial top-k list + counts in the split scratch; k_assoc_merge_heavy (next launch) joins them.
-        const int n = min(heavy[0], heavy_cap), ns = HEAVY_SPLIT > 1 ? min(n, HEAVY_SPLIT_CAP) : 0;
-        const LocalMerge none{};
-        for (int v = blockIdx.x; v < ns * HEAVY_SPLIT; v += heavy_blocks) {
-            const int h = v / HEAVY_SPLIT, sub = v % HEAVY_SPLIT;
-            heavy_entry(g, node_pts, node_nrm, heavy[1 + h], top_k, d2min, part_rec, part_cnt, &lds, none, sub, HEAVY_SPLIT, (int64_t)v);
-            __syncthreads();                                 // the LDS lists are reused by the next node
-        }
-        for (int h = ns + blockIdx.x; h < n; h += heavy_blocks) {      // not shared (or beyond the scratch): whole nodes, final results
-            heavy_entry(g, node_pts, node_nrm, heavy[1 + h], top_k, d2min, rec, counts, &lds, lm, 0, 1, -1);
+        const int n = min(heavy[0], heavy_cap);
+        for (int h = blockIdx.x; h < n; h += heavy_blocks) {
+            heavy_entry(g, node_pts, node_nrm, heavy[1 + h], top_k, d2min, rec, counts, &lds, lm);
             __syncthreads();
         }
         return;
@@ -1019,91 +1001,6 @@ __global__ __launch_bounds__(256) void k_assoc_merge(const double* __restrict__ 
     if (lane == 0) { valid[node] = ok ? 1 : 0; st3(controls + 3 * node, mp); }   // :355-356 (controls stay at orig otherwise, :271-272)
 }
 
-// The HEAVY_SPLIT partial lists of a heavy node (k_assoc_heavy_knn) -> its list, counts and — single-rank runs — its target:
-// one wave per node, the insertion and the target rule are k_assoc_merge's (a partial list is the top-k of its share of
-// the ball, so the top-k of their union is the node's).
-__global__ __launch_bounds__(256) void k_assoc_merge_heavy(const double* __restrict__ node_pts, const double* __restrict__ node_nrm,
-                                                           const int32_t* __restrict__ heavy, int heavy_cap, int top_k,
-                                                           const mvs_cand* __restrict__ part_rec, const int32_t* __restrict__ part_cnt,
-                                                           mvs_cand* __restrict__ rec, int32_t* __restrict__ counts, LocalMerge lm) {
-    const int n = HEAVY_SPLIT > 1 ? min(min(heavy[0], heavy_cap), HEAVY_SPLIT_CAP) : 0;
-    const int h = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (h >= n) return;                                       // wave-uniform
-    const int node = heavy[1 + h] & ~HEAVY_DMIN_FLAG;
-    const d3 orig = ld3(node_pts + 3 * node), nn = ld3(node_nrm + 3 * node);
-    double L_pd = 0, L_pl = 0, L_x = 0, L_y = 0, L_z = 0;
-    long long L_idx = -1;
-    int len = 0;
-    double t_pd = 0, t_apl = 0; long long t_idx = 0;
-    static_assert(HEAVY_SPLIT * 8 <= 64, "one pass of the wave takes every partial record");
-    const int r = lane >> 3, sl = lane & 7;
-    int n_ball = 0, n_pass = 0;
-    bool has = false;
-    double pd = 0, pl = 0; d3 tp = mk3(0, 0, 0); long long gi = 0;
-    if (r < HEAVY_SPLIT) {
-        const int64_t v = (int64_t)h * HEAVY_SPLIT + r;
-        if (sl == 0) { n_ball = part_cnt[2 * v]; n_pass = part_cnt[2 * v + 1]; }
-        const mvs_cand c = part_rec[v * 8 + sl];
-        if (c.index >= 0) { has = true; pd = c.proj_dist; pl = c.proj_len; tp = mk3(c.pos[0], c.pos[1], c.pos[2]); gi = c.index; }
-    }
-    n_ball = wave_sum_i(n_ball); n_pass = wave_sum_i(n_pass);
-    const double apl = fabs(pl);
-    unsigned long long pend = __ballot(has);
-    while (pend) {
-        const int src = __ffsll((long long)pend) - 1;
-        const double c_pd = rl_d(pd, src), c_pl = rl_d(pl, src);
-        const double c_x = rl_d(tp.x, src), c_y = rl_d(tp.y, src), c_z = rl_d(tp.z, src);
-        const long long c_i = rl_ll(gi, src);
-        const bool less = lane < len && key_less(L_pd, fabs(L_pl), L_idx, c_pd, fabs(c_pl), c_i);
-        const int pos = __popcll(__ballot(less));
-        const double u_pd = shfl_up_d(L_pd), u_pl = shfl_up_d(L_pl);
-        const double u_x = shfl_up_d(L_x), u_y = shfl_up_d(L_y), u_z = shfl_up_d(L_z);
-        const long long u_i = shfl_up_ll(L_idx);
-        if (lane > pos && lane <= len && lane < top_k) {
-            L_pd = u_pd; L_pl = u_pl; L_x = u_x; L_y = u_y; L_z = u_z; L_idx = u_i;
-        } else if (lane == pos) {
-            L_pd = c_pd; L_pl = c_pl; L_x = c_x; L_y = c_y; L_z = c_z; L_idx = c_i;
-        }
-        len = min(len + 1, top_k);
-        if (len == top_k) {
-            t_pd = rl_d(L_pd, top_k - 1); t_apl = fabs(rl_d(L_pl, top_k - 1)); t_idx = rl_ll(L_idx, top_k - 1);
-        }
-        if (lane == src) has = false;
-        pend = __ballot(has && (len < top_k || key_less(pd, apl, gi, t_pd, t_apl, t_idx)));
-    }
-    if (lane < 8) {
-        mvs_cand* o = rec + (int64_t)node * 8 + lane;
-        const bool live = lane < len;
-        o->proj_dist = live ? L_pd : 0.0;
-        o->proj_len = live ? L_pl : 0.0;
-        o->pos[0] = live ? L_x : 0.0; o->pos[1] = live ? L_y : 0.0; o->pos[2] = live ? L_z : 0.0;
-        o->index = live ? L_idx : -1;
-    }
-    if (lane == 0) { counts[2 * node] = n_ball; counts[2 * node + 1] = n_pass; }
-    if (lm.controls) {                                        // the tail of select_node: means best first, rejection tests
-        bool ok = n_ball < lm.max_result && len > 0;
-        d3 mp = orig;
-        double m_pl = 0, m_pd = 0;
-        d3 acc = mk3(0, 0, 0);
-        for (int sidx = 0; sidx < len; ++sidx) {
-            m_pl += rl_d(L_pl, sidx); m_pd += rl_d(L_pd, sidx);
-            acc = acc + mk3(rl_d(L_x, sidx), rl_d(L_y, sidx), rl_d(L_z, sidx));
-        }
-        if (ok) {
-            const double dn = (double)len;
-            m_pl /= dn; m_pd /= dn; acc = acc / dn;
-            if (m_pl >= lm.proj_len_err || m_pd >= lm.proj_dist_err) ok = false;
-            if (ok) {
-                const d3 dir = acc - orig;
-                if (fabs(dot3(dir, nn) / (norm3(dir) * norm3(nn))) < lm.min_cos) ok = false;
-            }
-            if (ok) mp = acc;
-        }
-        if (lm.top_idx && lane < 8) lm.top_idx[(int64_t)node * 8 + lane] = (n_ball < lm.max_result && len > 0 && lane < len) ? L_idx : -1;
-        if (lane == 0) { lm.valid[node] = ok ? 1 : 0; st3(lm.controls + 3 * node, mp); }
-    }
-}
-
 }  // namespace
 
 #ifdef MVS_STAMPS
@@ -1148,14 +1045,10 @@ void launch_assoc_local(const GridDev& g, const double* node_pts, const double* 
 }
 // the deferred heavy-node pass of launch_assoc_local together with the node graph (grid already built in ws by
 // knn_grid_build on the same node positions): nbr[K * nn] = each node's nn nearest nodes, itself included
-size_t assoc_split_scratch_bytes(int K) {                  // [records | counts] of the partial lists of the split heavy nodes
-    const size_t n = (size_t)std::min(K, HEAVY_SPLIT_CAP) * HEAVY_SPLIT;
-    return n * 8 * sizeof(mvs_cand) + n * 2 * sizeof(int32_t);
-}
 void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                             float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, int heavy_cap,
                             double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s,
-                            const SellDev* mesh, const double* mesh_pts, int cot_blocks, void* split_scratch, bool with_knn) {
+                            const SellDev* mesh, const double* mesh_pts, int cot_blocks, bool with_knn) {
     if (K <= 0) return;
     const LocalMerge lm{controls, valid, top_idx, p.proj_len_err, p.proj_dist_err, p.min_cos, p.max_result};
     const void *geo, *sorted;
@@ -1163,15 +1056,9 @@ void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const doub
     knn_grid_views(knn_ws, K, &geo, &cs, &sorted);
     const int heavy_blocks = std::min(heavy_cap, 256), knn_blocks = with_knn ? (K + HEAVY_WAVES - 1) / HEAVY_WAVES : 0;    // (!with_knn: the graph came with k_assoc_local)
     const int cot = mesh ? cot_blocks : 0;
-    mvs_cand* part_rec = (mvs_cand*)split_scratch;
-    int32_t* part_cnt = (int32_t*)((char*)split_scratch + (size_t)std::min(K, HEAVY_SPLIT_CAP) * HEAVY_SPLIT * 8 * sizeof(mvs_cand));
     k_assoc_heavy_knn<<<dim3(heavy_blocks + knn_blocks + cot), dim3(64 * HEAVY_WAVES), 0, s>>>(
-        g, node_pts, node_nrm, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm, heavy_blocks, part_rec, part_cnt, K, nn, (const NgGeom*)geo, cs,
+        g, node_pts, node_nrm, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm, heavy_blocks, K, nn, (const NgGeom*)geo, cs,
         (const float4*)sorted, nbr, knn_blocks, mesh ? *mesh : SellDev{}, mesh_pts);
-    // the split nodes' partial lists -> lists, counts, targets (a wave per node; the list is short: waves beyond it leave)
-    if (HEAVY_SPLIT > 1)
-        k_assoc_merge_heavy<<<dim3((std::min(heavy_cap, HEAVY_SPLIT_CAP) + 3) / 4), dim3(256), 0, s>>>(
-            node_pts, node_nrm, heavy, heavy_cap, p.top_k, part_rec, part_cnt, rec, counts, lm);
 }
 // owner-merges exchange: scatter the all-gathered per-owner blocks [block_nodes*3 doubles | block_nodes bytes] into the handle's
 // dense node targets (the owners keep the index lists: -1 here)

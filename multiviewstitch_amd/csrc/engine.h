@@ -121,7 +121,6 @@ struct mvs_deform_s {
     mvs_cand *d_records = nullptr;
     int64_t *d_top_idx = nullptr;
     int32_t *d_heavy = nullptr;       // [1 + K]: nodes deferred to the workgroup-per-node association kernel
-    void *d_heavy_split = nullptr;    // partial lists of the heavy nodes that several workgroups share (assoc_split_scratch_bytes)
     int32_t *d_heavy2 = nullptr;      // second list: single-rank iterations alternate (each resets the other's counter)
     float* d_prev_d2 = nullptr;        // sharded step: global nearest distance of every node at the previous association ...
     double* d_prev_node = nullptr;     // ... and where the node stood (bound for the next nearest-distance search)
@@ -196,11 +195,10 @@ void launch_assoc_local(const GridDev& g, const double* node_pts, const double* 
                         mvs_cand* rec, int32_t* counts, int32_t* heavy /*counter already 0*/, int32_t* heavy_next /*reset for the next call*/,
                         int heavy_cap, double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s, bool defer_heavy = false,
                         int nn = 0, int32_t* nbr = nullptr, void* knn_ws = nullptr /* != NULL: the node-graph queries share the launch (grid built in it) */);
-size_t assoc_split_scratch_bytes(int K);
 void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                             float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, int heavy_cap,
                             double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s,
-                            const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks, void* split_scratch,
+                            const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks,
                             bool with_knn = true /*false: the graph came with launch_assoc_local*/);
 void launch_install_targets(const void* blocks, int K, int block_nodes, int64_t stride_bytes, double* controls, uint8_t* valid, int64_t* top_idx,
                             hipStream_t s);
