@@ -431,6 +431,7 @@ def main():
         collectives["bytes_all_reduce"] = int(K) * 4
         collectives["exchange"] = exchange
         if exchange == "owner_merges":          # "all_gather" timer = all-to-all (records, counts) + block merge + all-gather of the targets
+            collectives["all_gather_ms_covers"] = "all-to-all of records and counts by node block + merge of the owned block + all-gather of the merged targets"
             collectives["bytes_all_to_all_in_per_rank"] = int(K) * 392
             collectives["bytes_all_gather_in_per_rank"] = int(bufs["owner"]["stride"]) * world
         else:
