@@ -359,6 +359,12 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals,
                       int64_t F, const int32_t* faces, mvs_deform_t* out);
 int mvs_deform_destroy(mvs_deform_t h);
 
+/* New positions (and, if given, normals) for the handle's mesh — SAME topology: the next fit starts from them, e.g. from the
+ * template's rest pose again for the next scan of a sequence.  The reference builds a new `Deformation` per call
+ * (Processor.cpp:1135); here everything that depends on the topology alone (adjacency and patch tables, node set, the solver's
+ * launch plans) stays, which is what mvs_deform_create spends its time on.  The target is kept too (set a new one as needed). */
+int mvs_deform_set_vertices(mvs_deform_t h, const double* points /*V*3*/, const double* normals /*V*3 or NULL: keep*/);
+
 /* UniformSampling()  Deformation.cpp:63-106 (knn = 16). Exact NN on float32
  * coordinates.  K receives sampIdx.size(). */
 int mvs_deform_sample_nodes(mvs_deform_t h, int knn, int64_t* K);

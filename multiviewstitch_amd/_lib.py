@@ -123,6 +123,7 @@ _SIGS = {
     "mvs_deform_assoc_merge_packed": (C.c_int, [_VP, _VP, _VP, _I32]),
     "mvs_deform_assoc_merge_block": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I64, _I64, _I64, _VP]),
     "mvs_deform_set_node_targets_dev": (C.c_int, [_VP, _VP, _I32, _I64, _I64]),
+    "mvs_deform_set_vertices": (C.c_int, [_VP, _VP, _VP]),
     "mvs_deform_solve": (C.c_int, [_VP, _VP, _VP]),
     "mvs_comm_unique_id": (C.c_int, [_VP]),
     "mvs_comm_init": (C.c_int, [_I32, _I32, _VP, _VP]),

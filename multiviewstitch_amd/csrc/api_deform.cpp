@@ -905,6 +905,26 @@ int mvs_deform_set_nodes(mvs_deform_t h, const int32_t* vertex_idx, int64_t K) {
     return MVS_OK;
 }
 
+// Same topology, new positions (e.g. the template's rest pose again, for the next scan): everything that depends on the
+// topology alone — adjacency tables, patch tables, node set, launch plans — is kept, which is what mvs_deform_create spends
+// its 20 ms on.
+int mvs_deform_set_vertices(mvs_deform_t h, const double* points, const double* normals) {
+    if (!h || !points) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_pts, points, sizeof(double) * 3 * (size_t)h->V, hipMemcpyHostToDevice, h->stream));
+    if (normals) HIPCHK(hipMemcpyAsync(h->d_nrm, normals, sizeof(double) * 3 * (size_t)h->V, hipMemcpyHostToDevice, h->stream));
+    if (h->K > 0) {
+        launch_gather_nodes(h->d_pts, h->d_nrm, h->d_nodes, (int)h->K, h->d_node_pts, h->d_node_nrm, h->stream);
+        HIPCHK(hipMemcpyAsync(h->d_ctrl_raw, h->d_node_pts, sizeof(double) * h->K * 3, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemsetAsync(h->d_valid, 0, (size_t)h->K, h->stream));
+        h->d_ctrl_final = h->d_ctrl_raw;
+    }
+    h->graph_ready_nn = 0; h->weights_ready = false; h->heavy_pending = nullptr; h->graph_in_local = false;
+    HIPCHK(hipStreamSynchronize(h->stream));                 // (the host arrays may be released on return)
+    return mvs_check_hip(hipGetLastError(), "set_vertices");
+}
+
 int mvs_deform_sample_nodes(mvs_deform_t h, int knn, int64_t* K) {
     // UniformSampling, Deformation.cpp:63-106: exact kNN table on the GPU, greedy suppression
     // in vertex order on the host (inherently sequential).

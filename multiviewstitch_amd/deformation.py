@@ -175,6 +175,15 @@ class Deformation:
         rc = L.check(L.lib().mvs_deform_iterate_sharded(self._h, comm._c, C.byref(self.params), n_outer, C.byref(st)))
         return _stats(st, rc)
 
+    def set_vertices(self, points, normals=None):
+        """new positions (and normals) for the same topology — e.g. the template again for the next scan; tables, nodes and
+        launch plans are kept (mvs_deform_set_vertices)"""
+        p = L.arr(points, np.float64).reshape(-1, 3)
+        n = L.arr(normals, np.float64).reshape(-1, 3) if normals is not None else None
+        if len(p) != self.V or (n is not None and len(n) != self.V):
+            raise ValueError("set_vertices: the vertex count of the handle's mesh is fixed")
+        L.check(L.lib().mvs_deform_set_vertices(self._h, L.ptr(p), L.ptr(n)))
+
     def sync(self):
         L.check(L.lib().mvs_deform_sync(self._h))
 

@@ -318,3 +318,29 @@ def test_fused_local_rhs_kernel_matches_the_two_row_kernels(eng, oracle, monkeyp
     o.set_target(tp, tn)
     o.iterate(oracle.Params.default(), 3)
     assert rms(outs[1][0], o.vertices()) <= 1e-6
+
+
+def test_a_handle_is_reused_for_the_next_fit(eng):
+    """mvs_deform_set_vertices: the template's rest pose again (same topology) — the second fit on the handle gives what a fresh
+    handle gives (both solves end within cg_tol of the same systems: 1e-7 on the vertices, the same valid nodes), against
+    another target too; a wrong vertex count is refused."""
+    sc, tp, tn, _ = scene_and_target(2)
+    fresh = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    fresh.UniformSampling(16)
+    fresh.set_target(tp, tn)
+    st0 = fresh.iterate(3)
+    want = fresh.vertices()
+    assert rms(want, sc.verts) > 1e-4                                      # the fit moved the mesh
+    d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    d.UniformSampling(16)
+    d.set_target(tp[::2], tn[::2])                                         # a first scan: something else
+    d.iterate(2)
+    d.set_vertices(sc.verts, sc.normals)                                   # ... the template again, then the scan of `fresh`
+    assert np.array_equal(d.vertices(), sc.verts)
+    d.set_target(tp, tn)
+    st1 = d.iterate(3)
+    assert st1["n_valid"] == st0["n_valid"] and st1["arap_iters_run"] == st0["arap_iters_run"] and st1["status"] == 0
+    assert rms(d.vertices(), want) < 1e-7
+    assert np.array_equal(d.node_targets()["valid"], fresh.node_targets()["valid"])
+    with pytest.raises(ValueError):
+        d.set_vertices(sc.verts[:-1])
