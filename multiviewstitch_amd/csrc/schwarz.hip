@@ -115,7 +115,8 @@ __global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, doubl
                                                       const double* __restrict__ ctrl, const double* __restrict__ pts,
                                                       double* __restrict__ sol, double* __restrict__ rot, RasSmooth sm,
                                                       double* __restrict__ pwr) {
-    const int p = blockIdx.x, row = threadIdx.x;
+    const int p = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;   // (XCD-aware, as the sweeps)
+    const int row = threadIdx.x;
     const int LS = R.LS, base = p * LS, nloc = R.pnloc[p];
     const bool live = row < nloc;                                      // rows nloc..LS-1 are padding: inert (pd = 0, pw = 0)
     const int g = R.l2g[base + row];
