@@ -264,7 +264,7 @@ __device__ inline float dmin_node(const GridDev& g, const double* __restrict__ n
 __global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __restrict__ node_pts, int K,
                                                     float* __restrict__ d2min, const float* __restrict__ prev_d2,
                                                     const double* __restrict__ prev_node) {
-    const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int node = blockIdx.x * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (node >= K) return;                       // wave-uniform
     float limit2 = INFINITY;
     if (prev_d2) {
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* _
                                                       const float* __restrict__ d2min, mvs_cand* __restrict__ rec,
                                                       int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap,
                                                       float* __restrict__ prev_d2, double* __restrict__ prev_node) {
-    const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int node = blockIdx.x * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (node >= K) return;
     if (prev_d2 && (threadIdx.x & 63) < 3) {     // remember the global nearest distance and where the node stood (k_assoc_dmin)
         const int c = threadIdx.x & 63;
@@ -834,11 +834,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         // passengers: the 9-NN graph queries of the nodes (a wave each, like the nodes' own searches; the grid of the node
         // positions was built by the launch before).  They used to ride with the heavy nodes — 1024-thread workgroups at 128
         // registers, one per CU: 509 of them were two of that launch's four rounds — and fill the half-empty last round here
-        const int q = ((int)blockIdx.x - assoc_blocks) * 4 + (int)(threadIdx.x >> 6);
+        const int q = ((int)blockIdx.x - assoc_blocks) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
         if (q < K) ng_knn_query(q, node_pts, K, nn, geo, ng_cs, ng_sorted, nbr, nullptr, nullptr);
         return;
     }
-    const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int node = blockIdx.x * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (node >= K) return;
     bool deferred = false;
     const float best = dmin_node(g, node_pts, node, INFINITY, heavy ? &deferred : nullptr);
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(256) void k_assoc_merge(const double* __restrict__ 
     // one packed buffer per rank [records | counts]: both = the packed size)
     // node0 > 0 (owner-merges exchange): the K nodes of this launch are the block node0 .. node0 + K - 1 of the handle's nodes;
     // records, counts and the outputs are indexed inside the block, the node positions / normals by the node itself
-    const int q = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int q = blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
     if (q >= K) return;                                       // wave-uniform
     const int lane = threadIdx.x & 63;
     const d3 orig = ld3(node_pts + 3 * (int64_t)(node0 + q)), nn = ld3(node_nrm + 3 * (int64_t)(node0 + q));
@@ -1015,14 +1015,15 @@ extern "C" int mvs_debug_assoc_cycles(unsigned long long* out, int n) {
 void launch_assoc_dmin(const GridDev& g, const double* node_pts, int K, float* d2min, hipStream_t s, const float* prev_d2,
                        const double* prev_node) {
     if (K <= 0) return;
-    k_assoc_dmin<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, K, d2min, prev_d2, prev_node);
+    k_assoc_dmin<<<dim3(K), dim3(64), 0, s>>>(            // (a wave per workgroup, as k_assoc_local)
+        g, node_pts, K, d2min, prev_d2, prev_node);
 }
 void launch_assoc_select(const GridDev& g, const double* node_pts, const double* node_nrm, int K, int top_k,
                          float* d2min, mvs_cand* rec, int32_t* counts, int32_t* heavy, int heavy_cap, hipStream_t s, bool defer_heavy,
                          float* prev_d2, double* prev_node) {
     if (K <= 0) return;
     if (heavy) (void)hipMemsetAsync(heavy, 0, sizeof(int32_t), s);
-    k_assoc_select<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, top_k, d2min, rec, counts, heavy, heavy_cap, prev_d2, prev_node);
+    k_assoc_select<<<dim3(K), dim3(64), 0, s>>>(g, node_pts, node_nrm, K, top_k, d2min, rec, counts, heavy, heavy_cap, prev_d2, prev_node);
     if (heavy && !defer_heavy) k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, top_k, d2min, rec, counts, heavy, heavy_cap, LocalMerge{});
 }
 // dmin + select of a single-rank run in one launch (+ the heavy-node pass); d2min is still written (getters, heavy pass)
@@ -1037,8 +1038,11 @@ void launch_assoc_local(const GridDev& g, const double* node_pts, const double* 
     const void *geo = nullptr, *sorted = nullptr;
     const int* cs = nullptr;
     if (knn_ws) knn_grid_views(knn_ws, K, &geo, &cs, &sorted);
-    const int ab = (K + 3) / 4, kb = knn_ws ? (K + 3) / 4 : 0;
-    k_assoc_local<<<dim3(ab + kb), dim3(256), 0, s>>>(g, node_pts, node_nrm, K, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm, heavy_next, ab, nn,
+    // one wave per workgroup: the waves' chains differ in length (a node near a hole of the scan, a graph query in a dense spot) and
+    // a 4-wave workgroup holds its slots until its slowest wave is done — 53.7 us at 4, 53.5 at 2, 51.3 at 1
+    static const int wpb = getenv("MVS_ASSOC_WPB") ? std::max(1, std::min(4, atoi(getenv("MVS_ASSOC_WPB")))) : 1;      // waves per workgroup
+    const int ab = (K + wpb - 1) / wpb, kb = knn_ws ? (K + wpb - 1) / wpb : 0;
+    k_assoc_local<<<dim3(ab + kb), dim3(64 * wpb), 0, s>>>(g, node_pts, node_nrm, K, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm, heavy_next, ab, nn,
                                                        (const NgGeom*)geo, cs, (const float4*)sorted, nbr);
     if (!defer_heavy)
         k_assoc_select_heavy<<<dim3(std::min(heavy_cap, 256)), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm);
@@ -1085,6 +1089,6 @@ void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, c
     if (K <= 0) return;
     if (rec_stride == 0) rec_stride = (int64_t)K * 8 * sizeof(mvs_cand);
     if (cnt_stride == 0) cnt_stride = (int64_t)K * 2 * sizeof(int32_t);
-    k_assoc_merge<<<dim3((K + 3) / 4), dim3(256), 0, s>>>(node_pts, node_nrm, K, p, rec_all, counts_all, nranks,
+    k_assoc_merge<<<dim3(K), dim3(64), 0, s>>>(node_pts, node_nrm, K, p, rec_all, counts_all, nranks,
                                                              controls, valid, top_idx, rec_stride, cnt_stride, node0);
 }
