@@ -822,8 +822,9 @@ __global__ __launch_bounds__(256) void k_assoc_select(GridDev g, const double* _
 
 // single-rank association: nearest distance and ball query of a node by the same wave (no exchange of d2min in between:
 // one launch and one walk over the node's cells less than k_assoc_dmin + k_assoc_select)
-// (80 VGPRs instead of 84: six waves per SIMD instead of five, no spills; 35.6 -> 33.4 us)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_assoc_local(GridDev g, const double* __restrict__ node_pts,
+// (80 VGPRs instead of 84: six waves per SIMD instead of five, no spills; 35.6 -> 33.4 us.  With the graph queries on board
+//  and one-wave workgroups — round 2 — seven waves at 72 VGPRs: 53.8 / 51.6 / 49.9 / 54.7 us at 5 / 6 / 7 / 8 waves)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_assoc_local(GridDev g, const double* __restrict__ node_pts,
                                                      const double* __restrict__ node_nrm, int K, int top_k,
                                                      float* __restrict__ d2min, mvs_cand* __restrict__ rec,
                                                      int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap, LocalMerge lm,
@@ -864,7 +865,14 @@ __device__ inline void heavy_entry(const GridDev& g, const double* __restrict__ 
     const int node = entry & ~HEAVY_DMIN_FLAG;
     float dm = d2min[node];
     if (entry & HEAVY_DMIN_FLAG) {
+#ifdef MVS_STAMPS
+        unsigned long long tc0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc0_) :: "memory");
+#endif
         dm = dmin_coarse_wg(g, node_pts, node, dm, lds);
+#ifdef MVS_STAMPS
+        { unsigned long long tc1_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc1_) :: "memory");
+          if (threadIdx.x == 0 && node < 16384) g_dmin_shell[8 * node + 7] = tc1_ - tc0_; }
+#endif
         __syncthreads();                                     // (every wave has read d2min[node] before it is replaced)
         if (threadIdx.x == 0) d2min[node] = dm;
     }

@@ -31,3 +31,10 @@ heavy = np.flatnonzero(nr > 0)
 print("heavy nodes", len(heavy))
 for i in heavy[np.argsort(-sel[heavy])][:25]:
     print(f"node {i}: total {sel[i]} cycles; list built {tA[i]}, wave 0 scanned {tB[i]}, all waves scanned {tC[i]}; ranges {nr[i]}, ball {ball[i]}")
+# the far nodes' coarse-shell walk by the workgroup (dmin_coarse_wg), cycles
+buf2 = np.zeros(16384 * 8, np.uint64)
+if lib.mvs_debug_dmin_shells(buf2.ctypes.data_as(C.c_void_p), len(buf2)) == 0:
+    cw = buf2.reshape(-1, 8)[:K, 7].astype(np.int64)
+    far = cw[(cw > 0) & (cw < 10**7)]
+    if len(far):
+        print(f"far nodes {len(far)}: coarse walk by the workgroup, cycles p50/p90/max {np.percentile(far, [50, 90, 100]).astype(int)}")
