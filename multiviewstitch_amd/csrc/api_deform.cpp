@@ -451,6 +451,7 @@ void peek_ring(mvs_deform_s* h, const mvs_deform_params& p, bool ras) {
     if (q >= done) return;
     if (done > MVS_RING && q < done - MVS_RING) q = done - MVS_RING;
     const double tol2 = PEEK_AT * PEEK_AT * p.cg_tol * p.cg_tol;
+    static const bool plan_lowering = !(getenv("MVS_PLAN_LOWER") && getenv("MVS_PLAN_LOWER")[0] == '0');
     for (; q < done; ++q) {
         const volatile double* row = h->h_ctl + MVS_CTL_RING + (q % MVS_RING) * 8;
         const volatile double* used = h->h_ctl + MVS_CTL_USED + (q % MVS_RING) * 8;
@@ -466,6 +467,23 @@ void peek_ring(mvs_deform_s* h, const mvs_deform_params& p, bool ras) {
                     want = ran + ras_spares(ran);
                     const int rise = 0;
                     h->ras_rise[it] = rise; h->ras_seen[it] = ran;
+                    // ... and a plan that has been more than generous for four passes in a row comes down to what they needed
+                    // (plus the spare): right after a calibration or a harvest of a few passes the plans carry the first
+                    // passes' needs, which fall quickly (the bench's window, passes 3-22: 27 launches for 19 sweeps that run)
+                    int* hist = h->ras_hist[it];
+                    if (h->ras_hist_n[it] == 4) { hist[0] = hist[1]; hist[1] = hist[2]; hist[2] = hist[3]; hist[3] = ran; }
+                    else hist[h->ras_hist_n[it]++] = ran;
+                    static const int HN = getenv("MVS_PLAN_HIST") ? std::max(1, std::min(4, atoi(getenv("MVS_PLAN_HIST")))) : 4;
+                    if (plan_lowering && h->ras_hist_n[it] >= HN && u > 0) {
+                        int m = 0;
+                        for (int k = h->ras_hist_n[it] - HN; k < h->ras_hist_n[it]; ++k) m = std::max(m, hist[k]);
+                        const int low = m + ras_spares(m);
+                        if (low < h->ras_plan[it] && want <= low) {
+                            if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] pass %llu solve %d: plan %d -> %d (the last four passes ran <= %d sweeps)\n",
+                                                                (unsigned long long)q, it, h->ras_plan[it], low, m);
+                            h->ras_plan[it] = low;
+                        }
+                    }
                 }
                 if (rel2 > tol2) want = std::max(want, h->ras_plan[it] + ras_spares(h->ras_plan[it]) + 1);     // it missed although every sweep ran
                 want = std::min(RAS_MAX_SWEEPS, want);
@@ -898,7 +916,7 @@ int mvs_deform_set_nodes(mvs_deform_t h, const int32_t* vertex_idx, int64_t K) {
     if (K) HIPCHK(hipMemcpyAsync(h->d_ctrl_raw, h->d_node_pts, sizeof(double) * K * 3, hipMemcpyDeviceToDevice, h->stream));
     h->d_ctrl_final = h->d_ctrl_raw;
     h->cg_iters = 0;                                  // new node set: every launch plan and the solver bracket start over
-    for (int i = 0; i < 8; ++i) { h->cg_plan[i] = 0; h->ras_plan[i] = 0; h->bump_seq[i] = 0; h->ras_seen[i] = 0; h->ras_rise[i] = 0; }
+    for (int i = 0; i < 8; ++i) { h->cg_plan[i] = 0; h->ras_plan[i] = 0; h->bump_seq[i] = 0; h->ras_seen[i] = 0; h->ras_rise[i] = 0; h->ras_hist_n[i] = 0; }
     HIPCHK(hipMemsetAsync(h->d_ctl, 0, sizeof(double) * 4, h->stream));     // verdicts of the old node set say nothing about the new one
     h->ras_a = 0.0; h->ras_m = 0;
     HIPCHK(hipStreamSynchronize(h->stream));

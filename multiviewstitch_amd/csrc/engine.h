@@ -164,6 +164,8 @@ struct mvs_deform_s {
     double* d_bpure = nullptr;      // [V*3] right-hand side without its Dirichlet share (k_arap_rhs -> k_arap_local's true residual)
     double* d_ras_tail = nullptr;   // [8][RAS_TAIL_MAX] sweep slots of the in-kernel sweeps of TAIL launches
     volatile double* h_ctl = nullptr;
+    int ras_hist[8][4] = {};        // sweeps each solve ran in the last four passes the host has looked at (peek_ring), oldest first
+    int ras_hist_n[8] = {};
     bool graph_in_local = false;    // this pass's node graph was searched in the k_assoc_local launch (enqueue_assoc_local)
     uint64_t seq_enqueued = 0;      // outer iterations enqueued since creation (the device counts the finalized ones in MVS_CTL_SEQ)
     uint64_t seq_peeked = 0;        // ... whose ring row the host has already looked at
