@@ -3,6 +3,7 @@
 // index).  Build = bbox reduce, cell histogram, exclusive
 // scan, scatter into cell-sorted SoA.  Runs once per mvs_deform_set_target.
 #include "engine.h"
+#include <cstdlib>
 #include "dev_common.h"
 #include "grid_dev.h"
 #include <algorithm>
@@ -206,7 +207,8 @@ int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* 
         HIPCHK(hipFree(d_counts)); d_counts = nullptr;
         const double occ = (double)P / (double)std::max<unsigned long long>(1, nz);
         // surface-like data: occupancy ~ h^2
-        float hn = hh * (float)std::sqrt(16.0 / occ);
+        static const double want_occ = getenv("MVS_GRID_OCC") ? atof(getenv("MVS_GRID_OCC")) : 16.0;      // (experiments)
+        float hn = hh * (float)std::sqrt(want_occ / occ);
         hn = std::max(hn, ext / 1024.f);
         hn = std::min(hn, ext / 4.f);
         g = make_geom(mn, mx, hn);
