@@ -195,6 +195,87 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
     __syncthreads();
     if (s_done) return;
     double bn_acc = 0.0;
+    // Degree <= 8 (one 64-entry slice per 8 rows) and a grid that holds every 16-row group at once: FOUR lanes per row, two
+    // entries each — a wave then takes 16 rows, 3423 wave-tasks for the metric mesh against the launch's 4080 waves: every wave
+    // has ONE group.  With 8 lanes per row they were 6845 tasks, two dependent load chains one after the other for two waves in
+    // three (the 92 VGPRs allow one 1024-thread workgroup per CU, so more workgroups would only queue).
+    const int ngroups16 = (m.nslices + 1) >> 1;
+    if (m.single_pass && ngroups16 <= nbw * NW) {
+        const int G = blockIdx.x * NW + (threadIdx.x >> 6);
+        const int lane = threadIdx.x & 63, r16 = lane >> 2, q = lane & 3;
+        const int row = 16 * G + r16;
+        const bool live = G < ngroups16 && row < m.V;
+        const bool freerow = live && !m.is_ctrl[row];
+        d3 bb = mk3(0, 0, 0), ax = mk3(0, 0, 0), bd = mk3(0, 0, 0);
+        if (freerow) {
+            const d3 pi = ld3(pts + 3 * row);
+            const double* Ri = rot + 9 * (int64_t)row;
+            const int e0 = 64 * (2 * G + (r16 >> 3)) + (r16 & 7) * 8 + q;
+            double w[2]; int j[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { w[u] = m.w[e0 + 4 * u]; j[u] = m.col[e0 + 4 * u]; }
+            double ri[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) ri[c] = Ri[c];
+            d3 xj[2], pj[2]; double rj[2][9]; int cj[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                xj[u] = mk3(0, 0, 0); pj[u] = pi; cj[u] = 0;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) rj[u][c] = 0.0;
+                if (w[u] != 0.0) {
+                    const double* Rj = rot + 9 * (int64_t)j[u];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) rj[u][c] = Rj[c];
+                    xj[u] = ld3(sol + 3 * j[u]); pj[u] = ld3(pts + 3 * j[u]); cj[u] = m.is_ctrl[j[u]];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (w[u] == 0.0) continue;
+                double M[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) M[c] = w[u] * ri[c] + w[u] * rj[u][c];
+                bb = bb + mulMv(M, pi - pj[u]);
+                if (cj[u]) { bb = bb + (2.0 * w[u]) * xj[u]; bd = bd + (2.0 * w[u]) * xj[u]; }      // Dirichlet column moved to the rhs
+                else ax = ax - (2.0 * w[u]) * xj[u];
+            }
+        }
+        // sums over the 4 lanes of a row (every lane active)
+        auto red4 = [](double v) { v += dpp_d<0xB1>(v); v += dpp_d<0x4E>(v); return v; };
+        bb = mk3(red4(bb.x), red4(bb.y), red4(bb.z));
+        ax = mk3(red4(ax.x), red4(ax.y), red4(ax.z));
+        if (bpure) bd = mk3(red4(bd.x), red4(bd.y), red4(bd.z));
+        if (live && q < 3) {
+            double res = 0.0;
+            if (bpure) bpure[3 * row + q] = freerow ? (q == 0 ? bb.x - bd.x : (q == 1 ? bb.y - bd.y : bb.z - bd.z)) : 0.0;
+            if (freerow) {
+                const double di = m.diag[row];
+                const double b_c = q == 0 ? bb.x : (q == 1 ? bb.y : bb.z);
+                const double a_c = (q == 0 ? ax.x : (q == 1 ? ax.y : ax.z)) + di * sol[3 * row + q];
+                res = b_c - a_c;
+                bn_acc += b_c * b_c / di;
+            }
+            bout[3 * row + q] = freerow ? (q == 0 ? bb.x : (q == 1 ? bb.y : bb.z)) : 0.0;
+            if (rws) {
+                double* o = rws + 9 * (int64_t)row;
+                o[q] = res; o[3 + q] = 0.0; o[6 + q] = 0.0;
+                p[3 * row + q] = 0.0;
+            }
+        }
+        // component sums of ||b||^2 over the wave: lane q < 3 of every row holds component q
+        double v4[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double t = q == c ? bn_acc : 0.0;
+            t += dpp_d<0xB1>(t); t += dpp_d<0x4E>(t);                       // the row's 4 lanes
+            t += dpp_d<0x141>(t); t += dpp_d<0x140>(t);                     // the 16-lane DPP row (4 mesh rows)
+            t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+            v4[c] = t;
+        }
+        block_store_partials<3>(v4, ered + it * EIT + NBMAX);
+        return;
+    }
     for (int g = blockIdx.x * NW + (threadIdx.x >> 6); g < m.nslices; g += nbw * NW) {
         const RowCtx r = row_ctx(m, g);
         const bool freerow = r.live && !m.is_ctrl[r.row];
