@@ -532,6 +532,13 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
                                                     int it, double tol, double* __restrict__ ered, double* __restrict__ rot,
                                                     const double* __restrict__ bvec) {
     if (block_done(ered + EFIN, it, tol)) return;
+#ifdef MVS_STAMPS
+#define LSTAMP(k) do { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        if ((threadIdx.x & 63) == 0 && it == 2) g_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } while (0)
+#else
+#define LSTAMP(k)
+#endif
+    LSTAMP(0);
     double e_acc = 0.0;
     double g0 = 0.0, g1 = 0.0, g2 = 0.0;          // true residual of the global solve whose result `sol` is: sum r_c^2 / d_i over the free rows
     for (int i = blockIdx.x * 256 + threadIdx.x; i < m.V; i += gridDim.x * 256) {
@@ -580,8 +587,10 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
             const double inv_d = 1.0 / m.diag[i];
             g0 += res.x * res.x * inv_d; g1 += res.y * res.y * inv_d; g2 += res.z * res.z * inv_d;
         }
+        LSTAMP(1);
         double R[9];
         closest_rotation(c, R);
+        LSTAMP(2);
 #pragma unroll
         for (int k = 0; k < 9; ++k) rot[9 * (int64_t)i + k] = R[k];
 #pragma unroll
@@ -600,6 +609,7 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
                 e_acc += w * sqn3(qq - mulMv(R, pp));
             }
     }
+    LSTAMP(3);
     e_acc = wave_total(e_acc);
     __shared__ double sm[4][4];
     if (bvec) { g0 = wave_total(g0); g1 = wave_total(g1); g2 = wave_total(g2); }
