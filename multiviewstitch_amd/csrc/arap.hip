@@ -182,6 +182,29 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
         return;
     }
     if (!judge_block && blockIdx.x == 0 && it >= 1 && ctl) judge_solve(ered, it - 1, gridDim.x, cg_tol, ctl, ring_slot, !arap_done_before(efin, it - 1, tol), prev_scal);
+    // Degree <= 8 (one 64-entry slice per 8 rows) and a grid that holds every 16-row group at once: FOUR lanes per row, two
+    // entries each — a wave then takes 16 rows, 3423 wave-tasks for the metric mesh against the launch's 4080 waves: every wave
+    // has ONE group.  With 8 lanes per row they were 6845 tasks, two dependent load chains one after the other for two waves in
+    // three (the 92 VGPRs allow one 1024-thread workgroup per CU, so more workgroups would only queue).  The row's own
+    // operands are fetched HERE, in front of the stop rule's fold and barrier, so that the two latencies overlap.
+    const int ngroups16 = (m.nslices + 1) >> 1;
+    const bool four_lanes = m.single_pass && ngroups16 <= nbw * NW;
+    const int G4 = blockIdx.x * NW + (threadIdx.x >> 6), r16 = (threadIdx.x & 63) >> 2, q4 = threadIdx.x & 3;
+    const int row4 = 16 * G4 + r16;
+    const bool live4 = four_lanes && G4 < ngroups16 && row4 < m.V;
+    const bool free4 = live4 && !m.is_ctrl[row4];
+    d3 pi4 = mk3(0, 0, 0);
+    double ri4[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, w4[2] = {0.0, 0.0};
+    int j4[2] = {0, 0};
+    if (free4) {
+        pi4 = ld3(pts + 3 * row4);
+        const double* Ri = rot + 9 * (int64_t)row4;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) ri4[c] = Ri[c];
+        const int e0 = 64 * (2 * G4 + (r16 >> 3)) + (r16 & 7) * 8 + q4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { w4[u] = m.w[e0 + 4 * u]; j4[u] = m.col[e0 + 4 * u]; }
+    }
     if (threadIdx.x < 64) {                      // wave 0 decides
         bool done = arap_done_before(efin, it - 1, tol);
         if (it >= 1) {
@@ -195,28 +218,15 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
     __syncthreads();
     if (s_done) return;
     double bn_acc = 0.0;
-    // Degree <= 8 (one 64-entry slice per 8 rows) and a grid that holds every 16-row group at once: FOUR lanes per row, two
-    // entries each — a wave then takes 16 rows, 3423 wave-tasks for the metric mesh against the launch's 4080 waves: every wave
-    // has ONE group.  With 8 lanes per row they were 6845 tasks, two dependent load chains one after the other for two waves in
-    // three (the 92 VGPRs allow one 1024-thread workgroup per CU, so more workgroups would only queue).
-    const int ngroups16 = (m.nslices + 1) >> 1;
-    if (m.single_pass && ngroups16 <= nbw * NW) {
-        const int G = blockIdx.x * NW + (threadIdx.x >> 6);
-        const int lane = threadIdx.x & 63, r16 = lane >> 2, q = lane & 3;
-        const int row = 16 * G + r16;
-        const bool live = G < ngroups16 && row < m.V;
-        const bool freerow = live && !m.is_ctrl[row];
+    if (four_lanes) {
+        const int q = q4, row = row4;
+        const bool live = live4, freerow = free4;
         d3 bb = mk3(0, 0, 0), ax = mk3(0, 0, 0), bd = mk3(0, 0, 0);
         if (freerow) {
-            const d3 pi = ld3(pts + 3 * row);
-            const double* Ri = rot + 9 * (int64_t)row;
-            const int e0 = 64 * (2 * G + (r16 >> 3)) + (r16 & 7) * 8 + q;
-            double w[2]; int j[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) { w[u] = m.w[e0 + 4 * u]; j[u] = m.col[e0 + 4 * u]; }
-            double ri[9];
-#pragma unroll
-            for (int c = 0; c < 9; ++c) ri[c] = Ri[c];
+            const d3 pi = pi4;
+            const double (&ri)[9] = ri4;
+            const double (&w)[2] = w4;
+            const int (&j)[2] = j4;
             d3 xj[2], pj[2]; double rj[2][9]; int cj[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -531,7 +541,10 @@ __global__ __launch_bounds__(TPB) void k_cg_iter(SellDev m, const double* __rest
 __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __restrict__ pts, const double* __restrict__ sol,
                                                     int it, double tol, double* __restrict__ ered, double* __restrict__ rot,
                                                     const double* __restrict__ bvec) {
-    if (block_done(ered + EFIN, it, tol)) return;
+    // the stop rule's verdict (one thread: two dependent loads and an fp64 division) travels WITH the first vertex's loads, not in
+    // front of them: the workgroup's barrier comes after those loads have been issued
+    __shared__ int s_stop;
+    if (threadIdx.x == 0) s_stop = arap_done_before(ered + EFIN, it, tol) ? 1 : 0;
 #ifdef MVS_STAMPS
 #define LSTAMP(k) do { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
         if ((threadIdx.x & 63) == 0 && it == 2) g_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } while (0)
@@ -541,24 +554,39 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
     LSTAMP(0);
     double e_acc = 0.0;
     double g0 = 0.0, g1 = 0.0, g2 = 0.0;          // true residual of the global solve whose result `sol` is: sum r_c^2 / d_i over the free rows
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < m.V; i += gridDim.x * 256) {
-        const int g = i >> 3, r = i & 7, off = m.single_pass ? 64 * g : m.slice_off[g], passes = m.single_pass ? 1 : (m.slice_off[g + 1] - off) >> 6;
-        const d3 pi = ld3(pts + 3 * i), qi = ld3(sol + 3 * i);
+    // the first eight edges of a vertex (all of them when the degree is <= 8): weights and edge vectors of the rest and the current pose
+    struct Edges { int off, passes; d3 pi, qi; double w0[8]; d3 pp0[8], qq0[8]; bool judge; };
+    auto fetch = [&](int i, Edges& E) {
+        const int g = i >> 3, r = i & 7;
+        E.off = m.single_pass ? 64 * g : m.slice_off[g];
+        E.passes = m.single_pass ? 1 : (m.slice_off[g + 1] - E.off) >> 6;
+        E.pi = ld3(pts + 3 * i); E.qi = ld3(sol + 3 * i);
+        E.judge = bvec != nullptr && m.is_ctrl[i] == 0;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const int e = E.off + r * 8 + l;
+            E.w0[l] = m.w[e];
+            const int j = E.w0[l] == 0.0 ? i : m.col[e];
+            E.pp0[l] = E.pi - ld3(pts + 3 * j); E.qq0[l] = E.qi - ld3(sol + 3 * j);
+        }
+    };
+    const int i_first = blockIdx.x * 256 + threadIdx.x;
+    Edges E;
+    if (i_first < m.V) fetch(i_first, E);
+    __syncthreads();
+    if (s_stop) return;
+    for (int i = i_first; i < m.V; i += gridDim.x * 256) {
+        if (i != i_first) fetch(i, E);
+        const int r = i & 7, off = E.off, passes = E.passes;
+        const d3 pi = E.pi, qi = E.qi;
         double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        // the first eight edges (all of them when the degree is <= 8) stay in registers for the energy term
-        double w0[8];
-        d3 pp0[8], qq0[8];
-        const bool judge = bvec != nullptr && m.is_ctrl[i] == 0;
+        double (&w0)[8] = E.w0;
+        d3 (&pp0)[8] = E.pp0;
+        d3 (&qq0)[8] = E.qq0;
+        const bool judge = E.judge;
         // r_i = b_i - (d_i x_i - sum_{free j} 2 w_ij x_j) = (b_i - sum_{ctrl j} 2 w_ij x_j) - sum_j 2 w_ij (x_i - x_j): the first
         // bracket is the `bpure` the rhs kernel wrote (bvec), the edge differences are the ones of the covariance
         d3 ax = mk3(0, 0, 0);
-#pragma unroll
-        for (int l = 0; l < 8; ++l) {
-            const int e = off + r * 8 + l;
-            w0[l] = m.w[e];
-            const int j = w0[l] == 0.0 ? i : m.col[e];
-            pp0[l] = pi - ld3(pts + 3 * j); qq0[l] = qi - ld3(sol + 3 * j);
-        }
 #pragma unroll
         for (int l = 0; l < 8; ++l) {
             if (w0[l] == 0.0) continue;
