@@ -2,6 +2,7 @@
 // the drop-in for class Deformation (R/Deformation/Deformation.h:224-252).
 // Host orchestration only; every per-point / per-vertex operation is a HIP kernel.
 #include "engine.h"
+#include "knobs.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -10,6 +11,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <tuple>
+#include <mutex>
 #include <sched.h>
 
 // ------------------------------------------------------------------ errors ----
@@ -28,6 +30,10 @@ int mvs_check_hip(hipError_t e, const char* what) {
     return e == hipErrorOutOfMemory ? MVS_E_OOM : MVS_E_HIP;
 }
 int mvs_current_device() { return g_device; }
+int mvs_debug_level() {
+    static const int level = [] { const char* e = getenv("MVS_DEBUG_CG"); return (e && *e) ? (e[0] == '2' ? 2 : 1) : 0; }();
+    return level;
+}
 
 extern "C" {
 
@@ -73,6 +79,28 @@ template <class T> int dmalloc(T** p, size_t n) {
     return mvs_check_hip(hipMalloc((void**)p, n * sizeof(T)), "hipMalloc");
 }
 template <class T> void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+// Streams of destroyed handles are kept for the next handle: hipStreamCreate is the most expensive call of a cold
+// mvs_deform_create on this runtime (5.7 ms for a new hardware queue, measured; the whole device-side mesh build is < 1 ms).
+// A released stream has been synchronised by mvs_deform_destroy.  At most 64 idle streams are kept per process.
+struct PooledStream { int device; hipStream_t s; };
+std::mutex g_pool_mutex;
+std::vector<PooledStream> g_pool;
+int stream_acquire(int device, hipStream_t* out) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i].device == device) { *out = g_pool[i].s; g_pool.erase(g_pool.begin() + i); return MVS_OK; }
+    }
+    return mvs_check_hip(hipStreamCreateWithFlags(out, hipStreamNonBlocking), "hipStreamCreate");
+}
+void stream_release(int device, hipStream_t s) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        if (g_pool.size() < 64) { g_pool.push_back({device, s}); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
 
 int need_device() {
     if (mvs_device_count() == 0) { mvs_set_error("no HIP device: the MI355X engine has no CPU fallback"); return MVS_E_NO_DEVICE; }
@@ -130,12 +158,12 @@ void collect_timers(mvs_deform_s* h) {
 }
 
 void free_nodes(mvs_deform_s* h) {
-    dfree(h->d_nodes); dfree(h->d_nbr); dfree(h->d_node_pts); dfree(h->d_node_nrm); dfree(h->d_ctrl_raw);
-    dfree(h->d_ctrl_a); dfree(h->d_ctrl_b); dfree(h->d_valid); dfree(h->d_d2min); dfree(h->d_counts);
-    dfree(h->d_records); dfree(h->d_top_idx); dfree(h->d_heavy); dfree(h->d_heavy2);
-    dfree(h->d_prev_d2); dfree(h->d_prev_node);
+    if (h->arena_nodes) { (void)hipFree(h->arena_nodes); h->arena_nodes = nullptr; }
+    h->d_nodes = nullptr; h->d_nbr = nullptr; h->d_node_pts = nullptr; h->d_node_nrm = nullptr; h->d_ctrl_raw = nullptr;
+    h->d_ctrl_a = nullptr; h->d_ctrl_b = nullptr; h->d_valid = nullptr; h->d_d2min = nullptr; h->d_counts = nullptr;
+    h->d_records = nullptr; h->d_top_idx = nullptr; h->d_heavy = nullptr; h->d_heavy2 = nullptr;
+    h->d_prev_d2 = nullptr; h->d_prev_node = nullptr; h->d_knn_ws = nullptr;
     h->prev_valid = false;
-    if (h->d_knn_ws) { (void)hipFree(h->d_knn_ws); h->d_knn_ws = nullptr; }
     h->d_ctrl_final = nullptr; h->K = 0; h->nbr_k = 0; h->h_nodes.clear();
     h->graph_ready_nn = 0; h->weights_ready = false; h->heavy_pending = nullptr;
 }
@@ -153,10 +181,10 @@ inline int ras_spares(int used) { return RAS_SPARES + used / 8; }
 // cannot know) and normally improves it by another 10-20x, but near convergence the float32 / bfloat16 local corrections
 // make the residual history noisy (a sweep may give back some of it in the ill-conditioned late regime of a long fit,
 // scripts/pass_trace.py) — the factor 2 keeps the RESULT below cg_tol, which is what every solve is judged by.
-const double STOP_AT = getenv("MVS_STOP_AT") ? atof(getenv("MVS_STOP_AT")) : 0.5;
+#define STOP_AT MVS_KNOB("MVS_STOP_AT", 0.5, 0.01, 1.0)
 // lowest bracket end the harvest goes to: with the step count capped at 32, a lower `a` only weakens the damping of every
 // mode inside the bracket (1 / T_32 at a = 0.002 is 0.26, at 0.01 it is 0.02) — measured in the late regime of scripts/soak.py
-const double RAS_A_FLOOR = getenv("MVS_RAS_FLOOR") ? atof(getenv("MVS_RAS_FLOOR")) : 0.01;
+#define RAS_A_FLOOR MVS_KNOB("MVS_RAS_FLOOR", 0.01, 0.001, 0.06)
 constexpr double PEEK_AT = 1.0;          // CG: a solve that ends above PEEK_AT * cg_tol gets a longer plan inside the batch
 
 struct CgPlan {                      // CG launches per ARAP iteration and where each solve's slots start
@@ -170,33 +198,29 @@ struct RasPlan {                     // sweeps per ARAP iteration of the patch s
     int n[8];
     int64_t total(int iters) const { int64_t t = 0; for (int i = 0; i < iters; ++i) t += n[i]; return t; }
 };
-constexpr int RAS_FIRST_PLAN = 64;   // sweeps of an uncalibrated solve (5-7 are needed at the usual node density; the rest degenerate into copies)
+// launches of a solve that has no history yet (first pass of a handle or of a node set): from the template pose 4-6 sweeps
+// run at the usual node density, the launches left over return after one scalar load, and should the eight not suffice the
+// last one keeps sweeping in the kernel (TAIL) — the DEVICE decides; round 2 probed such a solve in chunks of sweeps with a
+// host look at the residual after each (five synchronisations per solve, 8 ms for the first outer iteration)
+constexpr int RAS_FIRST_PLAN = 8;
 constexpr int RAS_MAX_SWEEPS = 128;
 
 RasPlan probe_ras(const mvs_deform_s* h) {
     RasPlan r;
     for (int i = 0; i < 8; ++i) r.n[i] = h->ras_plan[i] > 0 ? h->ras_plan[i] : RAS_FIRST_PLAN;
     // experiment (scripts/host_bound.py): at most this many LAUNCHES per solve — the rest of the sweeps run inside the last one
-    static const int cap = getenv("MVS_RAS_PLAN_CAP") ? atoi(getenv("MVS_RAS_PLAN_CAP")) : 0;
+    const int cap = (int)MVS_KNOB("MVS_RAS_PLAN_CAP", 0, 0, 128);
     if (cap > 0) for (int i = 0; i < 8; ++i) if (h->ras_plan[i] > 0) r.n[i] = std::min(r.n[i], cap);
     return r;
 }
 bool use_ras(const mvs_deform_s* h, const mvs_deform_params& p) { return h->has_ras && p.solver != MVS_SOLVER_CG; }
 
 int ensure_ras_slots(mvs_deform_s* h, int arap_iters, const RasPlan& rp) {
-    // sized once for the largest plan: the host may add sweeps to a solve between two passes of a batch (peek_ring), and a
+    // the sweep slots are part of the handle's table arena, sized once for the largest plan (RAS_MAX_SWEEPS sweeps of each of
+    // 8 ARAP iterations, mesh_build): the host may add sweeps to a solve between two passes of a batch (peek_ring), and a
     // re-allocation would pull the buffer from under the passes still in flight
     (void)rp;
-    const int64_t need = (int64_t)RAS_MAX_SWEEPS * arap_iters;
-    if (need > h->ras_slots_cap) {
-        dfree(h->d_ras_slots); dfree(h->d_ras_iters);
-        dfree(h->d_ras_tail);
-        int rc = dmalloc(&h->d_ras_slots, (size_t)need * ras_slot_size(h));
-        if (!rc) rc = dmalloc(&h->d_ras_iters, (size_t)need * h->ras.NP);
-        if (!rc) rc = dmalloc(&h->d_ras_tail, (size_t)8 * RAS_TAIL_MAX * ras_slot_size(h));
-        if (rc) return rc;
-        h->ras_slots_cap = need;
-    }
+    if ((int64_t)RAS_MAX_SWEEPS * arap_iters > h->ras_slots_cap || !h->d_ras_slots) { mvs_set_error("sweep slots not provisioned"); return MVS_E_STATE; }
     return MVS_OK;
 }
 
@@ -214,11 +238,8 @@ int ensure_slots(mvs_deform_s* h, int arap_iters, const CgPlan& cg) {
 
 // association of the handle's nodes against the handle's (local) target, nranks = 1
 static int ensure_nbr(mvs_deform_s* h, int nn) {
-    if (nn == h->nbr_k) return MVS_OK;
-    dfree(h->d_nbr);
-    h->nbr_k = 0;
-    int rc = dmalloc(&h->d_nbr, (size_t)h->K * nn);
-    if (rc) return rc;
+    // the node arena holds K * 64 neighbour slots (graph_k <= 63); the table in use is [K][nn]
+    if (!h->d_nbr || nn < 1 || nn > 64) { mvs_set_error("no node set / graph_k out of range"); return MVS_E_STATE; }
     h->nbr_k = nn;
     return MVS_OK;
 }
@@ -318,17 +339,12 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     double* x_cur = h->d_sol;            // the patch solver ping-pongs between d_sol and d_ras_x2
     int64_t ras_slot = 0;
     const double* prev_scal = nullptr;   // the 8 scalars of the last sweep slot of the previous solve (idle flag, sweeps that ran)
-    // fused mode (RasDev::fuse): the local step of iteration k and the right-hand side of k+1 are ONE patch kernel; only
-    // iteration 0's right-hand side (R = I) is a launch of its own, and the first sweep of a solve closes the previous
-    // iteration's stop-rule bookkeeping (what k_arap_rhs did)
-    const bool fuse = ras && h->ras.fuse != 0;
     for (int it = 0; ras && it < p.arap_iters; ++it) {
-        if (it == 0 || !fuse) {
+        {
             Tic t = tic(h, "rhs");
             launch_arap_rhs(h->sell, h->d_pts, x_cur, h->d_rot, it, p.arap_tol, h->d_energy, nullptr, nullptr, h->d_ras_b, p.cg_tol, h->d_ctl, slot, prev_scal, h->d_bar, h->d_bpure, s);
             toc(t, 1);
         }
-        const double* before_scal = prev_scal;               // (fused mode: the solve the fused kernel's extra block judges)
         {
             Tic t = tic(h, "cg");
             const int ss = ras_slot_size(h);
@@ -338,43 +354,18 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
                 // the last planned sweep of a solve is a TAIL launch: should the plan turn out too short it keeps sweeping in
                 // the kernel (its extra sweeps' partial sums go to the solve's tail slots)
                 launch_ras_sweep(h, h->d_ras_b, x_cur, x_next, it, p.arap_tol, i, p.cg_tol, STOP_AT, i > 0 ? cur - ss : nullptr, cur,
-                                 h->d_ras_iters + (size_t)ras_slot * h->ras.NP, s, last ? h->d_ras_tail + (size_t)it * RAS_TAIL_MAX * ss : nullptr,
-                                 fuse && i == 0 && it >= 1);
+                                 h->d_ras_iters + (size_t)ras_slot * h->ras.NP, s, last ? h->d_ras_tail + (size_t)it * RAS_TAIL_MAX * ss : nullptr);
                 x_cur = x_next;
                 ++ras_slot;
             };
-            int launched = 0;
-            if (h->ras_plan[it] > 0) {
-                for (int i = 0; i < rp.n[it]; ++i) sweep(i, i == rp.n[it] - 1);
-                launched = rp.n[it];
-            } else {
-                // this solve has no calibrated sweep count yet (first call on the handle): sweeps go out in chunks and the
-                // host looks at the residual after each — a few synchronisations once, instead of a worst-case plan
-                const int NPpad = h->ras.NPpad;
-                std::vector<double> part((size_t)3 * NPpad + 8);
-                bool conv = false;
-                while (!conv && launched < RAS_FIRST_PLAN) {
-                    const int chunk = std::min(launched == 0 ? 6 : 4, RAS_FIRST_PLAN - launched);
-                    for (int i = 0; i < chunk; ++i) sweep(launched + i, false);
-                    launched += chunk;
-                    HIPCHK(hipMemcpyAsync(part.data(), h->d_ras_slots + (size_t)(ras_slot - 1) * ss, sizeof(double) * part.size(), hipMemcpyDeviceToHost, s));
-                    HIPCHK(hipStreamSynchronize(s));
-                    conv = true;                                  // residual of the INPUT of the last sweep launched
-                    for (int c = 0; c < 3; ++c) {
-                        double g = 0.0;
-                        for (int q = 0; q < 4 * h->ras.NP; ++q) g += part[(size_t)c * NPpad + q];
-                        if (g > 0.0 && g > STOP_AT * STOP_AT * p.cg_tol * p.cg_tol * part[(size_t)3 * NPpad + 3 + c]) conv = false;
-                    }
-                }
-                h->ras_plan[it] = launched;                       // harvest_ras reads the slots with this layout, then re-plans
-            }
+            for (int i = 0; i < rp.n[it]; ++i) sweep(i, i == rp.n[it] - 1);
+            const int launched = rp.n[it];
             toc(t, launched);
             prev_scal = h->d_ras_slots + (size_t)(ras_slot - 1) * ss + 3 * (size_t)h->ras.NPpad;
         }
         {
             Tic t = tic(h, "local");
-            if (fuse) launch_ras_local_rhs(h, x_cur, it, p.arap_iters, p.arap_tol, p.cg_tol, slot, before_scal, s);
-            else launch_arap_local(h->sell, h->d_pts, x_cur, it, p.arap_tol, h->d_energy, h->d_rot, h->d_bpure, s);
+            launch_arap_local(h->sell, h->d_pts, x_cur, it, p.arap_tol, h->d_energy, h->d_rot, h->d_bpure, s);
             toc(t, 1);
         }
     }
@@ -451,7 +442,7 @@ void peek_ring(mvs_deform_s* h, const mvs_deform_params& p, bool ras) {
     if (q >= done) return;
     if (done > MVS_RING && q < done - MVS_RING) q = done - MVS_RING;
     const double tol2 = PEEK_AT * PEEK_AT * p.cg_tol * p.cg_tol;
-    static const bool plan_lowering = !(getenv("MVS_PLAN_LOWER") && getenv("MVS_PLAN_LOWER")[0] == '0');
+    const bool plan_lowering = MVS_KNOB("MVS_PLAN_LOWER", 1, 0, 1) != 0.0;
     for (; q < done; ++q) {
         const volatile double* row = h->h_ctl + MVS_CTL_RING + (q % MVS_RING) * 8;
         const volatile double* used = h->h_ctl + MVS_CTL_USED + (q % MVS_RING) * 8;
@@ -465,21 +456,19 @@ void peek_ring(mvs_deform_s* h, const mvs_deform_params& p, bool ras) {
                 if (u != 0) {
                     const int ran = std::abs(u) + (u < 0 ? 1 : 0);
                     want = ran + ras_spares(ran);
-                    const int rise = 0;
-                    h->ras_rise[it] = rise; h->ras_seen[it] = ran;
                     // ... and a plan that has been more than generous for four passes in a row comes down to what they needed
                     // (plus the spare): right after a calibration or a harvest of a few passes the plans carry the first
                     // passes' needs, which fall quickly (the bench's window, passes 3-22: 27 launches for 19 sweeps that run)
                     int* hist = h->ras_hist[it];
                     if (h->ras_hist_n[it] == 4) { hist[0] = hist[1]; hist[1] = hist[2]; hist[2] = hist[3]; hist[3] = ran; }
                     else hist[h->ras_hist_n[it]++] = ran;
-                    static const int HN = getenv("MVS_PLAN_HIST") ? std::max(1, std::min(4, atoi(getenv("MVS_PLAN_HIST")))) : 4;
+                    const int HN = (int)MVS_KNOB("MVS_PLAN_HIST", 4, 1, 4);
                     if (plan_lowering && h->ras_hist_n[it] >= HN && u > 0) {
                         int m = 0;
                         for (int k = h->ras_hist_n[it] - HN; k < h->ras_hist_n[it]; ++k) m = std::max(m, hist[k]);
                         const int low = m + ras_spares(m);
                         if (low < h->ras_plan[it] && want <= low) {
-                            if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] pass %llu solve %d: plan %d -> %d (the last four passes ran <= %d sweeps)\n",
+                            if (mvs_debug_level()) fprintf(stderr, "[mvs] pass %llu solve %d: plan %d -> %d (the last four passes ran <= %d sweeps)\n",
                                                                 (unsigned long long)q, it, h->ras_plan[it], low, m);
                             h->ras_plan[it] = low;
                         }
@@ -488,7 +477,7 @@ void peek_ring(mvs_deform_s* h, const mvs_deform_params& p, bool ras) {
                 if (rel2 > tol2) want = std::max(want, h->ras_plan[it] + ras_spares(h->ras_plan[it]) + 1);     // it missed although every sweep ran
                 want = std::min(RAS_MAX_SWEEPS, want);
                 if (want > h->ras_plan[it]) {
-                    if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] pass %llu solve %d ran %d of %d sweeps (ended at %.2e of cg_tol): plan %d from pass %llu on\n",
+                    if (mvs_debug_level()) fprintf(stderr, "[mvs] pass %llu solve %d ran %d of %d sweeps (ended at %.2e of cg_tol): plan %d from pass %llu on\n",
                                                         (unsigned long long)q, it, std::abs(u), h->ras_plan[it], std::sqrt(rel2) / p.cg_tol, want, (unsigned long long)h->seq_enqueued);
                     h->ras_plan[it] = want;
                 }
@@ -511,7 +500,7 @@ int read_judgement(mvs_deform_s* h, const mvs_deform_params& p, Judgement* j) {
     HIPCHK(hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     j->esc = ctl[MVS_CTL_ESC] != 0.0;
-    if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] predicted stops: true / predicted residual (running maximum) %.2f\n", std::sqrt(std::max(1.0, ctl[MVS_CTL_PSAFE])));
+    if (mvs_debug_level()) fprintf(stderr, "[mvs] predicted stops: true / predicted residual (running maximum) %.2f\n", std::sqrt(std::max(1.0, ctl[MVS_CTL_PSAFE])));
     j->worst2 = ctl[MVS_CTL_WORST];
     j->missed = (int)ctl[MVS_CTL_MISSED];
     j->solves = (int)ctl[MVS_CTL_SOLVES];
@@ -587,7 +576,7 @@ int harvest(mvs_deform_s* h, const mvs_deform_params& p, const CgPlan& plan, mvs
         else h->cg_plan[it] = std::min(p.cg_max_iters, first + first / 8 + 2);
         need = std::max(need, first);
         launches += cg; active += first;
-        if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] arap it %d: CG frozen at %d of %d (gamma0 %.3e bn %.3e), true residual %.3e\n", it, first, cg, gamma_of(0, 0), S[MVS_CG_FIN + 6], std::sqrt(std::max(0.0, jd.last_row[it])));
+        if (mvs_debug_level()) fprintf(stderr, "[mvs] arap it %d: CG frozen at %d of %d (gamma0 %.3e bn %.3e), true residual %.3e\n", it, first, cg, gamma_of(0, 0), S[MVS_CG_FIN + 6], std::sqrt(std::max(0.0, jd.last_row[it])));
     }
     if (converged) *converged = all_conv && jd.missed == 0;
     for (int it = run; it < p.arap_iters; ++it)            // solves skipped by the energy stop rule keep a safe count
@@ -676,10 +665,10 @@ int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* s
             h->ras_plan[it] = std::min(RAS_MAX_SWEEPS, most + ras_spares(most));
             worst_first = std::max(worst_first, ran - 1);
         }
-        if (getenv("MVS_DEBUG_CG")) {
+        if (mvs_debug_level()) {
             fprintf(stderr, "[mvs] arap it %d: %d of %d planned sweeps ran%s (true final residual %.3e) -> plan %d\n", it, ran, n, idle ? "" : " — no spare left",
                     std::sqrt(std::max(0.0, final2)), h->ras_plan[it]);
-            if (getenv("MVS_DEBUG_CG")[0] == '2') {
+            if (mvs_debug_level() >= 2) {
                 fprintf(stderr, "[mvs]   residual of each sweep's input:");
                 for (int i = 0; i < std::min(n - 1, ran); ++i) fprintf(stderr, " %.2e", std::sqrt(rel2_at(i)));
                 fprintf(stderr, "\n");
@@ -699,7 +688,7 @@ int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* s
             for (int it = 0; it < run; ++it) h->ras_plan[it] = std::min(RAS_MAX_SWEEPS, h->ras_plan[it] + 2);   // the old plan was measured with stronger local solves
         }
         if (a != h->ras_a) { h->ras_a = a; h->ras_m = ras_steps_for(a); }
-        if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] patch solver bracket a = %.4f, %d steps per sweep\n", h->ras_a, h->ras_m);
+        if (mvs_debug_level()) fprintf(stderr, "[mvs] patch solver bracket a = %.4f, %d steps per sweep\n", h->ras_a, h->ras_m);
     }
     for (int it = run; it < p.arap_iters; ++it)            // solves skipped by the energy stop rule keep a safe count
         if (h->ras_plan[it] == 0) h->ras_plan[it] = h->ras_plan[std::max(0, run - 1)];
@@ -735,6 +724,8 @@ CgPlan probe_cg(const mvs_deform_s* h, const mvs_deform_params& p) {
 extern "C" {
 
 // ------------------------------------------------------------------- create ----
+// Deformation::Deformation(points, normals, facets), Deformation.cpp:29-46: the mesh is checked and every table the solvers
+// need is built ON THE DEVICE (meshbuild.hip) — two allocations, three uploads, one synchronisation.
 int mvs_deform_create(int64_t V, const double* points, const double* normals, int64_t F, const int32_t* faces,
                       mvs_deform_t* out) {
     if (!out) { mvs_set_error("out is NULL"); return MVS_E_INVALID_ARG; }
@@ -742,97 +733,17 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals, in
     if (V <= 0 || F < 0 || !points || !normals || (F > 0 && !faces) || V > 0x7ffffff0LL || F > 0x2aaaaaa0LL) {
         mvs_set_error("bad mesh arguments"); return MVS_E_INVALID_ARG;
     }
-    const auto t_create0 = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) { if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] create: %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count()); };
-    // validity (what Polyhedron_incremental_builder_3 / is_valid reject, Deformation.cpp:36-45) and the adjacency rows
-    // (neighbours ascending, the <= 2 opposite vertices ascending).  Half-edges are bucketed by their source vertex
-    // (counting sort), each vertex then orders its own dozen entries: linear in F instead of two global sorts.
-    std::vector<int32_t> hptr(V + 1, 0);
-    for (int64_t f = 0; f < F; ++f) {
-        const int v[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
-        for (int k = 0; k < 3; ++k)
-            if (v[k] < 0 || v[k] >= V) { mvs_set_error("facet %lld: vertex index out of range", (long long)f); return MVS_E_BAD_MESH; }
-        if (v[0] == v[1] || v[1] == v[2] || v[0] == v[2]) { mvs_set_error("facet %lld: repeated vertex", (long long)f); return MVS_E_BAD_MESH; }
-        for (int k = 0; k < 3; ++k) hptr[v[k] + 1] += 2;                 // every corner is the source of two half-edges of its facet
-    }
-    for (int64_t i = 0; i < V; ++i) hptr[i + 1] += hptr[i];
-    struct Half { int32_t j, opp, fwd; };                                // neighbour, opposite vertex, 1 = in facet orientation
-    std::vector<Half> hal((size_t)F * 6);
-    {
-        std::vector<int32_t> cur(hptr.begin(), hptr.end() - 1);
-        for (int64_t f = 0; f < F; ++f)
-            for (int k = 0; k < 3; ++k) {
-                const int a = faces[3 * f + k], b = faces[3 * f + (k + 1) % 3], c = faces[3 * f + (k + 2) % 3];
-                hal[cur[a]++] = {b, c, 1};
-                hal[cur[b]++] = {a, c, 0};
-            }
-    }
-    std::vector<int32_t> rowptr(V + 1, 0), col, o0, o1;
-    col.reserve((size_t)F * 3); o0.reserve((size_t)F * 3); o1.reserve((size_t)F * 3);
-    for (int64_t i = 0; i < V; ++i) {
-        Half* b = hal.data() + hptr[i];
-        Half* e = hal.data() + hptr[i + 1];
-        std::sort(b, e, [](const Half& x, const Half& y) { return x.j != y.j ? x.j < y.j : x.opp < y.opp; });
-        for (Half* q = b; q < e;) {
-            Half* r = q;
-            int fwd = 0;
-            while (r < e && r->j == q->j) { fwd += r->fwd; ++r; }
-            if (fwd > 1) { mvs_set_error("directed edge (%d,%d) used twice: non-manifold or inconsistently oriented", (int)i, q->j); return MVS_E_NONMANIFOLD; }
-            col.push_back(q->j); o0.push_back(q->opp); o1.push_back(r - q > 1 ? (q + 1)->opp : -1);
-            q = r;
-        }
-        rowptr[i + 1] = (int32_t)col.size();
-    }
+    const auto t_c0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (mvs_debug_level()) fprintf(stderr, "[mvs] create (api): %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_c0).count()); };
     int rc = need_device();
     if (rc) return rc;
-    // ELL-8 by row group: group = 8 rows = one wave; entry (row r of group, pass t, lane l) at goff + (8 t + r) * 8 + l
-    const int nslices = (int)((V + 7) / 8);
-    std::vector<int32_t> slice_off(nslices + 1, 0);
-    for (int g = 0; g < nslices; ++g) {
-        int dmax = 0;
-        for (int64_t i = (int64_t)g * 8; i < std::min<int64_t>(V, (int64_t)g * 8 + 8); ++i) dmax = std::max(dmax, rowptr[i + 1] - rowptr[i]);
-        slice_off[g + 1] = slice_off[g] + ((dmax + 7) / 8) * 64;
-    }
-    const int64_t ne = slice_off[nslices];
-    std::vector<int32_t> scol(ne), sopp0(ne, -1), sopp1(ne, -1);
-    for (int g = 0; g < nslices; ++g) {
-        const int passes = (slice_off[g + 1] - slice_off[g]) / 64;
-        for (int r = 0; r < 8; ++r) {
-            const int64_t i = (int64_t)g * 8 + r;
-            for (int t = 0; t < passes; ++t)
-                for (int l = 0; l < 8; ++l) {
-                    const int64_t e = slice_off[g] + (8 * t + r) * 8 + l;
-                    const int k = 8 * t + l;
-                    if (i < V && k < rowptr[i + 1] - rowptr[i]) {
-                        scol[e] = col[rowptr[i] + k]; sopp0[e] = o0[rowptr[i] + k]; sopp1[e] = o1[rowptr[i] + k];
-                    } else scol[e] = (int32_t)std::min<int64_t>(i, V - 1);
-                }
-        }
-    }
-    // vertex -> facet CSR (ascending facet index)
-    std::vector<int32_t> vf_ptr(V + 1, 0), vf((size_t)F * 3);
-    for (int64_t f = 0; f < 3 * F; ++f) vf_ptr[faces[f] + 1]++;
-    for (int64_t i = 0; i < V; ++i) vf_ptr[i + 1] += vf_ptr[i];
-    {
-        std::vector<int32_t> cur(vf_ptr.begin(), vf_ptr.end() - 1);
-        for (int64_t f = 0; f < F; ++f) for (int k = 0; k < 3; ++k) vf[cur[faces[3 * f + k]]++] = (int32_t)f;
-    }
-
-    lap("ELL tables");
+    lap("device");
     mvs_deform_s* h = new mvs_deform_s;
-    h->device = g_device; h->V = V; h->F = F; h->n_entries = ne;
+    h->device = g_device; h->V = V; h->F = F;
 #define TRY(x) do { rc = (x); if (rc) { mvs_deform_destroy(h); return rc; } } while (0)
-    TRY(mvs_check_hip(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking), "hipStreamCreate"));
+    TRY(stream_acquire(g_device, &h->own_stream));
     h->stream = h->own_stream;
-    TRY(dmalloc(&h->d_pts, (size_t)V * 3)); TRY(dmalloc(&h->d_nrm, (size_t)V * 3)); TRY(dmalloc(&h->d_sol, (size_t)V * 3));
-    TRY(dmalloc(&h->d_rot, (size_t)V * 9)); TRY(dmalloc(&h->d_faces, (size_t)F * 3));
-    TRY(dmalloc(&h->d_vf_ptr, (size_t)V + 1)); TRY(dmalloc(&h->d_vf, (size_t)F * 3));
-    TRY(dmalloc(&h->d_slice_off, (size_t)nslices + 1)); TRY(dmalloc(&h->d_col, (size_t)ne)); TRY(dmalloc(&h->d_opp0, (size_t)ne));
-    TRY(dmalloc(&h->d_opp1, (size_t)ne)); TRY(dmalloc(&h->d_w, (size_t)ne)); TRY(dmalloc(&h->d_diag, (size_t)V));
-    TRY(dmalloc(&h->d_is_ctrl, (size_t)V));
-    for (int k = 0; k < 2; ++k) TRY(dmalloc(&h->d_rws[k], (size_t)V * 9));
-    TRY(dmalloc(&h->d_p, (size_t)V * 3)); TRY(dmalloc(&h->d_coef, (size_t)ne)); TRY(dmalloc(&h->d_energy, MVS_ERED_SIZE)); TRY(dmalloc(&h->d_info, 8));
-    TRY(dmalloc(&h->d_ras_b, (size_t)V * 3)); TRY(dmalloc(&h->d_ctl, MVS_CTL_SIZE)); TRY(dmalloc(&h->d_bar, (size_t)MVS_BAR_WORDS * MVS_BAR_STRIDE)); TRY(dmalloc(&h->d_bpure, (size_t)V * 3));
+    lap("stream");
     {   // pinned, host-coherent mirror of the control block: the last kernel of every pass writes it, the host reads it
         // without synchronising (throttle / peek_ring)
         void* hp = nullptr;
@@ -840,25 +751,10 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals, in
         std::memset(hp, 0, sizeof(double) * MVS_CTL_SIZE);
         h->h_ctl = (volatile double*)hp;
     }
-    auto up = [&](void* d, const void* s, size_t n) { return mvs_check_hip(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, h->stream), "upload"); };
-    TRY(up(h->d_pts, points, sizeof(double) * V * 3)); TRY(up(h->d_nrm, normals, sizeof(double) * V * 3));
-    TRY(up(h->d_sol, points, sizeof(double) * V * 3));
-    if (F) { TRY(up(h->d_faces, faces, sizeof(int32_t) * F * 3)); TRY(up(h->d_vf, vf.data(), sizeof(int32_t) * F * 3)); }
-    TRY(up(h->d_vf_ptr, vf_ptr.data(), sizeof(int32_t) * (V + 1)));
-    TRY(up(h->d_slice_off, slice_off.data(), sizeof(int32_t) * (nslices + 1)));
-    if (ne) { TRY(up(h->d_col, scol.data(), sizeof(int32_t) * ne)); TRY(up(h->d_opp0, sopp0.data(), sizeof(int32_t) * ne)); TRY(up(h->d_opp1, sopp1.data(), sizeof(int32_t) * ne)); }
-    TRY(mvs_check_hip(hipMemsetAsync(h->d_is_ctrl, 0, sizeof(int32_t) * V, h->stream), "memset"));
-    TRY(mvs_check_hip(hipMemsetAsync(h->d_rot, 0, sizeof(double) * V * 9, h->stream), "memset"));
-    TRY(mvs_check_hip(hipMemsetAsync(h->d_info, 0, sizeof(int32_t) * 8, h->stream), "memset"));
-    TRY(mvs_check_hip(hipMemsetAsync(h->d_ctl, 0, sizeof(double) * MVS_CTL_SIZE, h->stream), "memset"));
-    TRY(mvs_check_hip(hipMemsetAsync(h->d_energy, 0, sizeof(double) * MVS_ERED_SIZE, h->stream), "memset"));
-    TRY(mvs_check_hip(hipStreamSynchronize(h->stream), "sync"));
-    lap("allocations + uploads");
-    TRY(ras_build(h, points, rowptr, col, slice_off));
-    lap("patch tables");
+    lap("pinned mirror");
+    TRY(mesh_build(h, points, normals, faces));
+    lap("mesh_build");
 #undef TRY
-    h->sell.V = (int32_t)V; h->sell.nslices = nslices; h->sell.single_pass = (ne == (int64_t)nslices * 64) ? 1 : 0; h->sell.slice_off = h->d_slice_off; h->sell.col = h->d_col;
-    h->sell.opp0 = h->d_opp0; h->sell.opp1 = h->d_opp1; h->sell.w = h->d_w; h->sell.diag = h->d_diag; h->sell.is_ctrl = h->d_is_ctrl;
     *out = h;
     return MVS_OK;
 }
@@ -868,59 +764,66 @@ int mvs_deform_destroy(mvs_deform_t h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_nodes(h);
-    dfree(h->d_pts); dfree(h->d_nrm); dfree(h->d_sol); dfree(h->d_rot); dfree(h->d_faces); dfree(h->d_vf_ptr); dfree(h->d_vf);
-    dfree(h->d_slice_off); dfree(h->d_col); dfree(h->d_opp0); dfree(h->d_opp1); dfree(h->d_is_ctrl); dfree(h->d_w); dfree(h->d_diag);
-    dfree(h->d_spos); dfree(h->d_tpos); dfree(h->d_tnrm); dfree(h->d_cell_start); dfree(h->d_coarse_cnt);
-    for (int k = 0; k < 2; ++k) dfree(h->d_rws[k]);
-    dfree(h->d_p); dfree(h->d_coef); dfree(h->d_slots); dfree(h->d_energy); dfree(h->d_info); dfree(h->d_ctl); dfree(h->d_bar); dfree(h->d_ras_tail); dfree(h->d_bpure);
+    for (void* a : {h->arena_mesh, h->arena_tab, h->arena_target, h->arena_probe}) if (a) (void)hipFree(a);
+    dfree(h->d_slots);
     if (h->d_sh) { (void)hipFree(h->d_sh); h->d_sh = nullptr; }
     if (h->h_ctl) { (void)hipHostFree((void*)h->h_ctl); h->h_ctl = nullptr; }
-    ras_free(h);
     for (auto& pr : h->pending) { (void)hipEventDestroy(pr.second.first); (void)hipEventDestroy(pr.second.second); }
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
-    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->own_stream) stream_release(h->device, h->own_stream);
     delete h;
     return MVS_OK;
 }
 
 // -------------------------------------------------------------------- nodes ----
-int mvs_deform_set_nodes(mvs_deform_t h, const int32_t* vertex_idx, int64_t K) {
-    if (!h || K < 0 || (K > 0 && !vertex_idx)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
-    HIPCHK(hipSetDevice(h->device));
-    std::vector<int32_t> ctrl_id(h->V, 0);
-    for (int64_t k = 0; k < K; ++k) {
-        const int v = vertex_idx[k];
-        if (v < 0 || v >= h->V) { mvs_set_error("node %lld: vertex index out of range", (long long)k); return MVS_E_INVALID_ARG; }
-        if (ctrl_id[v]) { mvs_set_error("node %lld: vertex %d listed twice", (long long)k, v); return MVS_E_INVALID_ARG; }
-        ctrl_id[v] = (int32_t)k + 1;
-    }
-    HIPCHK(hipStreamSynchronize(h->stream));
+// device side of a node set (indices validated by the caller): ONE allocation for the 17 per-node arrays
+static int install_nodes(mvs_deform_s* h, const int32_t* vertex_idx, int64_t K) {
     free_nodes(h);
     h->K = K;
     h->h_nodes.assign(vertex_idx, vertex_idx + K);
-    int rc;
-#define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
-    TRY(dmalloc(&h->d_nodes, (size_t)K)); TRY(dmalloc(&h->d_node_pts, (size_t)K * 3)); TRY(dmalloc(&h->d_node_nrm, (size_t)K * 3));
-    TRY(dmalloc(&h->d_ctrl_raw, (size_t)K * 3)); TRY(dmalloc(&h->d_ctrl_a, (size_t)K * 3)); TRY(dmalloc(&h->d_ctrl_b, (size_t)K * 3));
-    TRY(dmalloc(&h->d_valid, (size_t)K)); TRY(dmalloc(&h->d_d2min, (size_t)K)); TRY(dmalloc(&h->d_counts, (size_t)K * 2));
-    TRY(dmalloc(&h->d_prev_d2, (size_t)K)); TRY(dmalloc(&h->d_prev_node, (size_t)K * 3));
-    TRY(dmalloc(&h->d_records, (size_t)K * 8)); TRY(dmalloc(&h->d_top_idx, (size_t)K * 8)); TRY(dmalloc(&h->d_heavy, (size_t)K + 1)); TRY(dmalloc(&h->d_heavy2, (size_t)K + 1));
-    TRY(mvs_check_hip(hipMemsetAsync(h->d_heavy, 0, sizeof(int32_t), h->stream), "memset")); TRY(mvs_check_hip(hipMemsetAsync(h->d_heavy2, 0, sizeof(int32_t), h->stream), "memset"));
-    h->heavy_flip = 0;
-    if (K >= 1024) TRY(mvs_check_hip(hipMalloc(&h->d_knn_ws, knn_grid_ws_bytes((int)K)), "hipMalloc"));   // small graphs: brute force
-#undef TRY
-    HIPCHK(hipMemcpyAsync(h->d_is_ctrl, ctrl_id.data(), sizeof(int32_t) * h->V, hipMemcpyHostToDevice, h->stream));
-    if (K) HIPCHK(hipMemcpyAsync(h->d_nodes, vertex_idx, sizeof(int32_t) * K, hipMemcpyHostToDevice, h->stream));
+    const size_t ws_bytes = K >= 1024 ? knn_grid_ws_bytes((int)K) : 0;     // small graphs: brute force
+    auto lay = [&](Arena& a) {
+        h->d_heavy = a.take<int32_t>((size_t)K + 1); h->d_heavy2 = a.take<int32_t>((size_t)K + 1);      // (their counters are zeroed below)
+        h->d_valid = a.take<uint8_t>((size_t)K);
+        h->d_nodes = a.take<int32_t>(K); h->d_node_pts = a.take<double>((size_t)K * 3); h->d_node_nrm = a.take<double>((size_t)K * 3);
+        h->d_ctrl_raw = a.take<double>((size_t)K * 3); h->d_ctrl_a = a.take<double>((size_t)K * 3); h->d_ctrl_b = a.take<double>((size_t)K * 3);
+        h->d_d2min = a.take<float>(K); h->d_counts = a.take<int32_t>((size_t)K * 2);
+        h->d_prev_d2 = a.take<float>(K); h->d_prev_node = a.take<double>((size_t)K * 3);
+        h->d_records = a.take<mvs_cand>((size_t)K * 8); h->d_top_idx = a.take<int64_t>((size_t)K * 8);
+        h->d_nbr = a.take<int32_t>((size_t)K * 64);                            // graph_k <= 63
+        h->d_knn_ws = ws_bytes ? (void*)a.take<char>(ws_bytes) : nullptr;
+    };
+    {
+        Arena a; lay(a);
+        HIPCHK(hipMalloc(&h->arena_nodes, a.off + 256));
+        Arena b; b.base = (char*)h->arena_nodes; lay(b);
+    }
+    HIPCHK(hipMemsetAsync(h->d_heavy, 0, sizeof(int32_t), h->stream)); HIPCHK(hipMemsetAsync(h->d_heavy2, 0, sizeof(int32_t), h->stream));
     HIPCHK(hipMemsetAsync(h->d_valid, 0, (size_t)std::max<int64_t>(K, 1), h->stream));
-    launch_gather_nodes(h->d_pts, h->d_nrm, h->d_nodes, (int)K, h->d_node_pts, h->d_node_nrm, h->stream);
+    h->heavy_flip = 0;
+    HIPCHK(hipMemsetAsync(h->d_is_ctrl, 0, sizeof(int32_t) * h->V, h->stream));
+    if (K) HIPCHK(hipMemcpyAsync(h->d_nodes, h->h_nodes.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice, h->stream));   // (from the handle's own copy: it outlives the call)
+    launch_gather_nodes(h->d_pts, h->d_nrm, h->d_nodes, (int)K, h->d_node_pts, h->d_node_nrm, h->stream, h->d_is_ctrl);
     if (K) HIPCHK(hipMemcpyAsync(h->d_ctrl_raw, h->d_node_pts, sizeof(double) * K * 3, hipMemcpyDeviceToDevice, h->stream));
     h->d_ctrl_final = h->d_ctrl_raw;
     h->cg_iters = 0;                                  // new node set: every launch plan and the solver bracket start over
-    for (int i = 0; i < 8; ++i) { h->cg_plan[i] = 0; h->ras_plan[i] = 0; h->bump_seq[i] = 0; h->ras_seen[i] = 0; h->ras_rise[i] = 0; h->ras_hist_n[i] = 0; }
+    for (int i = 0; i < 8; ++i) { h->cg_plan[i] = 0; h->ras_plan[i] = 0; h->bump_seq[i] = 0; h->ras_hist_n[i] = 0; }
     HIPCHK(hipMemsetAsync(h->d_ctl, 0, sizeof(double) * 4, h->stream));     // verdicts of the old node set say nothing about the new one
     h->ras_a = 0.0; h->ras_m = 0;
-    HIPCHK(hipStreamSynchronize(h->stream));
     return MVS_OK;
+}
+
+int mvs_deform_set_nodes(mvs_deform_t h, const int32_t* vertex_idx, int64_t K) {
+    if (!h || K < 0 || (K > 0 && !vertex_idx)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<char> seen(h->V, 0);
+    for (int64_t k = 0; k < K; ++k) {
+        const int v = vertex_idx[k];
+        if (v < 0 || v >= h->V) { mvs_set_error("node %lld: vertex index out of range", (long long)k); return MVS_E_INVALID_ARG; }
+        if (seen[v]) { mvs_set_error("node %lld: vertex %d listed twice", (long long)k, v); return MVS_E_INVALID_ARG; }
+        seen[v] = 1;
+    }
+    return install_nodes(h, vertex_idx, K);
 }
 
 // Same topology, new positions (e.g. the template's rest pose again, for the next scan): everything that depends on the
@@ -949,29 +852,32 @@ int mvs_deform_sample_nodes(mvs_deform_t h, int knn, int64_t* K) {
     if (!h || knn < 1 || knn > 64) { mvs_set_error("knn must be 1..64"); return MVS_E_INVALID_ARG; }
     HIPCHK(hipSetDevice(h->device));
     const int64_t V = h->V;
-    int32_t* d_tab = nullptr;
-    int rc = dmalloc(&d_tab, (size_t)V * knn);
-    if (rc) return rc;
-    void* ws = nullptr;
-    if (V >= 1024 && hipMalloc(&ws, knn_grid_ws_bytes((int)V)) == hipSuccess) launch_knn_grid(h->d_pts, (int)V, knn, d_tab, ws, h->stream);
+    // one allocation: the table, then the search grid's workspace
+    const size_t tab_bytes = (sizeof(int32_t) * (size_t)V * knn + 255) & ~(size_t)255;
+    const size_t ws_bytes = V >= 1024 ? knn_grid_ws_bytes((int)V) : 0;
+    char* d_mem = nullptr;
+    HIPCHK(hipMalloc((void**)&d_mem, tab_bytes + ws_bytes + 256));
+    int32_t* d_tab = (int32_t*)d_mem;
+    if (ws_bytes) launch_knn_grid(h->d_pts, (int)V, knn, d_tab, d_mem + tab_bytes, h->stream);
     else launch_knn(h->d_pts, (int)V, knn, d_tab, h->stream);
     std::vector<int32_t> tab((size_t)V * knn);
-    rc = mvs_check_hip(hipMemcpyAsync(tab.data(), d_tab, sizeof(int32_t) * V * knn, hipMemcpyDeviceToHost, h->stream), "download");
+    int rc = mvs_check_hip(hipMemcpyAsync(tab.data(), d_tab, sizeof(int32_t) * V * knn, hipMemcpyDeviceToHost, h->stream), "download");
     if (!rc) rc = mvs_check_hip(hipStreamSynchronize(h->stream), "sync");
-    (void)hipFree(d_tab);
-    if (ws) (void)hipFree(ws);
+    (void)hipFree(d_mem);
     if (rc) return rc;
     std::vector<char> removed(V, 0);
     std::vector<int32_t> samp;
+    samp.reserve((size_t)V / 4 + 16);
     for (int64_t i = 0; i < V; ++i) {
         if (removed[i]) continue;                           // :85
         samp.push_back((int32_t)i);
+        const int32_t* row = tab.data() + (size_t)i * knn;
         for (int j = 0; j < knn; ++j) {
-            const int nb = tab[(size_t)i * knn + j];
+            const int nb = row[j];
             if (nb >= 0 && nb != i) removed[nb] = 1;        // :98-102
         }
     }
-    rc = mvs_deform_set_nodes(h, samp.data(), (int64_t)samp.size());
+    rc = install_nodes(h, samp.data(), (int64_t)samp.size());   // (distinct and in range by construction)
     if (rc) return rc;
     if (K) *K = (int64_t)samp.size();
     return MVS_OK;
@@ -1238,7 +1144,7 @@ int mvs_deform_get_node_targets(mvs_deform_t h, int smoothed, double* controls, 
 }
 int mvs_deform_get_node_graph(mvs_deform_t h, int32_t* nbr) {
     if (!h || !nbr) return MVS_E_INVALID_ARG;
-    if (!h->d_nbr) { mvs_set_error("node graph not built yet"); return MVS_E_STATE; }
+    if (!h->d_nbr || h->nbr_k == 0) { mvs_set_error("node graph not built yet"); return MVS_E_STATE; }
     return download(h, nbr, h->d_nbr, sizeof(int32_t) * (size_t)h->K * h->nbr_k);
 }
 int mvs_deform_compute_normals(mvs_deform_t h, double* normals) {
@@ -1285,6 +1191,44 @@ int mvs_debug_heavy_count(mvs_deform_t h, int* n, int* flagged) {
     for (int i = 0; i < l[0] && i < (int)h->K; ++i) f += (l[1 + i] & 0x40000000) != 0;
     if (n) *n = l[0];
     if (flagged) *flagged = f;
+    return MVS_OK;
+}
+
+// diagnostics (tests/test_gpu_meshbuild.py; not part of the ABI): the tables the device build left, copied to the host.
+// what = 0: dims as int64[8] {NP, LS, W, nslices, ne, single_pass, has_patches, total local rows}; 1 slice_off, 2 col, 3 opp0,
+// 4 opp1, 5 vf_ptr, 6 vf, 7 pnloc, 8 pown, 9 pnh, 10 l2g, 11 hl2g, 12 lcol (int16), 13 gent, 14 gcol.  out == NULL: only *bytes.
+int mvs_debug_mesh_table(mvs_deform_t h, int what, void* out, int64_t* bytes) {
+    if (!h || !bytes) return MVS_E_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    const RasDev& R = h->ras;
+    const int64_t rows = h->has_ras ? (int64_t)R.NP * R.LS : 0, ent = rows * R.W, ne = h->n_entries, ns = h->sell.nslices;
+    const void* src = nullptr;
+    int64_t n = 0;
+    int64_t dims[8] = {h->has_ras ? R.NP : 0, h->has_ras ? R.LS : 0, h->has_ras ? R.W : 0, ns, ne, h->sell.single_pass, h->has_ras ? 1 : 0, h->ras_rows};
+    switch (what) {
+        case 0: n = sizeof dims; break;
+        case 1: src = h->d_slice_off; n = 4 * (ns + 1); break;
+        case 2: src = h->d_col; n = 4 * ne; break;
+        case 3: src = h->d_opp0; n = 4 * ne; break;
+        case 4: src = h->d_opp1; n = 4 * ne; break;
+        case 5: src = h->d_vf_ptr; n = 4 * (h->V + 1); break;
+        case 6: src = h->d_vf; n = 4 * 3 * h->F; break;
+        case 7: src = R.pnloc; n = 4 * (int64_t)R.NP; break;
+        case 8: src = R.pown; n = 4 * (int64_t)R.NP; break;
+        case 9: src = R.pnh; n = 4 * (int64_t)R.NP; break;
+        case 10: src = R.l2g; n = 4 * rows; break;
+        case 11: src = R.hl2g; n = 4 * rows; break;
+        case 12: src = R.lcol; n = 2 * ent; break;
+        case 13: src = R.gent; n = 4 * ent; break;
+        case 14: src = R.gcol; n = 4 * ent; break;
+        default: return MVS_E_INVALID_ARG;
+    }
+    *bytes = n;
+    if (!out) return MVS_OK;
+    if (what == 0) { std::memcpy(out, dims, sizeof dims); return MVS_OK; }
+    if (what >= 7 && !h->has_ras) return MVS_E_STATE;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (n) HIPCHK(hipMemcpy(out, src, (size_t)n, hipMemcpyDeviceToHost));
     return MVS_OK;
 }
 

@@ -102,10 +102,11 @@ __device__ inline bool block_done(const double* __restrict__ efin, int it, doubl
 // ------------------------------------------------------------ small kernels --
 __global__ void k_gather_nodes(const double* __restrict__ pts, const double* __restrict__ nrm,
                                const int32_t* __restrict__ nodes, int K, double* __restrict__ node_pts,
-                               double* __restrict__ node_nrm) {
+                               double* __restrict__ node_nrm, int32_t* __restrict__ is_ctrl) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     const int v = nodes[k];
+    if (is_ctrl) is_ctrl[v] = k + 1;           // (a new node set: the table was zeroed before; node number + 1 at its vertex)
     st3(node_pts + 3 * k, ld3(pts + 3 * v));   // controls[i] = orig[i] = p   Deformation.cpp:270-272
     st3(node_nrm + 3 * k, ld3(nrm + 3 * v));   // norm = normals[idx]         :304
 }
@@ -729,8 +730,8 @@ extern "C" int mvs_debug_stamps(unsigned long long* out, int n) {
 int arap_grid_blocks(const SellDev& m) { return std::max(1, std::min((m.nslices + NW - 1) / NW, NBMAX)); }
 
 void launch_gather_nodes(const double* pts, const double* nrm, const int32_t* nodes, int K, double* node_pts,
-                         double* node_nrm, hipStream_t s) {
-    if (K > 0) k_gather_nodes<<<dim3((K + 255) / 256), dim3(256), 0, s>>>(pts, nrm, nodes, K, node_pts, node_nrm);
+                         double* node_nrm, hipStream_t s, int32_t* is_ctrl) {
+    if (K > 0) k_gather_nodes<<<dim3((K + 255) / 256), dim3(256), 0, s>>>(pts, nrm, nodes, K, node_pts, node_nrm, is_ctrl);
 }
 void launch_smooth(const double* orig, const double* cur, const int32_t* nbr, int nn, int K, double* out, hipStream_t s) {
     if (K > 0) k_smooth<<<dim3((K + 255) / 256), dim3(256), 0, s>>>(orig, cur, nbr, nn, K, out);

@@ -146,7 +146,9 @@ __device__ inline void judge_solve(const double* __restrict__ ered, int it, int 
         const int c = wv - 1;
         double gam, bn;
         fold_partials2(ered + it * EIT + (4 + c) * NBMAX, ered + it * EIT + (1 + c) * NBMAX, nb, &gam, &bn);
-        if ((threadIdx.x & 63) == 0) s_rel[c] = bn > 0.0 ? gam / bn : 0.0;
+        // (a right-hand side that is exactly zero has a zero residual; anything else that is not a positive norm — a NaN in b
+        //  or in x — must not pass as converged)
+        if ((threadIdx.x & 63) == 0) s_rel[c] = bn > 0.0 ? gam / bn : ((bn == 0.0 && gam == 0.0) ? 0.0 : INFINITY);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -156,8 +158,9 @@ __device__ inline void judge_solve(const double* __restrict__ ered, int it, int 
         // patch solver: how many of the planned sweeps did work (scal = the 8 scalars of the solve's last sweep slot:
         // [6] some sweep found the solve finished, [7] sweeps that ran) — negative when no spare was left
         used[it] = scal ? (scal[6] != 0.0 ? scal[7] : -scal[7]) : 0.0;
-        double rel2 = fmax(s_rel[0], fmax(s_rel[1], s_rel[2]));
-        if (!(rel2 == rel2)) rel2 = INFINITY;                             // a NaN residual is a miss
+        double rel2 = 0.0;                                                // NaN-propagating maximum: a NaN in ANY component is a miss
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const double v = s_rel[c]; if (!(v <= rel2)) rel2 = (v == v) ? v : INFINITY; }
         row[it] = rel2;
         ctl[MVS_CTL_WORST] = fmax(ctl[MVS_CTL_WORST], rel2);
         ctl[MVS_CTL_SOLVES] += 1.0;

@@ -20,6 +20,7 @@
 // k_assoc_select_heavy, a 16-wave workgroup per node (cell look-ups shared through an LDS list, ranges scanned
 // round-robin, the 16 top-k lists merged in LDS).  A single-rank run fuses dmin + select into k_assoc_local.
 #include "engine.h"
+#include "knobs.h"
 #include "dev_common.h"
 #include "grid_dev.h"
 #include "knn_dev.h"
@@ -1048,7 +1049,7 @@ void launch_assoc_local(const GridDev& g, const double* node_pts, const double* 
     if (knn_ws) knn_grid_views(knn_ws, K, &geo, &cs, &sorted);
     // one wave per workgroup: the waves' chains differ in length (a node near a hole of the scan, a graph query in a dense spot) and
     // a 4-wave workgroup holds its slots until its slowest wave is done — 53.7 us at 4, 53.5 at 2, 51.3 at 1
-    static const int wpb = getenv("MVS_ASSOC_WPB") ? std::max(1, std::min(4, atoi(getenv("MVS_ASSOC_WPB")))) : 1;      // waves per workgroup
+    const int wpb = (int)MVS_KNOB("MVS_ASSOC_WPB", 1, 1, 4);      // waves per workgroup
     const int ab = (K + wpb - 1) / wpb, kb = knn_ws ? (K + wpb - 1) / wpb : 0;
     k_assoc_local<<<dim3(ab + kb), dim3(64 * wpb), 0, s>>>(g, node_pts, node_nrm, K, p.top_k, d2min, rec, counts, heavy, heavy_cap, lm, heavy_next, ab, nn,
                                                        (const NgGeom*)geo, cs, (const float4*)sorted, nbr);

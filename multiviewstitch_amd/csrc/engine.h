@@ -51,11 +51,6 @@ struct RasDev {                // patches of the restricted additive Schwarz sol
                                // for a vertex outside the patch, LS + its place in the patch's halo list; -1 padding
     const int32_t* gent;       // same layout: entry id in the ELL-8 adjacency (addresses SellDev::w), -1 padding
     const int32_t* gcol;       // same layout: vertex of the column, -1 padding (k_ras_prepare only)
-    const int32_t* pn1;        // NP: owned rows + first overlap ring (the rows whose rotation the fused local+rhs kernel needs)
-    int32_t fuse;              // 1: every neighbour of an owned row lies within the first ring of its patch and NP <= MVS_NBMAX:
-                               //    local step of ARAP iteration k and right-hand side of k+1 run as ONE patch kernel (k_ras_local_rhs)
-    int32_t stage_slots;       // x / rest-position staging slots the fused kernel needs (LS + largest halo)
-    int32_t n1max;             // largest pn1
     int32_t HS;                // halo slots per patch (stride of hl2g)
     const int32_t* pnh;        // NP: halo vertices of each patch (columns outside the patch, each listed once)
     const int32_t* hl2g;       // [NP][HS] halo slot -> vertex
@@ -91,6 +86,19 @@ struct RasDev {                // patches of the restricted additive Schwarz sol
 #define MVS_CTL_USED   (MVS_CTL_RING + MVS_RING * 8)   /* [MVS_RING][8]: sweeps solve `it` of that pass actually ran (patch solver);
                                                           negative: it ran every planned sweep (no spare was left); 0: unknown */
 #define MVS_CTL_SIZE   (MVS_CTL_USED + MVS_RING * 8)
+
+// One hipMalloc, many arrays: a layout function is run twice over an Arena — first with base == NULL to learn the size,
+// then over the allocation to hand out the (256-byte aligned) pieces.  mvs_deform_create made ~30 hipMallocs before (3 ms).
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0;
+    template <class T> T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += (n ? n : 1) * sizeof(T);
+        return p;
+    }
+};
 
 struct PhaseTimer {
     double total_ms = 0; int64_t launches = 0;
@@ -149,7 +157,6 @@ struct mvs_deform_s {
     int64_t ras_rows = 0;
     int ras_block = 1024;           // workgroup size of the sweep kernel
     double *d_ras_x2 = nullptr, *d_ras_b = nullptr, *d_ras_slots = nullptr, *d_ras_pw = nullptr, *d_ras_pd = nullptr;
-    double *d_ras_pwr = nullptr;     // raw cotangent weights in the patch-table layout (fused local+rhs kernel)
     int32_t *d_ras_iters = nullptr;
     int64_t ras_slots_cap = 0;
     int ras_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // calibrated sweeps per ARAP iteration (0 = not calibrated)
@@ -170,8 +177,6 @@ struct mvs_deform_s {
     uint64_t seq_enqueued = 0;      // outer iterations enqueued since creation (the device counts the finalized ones in MVS_CTL_SEQ)
     uint64_t seq_peeked = 0;        // ... whose ring row the host has already looked at
     uint64_t seq_harvested = 0;     // ... covered by the last harvest
-    int ras_seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // sweeps solve `it` ran in the pass peek_ring looked at last, and how much
-    int ras_rise[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // that was above the pass before (trend-aware provisioning)
     uint64_t bump_seq[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // first pass enqueued with the last in-batch correction of solve `it`
     // timing
     int timing = 0;                 // 0 off, 1 all phases, 2 "cg" groups only
@@ -180,6 +185,16 @@ struct mvs_deform_s {
     std::vector<hipEvent_t> event_pool;
     std::map<std::string, int64_t> pending_launches;
     mvs_deform_stats last{};
+    // device memory: one allocation per lifetime (meshbuild.hip, api_deform.cpp, grid.hip); every d_* pointer above points
+    // into one of these, nothing is freed piecewise
+    void* arena_mesh = nullptr;     // sized from V, F alone: vectors, control blocks, the build's workspace
+    void* arena_tab = nullptr;      // sized after the device build reported ne, LS, W: ELL-8 tables, patch tables, sweep slots
+    void* arena_nodes = nullptr;    // per node set (K)
+    void* arena_target = nullptr;   // per target (P, grid)
+    size_t arena_target_bytes = 0;
+    void* arena_probe = nullptr;    // grid build: probe histogram + partial sums (kept across targets)
+    size_t arena_probe_bytes = 0;
+    int32_t* d_deg = nullptr;       // [V] vertex degree (device build; the ELL-8 tables pad every row to a multiple of 8)
 };
 
 // ---- launchers (each enqueues on `s`; no host sync) ----
@@ -219,7 +234,7 @@ void launch_knn_grid(const double* pts, int n, int k, int32_t* out, void* ws, hi
                      double* smooth_out = nullptr);                                           // 5 launches
 // arap.hip
 void launch_gather_nodes(const double* pts, const double* nrm, const int32_t* nodes, int K,
-                         double* node_pts, double* node_nrm, hipStream_t s);
+                         double* node_pts, double* node_nrm, hipStream_t s, int32_t* is_ctrl = nullptr /* != NULL: also marks the nodes' vertices */);
 void launch_smooth(const double* orig, const double* cur, const int32_t* nbr, int nn, int K, double* out, hipStream_t s);
 // ctrl != NULL: also initialises sol (node targets / rest positions) and rot (identity), Deformation.cpp:383-392
 void launch_cot_weights(const SellDev& m, const double* pts, double* coef, const double* ctrl, double* sol, double* rot, hipStream_t s);
@@ -245,9 +260,12 @@ void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered,
                           double cg_tol, double* ctl, int ring_slot, double* host_ctl, const double* last_solve_scalars, hipStream_t s);
 int  arap_grid_blocks(const SellDev& m);
 // schwarz.hip
-int  ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& rowptr, const std::vector<int32_t>& col,
-               const std::vector<int32_t>& slice_off);
-void ras_free(mvs_deform_s* h);
+// meshbuild.hip — row a16 on the device (Deformation.cpp:29-46, Deformation.h:51-84): validity of the facet list, ELL-8
+// adjacency, vertex -> facet lists, the patches of the overlapping-patch solver; allocates arena_mesh / arena_tab and sets
+// every mesh pointer of the handle.  points / normals / faces: host arrays (V, V, F as in the handle).
+int  mesh_build(mvs_deform_s* h, const double* points, const double* normals, const int32_t* faces);
+// exclusive scan without allocation or host synchronisation: bsum = workspace of (n + 1 + 1023) / 1024 ints
+void scan_exclusive_i32_async(const int32_t* in, int64_t n, int32_t* out, int32_t* bsum, hipStream_t s);
 int  ras_slot_size(const mvs_deform_s* h);       // doubles per sweep slot: part[3][NPpad] | gamma[3] bn[3] pad
 // init_ctrl != NULL: also starts the solve like launch_cot_weights(ctrl != NULL) does — solution = node target or rest
 // position, R = I — for the rows each patch owns (the weights were then made earlier, by the fused association launch)
@@ -259,12 +277,7 @@ void ras_default_bracket(const mvs_deform_s* h, double* a, int* m);
 int  ras_steps_for(double a);
 #define RAS_TAIL_MAX 32      /* in-kernel sweeps a TAIL launch may add to a solve whose plan was too short */
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, double* xout, int it, double arap_tol, int sweep,
-                      double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots = nullptr,
-                      bool fold_energy = false /*fused mode, sweep 0 of it >= 1: closes ARAP iteration it-1 (energy, stop rule) as k_arap_rhs does*/);
-// local step of ARAP iteration `it` (rotations, energy, true residual of the solve whose result `x` is) and, when do_rhs, the
-// right-hand side of iteration it+1 — one patch kernel; its extra block judges solve it-1 and resets the tail barrier
-void launch_ras_local_rhs(const mvs_deform_s* h, const double* x, int it, int iters, double arap_tol, double cg_tol, int ring_slot,
-                          const double* prev_solve_scalars, hipStream_t s);
+                      double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots = nullptr);
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf,
                            int V, double* out, hipStream_t s);
 

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include "dev_common.h"
 #include "grid_dev.h"
+#include "knobs.h"
 #include <algorithm>
 #include <cmath>
 
@@ -126,14 +127,20 @@ __global__ void k_coarse_start(const int32_t* __restrict__ cs, int64_t ncoarse, 
 
 }  // namespace
 
-// in: n+1 entries (in[n] ignored, treated as 0); out: n+1 entries, out[n] = total.  Syncs the stream.
+// in: n entries; out: n+1 entries, out[n] = total; bsum: (n + 1 + 1023) / 1024 ints of workspace.  No allocation, no host sync.
+void scan_exclusive_i32_async(const int32_t* in, int64_t n, int32_t* out, int32_t* bsum, hipStream_t s) {
+    const int64_t nb = (n + 1 + SCAN_ELEMS - 1) / SCAN_ELEMS;
+    k_scan_block_sums<<<dim3((unsigned)nb), dim3(TPB), 0, s>>>(in, n, bsum);
+    k_scan_sums_serial<<<dim3(1), dim3(64), 0, s>>>(bsum, nb);
+    k_scan_apply<<<dim3((unsigned)nb), dim3(TPB), 0, s>>>(in, n, bsum, out);
+}
+
+// allocating, synchronising form (set-up paths of geom.hip / align.hip)
 int scan_exclusive_i32(const int32_t* in, int64_t n, int32_t* out, hipStream_t s) {
     const int64_t nb = (n + 1 + SCAN_ELEMS - 1) / SCAN_ELEMS;
     int32_t* bsum = nullptr;
     HIPCHK(hipMalloc(&bsum, sizeof(int32_t) * nb));
-    k_scan_block_sums<<<dim3((unsigned)nb), dim3(TPB), 0, s>>>(in, n, bsum);
-    k_scan_sums_serial<<<dim3(1), dim3(64), 0, s>>>(bsum, nb);
-    k_scan_apply<<<dim3((unsigned)nb), dim3(TPB), 0, s>>>(in, n, bsum, out);
+    scan_exclusive_i32_async(in, n, out, bsum, s);
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipFree(bsum));
     return MVS_OK;
@@ -154,30 +161,40 @@ GridGeom make_geom(const float mn[3], const float mx[3], float h) {
 
 }  // namespace
 
+// Two allocations at most (both kept by the handle and reused when the next target fits): a small probe arena (bounding-box
+// partials, the coarse probe histogram) and the target arena (cell tables, sorted points, the scatter's temporaries).  Two
+// host synchronisations: the bounding box and the probe's occupancy decide the grid's geometry, which sizes everything else.
+// (Round 2: 11 hipMallocs, 7 hipFrees — each a device synchronisation — and 5 stream synchronisations: 1.3 ms at config 3.)
 int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* nrm_dev, int64_t index_base) {
     hipStream_t s = h->stream;
     h->prev_valid = false;                              // a new target: the remembered nearest distances say nothing about it
-    if (h->d_spos) { (void)hipFree(h->d_spos); h->d_spos = nullptr; }
-    if (h->d_tpos) { (void)hipFree(h->d_tpos); h->d_tpos = nullptr; }
-    if (h->d_tnrm) { (void)hipFree(h->d_tnrm); h->d_tnrm = nullptr; }
-    if (h->d_cell_start) { (void)hipFree(h->d_cell_start); h->d_cell_start = nullptr; }
-    if (h->d_coarse_cnt) { (void)hipFree(h->d_coarse_cnt); h->d_coarse_cnt = nullptr; }
+    h->has_target = false;
     h->P = P;
     h->grid = GridDev{};
     h->grid.P = P; h->grid.index_base = index_base;
     h->grid.nx = h->grid.ny = h->grid.nz = 0;
+    h->d_spos = nullptr; h->d_tpos = nullptr; h->d_tnrm = nullptr; h->d_cell_start = nullptr; h->d_coarse_cnt = nullptr;
     if (P == 0) { h->has_target = true; return MVS_OK; }
     if (P > 0x7fffffffLL) { mvs_set_error("target too large for int32 indices"); return MVS_E_INVALID_ARG; }
 
-    // 1. bounding box of the float32-rounded coordinates
+    // 1. bounding box of the float32-rounded coordinates; the probe grid is at most 129^3 fine cells = 17^3 coarse cells
     const int nbb = (int)std::min<int64_t>(1024, (P + TPB - 1) / TPB);
-    float* d_part = nullptr;
-    HIPCHK(hipMalloc(&d_part, sizeof(float) * 6 * nbb));
+    const int64_t probe_cells_max = 17LL * 17 * 17 * 512;
+    float* d_part = nullptr; int32_t* d_probe = nullptr; unsigned long long* d_nz = nullptr;
+    {
+        auto lay = [&](Arena& a) { d_part = a.take<float>(6 * 1024); d_nz = a.take<unsigned long long>(1); d_probe = a.take<int32_t>(probe_cells_max + 1); };
+        Arena a; lay(a);
+        if (a.off + 256 > h->arena_probe_bytes) {
+            if (h->arena_probe) { HIPCHK(hipFree(h->arena_probe)); h->arena_probe = nullptr; h->arena_probe_bytes = 0; }
+            HIPCHK(hipMalloc(&h->arena_probe, a.off + 256));
+            h->arena_probe_bytes = a.off + 256;
+        }
+        Arena b; b.base = (char*)h->arena_probe; lay(b);
+    }
     k_bbox<<<dim3(nbb), dim3(TPB), 0, s>>>(pts_dev, P, d_part);
     std::vector<float> part(6 * (size_t)nbb);
     HIPCHK(hipMemcpyAsync(part.data(), d_part, sizeof(float) * 6 * nbb, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipFree(d_part));
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int b = 0; b < nbb; ++b)
         for (int c = 0; c < 3; ++c) { mn[c] = std::min(mn[c], part[6 * b + c]); mx[c] = std::max(mx[c], part[6 * b + 3 + c]); }
@@ -190,24 +207,19 @@ int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* 
     const int64_t MAX_CELLS = 1LL << 26;
     float hh = ext / 128.f;
     GridGeom g = make_geom(mn, mx, hh);
-    int32_t* d_counts = nullptr;
-    for (int pass = 0; pass < 2; ++pass) {
-        const int64_t ncells = (int64_t)g.NX * g.NY * g.NZ * 512;       // tiled order: padded to whole coarse cells
-        HIPCHK(hipMalloc(&d_counts, sizeof(int32_t) * (ncells + 1)));
-        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (ncells + 1), s));
-        if (pass == 1) break;
-        k_cell_count<<<dim3((unsigned)((P + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(pts_dev, P, g, d_counts, nullptr);
-        unsigned long long* d_nz = nullptr; unsigned long long nz = 0;
-        HIPCHK(hipMalloc(&d_nz, sizeof(unsigned long long)));
+    {
+        int64_t ncells = (int64_t)g.NX * g.NY * g.NZ * 512;       // tiled order: padded to whole coarse cells
+        while (ncells > probe_cells_max) { hh *= 1.26f; g = make_geom(mn, mx, hh); ncells = (int64_t)g.NX * g.NY * g.NZ * 512; }   // (rounding at the box's far faces)
+        HIPCHK(hipMemsetAsync(d_probe, 0, sizeof(int32_t) * (ncells + 1), s));
         HIPCHK(hipMemsetAsync(d_nz, 0, sizeof(unsigned long long), s));
-        k_count_nonzero<<<dim3((unsigned)((ncells + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(d_counts, ncells, d_nz);
+        k_cell_count<<<dim3((unsigned)((P + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(pts_dev, P, g, d_probe, nullptr);
+        k_count_nonzero<<<dim3((unsigned)((ncells + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(d_probe, ncells, d_nz);
+        unsigned long long nz = 0;
         HIPCHK(hipMemcpyAsync(&nz, d_nz, sizeof nz, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        HIPCHK(hipFree(d_nz));
-        HIPCHK(hipFree(d_counts)); d_counts = nullptr;
         const double occ = (double)P / (double)std::max<unsigned long long>(1, nz);
         // surface-like data: occupancy ~ h^2
-        static const double want_occ = getenv("MVS_GRID_OCC") ? atof(getenv("MVS_GRID_OCC")) : 16.0;      // (experiments)
+        const double want_occ = MVS_KNOB("MVS_GRID_OCC", 16.0, 1.0, 1024.0);      // (experiments)
         float hn = hh * (float)std::sqrt(want_occ / occ);
         hn = std::max(hn, ext / 1024.f);
         hn = std::min(hn, ext / 4.f);
@@ -216,34 +228,41 @@ int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* 
         hh = hn;
     }
     const int64_t ncells = (int64_t)g.NX * g.NY * g.NZ * 512;
+    const int64_t ncoarse = (int64_t)g.NX * g.NY * g.NZ;
 
     // 3. histogram, scan, scatter
-    int32_t* d_cell_of = nullptr;
-    HIPCHK(hipMalloc(&d_cell_of, sizeof(int32_t) * P));
-    k_cell_count<<<dim3((unsigned)((P + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(pts_dev, P, g, d_counts, d_cell_of);
-    HIPCHK(hipMalloc(&h->d_cell_start, sizeof(int32_t) * (ncells + 1)));
-    int rc = scan_exclusive_i32(d_counts, ncells, h->d_cell_start, s);
-    if (rc) return rc;
+    int32_t *d_counts = nullptr, *d_cell_of = nullptr, *d_bsum = nullptr;
+    {
+        auto lay = [&](Arena& a) {
+            h->d_cell_start = a.take<int32_t>(ncells + 1); h->d_coarse_cnt = a.take<int32_t>(ncoarse + 1);
+            h->d_spos = a.take<float4>(P); h->d_tpos = a.take<double>(3 * (size_t)P); h->d_tnrm = a.take<double>(3 * (size_t)P);
+            d_counts = a.take<int32_t>(ncells + 1); d_cell_of = a.take<int32_t>(P); d_bsum = a.take<int32_t>(ncells / SCAN_ELEMS + 8);
+        };
+        Arena a; lay(a);
+        if (a.off + 256 > h->arena_target_bytes) {
+            if (h->arena_target) { HIPCHK(hipFree(h->arena_target)); h->arena_target = nullptr; h->arena_target_bytes = 0; }
+            HIPCHK(hipMalloc(&h->arena_target, a.off + 256));
+            h->arena_target_bytes = a.off + 256;
+        }
+        Arena b; b.base = (char*)h->arena_target; lay(b);
+    }
     HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (ncells + 1), s));
-    HIPCHK(hipMalloc(&h->d_spos, sizeof(float4) * P));
-    HIPCHK(hipMalloc(&h->d_tpos, sizeof(double) * 3 * P));
-    HIPCHK(hipMalloc(&h->d_tnrm, sizeof(double) * 3 * P));
+    k_cell_count<<<dim3((unsigned)((P + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(pts_dev, P, g, d_counts, d_cell_of);
+    scan_exclusive_i32_async(d_counts, ncells, h->d_cell_start, d_bsum, s);
+    HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (ncells + 1), s));
     k_scatter<<<dim3((unsigned)((P + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(pts_dev, nrm_dev, P, d_cell_of, h->d_cell_start,
                                                                     d_counts, h->d_spos, h->d_tpos, h->d_tnrm);
-    HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipFree(d_counts));
-    HIPCHK(hipFree(d_cell_of));
+    k_coarse_start<<<dim3((unsigned)((ncoarse + 1 + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(h->d_cell_start, ncoarse, h->d_coarse_cnt);
     h->grid.minx = g.minx; h->grid.miny = g.miny; h->grid.minz = g.minz;
     h->grid.h = g.h; h->grid.inv_h = g.inv_h;
     h->grid.nx = g.nx; h->grid.ny = g.ny; h->grid.nz = g.nz;
     h->grid.spos = h->d_spos; h->grid.tpos = h->d_tpos; h->grid.tnrm = h->d_tnrm;
     h->grid.cell_start = h->d_cell_start;
     h->grid.NX = g.NX; h->grid.NY = g.NY; h->grid.NZ = g.NZ;
-    const int64_t ncoarse = (int64_t)g.NX * g.NY * g.NZ;
-    HIPCHK(hipMalloc(&h->d_coarse_cnt, sizeof(int32_t) * (ncoarse + 1)));
-    k_coarse_start<<<dim3((unsigned)((ncoarse + 1 + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(h->d_cell_start, ncoarse, h->d_coarse_cnt);
-    HIPCHK(hipStreamSynchronize(s));
     h->grid.coarse_start = h->d_coarse_cnt;
+    // the caller's pts / nrm buffers are read by the kernels just enqueued: they must not be released before those have run
+    // (mvs_deform_set_target frees its staging copies) — one synchronisation at the end, as before
+    HIPCHK(hipStreamSynchronize(s));
     h->has_target = true;
-    return MVS_OK;
+    return mvs_check_hip(hipGetLastError(), "grid_build");
 }

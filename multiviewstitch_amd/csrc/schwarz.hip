@@ -26,6 +26,7 @@
 #include "dev_common.h"
 #include "arap_dev.h"
 #include "svd3_dev.h"
+#include "knobs.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -113,8 +114,7 @@ struct ChebCoef { double c0, c1[32], c2[32]; };      // d_0 = c0 D^-1 r ;  d_{k+
 template <int W>
 __global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, double* __restrict__ pw, double* __restrict__ pd,
                                                       const double* __restrict__ ctrl, const double* __restrict__ pts,
-                                                      double* __restrict__ sol, double* __restrict__ rot, RasSmooth sm,
-                                                      double* __restrict__ pwr) {
+                                                      double* __restrict__ sol, double* __restrict__ rot, RasSmooth sm) {
     const int p = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;   // (XCD-aware, as the sweeps)
     const int row = threadIdx.x;
     const int LS = R.LS, base = p * LS, nloc = R.pnloc[p];
@@ -154,7 +154,6 @@ __global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, doubl
         const int ge = gent[e * LS + row], gc = gcol[e * LS + row];
         const double w = ge >= 0 ? m.w[ge] : 0.0;
         o[e * LS + row] = (ge >= 0 && !fixed && !m.is_ctrl[gc]) ? 2.0 * w : 0.0;
-        if (pwr) pwr[(int64_t)base * W + e * LS + row] = live ? w : 0.0;      // raw weights: covariance, right-hand side (k_ras_local_rhs)
     }
 }
 
@@ -214,7 +213,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
                                                     double* __restrict__ ered, int nb_rhs, int sweep, double cg_tol, double stop_margin, double slow2,
                                                     double predict2, ChebCoef cc, int cheb_m, ChebCoef cc_strong, int cheb_m_strong,
                                                     double* __restrict__ ctl, double* __restrict__ slot_prev,
-                                                    double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur, RasTail tail, int fold_energy) {
+                                                    double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur, RasTail tail) {
     // LDS: fp64 x of the local rows and the halo while the residual is formed (24 KB), then the correction directions as
     // bfloat16 triples, double-buffered (2 x 8 KB of the same array).  The neighbours' directions only steer the inexact
     // local solve; the residual that decides convergence and the solution stay fp64.
@@ -277,16 +276,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         const double bn = fold_partials(ered + it * EIT + (1 + (wv - 3)) * NBMAX, nb_rhs);
         if (lane == 0) s_bn[wv - 3] = bn;
     } else if (wv == 6) {
-        bool done;
-        if (fold_energy) {
-            // fused mode, first sweep of ARAP iteration it >= 1: nobody has closed iteration it-1 yet (the fused local + rhs kernel
-            // left its energy partials) — k_arap_rhs's bookkeeping, by every workgroup for itself and by workgroup 0 for the record
-            double* efin = ered + EFIN;
-            done = arap_done_before(efin, it - 1, arap_tol);
-            const double e_prev = done ? 0.0 : fold_partials(ered + (it - 1) * EIT, nb_rhs);   // (did not run: its partials are stale)
-            if (p == 0 && lane == 0) efin[it - 1] = e_prev;
-            if (!done && arap_tol > 0.0 && it >= 2 && fabs((efin[it - 2] - e_prev) / e_prev) < arap_tol) done = true;
-        } else done = arap_done_before(ered + EFIN, it, arap_tol);
+        const bool done = arap_done_before(ered + EFIN, it, arap_tol);
         if (lane == 0) {
             s_done = done ? 1 : 0;
             s_esc = ctl[MVS_CTL_ESC] != 0.0 ? 1 : 0;                   // a solve missed cg_tol since the last harvest: strong local solves
@@ -306,7 +296,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     const double stop = healthy ? cg_tol : stop_margin * cg_tol;
     bool frozen = sweep > 0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) if (s_gam[c] > 0.0 && s_gam[c] > stop * stop * bn[c]) frozen = false;
+    for (int c = 0; c < 3; ++c) if (!(s_gam[c] <= stop * stop * bn[c])) frozen = false;       // (NaN-propagating: a NaN residual is not converged)
     // Predicted stop.  What is known here is the residual of the PREVIOUS sweep's input (g1) and of the one before (g2): this
     // sweep's own input is one sweep better than g1.  While the sweeps converge healthily (rate g1/g2 below RAS_SLOW, normal
     // coefficient set) that input is predicted at g1 * (g1/g2); when the prediction, times the safety factor the judge keeps
@@ -320,7 +310,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         double prel2 = 0.0;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            if (s_gam[c] > 0.0) {
+            if (!(s_gam[c] == 0.0)) {
                 const double pg = s_gam[c] * (s_gam[c] / s_gam2[c]);
                 if (!(pg * s_psafe <= predict2 * cg_tol * cg_tol * bn[c])) pred = false;
                 prel2 = fmax(prel2, pg / bn[c]);
@@ -455,13 +445,13 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         const double stop_k = (known && !slow) ? cg_tol : stop_margin * cg_tol;           // preamble: what a sweep computes does not depend
 #pragma unroll
         for (int c = 0; c < 3; ++c)                                                        // on where the plan ended
-            if (s_gam[c] > 0.0 && s_gam[c] > stop_k * stop_k * bn[c]) conv = false;
+            if (!(s_gam[c] <= stop_k * stop_k * bn[c])) conv = false;
         if (!conv && known && !slow && predict2 > 0.0 && !s_esc) {                         // (predicted stop: the output just written)
             conv = true;
             double prel2 = 0.0;
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                if (s_gam[c] > 0.0) {
+                if (!(s_gam[c] == 0.0)) {
                     const double pg = s_gam[c] * (s_gam[c] / g_before[c]);
                     if (!(pg * s_psafe <= predict2 * cg_tol * cg_tol * bn[c])) conv = false;
                     prel2 = fmax(prel2, pg / bn[c]);
@@ -497,160 +487,6 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     if (row == 0) iters_cur[p] = steps;
 }
 
-// ---- local step of ARAP iteration `it` and right-hand side of iteration it+1 as ONE patch kernel ------------------------------
-// Round 1 ran them as two row kernels (k_arap_local: a thread per vertex, k_arap_rhs: 8 lanes per vertex) whose neighbour
-// gathers — positions, solution, 72-byte rotations — came from L2: 78 MB of gathers per ARAP iteration for 5 MB of distinct
-// data, and a kernel boundary between them only because a row's right-hand side needs its NEIGHBOURS' new rotations.
-// Here a workgroup stages x and the rest positions of its patch (local rows + halo) in LDS once, computes the rotations
-// of its owned rows AND their first ring (1.3x the rotations, all from LDS), keeps them in LDS, and assembles b for its
-// owned rows from there.  Same operations in the same order per row as the two kernels (k_arap_local, k_arap_rhs): the
-// rotations and b are bit-identical; the energy and residual sums are folded patch by patch instead of block by block.
-//   it, iters : this ARAP iteration, the schedule's length (do_rhs = it + 1 < iters)
-//   grid      : NP + 1 — the extra block judges the solve of iteration it-1 (ring, control block), resets the tail barrier of the
-//               coming solve and zero-fills the partial slots the row kernels' fold count expects beyond NP
-template <int W>
-__global__ __launch_bounds__(RTPB) void k_ras_local_rhs(SellDev m, RasDev R, const double* __restrict__ pw, const double* __restrict__ pwr,
-                                                        const double* __restrict__ pd, const double* __restrict__ pts,
-                                                        const double* __restrict__ x, double* __restrict__ rot,
-                                                        const double* bpure_in /*may alias bpure_out*/, double* __restrict__ bout, double* bpure_out,
-                                                        int it, int iters, double arap_tol, double* __restrict__ ered, int nb,
-                                                        double cg_tol, double* __restrict__ ctl, int ring_slot,
-                                                        const double* __restrict__ prev_scal, unsigned* __restrict__ bar) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    __shared__ double s_red[16][8];
-    __shared__ int s_flag;
-    double* efin = ered + EFIN;
-    const int p = blockIdx.x, row = threadIdx.x, lane = row & 63, wv = row >> 6;
-    if (p == R.NP) {                                               // ---- the extra block
-        if (bar && row < MVS_BAR_WORDS) bar[row * MVS_BAR_STRIDE] = 0u;
-        // (the row kernels and the sweeps fold `nb` partials per sum: the slots NP .. nb-1 of what the patches write hold zeros)
-        for (int q = R.NP + row; q < nb; q += blockDim.x) {
-            ered[it * EIT + q] = 0.0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { ered[it * EIT + (4 + c) * NBMAX + q] = 0.0; if (it + 1 < iters) ered[(it + 1) * EIT + (1 + c) * NBMAX + q] = 0.0; }
-        }
-        if (ctl && it >= 1) judge_solve(ered, it - 1, nb, cg_tol, ctl, ring_slot, !arap_done_before(efin, it - 1, arap_tol), prev_scal);
-        return;
-    }
-    if (row == 0) s_flag = arap_done_before(efin, it, arap_tol) ? 1 : 0;
-    __syncthreads();
-    if (s_flag) return;                                            // the reference's energy stop rule fired before this iteration
-    const int LS = R.LS, base = p * LS;
-    const int nloc = R.pnloc[p], nown = R.pown[p], n1 = R.pn1[p], nh = R.pnh[p];
-    double* xs = reinterpret_cast<double*>(dyn);                   // [stage_slots][3] x of the local rows, then of the halo
-    double* ps = xs + 3 * (size_t)R.stage_slots;                   // [stage_slots][3] rest positions, same slots
-    double* Rs = ps + 3 * (size_t)R.stage_slots;                   // [n1max][9] rotations of the owned rows and the first ring
-    const int g = R.l2g[base + row], gh = R.hl2g[base + row];
-    int lc[W];
-    double wr[W], w2[W];
-    {
-        const int16_t* lcol = R.lcol + (int64_t)base * W;
-        const double* pwp = pw + (int64_t)base * W;
-        const double* prp = pwr + (int64_t)base * W;
-#pragma unroll
-        for (int e = 0; e < W; ++e) {
-            lc[e] = (int)lcol[e * LS + row];
-            wr[e] = prp[e * LS + row];
-            w2[e] = pwp[e * LS + row];
-            if (lc[e] < 0) { lc[e] = row; wr[e] = 0.0; w2[e] = 0.0; }
-        }
-    }
-    const d3 xi = ld3(x + 3 * (int64_t)g), pi = ld3(pts + 3 * (int64_t)g);
-    const double dd = pd[base + row];                              // 0: control vertex or padding row
-    st3(xs + 3 * row, xi); st3(ps + 3 * row, pi);
-    if (row < nh) { st3(xs + 3 * (LS + row), ld3(x + 3 * (int64_t)gh)); st3(ps + 3 * (LS + row), ld3(pts + 3 * (int64_t)gh)); }
-    __syncthreads();
-    // ---- phase 1: rotation of every row up to the first ring; energy and true residual on the owned rows
-    double e_acc = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
-    const bool live = row < nloc;
-    if (live && row < n1) {
-        double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        d3 pp0[W], qq0[W];
-        d3 ax = mk3(0, 0, 0);
-        const bool judge = row < nown && dd != 0.0;
-#pragma unroll
-        for (int e = 0; e < W; ++e) {
-            const int j = wr[e] == 0.0 ? row : lc[e];
-            pp0[e] = pi - ld3(ps + 3 * j); qq0[e] = xi - ld3(xs + 3 * j);
-        }
-#pragma unroll
-        for (int e = 0; e < W; ++e) {
-            if (wr[e] == 0.0) continue;
-            const double w = wr[e];
-            const d3 pp = pp0[e], qq = qq0[e];
-            if (judge) ax = ax + (2.0 * w) * qq;
-            c[0] += w * (pp.x * qq.x); c[1] += w * (pp.x * qq.y); c[2] += w * (pp.x * qq.z);
-            c[3] += w * (pp.y * qq.x); c[4] += w * (pp.y * qq.y); c[5] += w * (pp.y * qq.z);
-            c[6] += w * (pp.z * qq.x); c[7] += w * (pp.z * qq.y); c[8] += w * (pp.z * qq.z);
-        }
-        double Rm[9];
-        closest_rotation(c, Rm);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Rs[9 * row + k] = Rm[k];
-        if (row < nown) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) rot[9 * (int64_t)g + k] = Rm[k];
-#pragma unroll
-            for (int e = 0; e < W; ++e) {
-                if (wr[e] == 0.0) continue;
-                e_acc += wr[e] * sqn3(qq0[e] - mulMv(Rm, pp0[e]));
-            }
-            if (judge) {
-                const d3 res = ld3(bpure_in + 3 * (int64_t)g) - ax;
-                const double inv_d = 1.0 / dd;
-                g0 = res.x * res.x * inv_d; g1 = res.y * res.y * inv_d; g2 = res.z * res.z * inv_d;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- phase 2: right-hand side of iteration it+1 on the owned rows (k_arap_rhs's row, the neighbours' rotations from LDS)
-    double bn0 = 0.0, bn1 = 0.0, bn2 = 0.0;
-    if (it + 1 < iters && row < nown) {
-        d3 bb = mk3(0, 0, 0), bd = mk3(0, 0, 0);
-        const bool freerow = dd != 0.0;
-        if (freerow) {
-            const double* Ri = Rs + 9 * row;
-#pragma unroll
-            for (int e = 0; e < W; ++e) {
-                const double w = wr[e];
-                if (w == 0.0) continue;
-                const int j = lc[e];
-                const double* Rj = Rs + 9 * j;
-                double M[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) M[k] = w * Ri[k] + w * Rj[k];
-                bb = bb + mulMv(M, pi - ld3(ps + 3 * j));
-                if (w2[e] == 0.0) { const d3 xj = ld3(xs + 3 * j); bb = bb + (2.0 * w) * xj; bd = bd + (2.0 * w) * xj; }   // Dirichlet column (free row, masked entry)
-            }
-            bn0 = bb.x * bb.x / dd; bn1 = bb.y * bb.y / dd; bn2 = bb.z * bb.z / dd;
-        }
-        st3(bout + 3 * (int64_t)g, freerow ? bb : mk3(0, 0, 0));
-        st3(bpure_out + 3 * (int64_t)g, freerow ? bb - bd : mk3(0, 0, 0));
-    }
-    // ---- the patch's seven sums -> its slots of the partial arrays (fixed order: waves by DPP, then wave 0 over the waves)
-    {
-        double v[7] = {e_acc, g0, g1, g2, bn0, bn1, bn2};
-#pragma unroll
-        for (int k = 0; k < 7; ++k) { const double t = wave_sum_u(v[k]); if (lane == 0) s_red[wv][k] = t; }
-        __syncthreads();
-        if (row < 7) {
-            double t = 0.0;
-            const int nwv = (int)(blockDim.x >> 6);
-            for (int w = 0; w < nwv; ++w) t += s_red[w][row];
-            if (row == 0) ered[it * EIT + p] = t;
-            else if (row < 4) ered[it * EIT + (3 + row) * NBMAX + p] = t;
-            else if (it + 1 < iters) ered[(it + 1) * EIT + (row - 3) * NBMAX + p] = t;
-        }
-    }
-}
-
-template <class T> int up(T** d, const std::vector<T>& h) {
-    *d = nullptr;
-    if (hipMalloc((void**)d, std::max<size_t>(1, h.size()) * sizeof(T)) != hipSuccess) { mvs_set_error("hipMalloc failed (patch tables)"); return MVS_E_OOM; }
-    if (!h.empty() && hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { mvs_set_error("upload failed (patch tables)"); return MVS_E_HIP; }
-    return MVS_OK;
-}
-
 }  // namespace
 
 #ifdef MVS_STAMPS
@@ -662,183 +498,16 @@ extern "C" int mvs_debug_ras_stamps(unsigned long long* out, int n) {
 }
 #endif
 
-void ras_free(mvs_deform_s* h) {
-    auto fr = [](const void* p) { if (p) (void)hipFree(const_cast<void*>(p)); };
-    fr(h->ras.pnloc); fr(h->ras.pown); fr(h->ras.l2g); fr(h->ras.lcol); fr(h->ras.gent); fr(h->ras.gcol); fr(h->ras.pnh); fr(h->ras.hl2g);
-    fr(h->d_ras_x2); fr(h->d_ras_b); fr(h->d_ras_pw); fr(h->d_ras_pd); fr(h->d_ras_slots); fr(h->d_ras_iters); fr(h->ras.pn1); fr(h->d_ras_pwr);
-    h->ras = RasDev{}; h->d_ras_x2 = h->d_ras_b = h->d_ras_slots = h->d_ras_pw = h->d_ras_pd = h->d_ras_pwr = nullptr; h->d_ras_iters = nullptr;
-    h->has_ras = false; h->ras_slots_cap = 0;
-}
-
-// Cut the mesh into patches (host, once per mesh: topology and rest positions only).  rowptr/col = vertex adjacency,
-// slice_off = the ELL-8 group offsets of the device adjacency (to address m.w by entry).  Leaves has_ras = false when
-// the mesh does not fit the kernel's limits (degree > 16): the caller then keeps the CG solver.
-int ras_build(mvs_deform_s* h, const double* pts, const std::vector<int32_t>& rowptr, const std::vector<int32_t>& col,
-              const std::vector<int32_t>& slice_off) {
-    const int V = (int)h->V;
-    h->has_ras = false;
-    if (V < 2048) return MVS_OK;                      // small meshes: a handful of CG launches is already cheap
-    int maxdeg = 0;
-    for (int i = 0; i < V; ++i) maxdeg = std::max(maxdeg, rowptr[i + 1] - rowptr[i]);
-    // entries stored per patch-local row: the smallest of 6 / 8 / 12 / 16 that holds the mesh's largest vertex degree (a closed
-    // triangulated surface averages 6; every stored entry is an LDS gather + 3 FMAs per Chebyshev step and 10 bytes of table)
-    const int W = maxdeg <= 6 ? 6 : (maxdeg <= 8 ? 8 : (maxdeg <= 12 ? 12 : 16));
-    if (maxdeg > 16) return MVS_OK;
-    // patches: a whole number of "rounds" of one patch per CU (a 257th patch would cost a second round of the whole chip),
-    // at most ~240 owned rows each so that three rings of overlap stay well inside the 1024-row limit
-    const int RINGS = 3;                              // 2..5 rings measured within 10 % of each other on the bench mesh
-    int cus = 256;
-    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
-    const int rounds = std::max(1, (V + cus * 240 - 1) / (cus * 240));
-    // small meshes: ~214 owned rows per patch as on the large ones (fewer, larger patches need fewer sweeps; a sweep costs
-    // the same few microseconds whether 40 or 256 CUs take part)
-    const int NP = std::min(cus * rounds, std::max(1, (V + 213) / 214));
-    if (NP > 4096) return MVS_OK;                     // slot layout limit (V > 850 K): keep CG
-    // recursive coordinate bisection of the rest positions into NP parts of equal size: compact, box-like patches
-    // (a Z-curve cut left ragged patches whose three-ring halo was up to 832 rows; bisection keeps it near 450)
-    std::vector<int32_t> order(V), part_begin(NP + 1, 0);
-    std::iota(order.begin(), order.end(), 0);
-    {
-        struct Job { int lo, hi, p0, parts; };
-        std::vector<Job> stack{{0, V, 0, NP}};
-        while (!stack.empty()) {
-            const Job j = stack.back();
-            stack.pop_back();
-            if (j.parts == 1) { part_begin[j.p0] = j.lo; continue; }
-            double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-            for (int q = j.lo; q < j.hi; ++q) for (int c = 0; c < 3; ++c) { const double v = pts[3 * order[q] + c]; mn[c] = std::min(mn[c], v); mx[c] = std::max(mx[c], v); }
-            int ax = 0;
-            for (int c = 1; c < 3; ++c) if (mx[c] - mn[c] > mx[ax] - mn[ax]) ax = c;
-            const int pl = j.parts / 2, nl = (int)((int64_t)(j.hi - j.lo) * pl / j.parts);
-            std::nth_element(order.begin() + j.lo, order.begin() + j.lo + nl, order.begin() + j.hi, [&](int a, int b) {
-                const double va = pts[3 * a + ax], vb = pts[3 * b + ax];
-                return va < vb || (va == vb && a < b);
-            });
-            stack.push_back({j.lo, j.lo + nl, j.p0, pl});
-            stack.push_back({j.lo + nl, j.hi, j.p0 + pl, j.parts - pl});
-        }
-        part_begin[NP] = V;
-    }
-    // pass 1: the rows of every patch (owned rows, then the overlap ring by ring)
-    std::vector<std::vector<int32_t>> prows(NP);
-    std::vector<int32_t> pnloc(NP), pown(NP), pn1(NP);
-    std::vector<int32_t> mark(V, -1), lidx(V, -1);
-    int max_nloc = 0;
-    int64_t total_rows = 0;
-    for (int p = 0; p < NP; ++p) {
-        std::vector<int32_t>& rows = prows[p];
-        rows.assign(order.begin() + part_begin[p], order.begin() + part_begin[p + 1]);
-        std::sort(rows.begin(), rows.end());            // owned rows in vertex order (gather locality)
-        for (int v : rows) mark[v] = p;
-        const int nown = (int)rows.size();
-        size_t level_begin = 0;
-        for (int ring = 0; ring < RINGS; ++ring) {
-            const size_t level_end = rows.size();
-            std::vector<int32_t> next;
-            for (size_t q = level_begin; q < level_end; ++q)
-                for (int e = rowptr[rows[q]]; e < rowptr[rows[q] + 1]; ++e)
-                    if (mark[col[e]] != p) { mark[col[e]] = p; next.push_back(col[e]); }
-            if (rows.size() + next.size() > (size_t)RTPB) { for (int v : next) mark[v] = -1; break; }   // keep what fits
-            std::sort(next.begin(), next.end());
-            rows.insert(rows.end(), next.begin(), next.end());
-            level_begin = level_end;
-            if (ring == 0) pn1[p] = (int)rows.size();
-        }
-        if (pn1[p] == 0) pn1[p] = nown;                                   // (no ring fitted: the fusion check below will fail)
-        if ((int)rows.size() > RTPB || nown > 256) return MVS_OK;     // cannot happen (<= 240 owned rows, rings cut at RTPB)
-        pown[p] = nown;
-        pnloc[p] = (int)rows.size();
-        max_nloc = std::max(max_nloc, pnloc[p]);
-        total_rows += pnloc[p];
-        for (size_t q = nown; q < rows.size(); ++q) mark[rows[q]] = -1;      // overlap rows may be owned by a later patch
-    }
-    // pass 2: tables with a FIXED stride of LS rows per patch (= the workgroup size), padded with inert rows, so that
-    // a workgroup's table loads need nothing but its patch number (one dependent hop less per sweep)
-    const int LS = std::max(448, (max_nloc + 63) / 64 * 64);          // the preamble of the sweep kernel uses seven waves
-    std::vector<int32_t> l2g((size_t)NP * LS, 0), gent((size_t)NP * LS * W, -1), gcolv((size_t)NP * LS * W, -1);
-    std::vector<int16_t> lcol((size_t)NP * LS * W, (int16_t)-1);
-    // columns outside a patch (the ring beyond its last overlap ring) get a slot of their own behind the local rows: the
-    // sweep loads each such vertex ONCE into the x staging instead of gathering it per matrix entry, and needs no
-    // vertex-of-the-column table at all
-    std::vector<std::vector<int32_t>> phalo(NP);
-    std::vector<int32_t> pnh(NP, 0);
-    int max_nh = 0, n1max = 0;
-    bool fuse_ok = NP <= MVS_NBMAX;
-    for (int p = 0; p < NP; ++p) {
-        const std::vector<int32_t>& rows = prows[p];
-        const int nloc = pnloc[p];
-        for (int q = 0; q < nloc; ++q) { lidx[rows[q]] = q; l2g[(size_t)p * LS + q] = rows[q]; }
-        std::vector<int32_t>& halo = phalo[p];
-        const size_t e0 = (size_t)p * LS * W;
-        for (int q = 0; q < nloc; ++q) {
-            const int i = rows[q], deg = rowptr[i + 1] - rowptr[i];
-            for (int k = 0; k < deg; ++k) {
-                const int j = col[rowptr[i] + k];
-                const int gidx = slice_off[i / 8] + (8 * (k / 8) + (i % 8)) * 8 + (k % 8);     // entry (row i, k-th neighbour) of the ELL-8 layout
-                if (lidx[j] < 0) { lidx[j] = LS + (int)halo.size(); halo.push_back(j); }       // first sight of an outside vertex
-                lcol[e0 + (size_t)k * LS + q] = (int16_t)lidx[j];
-                gent[e0 + (size_t)k * LS + q] = gidx;
-                gcolv[e0 + (size_t)k * LS + q] = j;
-            }
-        }
-        // fused local + rhs: the right-hand side of an owned row reads the rotations of its neighbours from the workgroup's
-        // LDS, where the rotations of the owned rows and the first ring live
-        for (int q = 0; q < pown[p] && fuse_ok; ++q)
-            for (int e = rowptr[rows[q]]; e < rowptr[rows[q] + 1]; ++e)
-                if (lidx[col[e]] < 0 || lidx[col[e]] >= pn1[p]) { fuse_ok = false; break; }
-        n1max = std::max(n1max, pn1[p]);
-        for (int v : rows) lidx[v] = -1;
-        for (int v : halo) lidx[v] = -1;
-        pnh[p] = (int)halo.size();
-        max_nh = std::max(max_nh, pnh[p]);
-    }
-    if (LS + max_nh > RTPB || max_nh > LS) return MVS_OK;            // x staging holds RTPB slots; a thread loads at most one halo vertex
-    const int HS = LS;                                                // as many slots as threads: the load needs no bound check (max_nh <= LS)
-    std::vector<int32_t> hl2g((size_t)NP * HS, 0);
-    for (int p = 0; p < NP; ++p) std::copy(phalo[p].begin(), phalo[p].end(), hl2g.begin() + (size_t)p * HS);
-    RasDev R{};
-    R.NP = NP; R.NPpad = (4 * NP + 63) / 64 * 64; R.W = W;
-    int rc;
-    int32_t *d_pnloc, *d_pown, *d_l2g, *d_gent, *d_gcol, *d_pnh, *d_hl2g, *d_pn1;
-    int16_t* d_lcol;
-    if ((rc = up(&d_pnloc, pnloc)) || (rc = up(&d_pown, pown)) || (rc = up(&d_l2g, l2g)) || (rc = up(&d_lcol, lcol)) || (rc = up(&d_gent, gent)) || (rc = up(&d_gcol, gcolv)) ||
-        (rc = up(&d_pnh, pnh)) || (rc = up(&d_hl2g, hl2g))) return rc;
-    if ((rc = up(&d_pn1, pn1))) return rc;
-    // Measured on the metric workload (scripts/fuse_compare.py): the fused kernel takes 23.1 us against 13.3 + 12.1 us of the two
-    // row kernels it replaces — it moves a quarter of their bytes, but the rotations' Jacobi chains set its duration just as
-    // they set k_arap_local's, the first ring's rotations are computed twice, and half of its threads idle through phase 1 —
-    // and a step comes out 0.591 ms against 0.581.  It stays an option (MVS_FUSE=1; parity-tested like the default path).
-    if (!getenv("MVS_FUSE") || getenv("MVS_FUSE")[0] != '1') fuse_ok = false;
-    const int stage_slots = (LS + max_nh + 63) / 64 * 64;
-    if (sizeof(double) * (6 * (size_t)stage_slots + 9 * (size_t)n1max) > 60 * 1024) fuse_ok = false;     // the fused kernel's LDS staging (dynamic, default limit 64 KB)
-    R.pn1 = d_pn1; R.fuse = fuse_ok ? 1 : 0; R.n1max = n1max; R.stage_slots = stage_slots;
-    R.pnloc = d_pnloc; R.pown = d_pown; R.LS = LS; R.l2g = d_l2g; R.lcol = d_lcol; R.gent = d_gent; R.gcol = d_gcol;
-    R.HS = HS; R.pnh = d_pnh; R.hl2g = d_hl2g;
-    h->ras = R;
-    if (hipMalloc((void**)&h->d_ras_x2, sizeof(double) * 3 * (size_t)V) != hipSuccess) {
-        mvs_set_error("hipMalloc failed (patch solver vectors)"); return MVS_E_OOM;
-    }
-    if (fuse_ok && hipMalloc((void**)&h->d_ras_pwr, sizeof(double) * (size_t)W * l2g.size()) != hipSuccess) { mvs_set_error("hipMalloc failed (patch matrix)"); return MVS_E_OOM; }
-    if (hipMalloc((void**)&h->d_ras_pw, sizeof(double) * (size_t)W * l2g.size()) != hipSuccess || hipMalloc((void**)&h->d_ras_pd, sizeof(double) * l2g.size()) != hipSuccess) {
-        mvs_set_error("hipMalloc failed (patch matrix)"); return MVS_E_OOM;
-    }
-    h->ras_rows = total_rows;
-    h->ras_block = LS;
-    h->has_ras = true;
-    if (getenv("MVS_DEBUG_CG")) fprintf(stderr, "[mvs] patch solver: %d patches, %lld local rows for %d vertices, workgroup %d threads, %d entries per row, fused local+rhs %s\n", NP, (long long)h->ras_rows, V, h->ras_block, W, fuse_ok ? "on" : "off");
-    return MVS_OK;
-}
-
 int ras_slot_size(const mvs_deform_s* h) { return ras_slot_doubles(h->ras.NPpad); }
 
 // once per outer iteration, after launch_cot_weights and the control set: the patch-local matrix
 void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s, const double* init_ctrl, const RasSmooth& sm) {
     const RasDev& R = h->ras;
     const dim3 grid(R.NP), blk(h->ras_block);
-    if (R.W == 6) k_ras_prepare<6><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm, R.fuse ? h->d_ras_pwr : nullptr);
-    else if (R.W == 8) k_ras_prepare<8><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm, R.fuse ? h->d_ras_pwr : nullptr);
-    else if (R.W == 12) k_ras_prepare<12><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm, R.fuse ? h->d_ras_pwr : nullptr);
-    else k_ras_prepare<16><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm, R.fuse ? h->d_ras_pwr : nullptr);
+    if (R.W == 6) k_ras_prepare<6><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
+    else if (R.W == 8) k_ras_prepare<8><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
+    else if (R.W == 12) k_ras_prepare<12><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
+    else k_ras_prepare<16><<<grid, blk, 0, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pd, init_ctrl, h->d_pts, h->d_sol, h->d_rot, sm);
 }
 
 // a = 0.4 K/V (capped at 0.06), steps ~ 2.6 / sqrt(a): 11 steps at the density the reference's 16-NN sampling produces.
@@ -846,17 +515,16 @@ void launch_ras_prepare(const mvs_deform_s* h, hipStream_t s, const double* init
 // patches of the bench mesh — 21 % residual per sweep instead of 6-9 %, and every so often, as the template deforms, a mode
 // slips below it and a solve stalls at 40 % per sweep: scripts/pass_trace.py, pass 18.  Measured, scripts/bracket_sweep.py.)
 // predicted stop (k_ras_sweep): margin on (predicted residual of a sweep's input) x (observed true / predicted), as a fraction of cg_tol; 0 = off
-const double RAS_PREDICT = getenv("MVS_PREDICT") ? atof(getenv("MVS_PREDICT")) : 0.33;
+#define RAS_PREDICT MVS_KNOB("MVS_PREDICT", 0.33, 0.0, 1.0)
 constexpr double RAS_SLOW = 0.15;     // a sweep that leaves more than this fraction of the residual calls for the strong set
 void ras_default_bracket(const mvs_deform_s* h, double* a, int* m) {
     const double dens = h->V > 0 ? (double)h->K / (double)h->V : 0.15;
     *a = std::min(0.06, std::max(0.005, 0.4 * dens));
-    if (const char* e = getenv("MVS_RAS_A")) { const double v = atof(e); if (v > 0.0) *a = v; }      // experiments (scripts/bracket_sweep.py)
+    { const double v = MVS_KNOB("MVS_RAS_A", 0.0, 0.0, 1.0); if (v > 0.0) *a = v; }      // experiments (scripts/bracket_sweep.py)
     *m = ras_steps_for(*a);
 }
 int ras_steps_for(double a) {
-    double c = 2.6;
-    if (const char* e = getenv("MVS_RAS_C")) { const double v = atof(e); if (v > 0.0) c = v; }
+    const double c = MVS_KNOB("MVS_RAS_C", 2.6, 0.5, 16.0);
     return std::min(32, std::max(6, (int)std::lround(c / std::sqrt(a))));
 }   // (2.6 re-measured with the bfloat16 steps: 1.6 / 2.0 / 2.6 / 3.2 / 4.0 -> 0.62 / 0.58 / 0.56 / 0.57 / 0.58 ms per outer iteration)
 
@@ -864,8 +532,7 @@ int ras_steps_for(double a) {
 // is the last planned sweep of the solve — the launch keeps sweeping (device-wide barrier between sweeps, at most
 // RAS_TAIL_MAX more) until the solve has converged, should the plan have been too short.
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, double* xout, int it, double arap_tol, int sweep,
-                      double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots,
-                      bool fold_energy) {
+                      double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots) {
     const RasDev& R = h->ras;
     const int nb = arap_grid_blocks(h->sell);
     // Chebyshev parameters: the bracket's lower end `a` and the step count live in the handle — initialised from the density
@@ -893,20 +560,8 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, doubl
     const dim3 grid(R.NP), blk(h->ras_block);     // as many waves as the largest patch has rows (idle waves only add barrier cost)
     const RasTail tail{h->d_bar, tail_slots, RAS_TAIL_MAX};
 #define MVS_SWEEP(W, T) k_ras_sweep<W, T><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, stop_margin, \
-                                                              RAS_SLOW * RAS_SLOW, RAS_PREDICT * RAS_PREDICT, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur, tail, fold_energy ? 1 : 0)
+                                                              RAS_SLOW * RAS_SLOW, RAS_PREDICT * RAS_PREDICT, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur, tail)
     if (tail_slots) { if (R.W == 6) MVS_SWEEP(6, true); else if (R.W == 8) MVS_SWEEP(8, true); else if (R.W == 12) MVS_SWEEP(12, true); else MVS_SWEEP(16, true); }
     else            { if (R.W == 6) MVS_SWEEP(6, false); else if (R.W == 8) MVS_SWEEP(8, false); else if (R.W == 12) MVS_SWEEP(12, false); else MVS_SWEEP(16, false); }
 #undef MVS_SWEEP
-}
-
-void launch_ras_local_rhs(const mvs_deform_s* h, const double* x, int it, int iters, double arap_tol, double cg_tol, int ring_slot,
-                          const double* prev_solve_scalars, hipStream_t s) {
-    const RasDev& R = h->ras;
-    const dim3 grid(R.NP + 1), blk(h->ras_block);
-    const size_t lds = sizeof(double) * (6 * (size_t)R.stage_slots + 9 * (size_t)R.n1max);
-    const int nb = arap_grid_blocks(h->sell);
-#define MVS_LR(W) k_ras_local_rhs<W><<<grid, blk, lds, s>>>(h->sell, R, h->d_ras_pw, h->d_ras_pwr, h->d_ras_pd, h->d_pts, x, h->d_rot, h->d_bpure, h->d_ras_b, \
-                                                           h->d_bpure, it, iters, arap_tol, h->d_energy, nb, cg_tol, h->d_ctl, ring_slot, prev_solve_scalars, h->d_bar)
-    if (R.W == 6) MVS_LR(6); else if (R.W == 8) MVS_LR(8); else if (R.W == 12) MVS_LR(12); else MVS_LR(16);
-#undef MVS_LR
 }

@@ -78,12 +78,13 @@ def test_compute_entries_fail_loudly_without_a_gpu():
     with pytest.raises(_lib.MvsError) as e:
         srt.depth_to_model(sc.depth[0], sc.cams[0], S.MIN_DSP, S.MAX_DSP, S.SMOOTH)
     assert e.value.code == -4
-    # mesh validation happens before the device is touched: same status as on the GPU box
+    # the mesh check is a kernel too (meshbuild.hip, round 3): without a device a bad mesh is refused like any other — there is
+    # no host-side restatement of the check to fall back on (tests/test_gpu_deform.py::test_bad_mesh_is_rejected holds the GPU case)
     bad = sc.faces.copy()
     bad[0] = bad[0][::-1]
     with pytest.raises(_lib.MvsError) as e:
         deformation.Deformation(sc.verts, sc.normals, bad)
-    assert e.value.code == -3
+    assert e.value.code == -4
 
 
 def test_product_never_imports_the_oracle():

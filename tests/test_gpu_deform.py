@@ -214,8 +214,11 @@ def test_patch_solver_adapts_to_the_node_density(eng, oracle, stride):
     ref = oracle.arap(sc.verts, sc.faces, nodes, tg, 5, 1e-4)
     assert st["arap_iters_run"] == ref["iters"] and st["cg_rel_residual"] <= 1.5 * d.params.cg_tol
     assert rms(d.vertices(), ref["pts"]) <= 1e-6
-    st2 = d.arap(tg)                                   # second call runs the calibrated sweep plan
-    assert st2["cg_rel_residual"] <= 1.5 * d.params.cg_tol and st2["cg_launches"] <= st["cg_launches"]
+    # the first call ran the short uncalibrated plan (8 launches per solve, the rest of the sweeps inside the last one);
+    # the second runs the plan the harvest made of it: what the solves used plus the spares
+    st2 = d.arap(tg)
+    assert st2["cg_rel_residual"] <= 1.5 * d.params.cg_tol and st2["status"] == 0
+    assert st2["cg_launches"] <= st["cg_active"] + 5 * (2 + st["cg_active"] // 8)      # (plan = what the first call's solves ran + spares)
 
 
 def test_results_are_bit_reproducible(eng):
@@ -294,30 +297,23 @@ def test_every_solve_of_a_batch_is_judged(eng):
         assert 0 < st["cg_rel_residual"] <= st["worst_rel_residual_in_batch"] <= d.params.cg_tol
 
 
-def test_fused_local_rhs_kernel_matches_the_two_row_kernels(eng, oracle, monkeypatch):
-    """MVS_FUSE=1: local step of ARAP iteration k and right-hand side of k+1 as one patch kernel (schwarz.hip,
-    k_ras_local_rhs).  Per row it performs the operations of k_arap_local and k_arap_rhs in their order — rotations are
-    bit-identical — only the energy / residual sums are folded in another order: same oracle parity, and against the
-    default path the vertices agree to the solves' tolerance."""
-    sc, tp, tn, _ = scene_and_target(2)
-    outs = []
-    for fuse in ("0", "1"):
-        monkeypatch.setenv("MVS_FUSE", fuse)
-        d = eng.Deformation(sc.verts, sc.normals, sc.faces)
-        d.UniformSampling(16)
-        d.set_target(tp, tn)
-        st = [d.iterate(1) for _ in range(3)]
-        assert all(s_["converged"] for s_ in st)
-        outs.append((d.vertices(), d.rotations(), [s_["energy"] for s_ in st], [s_["arap_iters_run"] for s_ in st]))
-    monkeypatch.delenv("MVS_FUSE")
-    assert outs[0][3] == outs[1][3]
-    assert np.allclose(outs[0][2], outs[1][2], rtol=1e-9)
-    assert rms(outs[0][0], outs[1][0]) <= 1e-8 and rms(outs[0][1].reshape(-1, 9), outs[1][1].reshape(-1, 9)) <= 1e-7
-    o = oracle.Deform(sc.verts, sc.normals, sc.faces)
-    o.sample_nodes(16)
-    o.set_target(tp, tn)
-    o.iterate(oracle.Params.default(), 3)
-    assert rms(outs[1][0], o.vertices()) <= 1e-6
+@pytest.mark.parametrize("solver", [0, 1])
+def test_a_nan_in_one_right_hand_side_is_a_miss_not_a_convergence(eng, solver):
+    """the stop tests and the judge must propagate NaNs.  One poisoned component of one node target puts NaNs
+    into ONE column of b and x; the solve must be reported MVS_W_UNCONVERGED, never as converged (fmax / `x > 0 &&` tests drop
+    NaNs: the solve used to end as MVS_OK with NaNs in the mesh)."""
+    sc, _, _, _ = scene_and_target(1)
+    d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    d.params.solver = solver
+    d.UniformSampling(16)
+    tg = sc.verts[d.nodes()] * 1.01
+    good = d.arap(tg)
+    assert good["status"] == 0 and good["converged"]
+    tg[5, 0] = np.nan
+    d.set_vertices(sc.verts, sc.normals)
+    st = d.arap(tg)
+    assert st["status"] == 1 and not st["converged"] and st["unconverged_solves"] >= 1
+    assert not np.isfinite(st["worst_rel_residual_in_batch"]) or st["worst_rel_residual_in_batch"] > d.params.cg_tol
 
 
 def test_a_handle_is_reused_for_the_next_fit(eng):
