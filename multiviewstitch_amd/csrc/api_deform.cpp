@@ -205,12 +205,13 @@ struct RasPlan {                     // sweeps per ARAP iteration of the patch s
 constexpr int RAS_FIRST_PLAN = 8;
 constexpr int RAS_MAX_SWEEPS = 128;
 
+int g_dbg_plan_cap = 0;              // tests (mvs_debug_tail): at most this many launches per solve, the rest of its sweeps run in the last one
 RasPlan probe_ras(const mvs_deform_s* h) {
     RasPlan r;
     for (int i = 0; i < 8; ++i) r.n[i] = h->ras_plan[i] > 0 ? h->ras_plan[i] : RAS_FIRST_PLAN;
     // experiment (scripts/host_bound.py): at most this many LAUNCHES per solve — the rest of the sweeps run inside the last one
-    const int cap = (int)MVS_KNOB("MVS_RAS_PLAN_CAP", 0, 0, 128);
-    if (cap > 0) for (int i = 0; i < 8; ++i) if (h->ras_plan[i] > 0) r.n[i] = std::min(r.n[i], cap);
+    const int cap = g_dbg_plan_cap > 0 ? g_dbg_plan_cap : (int)MVS_KNOB("MVS_RAS_PLAN_CAP", 0, 0, 128);
+    if (cap > 0) for (int i = 0; i < 8; ++i) r.n[i] = std::min(r.n[i], cap);
     return r;
 }
 bool use_ras(const mvs_deform_s* h, const mvs_deform_params& p) { return h->has_ras && p.solver != MVS_SOLVER_CG; }
@@ -266,7 +267,11 @@ void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
 
 
 // graph smoothing (optional) + ARAP + geometry update.  ctrl_src: K*3 node targets.
-int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctrl_src, bool graph_smooth, const CgPlan& plan) {
+// safe_local: behind every patch solve a k_arap_local launch of its own follows even when the solve's last launch performs the
+// local step itself (fused mode) — it returns at once when that happened.  Callers that do not follow the solves (enqueue-only
+// batches of several handles sharing the chip, where a tail loop may have to be abandoned) and handles that have seen an
+// abandoned solve ask for it; a handle stepping on its own does not pay the extra launch.
+int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctrl_src, bool graph_smooth, const CgPlan& plan, bool safe_local = false) {
     hipStream_t s = h->stream;
     const int K = (int)h->K, V = (int)h->V;
     const int slot = (int)(h->seq_enqueued % MVS_RING);          // this pass's row of the residual ring (MVS_CTL_RING)
@@ -338,11 +343,18 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     }
     double* x_cur = h->d_sol;            // the patch solver ping-pongs between d_sol and d_ras_x2
     int64_t ras_slot = 0;
+    // fused mode: the last planned launch of every solve ends with the ARAP local step on its patches' owned rows (schwarz.hip);
+    // nl = partial sums per reduction the local step leaves, whoever performs it
+    const bool fused = ras && ras_can_fuse_local(h);
+    if (h->saw_abandon) safe_local = true;
+    const int nl = ras ? ras_local_parts(h) : 0;
+    const int demand_local = (fused && !safe_local) ? 1 : 0;          // the judge of a solve insists that its fused local step ran
     const double* prev_scal = nullptr;   // the 8 scalars of the last sweep slot of the previous solve (idle flag, sweeps that ran)
     for (int it = 0; ras && it < p.arap_iters; ++it) {
         {
             Tic t = tic(h, "rhs");
-            launch_arap_rhs(h->sell, h->d_pts, x_cur, h->d_rot, it, p.arap_tol, h->d_energy, nullptr, nullptr, h->d_ras_b, p.cg_tol, h->d_ctl, slot, prev_scal, h->d_bar, h->d_bpure, s);
+            launch_arap_rhs(h->sell, h->d_pts, x_cur, h->d_rot, it, p.arap_tol, h->d_energy, nullptr, nullptr, h->d_ras_b, p.cg_tol, h->d_ctl, slot, prev_scal, h->d_bar, h->d_bpure, s,
+                            nl, demand_local);
             toc(t, 1);
         }
         {
@@ -354,7 +366,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
                 // the last planned sweep of a solve is a TAIL launch: should the plan turn out too short it keeps sweeping in
                 // the kernel (its extra sweeps' partial sums go to the solve's tail slots)
                 launch_ras_sweep(h, h->d_ras_b, x_cur, x_next, it, p.arap_tol, i, p.cg_tol, STOP_AT, i > 0 ? cur - ss : nullptr, cur,
-                                 h->d_ras_iters + (size_t)ras_slot * h->ras.NP, s, last ? h->d_ras_tail + (size_t)it * RAS_TAIL_MAX * ss : nullptr);
+                                 h->d_ras_iters + (size_t)ras_slot * h->ras.NP, s, last ? h->d_ras_tail + (size_t)it * RAS_TAIL_MAX * ss : nullptr, fused);
                 x_cur = x_next;
                 ++ras_slot;
             };
@@ -363,9 +375,9 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
             toc(t, launched);
             prev_scal = h->d_ras_slots + (size_t)(ras_slot - 1) * ss + 3 * (size_t)h->ras.NPpad;
         }
-        {
+        if (!fused || safe_local) {
             Tic t = tic(h, "local");
-            launch_arap_local(h->sell, h->d_pts, x_cur, it, p.arap_tol, h->d_energy, h->d_rot, h->d_bpure, s);
+            launch_arap_local(h->sell, h->d_pts, x_cur, it, p.arap_tol, h->d_energy, h->d_rot, h->d_bpure, s, fused ? h->d_ctl : nullptr, nl);
             toc(t, 1);
         }
     }
@@ -387,17 +399,17 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
             }
             toc(t, cg);
         }
-        { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, h->d_sol, it, p.arap_tol, h->d_energy, h->d_rot, h->d_bpure, s); toc(t, 1); }
+        { Tic t = tic(h, "local"); launch_arap_local(h->sell, h->d_pts, h->d_sol, it, p.arap_tol, h->d_energy, h->d_rot, h->d_bpure, s, nullptr, 0); toc(t, 1); }
     }
     Tic t = tic(h, "finalize");
     int n = 1;
     if (p.update_normals) {              // the node normals change too: separate gather after the normals kernel
-        launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, nullptr, nullptr, nullptr, p.cg_tol, h->d_ctl, slot, host_ctl, prev_scal, s);   // :400
+        launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, nullptr, nullptr, nullptr, p.cg_tol, h->d_ctl, slot, host_ctl, prev_scal, s, nl, demand_local);   // :400
         launch_vertex_normals(h->d_pts, h->d_faces, h->d_vf_ptr, h->d_vf, V, h->d_nrm, s);
         launch_gather_nodes(h->d_pts, h->d_nrm, h->d_nodes, K, h->d_node_pts, h->d_node_nrm, s);
         n = 3;
     } else {
-        launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, h->d_nrm, h->d_node_pts, h->d_node_nrm, p.cg_tol, h->d_ctl, slot, host_ctl, prev_scal, s);
+        launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, h->d_nrm, h->d_node_pts, h->d_node_nrm, p.cg_tol, h->d_ctl, slot, host_ctl, prev_scal, s, nl, demand_local);
     }
     toc(t, n);
     (void)V;
@@ -500,6 +512,11 @@ int read_judgement(mvs_deform_s* h, const mvs_deform_params& p, Judgement* j) {
     HIPCHK(hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     j->esc = ctl[MVS_CTL_ESC] != 0.0;
+    for (int it = 0; it < 8; ++it)                             // a tail loop was abandoned since the last look: from now on a local-step launch of
+        if (ctl[MVS_CTL_GAVEUP + it] > h->gaveup_seen[it]) {   // its own follows every solve of this handle (the chip is shared with somebody)
+            h->gaveup_seen[it] = ctl[MVS_CTL_GAVEUP + it];
+            h->saw_abandon = true;
+        }
     if (mvs_debug_level()) fprintf(stderr, "[mvs] predicted stops: true / predicted residual (running maximum) %.2f\n", std::sqrt(std::max(1.0, ctl[MVS_CTL_PSAFE])));
     j->worst2 = ctl[MVS_CTL_WORST];
     j->missed = (int)ctl[MVS_CTL_MISSED];
@@ -944,7 +961,7 @@ int mvs_deform_iterate(mvs_deform_t h, const mvs_deform_params* p, int n_outer, 
         const CgPlan cg = probe_cg(h, *p);
         for (int o = 0; o < n_outer; ++o) {
             enqueue_assoc_local(h, *p);
-            rc = enqueue_solve(h, *p, h->d_ctrl_raw, true, cg);
+            rc = enqueue_solve(h, *p, h->d_ctrl_raw, true, cg, true);
             if (rc) return rc;
         }
         return MVS_OK;
@@ -1191,6 +1208,15 @@ int mvs_debug_heavy_count(mvs_deform_t h, int* n, int* flagged) {
     for (int i = 0; i < l[0] && i < (int)h->K; ++i) f += (l[1 + i] & 0x40000000) != 0;
     if (n) *n = l[0];
     if (flagged) *flagged = f;
+    return MVS_OK;
+}
+
+// diagnostics (tests; not part of the ABI): maxspin = polls a workgroup waits at the tail loop's device-wide barrier before it
+// abandons the solve (<= 0: default); plan_cap = at most this many launches per solve, the remaining sweeps run inside the last
+// one (0: no cap).  Process-wide.
+int mvs_debug_tail(int maxspin, int plan_cap) {
+    ras_set_tail_maxspin(maxspin);
+    g_dbg_plan_cap = plan_cap > 0 ? plan_cap : 0;
     return MVS_OK;
 }
 

@@ -34,6 +34,7 @@
 #include "dev_common.h"
 #include "svd3_dev.h"
 #include "arap_dev.h"
+#include "local_dev.h"
 #include <algorithm>
 
 namespace {
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
                                                   double* __restrict__ rws, double* __restrict__ p,
                                                   double* __restrict__ bout, double cg_tol, double* __restrict__ ctl,
                                                   int ring_slot, const double* __restrict__ prev_scal, unsigned* __restrict__ bar,
-                                                  double* __restrict__ bpure) {
+                                                  double* __restrict__ bpure, int nl, int fused_local) {
     double* efin = ered + EFIN;
     __shared__ int s_done;
     // The LAST block of the grid does no rows when there is a solve to judge (it >= 1): it folds the true-residual partials the
@@ -178,11 +179,11 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
     const int nbw = judge_block ? (int)gridDim.x - 1 : (int)gridDim.x;          // blocks that work on rows
     if (bar && blockIdx.x == gridDim.x - 1 && threadIdx.x < MVS_BAR_WORDS) bar[threadIdx.x * MVS_BAR_STRIDE] = 0u;
     if (judge_block && blockIdx.x == nbw) {
-        judge_solve(ered, it - 1, gridDim.x, cg_tol, ctl, ring_slot, !arap_done_before(efin, it - 1, tol), prev_scal);
+        judge_solve(ered, it - 1, gridDim.x, cg_tol, ctl, ring_slot, !arap_done_before(efin, it - 1, tol), prev_scal, nl, fused_local);
         if (threadIdx.x < 3) ered[it * EIT + (1 + threadIdx.x) * NBMAX + blockIdx.x] = 0.0;      // its slot of the bnorm partials
         return;
     }
-    if (!judge_block && blockIdx.x == 0 && it >= 1 && ctl) judge_solve(ered, it - 1, gridDim.x, cg_tol, ctl, ring_slot, !arap_done_before(efin, it - 1, tol), prev_scal);
+    if (!judge_block && blockIdx.x == 0 && it >= 1 && ctl) judge_solve(ered, it - 1, gridDim.x, cg_tol, ctl, ring_slot, !arap_done_before(efin, it - 1, tol), prev_scal, nl, fused_local);
     // Degree <= 8 (one 64-entry slice per 8 rows) and a grid that holds every 16-row group at once: FOUR lanes per row, two
     // entries each — a wave then takes 16 rows, 3423 wave-tasks for the metric mesh against the launch's 4080 waves: every wave
     // has ONE group.  With 8 lanes per row they were 6845 tasks, two dependent load chains one after the other for two waves in
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
         bool done = arap_done_before(efin, it - 1, tol);
         if (it >= 1) {
             // iteration it-1 did not run if the rule had fired before it: its partials are stale
-            const double e_prev = done ? 0.0 : fold_partials(ered + (it - 1) * EIT, gridDim.x);
+            const double e_prev = done ? 0.0 : fold_partials(ered + (it - 1) * EIT, nl > 0 ? nl : (int)gridDim.x);
             if (blockIdx.x == 0 && threadIdx.x == 0) efin[it - 1] = e_prev;
             if (!done && tol > 0.0 && it >= 2 && fabs((efin[it - 2] - e_prev) / e_prev) < tol) done = true;
         }
@@ -541,11 +542,12 @@ __global__ __launch_bounds__(TPB) void k_cg_iter(SellDev m, const double* __rest
 // kernels' grid so that the energy partials land where their consumers fold them.
 __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __restrict__ pts, const double* __restrict__ sol,
                                                     int it, double tol, double* __restrict__ ered, double* __restrict__ rot,
-                                                    const double* __restrict__ bvec) {
+                                                    const double* __restrict__ bvec, const double* __restrict__ ctl, int nfold) {
     // the stop rule's verdict (one thread: two dependent loads and an fp64 division) travels WITH the first vertex's loads, not in
-    // front of them: the workgroup's barrier comes after those loads have been issued
+    // front of them: the workgroup's barrier comes after those loads have been issued.  ctl != NULL: this launch is the fall-back
+    // behind a patch solve whose last launch normally performs the local step itself (schwarz.hip) — nothing to do when it has.
     __shared__ int s_stop;
-    if (threadIdx.x == 0) s_stop = arap_done_before(ered + EFIN, it, tol) ? 1 : 0;
+    if (threadIdx.x == 0) s_stop = (arap_done_before(ered + EFIN, it, tol) || (ctl && ctl[MVS_CTL_LOCAL + it] == ctl[MVS_CTL_SEQ] + 1.0)) ? 1 : 0;
 #ifdef MVS_STAMPS
 #define LSTAMP(k) do { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
         if ((threadIdx.x & 63) == 0 && it == 2) g_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } while (0)
@@ -555,88 +557,14 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
     LSTAMP(0);
     double e_acc = 0.0;
     double g0 = 0.0, g1 = 0.0, g2 = 0.0;          // true residual of the global solve whose result `sol` is: sum r_c^2 / d_i over the free rows
-    // the first eight edges of a vertex (all of them when the degree is <= 8): weights and edge vectors of the rest and the current pose
-    struct Edges { int off, passes; d3 pi, qi; double w0[8]; d3 pp0[8], qq0[8]; bool judge; };
-    auto fetch = [&](int i, Edges& E) {
-        const int g = i >> 3, r = i & 7;
-        E.off = m.single_pass ? 64 * g : m.slice_off[g];
-        E.passes = m.single_pass ? 1 : (m.slice_off[g + 1] - E.off) >> 6;
-        E.pi = ld3(pts + 3 * i); E.qi = ld3(sol + 3 * i);
-        E.judge = bvec != nullptr && m.is_ctrl[i] == 0;
-#pragma unroll
-        for (int l = 0; l < 8; ++l) {
-            const int e = E.off + r * 8 + l;
-            E.w0[l] = m.w[e];
-            const int j = E.w0[l] == 0.0 ? i : m.col[e];
-            E.pp0[l] = E.pi - ld3(pts + 3 * j); E.qq0[l] = E.qi - ld3(sol + 3 * j);
-        }
-    };
     const int i_first = blockIdx.x * 256 + threadIdx.x;
-    Edges E;
-    if (i_first < m.V) fetch(i_first, E);
+    LocalEdges E;
+    if (i_first < m.V) local_fetch(m, pts, sol, bvec, i_first, E);
     __syncthreads();
     if (s_stop) return;
     for (int i = i_first; i < m.V; i += gridDim.x * 256) {
-        if (i != i_first) fetch(i, E);
-        const int r = i & 7, off = E.off, passes = E.passes;
-        const d3 pi = E.pi, qi = E.qi;
-        double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        double (&w0)[8] = E.w0;
-        d3 (&pp0)[8] = E.pp0;
-        d3 (&qq0)[8] = E.qq0;
-        const bool judge = E.judge;
-        // r_i = b_i - (d_i x_i - sum_{free j} 2 w_ij x_j) = (b_i - sum_{ctrl j} 2 w_ij x_j) - sum_j 2 w_ij (x_i - x_j): the first
-        // bracket is the `bpure` the rhs kernel wrote (bvec), the edge differences are the ones of the covariance
-        d3 ax = mk3(0, 0, 0);
-#pragma unroll
-        for (int l = 0; l < 8; ++l) {
-            if (w0[l] == 0.0) continue;
-            const double w = w0[l];
-            const d3 pp = pp0[l], qq = qq0[l];
-            if (judge) ax = ax + (2.0 * w) * qq;
-            c[0] += w * (pp.x * qq.x); c[1] += w * (pp.x * qq.y); c[2] += w * (pp.x * qq.z);
-            c[3] += w * (pp.y * qq.x); c[4] += w * (pp.y * qq.y); c[5] += w * (pp.y * qq.z);
-            c[6] += w * (pp.z * qq.x); c[7] += w * (pp.z * qq.y); c[8] += w * (pp.z * qq.z);
-        }
-        for (int t = 1; t < passes; ++t)
-#pragma unroll
-            for (int l = 0; l < 8; ++l) {
-                const int e = off + (8 * t + r) * 8 + l;
-                const double w = m.w[e];
-                if (w == 0.0) continue;
-                const int j = m.col[e];
-                const d3 pp = pi - ld3(pts + 3 * j), qq = qi - ld3(sol + 3 * j);
-                if (judge) ax = ax + (2.0 * w) * qq;
-                c[0] += w * (pp.x * qq.x); c[1] += w * (pp.x * qq.y); c[2] += w * (pp.x * qq.z);
-                c[3] += w * (pp.y * qq.x); c[4] += w * (pp.y * qq.y); c[5] += w * (pp.y * qq.z);
-                c[6] += w * (pp.z * qq.x); c[7] += w * (pp.z * qq.y); c[8] += w * (pp.z * qq.z);
-            }
-        if (judge) {
-            const d3 res = ld3(bvec + 3 * (int64_t)i) - ax;
-            const double inv_d = 1.0 / m.diag[i];
-            g0 += res.x * res.x * inv_d; g1 += res.y * res.y * inv_d; g2 += res.z * res.z * inv_d;
-        }
-        LSTAMP(1);
-        double R[9];
-        closest_rotation(c, R);
-        LSTAMP(2);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) rot[9 * (int64_t)i + k] = R[k];
-#pragma unroll
-        for (int l = 0; l < 8; ++l) {
-            if (w0[l] == 0.0) continue;
-            e_acc += w0[l] * sqn3(qq0[l] - mulMv(R, pp0[l]));
-        }
-        for (int t = 1; t < passes; ++t)
-#pragma unroll
-            for (int l = 0; l < 8; ++l) {
-                const int e = off + (8 * t + r) * 8 + l;
-                const double w = m.w[e];
-                if (w == 0.0) continue;
-                const int j = m.col[e];
-                const d3 pp = pi - ld3(pts + 3 * j), qq = qi - ld3(sol + 3 * j);
-                e_acc += w * sqn3(qq - mulMv(R, pp));
-            }
+        if (i != i_first) local_fetch(m, pts, sol, bvec, i, E);
+        local_vertex(m, pts, sol, bvec, i, E, rot, e_acc, g0, g1, g2);
     }
     LSTAMP(3);
     e_acc = wave_total(e_acc);
@@ -647,21 +575,28 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
     if (threadIdx.x == 0) ered[it * EIT + blockIdx.x] = (sm[0][0] + sm[1][0]) + (sm[2][0] + sm[3][0]);
     if (bvec && threadIdx.x >= 1 && threadIdx.x < 4)
         ered[it * EIT + (3 + threadIdx.x) * NBMAX + blockIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    // the consumers fold `nfold` partials per sum (the patch launches write one per patch): the slots beyond this grid hold zeros
+    if (blockIdx.x == 0)
+        for (int q = (int)gridDim.x + (int)threadIdx.x; q < nfold; q += 256) {
+            ered[it * EIT + q] = 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ered[it * EIT + (4 + c) * NBMAX + q] = 0.0;
+        }
 }
 
 __global__ void k_arap_finalize(SellDev m, int iters, double tol, int nb, double* __restrict__ ered,
                                 const double* __restrict__ sol, double* __restrict__ pts, int32_t* __restrict__ info,
                                 const double* __restrict__ nrm, double* __restrict__ node_pts, double* __restrict__ node_nrm,
                                 double cg_tol, double* __restrict__ ctl, int ring_slot, double* __restrict__ host_ctl,
-                                const double* __restrict__ last_scal) {
+                                const double* __restrict__ last_scal, int nl, int fused_local) {
     // assign_solution + overwrite_initial_geometry (Deformation.cpp:398-400)
     double* efin = ered + EFIN;
     if (blockIdx.x == gridDim.x - 1) {           // the extra block: stop-rule bookkeeping, the last solve's verdict, the host mirror
         // the last iteration's energy is only meaningful if that iteration ran (its kernels exit once the rule fired)
         const bool done = arap_done_before(efin, iters - 1, tol);
-        if (ctl) judge_solve(ered, iters - 1, nb, cg_tol, ctl, ring_slot, !done, last_scal);       // (contains the block's barrier)
+        if (ctl) judge_solve(ered, iters - 1, nb, cg_tol, ctl, ring_slot, !done, last_scal, nl, fused_local);       // (contains the block's barrier)
         if (threadIdx.x < 64) {
-            const double e_last = fold_partials(ered + (iters - 1) * EIT, nb);
+            const double e_last = fold_partials(ered + (iters - 1) * EIT, nl > 0 ? nl : nb);
             if (threadIdx.x == 0) {
                 efin[iters - 1] = done ? 0.0 : e_last;
                 int run = iters;
@@ -743,8 +678,9 @@ void launch_cot_weights(const SellDev& m, const double* pts, double* coef, const
 }
 void launch_arap_rhs(const SellDev& m, const double* pts, const double* sol, const double* rot, int it, double tol,
                      double* ered, double* rws, double* p, double* bout, double cg_tol, double* ctl, int ring_slot,
-                     const double* prev_solve_scalars, unsigned* bar, double* bpure, hipStream_t s) {
-    k_arap_rhs<<<dim3(arap_grid_blocks(m)), dim3(TPB), 0, s>>>(m, pts, sol, rot, it, tol, ered, rws, p, bout, cg_tol, ctl, ring_slot, prev_solve_scalars, bar, bpure);
+                     const double* prev_solve_scalars, unsigned* bar, double* bpure, hipStream_t s, int nfold_local, int fused_local) {
+    k_arap_rhs<<<dim3(arap_grid_blocks(m)), dim3(TPB), 0, s>>>(m, pts, sol, rot, it, tol, ered, rws, p, bout, cg_tol, ctl, ring_slot, prev_solve_scalars, bar, bpure,
+                                                              nfold_local, fused_local);
 }
 void launch_cg_w0(const SellDev& m, const double* coef, int it, double tol, const double* ered, double* rws,
                   double* slot0, hipStream_t s) {
@@ -758,15 +694,16 @@ void launch_cg_iter(const SellDev& m, const double* coef, int it, double tol, co
                                                              slot_next, rws_in, rws_out, p, x);
 }
 void launch_arap_local(const SellDev& m, const double* pts, const double* sol, int it, double tol, double* ered,
-                       double* rot, const double* b, hipStream_t s) {
-    k_arap_local<<<dim3(arap_grid_blocks(m)), dim3(256), 0, s>>>(m, pts, sol, it, tol, ered, rot, b);
+                       double* rot, const double* b, hipStream_t s, const double* ctl, int nfold) {
+    k_arap_local<<<dim3(arap_grid_blocks(m)), dim3(256), 0, s>>>(m, pts, sol, it, tol, ered, rot, b, ctl, nfold);
 }
 // node_pts != NULL: also gathers the nodes' new positions and (unchanged) normals, as k_gather_nodes would
 void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered, const double* sol,
                           double* pts, int32_t* info, const double* nrm, double* node_pts, double* node_nrm,
-                          double cg_tol, double* ctl, int ring_slot, double* host_ctl, const double* last_solve_scalars, hipStream_t s) {
+                          double cg_tol, double* ctl, int ring_slot, double* host_ctl, const double* last_solve_scalars, hipStream_t s,
+                          int nfold_local, int fused_local) {
     k_arap_finalize<<<dim3((m.V + 255) / 256 + 1), dim3(256), 0, s>>>(m, iters, tol, arap_grid_blocks(m), ered, sol, pts, info, nrm, node_pts, node_nrm,
-                                                                  cg_tol, ctl, ring_slot, host_ctl, last_solve_scalars);
+                                                                  cg_tol, ctl, ring_slot, host_ctl, last_solve_scalars, nfold_local, fused_local);
 }
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf, int V,
                            double* out, hipStream_t s) {

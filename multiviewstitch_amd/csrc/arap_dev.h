@@ -139,13 +139,14 @@ __device__ inline bool arap_done_before(const double* __restrict__ efin, int it,
 // right-hand side c; thread 0 writes rel^2 = max_c gamma_c / bnorm_c into the ring row and keeps the control block's
 // sticky summary (MVS_CTL_*, engine.h).  `ran` (thread 0's value counts): the iteration ran at all.
 __device__ inline void judge_solve(const double* __restrict__ ered, int it, int nb, double cg_tol, double* __restrict__ ctl,
-                                   int ring_slot, bool ran, const double* __restrict__ scal = nullptr) {
+                                   int ring_slot, bool ran, const double* __restrict__ scal = nullptr, int nl = 0, int fused_local = 0) {
+    // nb: partials of the right-hand side's norm (the rhs kernel's grid); nl: partials the local step left (0: as nb)
     __shared__ double s_rel[3];
     const int wv = threadIdx.x >> 6;
+    if (nl <= 0) nl = nb;
     if (wv >= 1 && wv <= 3) {
         const int c = wv - 1;
-        double gam, bn;
-        fold_partials2(ered + it * EIT + (4 + c) * NBMAX, ered + it * EIT + (1 + c) * NBMAX, nb, &gam, &bn);
+        const double gam = fold_partials(ered + it * EIT + (4 + c) * NBMAX, nl), bn = fold_partials(ered + it * EIT + (1 + c) * NBMAX, nb);
         // (a right-hand side that is exactly zero has a zero residual; anything else that is not a positive norm — a NaN in b
         //  or in x — must not pass as converged)
         if ((threadIdx.x & 63) == 0) s_rel[c] = bn > 0.0 ? gam / bn : ((bn == 0.0 && gam == 0.0) ? 0.0 : INFINITY);
@@ -161,6 +162,10 @@ __device__ inline void judge_solve(const double* __restrict__ ered, int it, int 
         double rel2 = 0.0;                                                // NaN-propagating maximum: a NaN in ANY component is a miss
 #pragma unroll
         for (int c = 0; c < 3; ++c) { const double v = s_rel[c]; if (!(v <= rel2)) rel2 = (v == v) ? v : INFINITY; }
+        // a solve whose tail loop was abandoned at the device-wide barrier (its sweeps ended at a timing-dependent point), or
+        // a fused solve whose last launch did not get to the local step (the partials above are then stale), is a miss
+        const double pass1 = ctl[MVS_CTL_SEQ] + 1.0;
+        if (ctl[MVS_CTL_GAVEUP + it] == pass1 || (fused_local && ctl[MVS_CTL_LOCAL + it] != pass1)) rel2 = INFINITY;
         row[it] = rel2;
         ctl[MVS_CTL_WORST] = fmax(ctl[MVS_CTL_WORST], rel2);
         ctl[MVS_CTL_SOLVES] += 1.0;
@@ -169,7 +174,7 @@ __device__ inline void judge_solve(const double* __restrict__ ered, int it, int 
         // true / predicted (decaying 6 % per predicted solve) is the safety factor of the next predictions
         const double pr = ctl[MVS_CTL_PRED];
         if (pr > 0.0) {
-            ctl[MVS_CTL_PSAFE] = fmax(rel2 / pr, 0.94 * ctl[MVS_CTL_PSAFE]);
+            if (rel2 < INFINITY) ctl[MVS_CTL_PSAFE] = fmax(rel2 / pr, 0.94 * ctl[MVS_CTL_PSAFE]);
             ctl[MVS_CTL_PRED] = 0.0;
         }
     }

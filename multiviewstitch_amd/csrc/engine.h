@@ -73,7 +73,7 @@ struct RasDev {                // patches of the restricted additive Schwarz sol
 #define MVS_CTL_MISSED 2     /* solves above cg_tol since the last harvest                                         */
 #define MVS_CTL_SOLVES 3     /* solves judged since the last harvest                                               */
 #define MVS_CTL_SEQ    4     /* outer iterations finalized since the handle was created                            */
-// barrier words of the tail loop (unsigned, one per 128 B line): root counter, give-up flag, 16 group counters, 16 group release words
+// barrier words of the tail loop (unsigned, one per 128 B line): root counter, decision word, 16 group counters, 16 group release words
 #define MVS_BAR_STRIDE 32
 #define MVS_BAR_GROUPS 16
 #define MVS_BAR_WORDS  (2 + 2 * MVS_BAR_GROUPS)
@@ -85,7 +85,11 @@ struct RasDev {                // patches of the restricted additive Schwarz sol
 #define MVS_RING       32
 #define MVS_CTL_USED   (MVS_CTL_RING + MVS_RING * 8)   /* [MVS_RING][8]: sweeps solve `it` of that pass actually ran (patch solver);
                                                           negative: it ran every planned sweep (no spare was left); 0: unknown */
-#define MVS_CTL_SIZE   (MVS_CTL_USED + MVS_RING * 8)
+#define MVS_CTL_LOCAL  (MVS_CTL_USED + MVS_RING * 8)  /* [8]: pass number + 1 of the last pass whose ARAP iteration `it` had its local step done by
+                                                          the solve's last launch (schwarz.hip, fused mode); the judge of a fused solve demands it */
+#define MVS_CTL_GAVEUP (MVS_CTL_LOCAL + 8)             /* [8]: pass number + 1 of the last pass in which the tail loop of solve `it` was abandoned
+                                                          (a workgroup's bounded wait at the device-wide barrier expired): such a solve counts as a miss */
+#define MVS_CTL_SIZE   (MVS_CTL_GAVEUP + 8)
 
 // One hipMalloc, many arrays: a layout function is run twice over an Arena — first with base == NULL to learn the size,
 // then over the allocation to hand out the (256-byte aligned) pieces.  mvs_deform_create made ~30 hipMallocs before (3 ms).
@@ -194,6 +198,8 @@ struct mvs_deform_s {
     size_t arena_target_bytes = 0;
     void* arena_probe = nullptr;    // grid build: probe histogram + partial sums (kept across targets)
     size_t arena_probe_bytes = 0;
+    bool saw_abandon = false;       // a tail loop of this handle was abandoned at its barrier: keep a local-step launch behind every solve
+    double gaveup_seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int32_t* d_deg = nullptr;       // [V] vertex degree (device build; the ELL-8 tables pad every row to a multiple of 8)
 };
 
@@ -245,7 +251,8 @@ void launch_arap_rhs(const SellDev& m, const double* pts, const double* sol, con
                      double* ered, double* rws, double* p, double* bout, double cg_tol, double* ctl, int ring_slot,
                      const double* prev_solve_scalars /*8 scalars of the last sweep slot of solve it-1, or NULL*/,
                      unsigned* bar /*tail-loop barrier words to reset, or NULL*/,
-                     double* bpure /*V*3: b without the Dirichlet columns' share (what the local step judges the solve against)*/, hipStream_t s);
+                     double* bpure /*V*3: b without the Dirichlet columns' share (what the local step judges the solve against)*/, hipStream_t s,
+                     int nfold_local = 0 /*partials per sum the local step left (0: this kernel's grid)*/, int fused_local = 0 /*the solve it judges was a fused one*/);
 void launch_cg_w0(const SellDev& m, const double* coef, int it, double tol, const double* ered, double* rws,
                   double* slot0, hipStream_t s);
 // slot_i = slot of CG iteration i of this solve (slot0 + i*MVS_CG_SLOT); alpha_i / gamma_i are written into it
@@ -253,11 +260,14 @@ void launch_cg_iter(const SellDev& m, const double* coef, int it, double tol, co
                     const double* slot0, double* slot_i, double* slot_next, const double* rws_in, double* rws_out,
                     double* p, double* x, hipStream_t s);
 // b != NULL (the `bpure` of launch_arap_rhs): also the residual partials of the solve whose result `sol` is (ered + it*EIT + 4*NBMAX)
+// ctl != NULL: fall-back launch behind a fused patch solve (returns at once when the solve's last launch did the local step);
+// nfold: partial sums per reduction the consumers fold (slots beyond this launch's grid are zero-filled)
 void launch_arap_local(const SellDev& m, const double* pts, const double* sol, int it, double tol, double* ered,
-                       double* rot, const double* b, hipStream_t s);
+                       double* rot, const double* b, hipStream_t s, const double* ctl, int nfold);
 void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered, const double* sol,
                           double* pts, int32_t* info, const double* nrm, double* node_pts, double* node_nrm,
-                          double cg_tol, double* ctl, int ring_slot, double* host_ctl, const double* last_solve_scalars, hipStream_t s);
+                          double cg_tol, double* ctl, int ring_slot, double* host_ctl, const double* last_solve_scalars, hipStream_t s,
+                          int nfold_local = 0, int fused_local = 0);
 int  arap_grid_blocks(const SellDev& m);
 // schwarz.hip
 // meshbuild.hip — row a16 on the device (Deformation.cpp:29-46, Deformation.h:51-84): validity of the facet list, ELL-8
@@ -277,7 +287,11 @@ void ras_default_bracket(const mvs_deform_s* h, double* a, int* m);
 int  ras_steps_for(double a);
 #define RAS_TAIL_MAX 32      /* in-kernel sweeps a TAIL launch may add to a solve whose plan was too short */
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, double* xout, int it, double arap_tol, int sweep,
-                      double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots = nullptr);
+                      double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots = nullptr,
+                      bool with_local = false /*last launch of a solve: also the ARAP local step on every patch's owned rows (when ras_can_fuse_local)*/);
+bool ras_can_fuse_local(const mvs_deform_s* h);   // patches <= MVS_NBMAX and workgroups <= 512 threads
+int  ras_local_parts(const mvs_deform_s* h);      // partial sums per reduction the local step leaves (what its consumers fold)
+void ras_set_tail_maxspin(int n);                 // tests: polls at the tail barrier before a workgroup abandons the solve (<= 0: default)
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf,
                            int V, double* out, hipStream_t s);
 

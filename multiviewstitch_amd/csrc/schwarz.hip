@@ -26,6 +26,7 @@
 #include "dev_common.h"
 #include "arap_dev.h"
 #include "svd3_dev.h"
+#include "local_dev.h"
 #include "knobs.h"
 #include <algorithm>
 #include <cmath>
@@ -163,37 +164,57 @@ __global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, doubl
 // which agent scope sends to memory past the eight per-XCD L2s, one after the other): the arrivals are counted per group of
 // 16 workgroups (different lines: concurrent), the last of a group reports to the root counter, the last at the root writes
 // the generation into one release word per group, and a workgroup polls only its group's word.
-// Words (MVS_BAR_STRIDE apart, k_arap_rhs zeroes them before every solve): [0] root, [1] give-up flag != 0: a workgroup gave up
-// waiting (not every workgroup of the launch was resident, e.g. many handles sweeping at once) — every later barrier then
-// falls through and the solve is reported as it stands; [2 + g] arrivals of group g; [2 + GROUPS + g] release word of group g.
-constexpr int TAIL_MAXSPIN = 1 << 16;
-__device__ inline bool tail_barrier(unsigned* bar, unsigned gen /* 1, 2, ... : the barrier's number within this solve */) {
+//
+// Every workgroup leaves barrier `gen` with the SAME verdict (round 3; round 2's give-up flag could be raised by one
+// workgroup while the release words were being written: some patches then swept once more than others).  The verdict is ONE
+// word, `dec`: it holds the last generation that was released, or ABANDONED.  The last arrival moves it gen-1 -> gen by
+// compare-and-swap; a workgroup whose bounded wait expires moves it gen-1 -> ABANDONED the same way; whichever swap succeeds
+// decides for everybody — the loser reads the winner's verdict from the swap's return value, late arrivals read it at the door,
+// the pollers get it through their release word (gen, or ABANDONED = 0xffffffff).  An abandoned solve stops at the same sweep
+// in every patch and is reported as a miss (MVS_CTL_GAVEUP -> MVS_W_UNCONVERGED): where it stopped depended on timing.
+// Words (MVS_BAR_STRIDE apart, k_arap_rhs zeroes them before every solve): [0] root counter, [1] dec, [2 + g] arrivals of group g,
+// [2 + GROUPS + g] release word of group g.
+constexpr unsigned TAIL_ABANDONED = 0xffffffffu;
+__device__ inline bool tail_barrier(unsigned* bar, unsigned gen /* 1, 2, ... : the barrier's number within this solve */, int maxspin) {
     __shared__ int s_ok;
-    __syncthreads();
+    __syncthreads();                                                   // (every wave's stores have been issued and waited for)
     if (threadIdx.x == 0) {
         int ok = 1;
-        unsigned* giveup = bar + MVS_BAR_STRIDE;
-        if (__hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ok = 0;
+        unsigned* dec = bar + MVS_BAR_STRIDE;
+        // publish this workgroup's stores before it arrives (cdna_hip_programming.md Guideline 16: release fence, then an explicit
+        // wait — ROCm 7.2 may drop the fence's own — then relaxed agent-scope atomics)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (__hip_atomic_load(dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == TAIL_ABANDONED) ok = 0;
         else {
             const unsigned nblk = gridDim.x, ng = nblk < (unsigned)MVS_BAR_GROUPS ? nblk : (unsigned)MVS_BAR_GROUPS;
             const unsigned g = blockIdx.x % ng, gsize = (nblk - g + ng - 1) / ng;
             unsigned* grp = bar + (2 + g) * MVS_BAR_STRIDE;
             unsigned* rel = bar + (2 + MVS_BAR_GROUPS + g) * MVS_BAR_STRIDE;
-            if (__hip_atomic_fetch_add(grp, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gsize * gen) {
-                if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == ng * gen)
+            if (__hip_atomic_fetch_add(grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gsize * gen) {
+                if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == ng * gen) {
+                    unsigned expect = gen - 1u;
+                    const bool won = __hip_atomic_compare_exchange_strong(dec, &expect, gen, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned verdict = won ? gen : TAIL_ABANDONED;
                     for (unsigned j = 0; j < ng; ++j)
-                        __hip_atomic_store(bar + (2 + MVS_BAR_GROUPS + j) * MVS_BAR_STRIDE, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(bar + (2 + MVS_BAR_GROUPS + j) * MVS_BAR_STRIDE, verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             int spin = 0;
-            while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
-                if (++spin > TAIL_MAXSPIN || __hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    __hip_atomic_store(giveup, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = 0;
+            unsigned r;
+            while ((r = __hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < gen) {
+                if (++spin > maxspin) {
+                    unsigned expect = gen - 1u;
+                    if (__hip_atomic_compare_exchange_strong(dec, &expect, TAIL_ABANDONED, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) r = TAIL_ABANDONED;
+                    else r = expect;                                   // somebody decided first: released (== gen) or abandoned
                     break;
                 }
                 __builtin_amdgcn_s_sleep(4);
             }
+            if (r == TAIL_ABANDONED) ok = 0;
+            // one acquire per workgroup, and the wait that holds the workgroup's barrier until the invalidate has completed
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         s_ok = ok;
     }
@@ -201,25 +222,38 @@ __device__ inline bool tail_barrier(unsigned* bar, unsigned gen /* 1, 2, ... : t
     return s_ok != 0;
 }
 
-struct RasTail {              // TAIL launches only (the last planned sweep of a solve)
+struct RasTail {              // the last planned launch of a solve (MODE >= 1)
     unsigned* bar;            // MVS_BAR_WORDS words, MVS_BAR_STRIDE apart (tail_barrier)
     double* slots;            // max_extra further sweep slots (partials of the in-kernel sweeps)
     int max_extra;            // in-kernel sweeps after this launch's own one
+    int maxspin;              // polls a workgroup waits at the barrier before it abandons the solve
+};
+struct RasLocal {             // MODE == 2: the launch also performs the ARAP local step of the solve's result on its owned rows
+    SellDev m;
+    const double* pts;        // rest positions
+    double* rot;              // rotations out
+    const double* bpure;      // right-hand side without its Dirichlet share (the true residual is measured against it)
+    int nfold;                // partials per sum the consumers fold (>= patches: the slots beyond them are zero-filled here)
 };
 
-template <int W, bool TAIL>
-__global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __restrict__ pw, const double* __restrict__ pd,
+// MODE 0: a planned sweep.  MODE 1: the last planned launch of a solve — should the plan turn out too short it keeps sweeping
+// behind the device-wide barrier.  MODE 2: MODE 1 and, once the solve has ended, the ARAP local step on the patch's owned rows
+// (workgroups of <= 512 threads: the local step wants ~210 VGPRs, k_arap_local's budget).
+template <int W, int MODE>
+__global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, const double* __restrict__ pw, const double* __restrict__ pd,
                                                     const double* __restrict__ bvec, double* xa, double* xb, int it, double arap_tol,
                                                     double* __restrict__ ered, int nb_rhs, int sweep, double cg_tol, double stop_margin, double slow2,
                                                     double predict2, ChebCoef cc, int cheb_m, ChebCoef cc_strong, int cheb_m_strong,
                                                     double* __restrict__ ctl, double* __restrict__ slot_prev,
-                                                    double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur, RasTail tail) {
+                                                    double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur, RasTail tail, RasLocal loc) {
+    constexpr bool TAIL = MODE >= 1;
     // LDS: fp64 x of the local rows and the halo while the residual is formed (24 KB), then the correction directions as
     // bfloat16 triples, double-buffered (2 x 8 KB of the same array).  The neighbours' directions only steer the inexact
     // local solve; the residual that decides convergence and the solution stay fp64.
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * RTPB * sizeof(float4)];
     __shared__ double s_gam[3], s_gam2[3], s_bn[3], s_psafe;
     __shared__ int s_done, s_esc, s_slow[3];
+    __shared__ double s_loc[4][4];                                      // (MODE 2: the local step's wave sums)
     double4* xs = reinterpret_cast<double4*>(smem);                    // 32-byte records: two 16-byte LDS accesses per gather instead of three 8-byte ones
     // workgroup -> patch, XCD-aware: consecutive workgroup ids go round the eight XCDs, and consecutive PATCHES are neighbours on the
     // mesh (recursive bisection) — each XCD takes a contiguous block of 32 patches, so the overlap and halo rows two neighbouring
@@ -230,9 +264,46 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     const int NPpad = R.NPpad;
     // ---- fast skip: an earlier sweep of this solve found it converged (and left the result in BOTH solution buffers): the
     //      launch plan holds a spare sweep per solve — the DEVICE decides how many of the planned sweeps run
+    // The local step of the solve's result on this patch's owned rows (MODE 2; the owned rows come first in a patch: thread
+    // `row` < nown takes vertex l2g[base + row]).  xfin: a buffer that holds the final x of EVERY vertex.  Per vertex the
+    // operations of k_arap_local (local_dev.h); the energy and residual partials are one per patch.
+    LocalEdges Epre;                                                    // (MODE 2: the edges of this thread's owned row)
+    auto local_step = [&](const double* __restrict__ xfin, int nown_, int g_, bool fetched) {
+        if constexpr (MODE == 2) {
+            double e_acc = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+            if (row < nown_) {
+                if (!fetched) local_fetch_a(loc.m, loc.pts, xfin, loc.bpure, g_, Epre);
+                local_fetch_b(loc.pts, xfin, Epre);
+                local_vertex(loc.m, loc.pts, xfin, loc.bpure, g_, Epre, loc.rot, e_acc, g0, g1, g2);
+            }
+            if (wv < 4) {                                              // (owned rows <= 256: the first four waves)
+                e_acc = wave_total(e_acc); g0 = wave_total(g0); g1 = wave_total(g1); g2 = wave_total(g2);
+                if (lane == 0) { s_loc[wv][0] = e_acc; s_loc[wv][1] = g0; s_loc[wv][2] = g1; s_loc[wv][3] = g2; }
+            }
+            __syncthreads();
+            if (row == 0) ered[it * EIT + p] = (s_loc[0][0] + s_loc[1][0]) + (s_loc[2][0] + s_loc[3][0]);
+            if (row >= 1 && row < 4) ered[it * EIT + (3 + row) * NBMAX + p] = (s_loc[0][row] + s_loc[1][row]) + (s_loc[2][row] + s_loc[3][row]);
+            if (p == 0) {
+                for (int q = R.NP + row; q < loc.nfold; q += (int)blockDim.x) {       // the consumers fold nfold partials per sum
+                    ered[it * EIT + q] = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) ered[it * EIT + (4 + c) * NBMAX + q] = 0.0;
+                }
+                if (row == 0) ctl[MVS_CTL_LOCAL + it] = ctl[MVS_CTL_SEQ] + 1.0;       // "done for this pass": the judge of a fused solve demands it
+            }
+        }
+    };
     if (sweep > 0 && slot_prev[3 * NPpad + 6] != 0.0) {
         if (p == 0 && row == 0) { slot_cur[3 * NPpad + 6] = 1.0; slot_cur[3 * NPpad + 7] = slot_prev[3 * NPpad + 7]; }
         if (row == 0) iters_cur[p] = 0;
+        if constexpr (MODE == 2) {
+            // the solve ended in an earlier launch (both buffers hold the result everywhere): only the local step is left — unless
+            // the reference's energy stop rule had ended the ARAP iterations before this one
+            if (row == 0) s_done = arap_done_before(ered + EFIN, it, arap_tol) ? 1 : 0;
+            const int nown_ = R.pown[p], g_ = R.l2g[base + row];
+            __syncthreads();
+            if (!s_done) local_step(xa, nown_, g_, false);
+        }
         return;
     }
     const int nloc = R.pnloc[p], nown = R.pown[p];
@@ -263,6 +334,12 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     const double dd = pd[base + row];
     const bool fixed = dd == 0.0;
     const d3 rhs = ld3(bvec + 3 * (int64_t)g);                         // (b is 0 on control rows; padding rows are fixed)
+    // MODE 2: the last planned launch of a solve is normally the one that finds it finished — its input is then the result and
+    // all that is left is the local step: the first hop of its fetches (own operands, weights, neighbour indices: ~40 registers)
+    // is issued HERE, beside the operand loads and the fold of the previous sweep's partials; a launch that has to sweep after
+    // all drops them.  (With the neighbours' positions fetched here too — 124 more registers — the kernel spills: 0.553 ms per
+    // step against 0.517.)
+    if constexpr (MODE == 2) { if (row < nown) local_fetch_a(loc.m, loc.pts, xin, loc.bpure, g, Epre); }
     // ---- preamble: waves 0..2 fold the residual partials of the previous sweep, waves 3..5 the bnorm partials of the rhs kernel
     if (wv < 3) {
         const double gam = sweep > 0 ? fold_n(slot_prev + wv * NPpad, R.NP * 4) : INFINITY;
@@ -333,6 +410,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         if (row < nown) st3(xout + 3 * (int64_t)g, xi);
         if (row < 12) slot_cur[(row >> 2) * NPpad + 4 * p + (row & 3)] = (frozen && !s_done) ? slot_prev[(row >> 2) * NPpad + 4 * p + (row & 3)] : 0.0;
         if (row == 0) iters_cur[p] = 0;
+        if (MODE == 2 && !s_done) local_step(xin, nown, g, true);      // this launch decided: the input is the result (complete since the last launch)
         return;
     }
     const double di = fixed ? 1.0 : dd;
@@ -426,12 +504,12 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
     //      that followed it is the confirming one, as in the planned sequence), else one more sweep from the other buffer.
     //      On every way out both solution buffers hold the result on this patch's owned rows.
     int extra = 0;
-    bool finished = false;
+    bool finished = false, abandoned = false;
     double* slot_k = slot_cur;                                         // partials of the sweep done last
     double g_before[3] = {s_gam[0], s_gam[1], s_gam[2]};               // residual of the input of the sweep BEFORE the one done last
     for (;;) {
         TSTAMP(0);
-        if (!tail_barrier(tail.bar, (unsigned)(extra + 1))) break;     // not every workgroup is there: report as it stands
+        if (!tail_barrier(tail.bar, (unsigned)(extra + 1), tail.maxspin)) { abandoned = true; break; }     // not every workgroup came in time: every patch stops HERE
         TSTAMP(1);
         if (wv < 3) {
             const double gam = fold_n(slot_k + wv * NPpad, R.NP * 4);
@@ -478,13 +556,21 @@ __global__ __launch_bounds__(RTPB) void k_ras_sweep(RasDev R, const double* __re
         TSTAMP(4);
         ++extra;
     }
-    // both buffers equal on the owned rows (xi is this thread's latest value of its row — for an owned row the value it wrote)
-    if (row < nown) { st3(xa + 3 * (int64_t)g, xi); st3(xb + 3 * (int64_t)g, xi); }
+    // both buffers equal on the owned rows (xi is this thread's latest value of its row — for an owned row the value it wrote).
+    // After a barrier that everybody passed, `xout` holds the last sweep's result of EVERY patch: only the other buffer is
+    // written (the local step of the other patches may be reading this patch's rows from `xout`).
+    if (abandoned) {
+        if (row < nown) { st3(xa + 3 * (int64_t)g, xi); st3(xb + 3 * (int64_t)g, xi); }
+        if (p == 0 && row == 0) ctl[MVS_CTL_GAVEUP + it] = ctl[MVS_CTL_SEQ] + 1.0;      // -> a miss, whatever the residual says
+    } else {
+        if (row < nown) st3(const_cast<double*>(xin) + 3 * (int64_t)g, xi);
+    }
     if (p == 0 && row == 3) {
         slot_cur[3 * NPpad + 6] = finished ? 1.0 : 0.0;
         slot_cur[3 * NPpad + 7] = ran_before + 1.0 + (double)extra;
     }
     if (row == 0) iters_cur[p] = steps;
+    if (MODE == 2 && !abandoned) local_step(xout, nown, g, false);
 }
 
 }  // namespace
@@ -531,8 +617,14 @@ int ras_steps_for(double a) {
 // one sweep of ARAP iteration `it`: slot_prev / slot_cur are the slots of sweeps (sweep-1) / sweep.  tail_slots != NULL: this
 // is the last planned sweep of the solve — the launch keeps sweeping (device-wide barrier between sweeps, at most
 // RAS_TAIL_MAX more) until the solve has converged, should the plan have been too short.
+static int g_tail_maxspin = 1 << 16;      // polls at the tail loop's barrier before a workgroup abandons the solve (tests lower it: mvs_debug_tail)
+void ras_set_tail_maxspin(int n) { g_tail_maxspin = n > 0 ? n : (1 << 16); }
+bool ras_can_fuse_local(const mvs_deform_s* h) { return h->has_ras && h->ras.NP <= MVS_NBMAX && h->ras_block <= 512; }
+int ras_local_parts(const mvs_deform_s* h) { return ras_can_fuse_local(h) ? std::max(h->ras.NP, arap_grid_blocks(h->sell)) : arap_grid_blocks(h->sell); }
+
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, double* xout, int it, double arap_tol, int sweep,
-                      double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots) {
+                      double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots,
+                      bool with_local) {
     const RasDev& R = h->ras;
     const int nb = arap_grid_blocks(h->sell);
     // Chebyshev parameters: the bracket's lower end `a` and the step count live in the handle — initialised from the density
@@ -558,10 +650,13 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, doubl
     const ChebCoef cc2 = coefs(strong_a);
     const int m2 = ras_steps_for(strong_a);
     const dim3 grid(R.NP), blk(h->ras_block);     // as many waves as the largest patch has rows (idle waves only add barrier cost)
-    const RasTail tail{h->d_bar, tail_slots, RAS_TAIL_MAX};
+    const RasTail tail{h->d_bar, tail_slots, RAS_TAIL_MAX, g_tail_maxspin};
+    const RasLocal loc{h->sell, h->d_pts, h->d_rot, h->d_bpure, ras_local_parts(h)};
+    const int mode = !tail_slots ? 0 : ((with_local && ras_can_fuse_local(h)) ? 2 : 1);
 #define MVS_SWEEP(W, T) k_ras_sweep<W, T><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, stop_margin, \
-                                                              RAS_SLOW * RAS_SLOW, RAS_PREDICT * RAS_PREDICT, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur, tail)
-    if (tail_slots) { if (R.W == 6) MVS_SWEEP(6, true); else if (R.W == 8) MVS_SWEEP(8, true); else if (R.W == 12) MVS_SWEEP(12, true); else MVS_SWEEP(16, true); }
-    else            { if (R.W == 6) MVS_SWEEP(6, false); else if (R.W == 8) MVS_SWEEP(8, false); else if (R.W == 12) MVS_SWEEP(12, false); else MVS_SWEEP(16, false); }
+                                                              RAS_SLOW * RAS_SLOW, RAS_PREDICT * RAS_PREDICT, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur, tail, loc)
+#define MVS_SWEEP_W(T) do { if (R.W == 6) MVS_SWEEP(6, T); else if (R.W == 8) MVS_SWEEP(8, T); else if (R.W == 12) MVS_SWEEP(12, T); else MVS_SWEEP(16, T); } while (0)
+    if (mode == 2) MVS_SWEEP_W(2); else if (mode == 1) MVS_SWEEP_W(1); else MVS_SWEEP_W(0);
+#undef MVS_SWEEP_W
 #undef MVS_SWEEP
 }
