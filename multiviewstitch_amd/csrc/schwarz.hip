@@ -94,6 +94,17 @@ __device__ inline double fast_inv(double x) {
 __device__ inline double fold_n(const double* __restrict__ part, int n) {
     const int lane = threadIdx.x & 63;
     double v = 0.0;
+    if (n <= 1024) {
+        // one patch per CU (the usual case): all sixteen loads of a lane are issued before the first add — as a loop over
+        // chunks of 256 the four round trips ran one after the other, on the critical path of every sweep's preamble (same
+        // order of additions as the loop: same bits)
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int k = 256 * (u >> 2) + lane + 64 * (u & 3); t[u] = k < n ? part[k] : 0.0; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v += (t[4 * c] + t[4 * c + 1]) + (t[4 * c + 2] + t[4 * c + 3]);
+        return wave_total(v);
+    }
     for (int base = 0; base < n; base += 256) {
         double t[4];
 #pragma unroll
@@ -295,6 +306,7 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
     };
     if (sweep > 0 && slot_prev[3 * NPpad + 6] != 0.0) {
         if (p == 0 && row == 0) { slot_cur[3 * NPpad + 6] = 1.0; slot_cur[3 * NPpad + 7] = slot_prev[3 * NPpad + 7]; }
+        if (p == 0 && row < 3) slot_cur[3 * NPpad + 3 + row] = slot_prev[3 * NPpad + 3 + row];      // (the right-hand side's norms: the harvest reads them from a solve's last slot)
         if (row == 0) iters_cur[p] = 0;
         if constexpr (MODE == 2) {
             // the solve ended in an earlier launch (both buffers hold the result everywhere): only the local step is left — unless
