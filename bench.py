@@ -227,9 +227,20 @@ def main():
         if want == "owner":
             # owner-merges exchange: checked once, before anything is timed, against the all-gather exchange on the
             # same records — identical node targets on this rank, and every rank must agree — else the all-gather form runs
-            ok, why = 1, ""
+            # (--exchange auto) or the bench fails (--exchange owner).  Every step a rank could decline on its own (buffer
+            # allocation, the comparison) is followed by an agreement all-reduce BEFORE the next collective, so that no rank
+            # ever waits in a collective its peers have left; an exception inside a collective itself is
+            # fatal for the whole job, as it should be.
+            def agree(ok):
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return int(t.item()) == 1
+            ok, why, obufs = True, "", None
             try:
                 obufs = shard.buffers_owner(K, world, rank)
+            except Exception as e:                          # noqa: BLE001
+                ok, why = False, f"{type(e).__name__}: {e}"
+            if agree(ok):
                 with torch.cuda.stream(shard.stream):
                     shard.dmin(obufs)
                     dist.all_reduce(obufs["d2min"], op=dist.ReduceOp.MIN)
@@ -243,16 +254,18 @@ def main():
                     mdist._sharded_exchange_owner(shard, obufs, world, None, None)
                 torch.cuda.synchronize(device)
                 b = d.node_targets()
-                if not (np.array_equal(a["controls"], b["controls"]) and np.array_equal(a["valid"], b["valid"])):
-                    ok, why = 0, "targets differ from the all-gather exchange"
-            except Exception as e:                          # noqa: BLE001  (a collective the backend lacks, ...)
-                ok, why = 0, f"{type(e).__name__}: {e}"
-            agree = torch.tensor([ok], dtype=torch.int32, device=device)
-            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-            if int(agree.item()) == 1:
+                same = np.array_equal(a["controls"], b["controls"]) and np.array_equal(a["valid"], b["valid"])
+                if not same:
+                    ok, why = False, "targets differ from the all-gather exchange"
+                ok = agree(same)
+            else:
+                ok = False
+            if ok:
                 bufs, exchange = obufs, "owner_merges"
             else:
-                log(f"[bench r{rank}] owner-merges exchange not used ({why or 'another rank declined'}): all-gather exchange")
+                log(f"[bench r{rank}] owner-merges exchange not used ({why or 'another rank declined'})")
+                if args.exchange == "owner":
+                    raise SystemExit(f"--exchange owner: the owner-merges check failed on rank {rank}: {why or 'another rank declined'}")
                 exchange = "all_gather (owner-merges check failed)"
 
         def run(n, timers=None):
@@ -457,9 +470,19 @@ def main():
     collectives = None
     if world > 1:
         timers = {"all_reduce": [], "all_gather": [], "sync": args.backend != "nccl"}
+        d.enable_timing(1)                                    # per-phase events on this rank's stream (instrumented pass only)
         run(min(args.steps, 10), timers=timers)
         fence()
         collectives = {"backend": args.backend, "steps": min(args.steps, 10)}
+        # what sharding buys: every rank's association time (its own views only) next to its replicated solve
+        mine = torch.tensor([d.kernel_time("assoc")[0], d.kernel_time("cg")[0] + d.kernel_time("rhs")[0] + d.kernel_time("local")[0]],
+                            dtype=torch.float64, device=device) / min(args.steps, 10)
+        every = torch.zeros(2 * world, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(every, mine)
+        d.enable_timing(0)
+        every = every.cpu().numpy().reshape(world, 2)
+        collectives["assoc_ms_per_step_by_rank"] = [round(float(x), 4) for x in every[:, 0]]
+        collectives["solve_ms_per_step_by_rank"] = [round(float(x), 4) for x in every[:, 1]]
         for name in ("all_reduce", "all_gather"):
             ms = [a.elapsed_time(b) if hasattr(a, "elapsed_time") else 1e3 * (b - a) for a, b in timers[name]]
             collectives[name + "_ms_per_step"] = round(float(np.mean(ms)), 4) if ms else None
@@ -536,6 +559,8 @@ def main():
             n_it += 1
         cpu_baseline = {"value": round(n_it / t_cpu, 4), "unit": "iter/s", "cores": 1, "kind": "port",
                         "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+                        "note": "kind 'port' = oracle/ (this build's C++ restatement, Jacobi-CG global solve to 1e-14), not the reference's "
+                                "factor-once SparseLU: it understates what the reference does per iteration",
                         "sample": f"outer iterations {max(args.warmup, 1)}..{max(args.warmup, 1) + n_it - 1} of the full workload "
                                   f"(the iterations the GPU value is timed on; oracle/, single thread as the reference, "
                                   f"kd-tree build {t_build:.2f}s excluded)"}

@@ -278,6 +278,15 @@ int mvs_init_alignment_sharded(const double* src, int64_t ns, const double* tgt_
                                const double* ground_ray, const double* view_ray, mvs_reduce_fn reduce, void* reduce_ctx,
                                double* R /*9*/, double* t /*3*/, double* scale);
 
+/* RemoveGround with the scan sharded over ranks by view (R/Alignment/Alignment.cpp:79-233): the arrays hold this
+ * rank's points / normals / facets (facets never join points of two ranks).  The moments, the two extents along the first pivot
+ * (:103-113), the candidate counts (:115-138), the plane-fit sums (:148-153) and the largest plane distance (:182-187) are reduced
+ * through `reduce`; removal and compaction are local; of the connected components (:227, RetainConnectRegion) the largest over
+ * ALL ranks stays (ties: the lower rank) and every other rank is left with V = F = 0.  Every rank returns the same ground_ray.
+ * Equal to mvs_remove_ground on the stitched scan up to the order of the floating-point sums. */
+int mvs_remove_ground_sharded(int64_t* V, double* pts, double* normals, int64_t* F, int32_t* faces, double dist_thres,
+                              mvs_reduce_fn reduce, void* reduce_ctx, int rank, double* ground_ray);
+
 /* PartRecognition::PartRecog (R/PartRecognition/PartRecognition.cpp:50-77): label of the nearest template vertex. */
 int mvs_part_recog(const double* tmpl_pts, const int32_t* tmpl_labels, int64_t V,
                    const double* pts, int64_t P, int32_t* out_labels);
@@ -286,6 +295,14 @@ int mvs_part_recog(const double* tmpl_pts, const int32_t* tmpl_labels, int64_t V
 int mvs_local_alignment_core(const double* src, const int32_t* s_labels, int64_t ns,
                              const double* tgt, const int32_t* t_labels, int64_t nt,
                              uint32_t group_mask, int label, double* R /*9*/, double* t /*3*/, double* scale);
+
+/* LocalAlignmentCore with the scan sharded over ranks by view (template replicated): the scan's labelled moments, the labels
+ * present (Alignment.cpp:475-477), its extent along the limb axis and the label at its far end (:519-528) are reduced through
+ * `reduce`; every rank returns the same R, t, scale. */
+int mvs_local_alignment_core_sharded(const double* src, const int32_t* s_labels, int64_t ns,
+                                     const double* tgt_local, const int32_t* t_labels_local, int64_t nt_local,
+                                     uint32_t group_mask, int label, mvs_reduce_fn reduce, void* reduce_ctx,
+                                     double* R /*9*/, double* t /*3*/, double* scale);
 
 /* Alignment::Align (Alignment.cpp:11-76; call site R/Processor/Processor.cpp:1130-1131) without its file I/O:
  * tgt / t_normals / t_faces are trimmed in place (ground removal + largest component; nt, nf in/out),
@@ -470,6 +487,11 @@ int mvs_comm_destroy(mvs_comm_t c);
 /* an mvs_reduce_fn over a communicator (ctx = the mvs_comm_t): n <= 16 host doubles, op 0 = sum, 1 = min */
 int mvs_comm_reduce(void* comm, double* v, int n, int op);
 int mvs_comm_info(mvs_comm_t c, int* rank, int* nranks);
+/* How the ranks' best-8 records meet in mvs_deform_iterate_sharded: AUTO = all-gather up to 3 ranks, owner-merges from 4 on
+ * (every rank receives and merges only the node block it owns: K * 392 bytes into a rank instead of N * K * 392, then one
+ * all-gather of 25 bytes per node); the result is the same bits either way. */
+enum { MVS_EXCHANGE_AUTO = 0, MVS_EXCHANGE_ALL_GATHER = 1, MVS_EXCHANGE_OWNER = 2 };
+int mvs_comm_set_exchange(mvs_comm_t c, int mode);
 int mvs_deform_iterate_sharded(mvs_deform_t h, mvs_comm_t c, const mvs_deform_params* p, int n_outer, mvs_deform_stats* stats);
 
 /* Read-back (host buffers). */

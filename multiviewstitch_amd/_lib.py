@@ -103,6 +103,8 @@ _SIGS = {
     "mvs_init_alignment": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _VP]),
     "mvs_init_alignment_sharded": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "mvs_comm_reduce": (C.c_int, [_VP, _VP, _I32, _I32]),
+    "mvs_remove_ground_sharded": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _D, _VP, _VP, _I32, _VP]),
+    "mvs_local_alignment_core_sharded": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _I64, _U32, _I32, _VP, _VP, _VP, _VP, _VP]),
     "mvs_part_recog": (C.c_int, [_VP, _VP, _I64, _VP, _I64, _VP]),
     "mvs_local_alignment_core": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _I64, _U32, _I32, _VP, _VP, _VP]),
     "mvs_align": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _D, _VP, _VP]),
@@ -129,6 +131,7 @@ _SIGS = {
     "mvs_comm_init": (C.c_int, [_I32, _I32, _VP, _VP]),
     "mvs_comm_destroy": (C.c_int, [_VP]),
     "mvs_comm_info": (C.c_int, [_VP, _VP, _VP]),
+    "mvs_comm_set_exchange": (C.c_int, [_VP, _I32]),
     "mvs_deform_iterate_sharded": (C.c_int, [_VP, _VP, _VP, _I32, _VP]),
     "mvs_deform_sync": (C.c_int, [_VP]),
     "mvs_deform_stream": (C.c_void_p, [_VP]),

@@ -85,6 +85,25 @@ class Alignment:
                                                    C.cast(reducer, C.c_void_p), None, L.ptr(R), L.ptr(tr), C.byref(sc)))
         return R, tr, sc.value
 
+    def RemoveGroundSharded(self, points, normals, facets, reducer, rank: int, dist_thres: float = DIST_THRESHOLD):
+        """RemoveGround with the scan sharded over ranks by view: the arrays are this rank's share (facets index its own points,
+        may be empty); every rank gets the same groundRay, the rank holding the largest component keeps it, the others end empty."""
+        p = L.arr(points, np.float64).reshape(-1, 3).copy()
+        n = L.arr(normals, np.float64).reshape(-1, 3).copy() if normals is not None and len(normals) else None
+        f = L.arr(facets, np.int32).reshape(-1, 3).copy()
+        V, F, gr = C.c_int64(len(p)), C.c_int64(len(f)), np.empty(3)
+        L.check(L.lib().mvs_remove_ground_sharded(C.byref(V), L.ptr(p) if len(p) else None, L.ptr(n), C.byref(F), L.ptr(f) if len(f) else None,
+                                                  dist_thres, C.cast(reducer, C.c_void_p), None, rank, L.ptr(gr)))
+        return gr, p[:V.value], (n[:V.value] if n is not None else None), f[:F.value]
+
+    def LocalAlignmentCoreSharded(self, src, s_labels, tgt_local, t_labels_local, group_mask: int, label: int, reducer):
+        s, t = L.arr(src, np.float64).reshape(-1, 3), L.arr(tgt_local, np.float64).reshape(-1, 3)
+        sl, tl = L.arr(s_labels, np.int32), L.arr(t_labels_local, np.int32).reshape(-1)
+        R, tr, sc = np.empty((3, 3)), np.empty(3), C.c_double()
+        L.check(L.lib().mvs_local_alignment_core_sharded(L.ptr(s), L.ptr(sl), len(s), L.ptr(t) if len(t) else None, L.ptr(tl) if len(tl) else None,
+                                                         len(t), group_mask, label, C.cast(reducer, C.c_void_p), None, L.ptr(R), L.ptr(tr), C.byref(sc)))
+        return R, tr, sc.value
+
     def LocalAlignmentCore(self, src, s_labels, tgt, t_labels, group_mask: int, label: int):
         s, t = L.arr(src, np.float64).reshape(-1, 3), L.arr(tgt, np.float64).reshape(-1, 3)
         sl, tl = L.arr(s_labels, np.int32), L.arr(t_labels, np.int32)

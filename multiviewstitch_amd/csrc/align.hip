@@ -467,60 +467,81 @@ int compact_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F
     return MVS_OK;
 }
 
-// Alignment::RetainConnectRegion on device arrays
-int retain_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F) {
-    if (*n <= 0) return MVS_OK;
+// Alignment::RetainConnectRegion on device arrays.  red.fn != NULL (view-sharded scan, facets never join points of two ranks):
+// the largest component over ALL ranks stays — ties to the lower rank, as the lower vertex index wins in the stitched scan —
+// and every other rank keeps nothing.
+int retain_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F, const Reducer& red = Reducer(), int rank = 0) {
+    if (*n <= 0 && !red.fn) return MVS_OK;
     Dev parent, size, keep, flag, part;
     int rc;
-    if ((rc = parent.alloc(sizeof(int32_t) * *n)) || (rc = size.alloc(sizeof(int32_t) * *n)) || (rc = keep.alloc(sizeof(int32_t) * (*n + 1))) ||
+    const int64_t n1 = std::max<int64_t>(*n, 1);
+    if ((rc = parent.alloc(sizeof(int32_t) * n1)) || (rc = size.alloc(sizeof(int32_t) * n1)) || (rc = keep.alloc(sizeof(int32_t) * (n1 + 1))) ||
         (rc = flag.alloc(sizeof(int32_t))) || (rc = part.alloc(sizeof(long long) * 2 * NBLK))) return rc;
-    k_cc_init<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n);
-    for (int round = 0; round < 64 && *F > 0; ++round) {             // O(log) rounds in practice; bounded
-        int32_t changed = 0;
-        HIPCHK(hipMemset(flag.p, 0, sizeof(int32_t)));
-        k_cc_hook<<<blocks(*F), dim3(TPB)>>>(faces, *F, parent.as<int32_t>(), flag.as<int32_t>());
-        k_cc_compress<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n);
-        HIPCHK(hipMemcpy(&changed, flag.p, sizeof changed, hipMemcpyDeviceToHost));
-        if (!changed) break;
-    }
-    HIPCHK(hipMemset(size.p, 0, sizeof(int32_t) * *n));
-    k_cc_sizes<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n, size.as<int32_t>());
-    k_cc_best<<<dim3(NBLK), dim3(TPB)>>>(size.as<int32_t>(), *n, part.as<long long>());
-    std::vector<long long> hp(2 * NBLK);
-    HIPCHK(hipMemcpy(hp.data(), part.p, sizeof(long long) * 2 * NBLK, hipMemcpyDeviceToHost));
     long long bs = -1, br = -1;
-    for (int b = 0; b < NBLK; ++b)
-        if (hp[2 * b + 1] >= 0 && (hp[2 * b] > bs || (hp[2 * b] == bs && hp[2 * b + 1] < br))) { bs = hp[2 * b]; br = hp[2 * b + 1]; }
+    if (*n > 0) {
+        k_cc_init<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n);
+        for (int round = 0; round < 64 && *F > 0; ++round) {             // O(log) rounds in practice; bounded
+            int32_t changed = 0;
+            HIPCHK(hipMemset(flag.p, 0, sizeof(int32_t)));
+            k_cc_hook<<<blocks(*F), dim3(TPB)>>>(faces, *F, parent.as<int32_t>(), flag.as<int32_t>());
+            k_cc_compress<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n);
+            HIPCHK(hipMemcpy(&changed, flag.p, sizeof changed, hipMemcpyDeviceToHost));
+            if (!changed) break;
+        }
+        HIPCHK(hipMemset(size.p, 0, sizeof(int32_t) * *n));
+        k_cc_sizes<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n, size.as<int32_t>());
+        k_cc_best<<<dim3(NBLK), dim3(TPB)>>>(size.as<int32_t>(), *n, part.as<long long>());
+        std::vector<long long> hp(2 * NBLK);
+        HIPCHK(hipMemcpy(hp.data(), part.p, sizeof(long long) * 2 * NBLK, hipMemcpyDeviceToHost));
+        for (int b = 0; b < NBLK; ++b)
+            if (hp[2 * b + 1] >= 0 && (hp[2 * b] > bs || (hp[2 * b] == bs && hp[2 * b + 1] < br))) { bs = hp[2 * b]; br = hp[2 * b + 1]; }
+    }
+    if (red.fn) {
+        double g = -(double)std::max<long long>(bs, 0);
+        if ((rc = red.run(&g, 1, 1))) return rc;
+        double win = (bs > 0 && (double)bs == -g) ? (double)rank : INFINITY;
+        if ((rc = red.run(&win, 1, 1))) return rc;
+        if (win != (double)rank) { *n = 0; *F = 0; return MVS_OK; }
+    }
+    if (*n <= 0) return MVS_OK;
     HIPCHK(hipMemset(keep.p, 0, sizeof(int32_t) * (*n + 1)));
     k_cc_keep<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n, (int)br, keep.as<int32_t>());
     return compact_dev(pts, nrm, n, faces, F, keep.as<int32_t>());
 }
 
-// Alignment::RemoveGround on device arrays
-int remove_ground_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F, double dist_thres, double* ground_ray, Work& w) {
+// Alignment::RemoveGround on device arrays.  red.fn != NULL: the arrays hold this rank's share of a scan sharded by view; the
+// moments, the two extents along the first pivot, the candidate counts, the plane-fit sums and the largest plane distance are
+// reduced over the ranks (Alignment.cpp:79-233: every one of them a sum or an extreme over all points), the removal and the
+// compaction are local
+int remove_ground_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F, double dist_thres, double* ground_ray, Work& w,
+                      const Reducer& red = Reducer(), int rank = 0) {
     Pca p;
-    int rc = pca_dev(pts, *n, nullptr, 0, w, &p);
+    int rc = pca_dev(pts, *n, nullptr, 0, w, &p, red);
     if (rc) return rc;
     const double* pivot = p.axis[0];
     Dev t, side, dist, keep;
-    if ((rc = t.alloc(sizeof(double) * *n)) || (rc = side.alloc((size_t)*n)) || (rc = dist.alloc(sizeof(double) * *n)) ||
-        (rc = keep.alloc(sizeof(int32_t) * (*n + 1)))) return rc;
+    const int64_t n1 = std::max<int64_t>(*n, 1);
+    if ((rc = t.alloc(sizeof(double) * n1)) || (rc = side.alloc((size_t)n1)) || (rc = dist.alloc(sizeof(double) * n1)) ||
+        (rc = keep.alloc(sizeof(int32_t) * (n1 + 1)))) return rc;
     Range rr;
     if ((rc = range_dev(pts, *n, nullptr, 0, pivot, p.bary, t.as<double>(), w, &rr))) return rc;   // t[i], Alignment.cpp:104
     k_rg_tmax<<<dim3(NBLK), dim3(TPB)>>>(t.as<double>(), *n, w.part.as<double>());
     if ((rc = w.fetch((size_t)NBLK * 2))) return rc;
     double tMax1 = DBL_MIN, tMax2 = DBL_MIN;
     for (int b = 0; b < NBLK; ++b) { tMax1 = std::max(tMax1, w.h[2 * b]); tMax2 = std::max(tMax2, w.h[2 * b + 1]); }
+    if (red.fn) { double e[2] = {-tMax1, -tMax2}; if ((rc = red.run(e, 2, 1))) return rc; tMax1 = -e[0]; tMax2 = -e[1]; }
     k_rg_side<<<dim3(NBLK), dim3(TPB)>>>(t.as<double>(), *n, tMax1 * dist_thres, tMax2 * dist_thres, side.as<uint8_t>(), w.part.as<double>());
     if ((rc = w.fetch((size_t)NBLK * 2))) return rc;
-    double c1 = 0, c2 = 0;
-    for (int b = 0; b < NBLK; ++b) { c1 += w.h[2 * b]; c2 += w.h[2 * b + 1]; }
-    const int which = c1 > c2 ? 1 : 2;                                          // :129-138
+    double c12[2] = {0, 0};
+    for (int b = 0; b < NBLK; ++b) { c12[0] += w.h[2 * b]; c12[1] += w.h[2 * b + 1]; }
+    if ((rc = red.run(c12, 2, 0))) return rc;
+    const int which = c12[0] > c12[1] ? 1 : 2;                                  // :129-138
     for (int c = 0; c < 3; ++c) ground_ray[c] = which == 1 ? -pivot[c] : pivot[c];
     k_rg_plane<<<dim3(NBLK), dim3(TPB)>>>(pts, side.as<uint8_t>(), *n, which, w.part.as<double>());
     if ((rc = w.fetch((size_t)NBLK * 9))) return rc;
     double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int b = 0; b < NBLK; ++b) for (int k = 0; k < 9; ++k) m[k] += w.h[(size_t)b * 9 + k];
+    if ((rc = red.run(m, 9, 0))) return rc;
     const double A[9] = {m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5]}, bb[3] = {m[6], m[7], m[8]};
     double Ai[9], ans[3];
     inv3(A, Ai);
@@ -534,10 +555,13 @@ int remove_ground_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int6
     if ((rc = w.fetch((size_t)NBLK))) return rc;
     double maxDist = DBL_MIN;
     for (int b = 0; b < NBLK; ++b) maxDist = std::max(maxDist, w.h[b]);
-    HIPCHK(hipMemset(keep.p, 0, sizeof(int32_t) * (*n + 1)));
-    k_rg_keep<<<blocks(*n), dim3(TPB)>>>(dist.as<double>(), *n, maxDist * 0.28, keep.as<int32_t>());   // :187-193
-    if ((rc = compact_dev(pts, nrm, n, faces, F, keep.as<int32_t>()))) return rc;                      // :196-219
-    return retain_dev(pts, nrm, n, faces, F);                                                          // :227
+    if (red.fn) { double e = -maxDist; if ((rc = red.run(&e, 1, 1))) return rc; maxDist = -e; }
+    HIPCHK(hipMemset(keep.p, 0, sizeof(int32_t) * (n1 + 1)));
+    if (*n > 0) {
+        k_rg_keep<<<blocks(*n), dim3(TPB)>>>(dist.as<double>(), *n, maxDist * 0.28, keep.as<int32_t>());   // :187-193
+        if ((rc = compact_dev(pts, nrm, n, faces, F, keep.as<int32_t>()))) return rc;                      // :196-219
+    }
+    return retain_dev(pts, nrm, n, faces, F, red, rank);                                                   // :227
 }
 
 int init_alignment_dev(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray, const double* view_ray,
@@ -582,12 +606,24 @@ void rotation_between(const double* before, const double* after, double* R) {   
     R[6] = -u[1] * s + u[0] * u[2] * (1 - c); R[7] = u[0] * s + u[1] * u[2] * (1 - c);  R[8] = c + u[2] * u[2] * (1 - c);
 }
 
+// red.fn != NULL: tgt / t_labels hold this rank's share of the scan; its moments, the labels present, the extent along the
+// limb axis and the label at the far end are reduced over the ranks (the template is replicated)
 int local_core_dev(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels, int64_t nt,
-                   uint32_t group, int label, Work& w, double* R, double* t, double* scale) {
+                   uint32_t group, int label, Work& w, double* R, double* t, double* scale, const Reducer& red = Reducer()) {
     Pca ps, pt;
     int rc;
-    if ((rc = pca_dev(src, ns, s_labels, group, w, &ps)) || (rc = pca_dev(tgt, nt, t_labels, group, w, &pt))) return rc;
+    if ((rc = pca_dev(src, ns, s_labels, group, w, &ps)) || (rc = pca_dev(tgt, nt, t_labels, group, w, &pt, red))) return rc;
     if (dotp(ps.axis[0], pt.axis[0]) < 0) for (int c = 0; c < 3; ++c) pt.axis[0][c] = -pt.axis[0][c];   // :444-446
+    if (red.fn) {                                 // labels present anywhere: OR over the ranks as a MIN of -bit, 16 labels per call
+        uint32_t all = 0;
+        for (int base = 0; base < 32; base += 16) {
+            double v[16];
+            for (int k = 0; k < 16; ++k) v[k] = ((pt.present >> (base + k)) & 1u) ? -1.0 : 0.0;
+            if ((rc = red.run(v, 16, 1))) return rc;
+            for (int k = 0; k < 16; ++k) if (v[k] < 0.0) all |= 1u << (base + k);
+        }
+        pt.present = all;
+    }
     uint32_t sset = ps.present & group, tset = pt.present & group;
     auto popc = [](uint32_t x) { int c = 0; while (x) { c += x & 1; x >>= 1; } return c; };
     if (popc(sset) < popc(tset)) { const uint32_t e = tset & ~sset; tset &= ~(e & (~e + 1u)); }          // :479-488
@@ -595,11 +631,25 @@ int local_core_dev(const double* src, const int32_t* s_labels, int64_t ns, const
     Range r1, r2;
     if ((rc = range_dev(src, ns, s_labels, sset, ps.axis[0], ps.bary, nullptr, w, &r1)) ||
         (rc = range_dev(tgt, nt, t_labels, tset, pt.axis[0], pt.bary, nullptr, w, &r2))) return rc;
-    if (r1.ilo < 0 || r1.ihi < 0 || r2.ilo < 0 || r2.ihi < 0) { mvs_set_error("limb group 0x%x has no extent", group); return MVS_E_DEGENERATE; }
     int32_t lab1 = 0, lab2 = 0;
+    if (red.fn) {
+        // the scan's extent over all ranks, and the label of the point at its far end (the rank that holds it says which)
+        int32_t mylab = 0;
+        if (r2.ihi >= 0) HIPCHK(hipMemcpy(&mylab, t_labels + r2.ihi, sizeof mylab, hipMemcpyDeviceToHost));
+        double e[2] = {r2.lo, -r2.hi};
+        const double myhi = r2.hi;
+        if ((rc = red.run(e, 2, 1))) return rc;
+        const bool any = -e[1] != DBL_MIN || e[0] != DBL_MAX;
+        double lv = (r2.ihi >= 0 && myhi == -e[1]) ? (double)mylab : INFINITY;
+        if ((rc = red.run(&lv, 1, 1))) return rc;
+        if (!any || !(lv < INFINITY)) { mvs_set_error("limb group 0x%x has no extent", group); return MVS_E_DEGENERATE; }
+        r2.lo = e[0]; r2.hi = -e[1]; r2.ilo = 0; r2.ihi = 0;
+        lab2 = (int32_t)lv;
+    }
+    if (r1.ilo < 0 || r1.ihi < 0 || r2.ilo < 0 || r2.ihi < 0) { mvs_set_error("limb group 0x%x has no extent", group); return MVS_E_DEGENERATE; }
     double far[3];
     HIPCHK(hipMemcpy(&lab1, s_labels + r1.ihi, sizeof lab1, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&lab2, t_labels + r2.ihi, sizeof lab2, hipMemcpyDeviceToHost));
+    if (!red.fn) HIPCHK(hipMemcpy(&lab2, t_labels + r2.ihi, sizeof lab2, hipMemcpyDeviceToHost));
     if (lab1 != label) { std::swap(r1.lo, r1.hi); std::swap(r1.ilo, r1.ihi); }                          // :513-517
     if (lab2 != label) { std::swap(r2.lo, r2.hi); std::swap(r2.ilo, r2.ihi); }                          // :525-528
     *scale = (r2.hi - r2.lo) / (r1.hi - r1.lo);                                                         // :529
@@ -719,6 +769,36 @@ int mvs_part_recog(const double* tmpl_pts, const int32_t* tmpl_labels, int64_t V
     if ((rc = up(dt, tmpl_pts, (size_t)V * 3)) || (rc = up(dl, tmpl_labels, (size_t)V)) || (rc = up(dp, pts, (size_t)P * 3)) || (rc = dout.alloc(sizeof(int32_t) * P))) return rc;
     if ((rc = part_recog_dev(dt.as<double>(), dl.as<int32_t>(), V, dp.as<double>(), P, dout.as<int32_t>()))) return rc;
     return down(out_labels, dout, (size_t)P);
+}
+
+int mvs_remove_ground_sharded(int64_t* V, double* pts, double* normals, int64_t* F, int32_t* faces, double dist_thres,
+                              mvs_reduce_fn reduce, void* reduce_ctx, int rank, double* ground_ray) {
+    if (!V || !F || *V < 0 || *F < 0 || (*V > 0 && !pts) || (*F > 0 && !faces) || !ground_ray || !reduce || rank < 0) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    Dev dp, dn, df; Work w;
+    if ((rc = up(dp, pts, (size_t)*V * 3)) || (normals && (rc = up(dn, normals, (size_t)*V * 3))) || (rc = up(df, faces, (size_t)*F * 3)) || (rc = w.init())) return rc;
+    Reducer red; red.fn = reduce; red.ctx = reduce_ctx;
+    int64_t n = *V, f = *F;
+    if ((rc = remove_ground_dev(dp.as<double>(), normals ? dn.as<double>() : nullptr, &n, df.as<int32_t>(), &f, dist_thres, ground_ray, w, red, rank))) return rc;
+    if ((rc = down(pts, dp, (size_t)n * 3)) || (normals && (rc = down(normals, dn, (size_t)n * 3))) || (rc = down(faces, df, (size_t)f * 3))) return rc;
+    *V = n; *F = f;
+    return MVS_OK;
+}
+
+int mvs_local_alignment_core_sharded(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt_local, const int32_t* t_labels_local,
+                                     int64_t nt_local, uint32_t group_mask, int label, mvs_reduce_fn reduce, void* reduce_ctx,
+                                     double* R, double* t, double* scale) {
+    if (!src || !s_labels || ns < 2 || nt_local < 0 || (nt_local > 0 && (!tgt_local || !t_labels_local)) || !reduce || !R || !t || !scale) {
+        mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG;
+    }
+    int rc = need_device();
+    if (rc) return rc;
+    Dev ds, dsl, dt, dtl; Work w;
+    if ((rc = up(ds, src, (size_t)ns * 3)) || (rc = up(dsl, s_labels, (size_t)ns)) || (rc = up(dt, tgt_local, (size_t)nt_local * 3)) ||
+        (rc = up(dtl, t_labels_local, (size_t)nt_local)) || (rc = w.init())) return rc;
+    Reducer red; red.fn = reduce; red.ctx = reduce_ctx;
+    return local_core_dev(ds.as<double>(), dsl.as<int32_t>(), ns, dt.as<double>(), dtl.as<int32_t>(), nt_local, group_mask, label, w, R, t, scale, red);
 }
 
 int mvs_local_alignment_core(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels, int64_t nt,

@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <cstring>
+#include <algorithm>
 
 namespace {
 
@@ -19,6 +20,11 @@ struct Rccl {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    // point-to-point, for the owner-merges exchange (optional: without them the all-gather form runs)
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
 };
 Rccl g_rccl;
 
@@ -38,6 +44,10 @@ int load_rccl() {
     r.AllReduce = (decltype(r.AllReduce))dlsym(lib, "ncclAllReduce");
     r.AllGather = (decltype(r.AllGather))dlsym(lib, "ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    r.Send = (decltype(r.Send))dlsym(lib, "ncclSend");
+    r.Recv = (decltype(r.Recv))dlsym(lib, "ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(lib, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(lib, "ncclGroupEnd");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.AllGather || !r.GetErrorString) {
         mvs_set_error("librccl lacks a symbol this library needs");
         return MVS_E_STATE;
@@ -57,6 +67,7 @@ struct mvs_comm_s {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1, device = 0;
     double* scratch = nullptr;               // 16 doubles on the device (mvs_comm_reduce)
+    int exchange = 0;                        // MVS_EXCHANGE_AUTO / _ALL_GATHER / _OWNER (mvs_comm_set_exchange)
 };
 
 extern "C" {
@@ -119,8 +130,24 @@ int mvs_comm_info(mvs_comm_t c, int* rank, int* nranks) {
     return MVS_OK;
 }
 
-// n_outer passes of the view-sharded body (mvs.h: mvs_deform_assoc_* comment): per pass ONE all-reduce(MIN) of K floats and
-// ONE all-gather of K * 392 bytes per rank on the handle's stream, then the identical merge and the replicated solve.
+int mvs_comm_set_exchange(mvs_comm_t c, int mode) {
+    if (!c || mode < MVS_EXCHANGE_AUTO || mode > MVS_EXCHANGE_OWNER) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    if (mode == MVS_EXCHANGE_OWNER && c->nranks > 1 && (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)) {
+        mvs_set_error("this RCCL has no point-to-point calls: the owner-merges exchange is not available"); return MVS_E_STATE;
+    }
+    c->exchange = mode;
+    return MVS_OK;
+}
+
+// n_outer passes of the view-sharded body (mvs.h: mvs_deform_assoc_* comment) on the handle's stream.  Per pass ONE
+// all-reduce(MIN) of K floats, then the ranks' best-8 records meet in one of two ways:
+//   all-gather (up to 3 ranks): ONE all-gather of K * 392 bytes per rank, the identical merge of all K nodes on every rank;
+//   owner-merges (from 4 ranks on, or on request): rank r owns the node block [r * ceil(K / N), (r + 1) * ceil(K / N)); grouped
+//     ncclSend / ncclRecv move every rank's records and counts of a block to its owner (K * 392 bytes INTO a rank instead of
+//     N * K * 392), the owner merges its block with the same kernel and total order (1 / N of the merge), ONE all-gather brings
+//     the 25 bytes per node of merged targets back and a small kernel installs them.  Same bits as the all-gather form
+//     (tests/test_gpu_scale.py with one rank through this very code; four emulated shards and world-2 gloo through dist.py).
+// then the replicated solve.  UNVERIFIED ON HARDWARE with more than one rank: this pool gives one GPU per box.
 int mvs_deform_iterate_sharded(mvs_deform_t h, mvs_comm_t c, const mvs_deform_params* p, int n_outer, mvs_deform_stats* stats) {
     if (!h || !c || !p || n_outer < 0) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     int64_t K = 0;
@@ -128,16 +155,33 @@ int mvs_deform_iterate_sharded(mvs_deform_t h, mvs_comm_t c, const mvs_deform_pa
     if (rc) return rc;
     if (K <= 0) { mvs_set_error("no nodes: call mvs_deform_sample_nodes / _set_nodes first"); return MVS_E_STATE; }
     HIPCHK(hipSetDevice(c->device));
-    const size_t rec_bytes = (size_t)K * 8 * sizeof(mvs_cand), blk = rec_bytes + (size_t)K * 2 * sizeof(int32_t);
-    if (h->sh_K != K || h->sh_nranks != c->nranks) {            // exchange buffers of this (K, nranks): d2min | my block | all blocks
+    const int N = c->nranks;
+    const bool p2p = g_rccl.Send && g_rccl.Recv && g_rccl.GroupStart && g_rccl.GroupEnd;
+    const bool owner = c->exchange == MVS_EXCHANGE_OWNER || (c->exchange == MVS_EXCHANGE_AUTO && N >= 4 && p2p);
+    const size_t RECB = sizeof(mvs_cand);
+    const size_t rec_bytes = (size_t)K * 8 * RECB, blk = rec_bytes + (size_t)K * 2 * sizeof(int32_t);
+    // owner-merges layout: block_nodes = ceil(K / N); this rank owns [k0, k1)
+    const int64_t bn = (K + N - 1) / N;
+    auto blk0 = [&](int r) { return std::min<int64_t>(K, (int64_t)r * bn); };
+    const int64_t k0 = blk0(c->rank), k1 = blk0(c->rank + 1), mine = k1 - k0;
+    const size_t tstride = ((size_t)bn * 25 + 31) / 32 * 32;                 // merged targets of a block: [bn * 3 doubles | bn bytes], padded
+    if (h->sh_K != K || h->sh_nranks != N) {            // exchange buffers of this (K, nranks): d2min | my block | all blocks | owner-merges buffers
         if (h->d_sh) { HIPCHK(hipStreamSynchronize(h->stream)); (void)hipFree(h->d_sh); h->d_sh = nullptr; }
-        const size_t d2 = ((size_t)K * sizeof(float) + 255) / 256 * 256, b1 = (blk + 255) / 256 * 256;
-        HIPCHK(hipMalloc(&h->d_sh, d2 + b1 + (size_t)c->nranks * blk));
-        h->sh_K = K; h->sh_nranks = c->nranks; h->sh_off_pack = d2; h->sh_off_all = d2 + b1;
+        auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+        const size_t d2 = al((size_t)K * sizeof(float)), b1 = al(blk), ball = al((size_t)N * blk);
+        const size_t rin = al((size_t)N * (size_t)bn * 8 * RECB), cin = al((size_t)N * (size_t)bn * 2 * sizeof(int32_t)), tb = al(tstride), tall = al((size_t)N * tstride);
+        HIPCHK(hipMalloc(&h->d_sh, d2 + b1 + ball + rin + cin + tb + tall));
+        HIPCHK(hipMemsetAsync((char*)h->d_sh + d2 + b1 + ball + rin + cin, 0, tb, h->stream));     // (the padding of this rank's target block travels too)
+        h->sh_K = K; h->sh_nranks = N; h->sh_off_pack = d2; h->sh_off_all = d2 + b1;
+        h->sh_off_recin = d2 + b1 + ball; h->sh_off_cntin = h->sh_off_recin + rin; h->sh_off_tblk = h->sh_off_cntin + cin; h->sh_off_tall = h->sh_off_tblk + tb;
     }
     float* d2min = (float*)h->d_sh;
     char* pack = (char*)h->d_sh + h->sh_off_pack;
     char* all = (char*)h->d_sh + h->sh_off_all;
+    char* rec_in = (char*)h->d_sh + h->sh_off_recin;
+    char* cnt_in = (char*)h->d_sh + h->sh_off_cntin;
+    char* tblk = (char*)h->d_sh + h->sh_off_tblk;
+    char* tall = (char*)h->d_sh + h->sh_off_tall;
     hipStream_t s = (hipStream_t)mvs_deform_stream(h);
     int status = MVS_OK;
     double worst = 0.0;
@@ -145,14 +189,45 @@ int mvs_deform_iterate_sharded(mvs_deform_t h, mvs_comm_t c, const mvs_deform_pa
     mvs_deform_stats st{};
     for (int o = 0; o < n_outer; ++o) {
         if ((rc = mvs_deform_assoc_dmin(h, p, d2min))) return rc;
-        if (c->nranks > 1 && (rc = check_nccl(g_rccl.AllReduce(d2min, d2min, (size_t)K, ncclFloat32, ncclMin, c->comm, s), "ncclAllReduce(min)"))) return rc;
+        if (N > 1 && (rc = check_nccl(g_rccl.AllReduce(d2min, d2min, (size_t)K, ncclFloat32, ncclMin, c->comm, s), "ncclAllReduce(min)"))) return rc;
         if ((rc = mvs_deform_assoc_select(h, p, d2min, (mvs_cand*)pack, (int32_t*)(pack + rec_bytes)))) return rc;
-        const void* gathered = pack;
-        if (c->nranks > 1) {
-            if ((rc = check_nccl(g_rccl.AllGather(pack, all, blk, ncclUint8, c->comm, s), "ncclAllGather"))) return rc;
-            gathered = all;
+        if (owner) {
+            const char* rec = pack;
+            const char* cnt = pack + rec_bytes;
+            if (N > 1) {
+                // every rank's records / counts of block r go to rank r; from every rank come those of this rank's block
+                if ((rc = check_nccl(g_rccl.GroupStart(), "ncclGroupStart"))) return rc;
+                for (int r = 0; r < N; ++r) {
+                    const int64_t a = blk0(r), n = blk0(r + 1) - a;
+                    if (n > 0) {
+                        if ((rc = check_nccl(g_rccl.Send(rec + (size_t)a * 8 * RECB, (size_t)n * 8 * RECB, ncclUint8, r, c->comm, s), "ncclSend(records)"))) return rc;
+                        if ((rc = check_nccl(g_rccl.Send(cnt + (size_t)a * 2 * sizeof(int32_t), (size_t)n * 2 * sizeof(int32_t), ncclUint8, r, c->comm, s), "ncclSend(counts)"))) return rc;
+                    }
+                    if (mine > 0) {
+                        if ((rc = check_nccl(g_rccl.Recv(rec_in + (size_t)r * mine * 8 * RECB, (size_t)mine * 8 * RECB, ncclUint8, r, c->comm, s), "ncclRecv(records)"))) return rc;
+                        if ((rc = check_nccl(g_rccl.Recv(cnt_in + (size_t)r * mine * 2 * sizeof(int32_t), (size_t)mine * 2 * sizeof(int32_t), ncclUint8, r, c->comm, s), "ncclRecv(counts)"))) return rc;
+                    }
+                }
+                if ((rc = check_nccl(g_rccl.GroupEnd(), "ncclGroupEnd"))) return rc;
+            } else {
+                HIPCHK(hipMemcpyAsync(rec_in, rec, (size_t)mine * 8 * RECB, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpyAsync(cnt_in, cnt, (size_t)mine * 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+            }
+            if (mine > 0 && (rc = mvs_deform_assoc_merge_block(h, p, (const mvs_cand*)rec_in, (const int32_t*)cnt_in, N, k0, k1, bn, tblk))) return rc;
+            const void* blocks = tblk;
+            if (N > 1) {
+                if ((rc = check_nccl(g_rccl.AllGather(tblk, tall, tstride, ncclUint8, c->comm, s), "ncclAllGather(targets)"))) return rc;
+                blocks = tall;
+            }
+            if ((rc = mvs_deform_set_node_targets_dev(h, blocks, N, bn, (int64_t)tstride))) return rc;
+        } else {
+            const void* gathered = pack;
+            if (N > 1) {
+                if ((rc = check_nccl(g_rccl.AllGather(pack, all, blk, ncclUint8, c->comm, s), "ncclAllGather"))) return rc;
+                gathered = all;
+            }
+            if ((rc = mvs_deform_assoc_merge_packed(h, p, gathered, N))) return rc;
         }
-        if ((rc = mvs_deform_assoc_merge_packed(h, p, gathered, c->nranks))) return rc;
         // the statistics are read back (and the launch plans re-made) every 32nd pass and at the end, as mvs_deform_iterate does
         const bool sync = o == n_outer - 1 || (o & 31) == 31;
         rc = mvs_deform_solve(h, p, sync ? &st : nullptr);

@@ -172,6 +172,7 @@ struct mvs_deform_s {
     // exchange buffers of mvs_deform_iterate_sharded (comm.cpp): d2min | this rank's packed block | every rank's block
     void* d_sh = nullptr;
     int64_t sh_K = 0; int sh_nranks = 0; size_t sh_off_pack = 0, sh_off_all = 0;
+    size_t sh_off_recin = 0, sh_off_cntin = 0, sh_off_tblk = 0, sh_off_tall = 0;      // owner-merges: records / counts of the owned block from every rank, merged targets
     double* d_bpure = nullptr;      // [V*3] right-hand side without its Dirichlet share (k_arap_rhs -> k_arap_local's true residual)
     double* d_ras_tail = nullptr;   // [8][RAS_TAIL_MAX] sweep slots of the in-kernel sweeps of TAIL launches
     volatile double* h_ctl = nullptr;

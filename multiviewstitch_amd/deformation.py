@@ -276,6 +276,10 @@ class Comm:
         L.check(L.lib().mvs_comm_init(rank, nranks, C.cast(buf, C.c_void_p), C.cast(C.byref(self._c), C.c_void_p)))
         self.rank, self.nranks = rank, nranks
 
+    def set_exchange(self, mode: int):
+        """0 auto (owner-merges from 4 ranks on), 1 all-gather, 2 owner-merges (mvs_comm_set_exchange)"""
+        L.check(L.lib().mvs_comm_set_exchange(self._c, int(mode)))
+
     def close(self):
         if getattr(self, "_c", None):
             L.lib().mvs_comm_destroy(self._c)

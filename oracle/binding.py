@@ -423,6 +423,36 @@ def init_alignment_sharded(src, tgt_local, ground_ray, view_ray, reducer):
     return R, tr, sc.value
 
 
+def remove_ground_sharded(pts, nrm, faces, reducer, rank, dist_thres=0.81):
+    """this rank's share of a scan sharded by view (facets index the local points); reducer as for init_alignment_sharded"""
+    p, f = _c(np.asarray(pts, np.float64).reshape(-1, 3), np.float64).copy(), _c(np.asarray(faces, np.int32).reshape(-1, 3), np.int32).copy()
+    n = _c(np.asarray(nrm, np.float64).reshape(-1, 3), np.float64).copy() if nrm is not None else None
+    V, F, gr = C.c_int64(len(p)), C.c_int64(len(f)), np.empty(3)
+    fn = lib().orc_remove_ground_sharded
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    rc = fn(C.addressof(V), p.ctypes.data, n.ctypes.data if n is not None else None, C.addressof(F), f.ctypes.data, dist_thres,
+            C.cast(reducer, C.c_void_p), None, rank, gr.ctypes.data)
+    if rc:
+        raise RuntimeError(f"orc_remove_ground_sharded -> {rc}")
+    return gr, p[:V.value], (n[:V.value] if n is not None else None), f[:F.value]
+
+
+def local_alignment_core_sharded(src, s_labels, tgt_local, t_labels_local, group_mask, label, reducer):
+    s, t = _c(src, np.float64), _c(np.asarray(tgt_local, np.float64).reshape(-1, 3), np.float64)
+    sl, tl = _c(s_labels, np.int32), _c(np.asarray(t_labels_local, np.int32).reshape(-1), np.int32)
+    R, tr, sc = np.empty((3, 3)), np.empty(3), C.c_double()
+    fn = lib().orc_local_alignment_core_sharded
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = fn(s.ctypes.data, sl.ctypes.data, len(s), t.ctypes.data, tl.ctypes.data, len(t), group_mask, label, C.cast(reducer, C.c_void_p), None,
+            R.ctypes.data, tr.ctypes.data, C.addressof(sc))
+    if rc:
+        raise RuntimeError(f"orc_local_alignment_core_sharded -> {rc}")
+    return R, tr, sc.value
+
+
 def init_alignment(src, tgt, ground_ray, view_ray):
     s, t = _c(src, np.float64), _c(tgt, np.float64)
     g, v = _c(ground_ray, np.float64), _c(view_ray, np.float64)

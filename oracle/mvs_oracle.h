@@ -136,6 +136,11 @@ int  orc_remove_ground(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t
 /* view-sharded InitAlignment (checker of mvs_init_alignment_sharded): tgt = this rank's share; reduce(ctx, v, n, op) all-reduces
  * n host doubles in place over the ranks, op 0 = sum, 1 = min; returns 0 on success */
 typedef int (*orc_reduce_fn)(void* ctx, double* v, int n, int op);
+/* view-sharded forms of RemoveGround (Alignment.cpp:79-233) and LocalAlignmentCore (:423-546): the scan arrays hold one rank's share */
+int  orc_remove_ground_sharded(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t* faces, double dist_thres, orc_reduce_fn reduce,
+                               void* ctx, int rank, double* ground_ray);
+int  orc_local_alignment_core_sharded(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels,
+                                      int64_t nt, uint32_t group_mask, int label, orc_reduce_fn reduce, void* ctx, double* R, double* t, double* scale);
 int  orc_init_alignment_sharded(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray,
                                 const double* view_ray, orc_reduce_fn reduce, void* ctx, double* R, double* t, double* scale);
 int  orc_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray,

@@ -171,8 +171,13 @@ int orc_pca(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, 
     return 0;
 }
 
+}  // extern "C"
+
+namespace {
 // Alignment::RetainConnectRegion (Alignment.cpp:618-654).  In place; returns new V, F through pointers.
-void orc_retain_connect_region(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t* faces) {
+// red.on(): the scan is sharded by view (facets never join points of two ranks): the largest component over ALL ranks stays,
+// ties to the lower rank (= the lower vertex index of the stitched scan), every other rank keeps nothing.
+bool retain(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t* faces, const Reducer& red, int rank) {
     const int64_t n = *V, nf = *F;
     std::vector<int32_t> par(n);
     for (int64_t i = 0; i < n; ++i) par[i] = (int32_t)i;
@@ -187,6 +192,14 @@ void orc_retain_connect_region(int64_t* V, double* pts, double* nrm, int64_t* F,
     for (int64_t i = 0; i < n; ++i) size[find((int)i)]++;
     int64_t best = 0;
     for (int64_t i = 1; i < n; ++i) if (size[i] > size[best]) best = i;    // ties -> lowest root = lowest vertex index
+    if (red.on()) {
+        const double mine = n > 0 ? (double)size[best] : 0.0;
+        double g = -mine;
+        if (!red.run(&g, 1, 1)) return false;
+        double win = (mine > 0 && mine == -g) ? (double)rank : INFINITY;
+        if (!red.run(&win, 1, 1)) return false;
+        if (win != (double)rank) { *V = 0; *F = 0; return true; }
+    }
     std::vector<int32_t> mp(n, -1);
     int64_t m = 0;
     for (int64_t i = 0; i < n; ++i)
@@ -201,13 +214,16 @@ void orc_retain_connect_region(int64_t* V, double* pts, double* nrm, int64_t* F,
         faces[3 * mf] = a; faces[3 * mf + 1] = b; faces[3 * mf + 2] = c; ++mf;
     }
     *V = m; *F = mf;
+    return true;
 }
 
-// Alignment::RemoveGround (Alignment.cpp:79-233).  In place.  ground_ray out.
-int orc_remove_ground(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t* faces, double dist_thres, double* ground_ray) {
+// Alignment::RemoveGround (Alignment.cpp:79-233).  In place.  ground_ray out.  red.on(): this rank's share of a scan sharded by
+// view — every sum and extreme over the points is reduced over the ranks, the removal is local.
+int remove_ground(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t* faces, double dist_thres, double* ground_ray,
+                  const Reducer& red, int rank) {
     const int64_t n = *V;
     Pca p;
-    if (!pca(pts, n, nullptr, 0, &p)) return -9;
+    if (!pca(pts, n, nullptr, 0, &p, red)) return -9;
     const V3 pivot = p.axis[0];
     const double den = norm(pivot) * norm(pivot);
     std::vector<double> t(n);
@@ -216,12 +232,15 @@ int orc_remove_ground(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t*
         t[i] = dot(pivot, v3(pts + 3 * i) - p.bary) / den;
         if (t[i] < 0) tMax1 = std::max(-t[i], tMax1); else tMax2 = std::max(t[i], tMax2);
     }
+    if (red.on()) { double e[2] = {-tMax1, -tMax2}; if (!red.run(e, 2, 1)) return -8; tMax1 = -e[0]; tMax2 = -e[1]; }
     std::vector<int64_t> idx1, idx2;
     for (int64_t i = 0; i < n; ++i) {                                       // :115-126
         if (t[i] < 0) { if (-t[i] > tMax1 * dist_thres) idx1.push_back(i); }
         else if (t[i] > tMax2 * dist_thres) idx2.push_back(i);
     }
-    const bool first = idx1.size() > idx2.size();                           // :129-138
+    double c12[2] = {(double)idx1.size(), (double)idx2.size()};
+    if (red.on() && !red.run(c12, 2, 0)) return -8;
+    const bool first = c12[0] > c12[1];                                     // :129-138
     const std::vector<int64_t>& idx = first ? idx1 : idx2;
     const V3 gr = first ? -1.0 * pivot : pivot;
     put(ground_ray, gr);
@@ -230,6 +249,12 @@ int orc_remove_ground(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t*
         const double a[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[3 * r + c] += a[r] * a[c];
         b = b + v3(pts + 3 * i);
+    }
+    if (red.on()) {
+        double m[12] = {A[0], A[1], A[2], A[3], A[4], A[5], A[6], A[7], A[8], b.x, b.y, b.z};
+        if (!red.run(m, 12, 0)) return -8;
+        for (int k = 0; k < 9; ++k) A[k] = m[k];
+        b = {m[9], m[10], m[11]};
     }
     double Ai[9];
     inv3(A, Ai);
@@ -240,6 +265,7 @@ int orc_remove_ground(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t*
     double maxDist = DBL_MIN;
     std::vector<double> dist(idx.size());
     for (size_t k = 0; k < idx.size(); ++k) { dist[k] = std::fabs(dot(ans, v3(pts + 3 * idx[k])) + d); maxDist = std::max(maxDist, dist[k]); }
+    if (red.on()) { double e = -maxDist; if (!red.run(&e, 1, 1)) return -8; maxDist = -e; }
     const double threshold = maxDist * 0.28;                                // :187
     std::vector<char> remove(n, 0);
     for (size_t k = 0; k < idx.size(); ++k) if (dist[k] < threshold) remove[idx[k]] = 1;
@@ -257,8 +283,22 @@ int orc_remove_ground(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t*
         faces[3 * mf] = a; faces[3 * mf + 1] = bb; faces[3 * mf + 2] = c; ++mf;
     }
     *V = m; *F = mf;
-    orc_retain_connect_region(V, pts, nrm, F, faces);                       // :227
-    return 0;
+    return retain(V, pts, nrm, F, faces, red, rank) ? 0 : -8;               // :227
+}
+}  // namespace
+
+extern "C" {
+
+void orc_retain_connect_region(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t* faces) { (void)retain(V, pts, nrm, F, faces, Reducer(), 0); }
+
+int orc_remove_ground(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t* faces, double dist_thres, double* ground_ray) {
+    return remove_ground(V, pts, nrm, F, faces, dist_thres, ground_ray, Reducer(), 0);
+}
+int orc_remove_ground_sharded(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t* faces, double dist_thres, orc_reduce_fn reduce,
+                              void* ctx, int rank, double* ground_ray) {
+    Reducer red;
+    red.fn = reduce; red.ctx = ctx;
+    return remove_ground(V, pts, nrm, F, faces, dist_thres, ground_ray, red, rank);
 }
 
 // Alignment::InitAlignment (Alignment.cpp:235-314): R (row-major), t, scale
@@ -318,14 +358,26 @@ void orc_part_recog(const double* tmpl, const int32_t* tmpl_labels, int64_t V, c
 
 // Alignment::LocalAlignmentCore (Alignment.cpp:423-546) on the points of src/tgt selected by group_mask;
 // slabel == tlabel == `label`.  Returns scale, R, translate.
-int orc_local_alignment_core(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels,
-                             int64_t nt, uint32_t group_mask, int label, double* R, double* t, double* scale) {
+int orc_local_alignment_core_sharded(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels,
+                                     int64_t nt, uint32_t group_mask, int label, orc_reduce_fn reduce, void* ctx, double* R, double* t, double* scale) {
+    Reducer red;
+    red.fn = reduce; red.ctx = ctx;
     Pca ps, pt;
-    if (!pca(src, ns, s_labels, group_mask, &ps) || !pca(tgt, nt, t_labels, group_mask, &pt)) return -9;
+    if (!pca(src, ns, s_labels, group_mask, &ps) || !pca(tgt, nt, t_labels, group_mask, &pt, red)) return -9;
     if (dot(ps.axis[0], pt.axis[0]) < 0) pt.axis[0] = -1.0 * pt.axis[0];          // :444-446
     uint32_t sset = 0, tset = 0;                                                   // label sets present (:475-477)
     for (int64_t i = 0; i < ns; ++i) if ((group_mask >> s_labels[i]) & 1u) sset |= 1u << s_labels[i];
     for (int64_t i = 0; i < nt; ++i) if ((group_mask >> t_labels[i]) & 1u) tset |= 1u << t_labels[i];
+    if (red.on()) {                                                                // the scan's labels over all ranks
+        uint32_t all = 0;
+        for (int base = 0; base < 32; base += 16) {
+            double v[16];
+            for (int k = 0; k < 16; ++k) v[k] = ((tset >> (base + k)) & 1u) ? -1.0 : 0.0;
+            if (!red.run(v, 16, 1)) return -8;
+            for (int k = 0; k < 16; ++k) if (v[k] < 0.0) all |= 1u << (base + k);
+        }
+        tset = all;
+    }
     auto popc = [](uint32_t x) { int c = 0; while (x) { c += x & 1; x >>= 1; } return c; };
     if (popc(sset) < popc(tset)) {                                                 // :479-488 erase ONE label missing in src
         const uint32_t extra = tset & ~sset;
@@ -338,8 +390,18 @@ int orc_local_alignment_core(const double* src, const int32_t* s_labels, int64_t
     if (r1.ilo < 0 || r1.ihi < 0) return -9;
     if (s_labels[r1.ihi] != label) { std::swap(r1.lo, r1.hi); std::swap(r1.ilo, r1.ihi); }  // :513-517
     Range r2 = range_along(tgt, nt, t_labels, tset & group_mask, pt.axis[0], pt.bary);      // :519-524
+    int lab2 = r2.ihi >= 0 ? t_labels[r2.ihi] : -1;
+    if (red.on()) {                                                                          // extent over all ranks; the far point's label
+        double e[2] = {r2.lo, -r2.hi};
+        const double myhi = r2.hi;
+        if (!red.run(e, 2, 1)) return -8;
+        double lv = (r2.ihi >= 0 && myhi == -e[1]) ? (double)lab2 : INFINITY;
+        if (!red.run(&lv, 1, 1)) return -8;
+        if (!(lv < INFINITY)) return -9;
+        r2.lo = e[0]; r2.hi = -e[1]; r2.ilo = r2.ihi = 0; lab2 = (int)lv;
+    }
     if (r2.ilo < 0 || r2.ihi < 0) return -9;
-    if (t_labels[r2.ihi] != label) { std::swap(r2.lo, r2.hi); std::swap(r2.ilo, r2.ihi); } // :525-528
+    if (lab2 != label) { std::swap(r2.lo, r2.hi); std::swap(r2.ilo, r2.ihi); }              // :525-528
     *scale = (r2.hi - r2.lo) / (r1.hi - r1.lo);                                             // :529
     rotation_between(ps.axis[0], pt.axis[0], R);                                            // :532
     const V3 far = v3(src + 3 * r1.ilo);                                                    // src_[fidx1] + baryCenter1
@@ -347,6 +409,10 @@ int orc_local_alignment_core(const double* src, const int32_t* s_labels, int64_t
     for (int k = 0; k < 9; ++k) sR[k] = *scale * R[k];
     put(t, far - mulMv(sR, far));                                                           // :535
     return 0;
+}
+int orc_local_alignment_core(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels,
+                             int64_t nt, uint32_t group_mask, int label, double* R, double* t, double* scale) {
+    return orc_local_alignment_core_sharded(src, s_labels, ns, tgt, t_labels, nt, group_mask, label, nullptr, nullptr, R, t, scale);
 }
 
 }  // extern "C"

@@ -305,6 +305,105 @@ def test_init_alignment_reductions_shard_by_view(world):
     _run_align(world, engine=False)
 
 
+# RemoveGround (Alignment.cpp:79-233) and LocalAlignmentCore (:423-546) with the scan sharded by view -------------------
+def _two_bodies():
+    """the body scene's scan cut into its connected pieces — the body on one "view", the ground patch under it on the other:
+    facets never join points of two ranks, and RemoveGround's last step keeps the larger piece, which lives on ONE rank"""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    from tests.util import body_scene
+    b = body_scene()
+    P, N, F = b["tgt"], b["t_nrm"], b["t_faces"]
+    e = np.concatenate([F[:, [0, 1]], F[:, [1, 2]]])
+    _, comp = connected_components(coo_matrix((np.ones(len(e)), (e[:, 0], e[:, 1])), shape=(len(P), len(P))), directed=False)
+    big = np.bincount(comp).argmax()
+    views = []
+    for sel in (comp == big, comp != big):
+        idx = np.flatnonzero(sel)
+        remap = -np.ones(len(P), np.int64)
+        remap[idx] = np.arange(len(idx))
+        f = F[sel[F[:, 0]]]
+        views.append((P[idx], N[idx], remap[f].astype(np.int32)))
+    return b, views
+
+
+def _ground_worker(rank, world, port, q, engine):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import binding as O
+    from multiviewstitch_amd import dist as mdist
+    b, views = _two_bodies()
+    empty = (np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3), np.int32))
+    p, n, f = views[rank] if rank < 2 else empty                       # with 3 ranks the last one holds nothing
+    red = mdist.host_reducer()
+    if engine:
+        from multiviewstitch_amd import alignment
+        A = alignment.Alignment()
+        gr, p2, n2, f2 = A.RemoveGroundSharded(p, n, f, red, rank)
+    else:
+        gr, p2, n2, f2 = O.remove_ground_sharded(p, n, f, red, rank)
+    # LocalAlignmentCore on the shares: the body's labelled points split over the ranks (nearest template vertex's label)
+    tl_full = O.part_recog(b["src"], b["s_labels"], b["tgt"])
+    cuts = np.linspace(0, len(b["tgt"]), world + 1).astype(int) if world == 2 else np.array([0, len(b["tgt"]) // 2, len(b["tgt"]) // 2, len(b["tgt"])])
+    sl = slice(cuts[rank], cuts[rank + 1])
+    group, label = (1 << 2) | (1 << 3) | (1 << 4), 4                   # left arm, LeftHand
+    if engine:
+        R, t, s = A.LocalAlignmentCoreSharded(b["src"], b["s_labels"], b["tgt"][sl], tl_full[sl], group, label, red)
+    else:
+        R, t, s = O.local_alignment_core_sharded(b["src"], b["s_labels"], b["tgt"][sl], tl_full[sl], group, label, red)
+    q.put((rank, gr, p2, f2, R, t, s))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_ground(world, engine):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ground_worker, args=(r, world, port, q, engine)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=240)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from oracle import binding as O
+    b, views = _two_bodies()
+    # the unsharded answer on the stitched scan (rank order = point order)
+    P = np.concatenate([v[0] for v in views]); N = np.concatenate([v[1] for v in views])
+    F = np.concatenate([views[0][2], views[1][2] + len(views[0][0])])
+    gr, p_ref, _, f_ref = O.remove_ground(P, N, F, 0.81)
+    for r in range(world):
+        assert np.abs(res[r][0] - gr).max() < 1e-9                                          # one ground ray everywhere
+    kept = [r for r in range(world) if len(res[r][1])]
+    assert len(kept) == 1                                                                   # the largest component lives on one rank
+    p_got, f_got = res[kept[0]][1], res[kept[0]][2]
+    assert len(p_got) == len(p_ref) and np.array_equal(f_got, f_ref if kept[0] == 0 else f_ref)
+    assert np.abs(p_got - p_ref).max() == 0.0
+    tl_full = O.part_recog(b["src"], b["s_labels"], b["tgt"])
+    want = O.local_alignment_core(b["src"], b["s_labels"], b["tgt"], tl_full, (1 << 2) | (1 << 3) | (1 << 4), 4)
+    for r in range(1, world):
+        assert all(np.array_equal(np.asarray(a), np.asarray(c)) for a, c in zip(res[0][3:], res[r][3:]))
+    assert np.abs(res[0][3] - want[0]).max() < 1e-9 and np.abs(res[0][4] - want[1]).max() < 1e-8 and abs(res[0][5] - want[2]) < 1e-10
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_remove_ground_and_local_alignment_reductions_shard_by_view(world):
+    _run_ground(world, engine=False)
+
+
+@pytest.mark.gpu
+def test_gpu_remove_ground_and_local_alignment_sharded_two_ranks_on_one_gpu():
+    """mvs_remove_ground_sharded / mvs_local_alignment_core_sharded in two processes sharing the box's GPU, reduced over gloo."""
+    _run_ground(2, engine=True)
+
+
 @pytest.mark.gpu
 def test_gpu_init_alignment_sharded_two_ranks_on_one_gpu():
     """mvs_init_alignment_sharded in two processes sharing the box's GPU, reduced over gloo by dist.host_reducer."""

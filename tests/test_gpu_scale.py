@@ -172,6 +172,12 @@ def test_library_owned_rccl_communicator_drives_the_sharded_passes(big):
     st = d.iterate_sharded(comm, 2)                      # and again on the calibrated handle (enqueue-only passes inside)
     ref.iterate(2)
     assert st["converged"] and np.array_equal(d.vertices(), ref.vertices())
+    # the owner-merges exchange of the C library (what it uses from four ranks on): block layout, merge of the owned block,
+    # installation of the gathered targets — the same bits again (with one rank the point-to-point calls are device copies)
+    comm.set_exchange(2)
+    st = d.iterate_sharded(comm, 2)
+    ref.iterate(2)
+    assert st["converged"] and np.array_equal(d.vertices(), ref.vertices())
     comm.close()
 
 
