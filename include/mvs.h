@@ -313,6 +313,17 @@ int mvs_align(double* src, double* s_normals, int64_t ns, const int32_t* s_label
               double* tgt, double* t_normals, int64_t* nt, int32_t* t_faces, int64_t* nf,
               const double* view_ray, double dist_thres, int32_t* t_labels, double* ground_ray);
 
+/* ------------------------------------------------------------------ tracing */
+/* SURVEY §8b "Side effects": the engine writes no files and prints nothing (the reference's only timer is a clock() pair around
+ * PartRecog printed to stdout, R/Alignment/Alignment.cpp:46-52).  A caller that wants timing registers a callback: every compute
+ * entry of this header then calls fn(ctx, "mvs_<entry>", 0, 0) when entered and fn(ctx, "mvs_<entry>", 1, ms) when left (ms = host
+ * wall time of the call; entries that only enqueue return before the device has finished — mvs_deform_kernel_time has the
+ * device-side phase times).  Process-wide; NULL switches it off.  mvs_set_trace_roctx(1) additionally marks every entry as a
+ * roctx range (rocprofv3 --marker-trace) when libroctx64 is present. */
+typedef void (*mvs_trace_fn)(void* ctx, const char* entry, int phase, double host_ms);
+int mvs_set_trace(mvs_trace_fn fn, void* ctx);
+int mvs_set_trace_roctx(int on);
+
 /* ----------------------------------------------------- Deformation (a16-a22) */
 typedef struct mvs_deform_s* mvs_deform_t;
 

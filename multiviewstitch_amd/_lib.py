@@ -79,6 +79,8 @@ _SIGS = {
     "mvs_device_count": (C.c_int, []),
     "mvs_set_device": (C.c_int, [_I32]),
     "mvs_device_name": (C.c_int, [C.c_char_p, _I32]),
+    "mvs_set_trace": (C.c_int, [_VP, _VP]),
+    "mvs_set_trace_roctx": (C.c_int, [_I32]),
     "mvs_depth_to_model": (C.c_int, [_VP, _VP, _D, _D, _D, _VP, _VP, _VP, _VP, _VP, _VP]),
     "mvs_depth_to_model_dev": (C.c_int, [_VP, _VP, _D, _D, _D, _VP, _VP, _VP, _VP, _VP, _VP]),
     "mvs_depth_unproject": (C.c_int, [_VP, _VP, _D, _D, _VP, _VP]),

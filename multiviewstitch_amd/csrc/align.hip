@@ -10,6 +10,7 @@
 // control flow between stages.  Conventions for the unpinned bits are those of
 // oracle/orc_align.cpp (PCA axis sign, component tie-break, erased label).
 #include "engine.h"
+#include "trace.h"
 #include "dev_common.h"
 #include "geom.h"
 #include <algorithm>
@@ -699,6 +700,7 @@ template <class T> int down(T* h, const Dev& d, size_t n) {
 extern "C" {
 
 int mvs_pca(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, double* bary, double* bbox, double* axes, double* evals) {
+    MVS_TRACE();
     if (!pts || n < 2 || !bary || !bbox || !axes || !evals) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     int rc = need_device();
     if (rc) return rc;
@@ -711,6 +713,7 @@ int mvs_pca(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, 
 }
 
 int mvs_retain_connect_region(int64_t* V, double* pts, double* normals, int64_t* F, int32_t* faces) {
+    MVS_TRACE();
     if (!V || !F || !pts || *V < 0 || *F < 0 || (*F > 0 && !faces)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     int rc = need_device();
     if (rc) return rc;
@@ -724,6 +727,7 @@ int mvs_retain_connect_region(int64_t* V, double* pts, double* normals, int64_t*
 }
 
 int mvs_remove_ground(int64_t* V, double* pts, double* normals, int64_t* F, int32_t* faces, double dist_thres, double* ground_ray) {
+    MVS_TRACE();
     if (!V || !F || !pts || !ground_ray || *V < 2 || *F < 0 || (*F > 0 && !faces)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     int rc = need_device();
     if (rc) return rc;
@@ -738,6 +742,7 @@ int mvs_remove_ground(int64_t* V, double* pts, double* normals, int64_t* F, int3
 
 int mvs_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray, const double* view_ray,
                        double* R, double* t, double* scale) {
+    MVS_TRACE();
     if (!src || !tgt || ns < 2 || nt < 2 || !ground_ray || !view_ray || !R || !t || !scale) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     int rc = need_device();
     if (rc) return rc;
@@ -748,6 +753,7 @@ int mvs_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t
 
 int mvs_init_alignment_sharded(const double* src, int64_t ns, const double* tgt_local, int64_t nt_local, const double* ground_ray,
                                const double* view_ray, mvs_reduce_fn reduce, void* reduce_ctx, double* R, double* t, double* scale) {
+    MVS_TRACE();
     if (!src || ns < 2 || nt_local < 0 || (nt_local > 0 && !tgt_local) || !ground_ray || !view_ray || !reduce || !R || !t || !scale) {
         mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG;
     }
@@ -761,6 +767,7 @@ int mvs_init_alignment_sharded(const double* src, int64_t ns, const double* tgt_
 }
 
 int mvs_part_recog(const double* tmpl_pts, const int32_t* tmpl_labels, int64_t V, const double* pts, int64_t P, int32_t* out_labels) {
+    MVS_TRACE();
     if (!tmpl_pts || !tmpl_labels || V < 1 || P < 0 || (P > 0 && (!pts || !out_labels)) || V > 0x7ffffff0LL) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     int rc = need_device();
     if (rc) return rc;
@@ -773,6 +780,7 @@ int mvs_part_recog(const double* tmpl_pts, const int32_t* tmpl_labels, int64_t V
 
 int mvs_remove_ground_sharded(int64_t* V, double* pts, double* normals, int64_t* F, int32_t* faces, double dist_thres,
                               mvs_reduce_fn reduce, void* reduce_ctx, int rank, double* ground_ray) {
+    MVS_TRACE();
     if (!V || !F || *V < 0 || *F < 0 || (*V > 0 && !pts) || (*F > 0 && !faces) || !ground_ray || !reduce || rank < 0) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     int rc = need_device();
     if (rc) return rc;
@@ -789,6 +797,7 @@ int mvs_remove_ground_sharded(int64_t* V, double* pts, double* normals, int64_t*
 int mvs_local_alignment_core_sharded(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt_local, const int32_t* t_labels_local,
                                      int64_t nt_local, uint32_t group_mask, int label, mvs_reduce_fn reduce, void* reduce_ctx,
                                      double* R, double* t, double* scale) {
+    MVS_TRACE();
     if (!src || !s_labels || ns < 2 || nt_local < 0 || (nt_local > 0 && (!tgt_local || !t_labels_local)) || !reduce || !R || !t || !scale) {
         mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG;
     }
@@ -803,6 +812,7 @@ int mvs_local_alignment_core_sharded(const double* src, const int32_t* s_labels,
 
 int mvs_local_alignment_core(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels, int64_t nt,
                              uint32_t group_mask, int label, double* R, double* t, double* scale) {
+    MVS_TRACE();
     if (!src || !tgt || !s_labels || !t_labels || ns < 2 || nt < 2 || !R || !t || !scale) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     int rc = need_device();
     if (rc) return rc;
@@ -813,6 +823,7 @@ int mvs_local_alignment_core(const double* src, const int32_t* s_labels, int64_t
 
 int mvs_align(double* src, double* s_normals, int64_t ns, const int32_t* s_labels, double* tgt, double* t_normals, int64_t* nt,
               int32_t* t_faces, int64_t* nf, const double* view_ray, double dist_thres, int32_t* t_labels, double* ground_ray) {
+    MVS_TRACE();
     if (!src || !s_normals || !s_labels || !tgt || !t_normals || !nt || !nf || !view_ray || !t_labels || ns < 2 || *nt < 2 || *nf < 0 ||
         (*nf > 0 && !t_faces)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     for (int64_t i = 0; i < ns; ++i) if (s_labels[i] < 0 || s_labels[i] > 31) { mvs_set_error("labels must be 0..31"); return MVS_E_INVALID_ARG; }

@@ -2,6 +2,7 @@
 // the drop-in for class Deformation (R/Deformation/Deformation.h:224-252).
 // Host orchestration only; every per-point / per-vertex operation is a HIP kernel.
 #include "engine.h"
+#include "trace.h"
 #include "knobs.h"
 #include <algorithm>
 #include <cmath>
@@ -13,6 +14,7 @@
 #include <tuple>
 #include <mutex>
 #include <sched.h>
+#include <dlfcn.h>
 
 // ------------------------------------------------------------------ errors ----
 static thread_local char g_err[512] = "";
@@ -35,7 +37,35 @@ int mvs_debug_level() {
     return level;
 }
 
+// ---- tracing (trace.h) ----
+static mvs_trace_fn g_trace_fn = nullptr;
+static void* g_trace_ctx = nullptr;
+static int (*g_roctx_push)(const char*) = nullptr;
+static int (*g_roctx_pop)() = nullptr;
+static bool g_roctx_on = false;
+bool mvs_trace_on() { return g_trace_fn != nullptr || g_roctx_on; }
+void mvs_trace_enter(const char* entry) {
+    if (g_roctx_on && g_roctx_push) (void)g_roctx_push(entry);
+    if (g_trace_fn) g_trace_fn(g_trace_ctx, entry, 0, 0.0);
+}
+void mvs_trace_leave(const char* entry, double host_ms) {
+    if (g_trace_fn) g_trace_fn(g_trace_ctx, entry, 1, host_ms);
+    if (g_roctx_on && g_roctx_pop) (void)g_roctx_pop();
+}
+
 extern "C" {
+
+int mvs_set_trace(mvs_trace_fn fn, void* ctx) { g_trace_ctx = ctx; g_trace_fn = fn; return MVS_OK; }
+int mvs_set_trace_roctx(int on) {
+    if (on && !g_roctx_push) {
+        void* lib = nullptr;
+        for (const char* name : {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so", "librocprofiler-sdk-roctx.so"}) { lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+        if (lib) { g_roctx_push = (int (*)(const char*))dlsym(lib, "roctxRangePushA"); g_roctx_pop = (int (*)())dlsym(lib, "roctxRangePop"); }
+        if (!g_roctx_push || !g_roctx_pop) { g_roctx_push = nullptr; g_roctx_pop = nullptr; mvs_set_error("roctx is not available on this host"); return MVS_E_STATE; }
+    }
+    g_roctx_on = on != 0;
+    return MVS_OK;
+}
 
 const char* mvs_last_error(void) { return g_err; }
 int mvs_abi_version(void) { return MVS_ABI_VERSION; }
@@ -745,6 +775,7 @@ extern "C" {
 // need is built ON THE DEVICE (meshbuild.hip) — two allocations, three uploads, one synchronisation.
 int mvs_deform_create(int64_t V, const double* points, const double* normals, int64_t F, const int32_t* faces,
                       mvs_deform_t* out) {
+    MVS_TRACE();
     if (!out) { mvs_set_error("out is NULL"); return MVS_E_INVALID_ARG; }
     *out = nullptr;
     if (V <= 0 || F < 0 || !points || !normals || (F > 0 && !faces) || V > 0x7ffffff0LL || F > 0x2aaaaaa0LL) {
@@ -777,6 +808,7 @@ int mvs_deform_create(int64_t V, const double* points, const double* normals, in
 }
 
 int mvs_deform_destroy(mvs_deform_t h) {
+    MVS_TRACE();
     if (!h) return MVS_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -831,6 +863,7 @@ static int install_nodes(mvs_deform_s* h, const int32_t* vertex_idx, int64_t K) 
 }
 
 int mvs_deform_set_nodes(mvs_deform_t h, const int32_t* vertex_idx, int64_t K) {
+    MVS_TRACE();
     if (!h || K < 0 || (K > 0 && !vertex_idx)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     HIPCHK(hipSetDevice(h->device));
     std::vector<char> seen(h->V, 0);
@@ -847,6 +880,7 @@ int mvs_deform_set_nodes(mvs_deform_t h, const int32_t* vertex_idx, int64_t K) {
 // topology alone — adjacency tables, patch tables, node set, launch plans — is kept, which is what mvs_deform_create spends
 // its 20 ms on.
 int mvs_deform_set_vertices(mvs_deform_t h, const double* points, const double* normals) {
+    MVS_TRACE();
     if (!h || !points) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -864,6 +898,7 @@ int mvs_deform_set_vertices(mvs_deform_t h, const double* points, const double* 
 }
 
 int mvs_deform_sample_nodes(mvs_deform_t h, int knn, int64_t* K) {
+    MVS_TRACE();
     // UniformSampling, Deformation.cpp:63-106: exact kNN table on the GPU, greedy suppression
     // in vertex order on the host (inherently sequential).
     if (!h || knn < 1 || knn > 64) { mvs_set_error("knn must be 1..64"); return MVS_E_INVALID_ARG; }
@@ -913,6 +948,7 @@ int mvs_deform_sizes(mvs_deform_t h, int64_t* V, int64_t* F, int64_t* K, int64_t
 
 // ------------------------------------------------------------------- target ----
 int mvs_deform_set_target_dev(mvs_deform_t h, int64_t P, const double* pts_dev, const double* normals_dev, int64_t index_base) {
+    MVS_TRACE();
     if (!h || P < 0 || (P > 0 && (!pts_dev || !normals_dev))) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     HIPCHK(hipSetDevice(h->device));
     // the caller's buffers were produced on some other stream (torch's current stream, the legacy default stream ...);
@@ -922,6 +958,7 @@ int mvs_deform_set_target_dev(mvs_deform_t h, int64_t P, const double* pts_dev, 
     return grid_build(h, P, pts_dev, normals_dev, index_base);
 }
 int mvs_deform_set_target(mvs_deform_t h, int64_t P, const double* pts, const double* normals, int64_t index_base) {
+    MVS_TRACE();
     if (!h || P < 0 || (P > 0 && (!pts || !normals))) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     HIPCHK(hipSetDevice(h->device));
     double *dp = nullptr, *dn = nullptr;
@@ -948,6 +985,7 @@ static int ready(mvs_deform_t h, const mvs_deform_params* p, bool need_target) {
 static constexpr int MAX_BATCH = 32;
 
 int mvs_deform_iterate(mvs_deform_t h, const mvs_deform_params* p, int n_outer, mvs_deform_stats* stats) {
+    MVS_TRACE();
     int rc = ready(h, p, true);
     if (rc) return rc;
     if (n_outer < 0) return MVS_E_INVALID_ARG;
@@ -1002,6 +1040,7 @@ int mvs_deform_iterate(mvs_deform_t h, const mvs_deform_params* p, int n_outer, 
 }
 
 int mvs_deform_assoc_dmin(mvs_deform_t h, const mvs_deform_params* p, float* d2min_dev) {
+    MVS_TRACE();
     int rc = ready(h, p, true);
     if (rc) return rc;
     if (!d2min_dev) return MVS_E_INVALID_ARG;
@@ -1012,6 +1051,7 @@ int mvs_deform_assoc_dmin(mvs_deform_t h, const mvs_deform_params* p, float* d2m
 }
 int mvs_deform_assoc_select(mvs_deform_t h, const mvs_deform_params* p, const float* d2min_dev, mvs_cand* records_dev,
                             int32_t* counts_dev) {
+    MVS_TRACE();
     int rc = ready(h, p, true);
     if (rc) return rc;
     if (!d2min_dev || !records_dev || !counts_dev) return MVS_E_INVALID_ARG;
@@ -1038,6 +1078,7 @@ int mvs_deform_assoc_select(mvs_deform_t h, const mvs_deform_params* p, const fl
 }
 int mvs_deform_assoc_merge(mvs_deform_t h, const mvs_deform_params* p, const mvs_cand* records_all_dev,
                            const int32_t* counts_all_dev, int nranks) {
+    MVS_TRACE();
     int rc = ready(h, p, false);
     if (rc) return rc;
     if (!records_all_dev || !counts_all_dev || nranks < 1) return MVS_E_INVALID_ARG;
@@ -1048,6 +1089,7 @@ int mvs_deform_assoc_merge(mvs_deform_t h, const mvs_deform_params* p, const mvs
     return mvs_check_hip(hipGetLastError(), "assoc_merge");
 }
 int mvs_deform_assoc_merge_packed(mvs_deform_t h, const mvs_deform_params* p, const void* packed_all_dev, int nranks) {
+    MVS_TRACE();
     int rc = ready(h, p, false);
     if (rc) return rc;
     if (!packed_all_dev || nranks < 1) return MVS_E_INVALID_ARG;
@@ -1063,6 +1105,7 @@ int mvs_deform_assoc_merge_packed(mvs_deform_t h, const mvs_deform_params* p, co
 // [block_nodes * 3 doubles | block_nodes bytes] (block_nodes >= k1 - k0: the padded size every rank all-gathers) ...
 int mvs_deform_assoc_merge_block(mvs_deform_t h, const mvs_deform_params* p, const mvs_cand* records_blk_dev, const int32_t* counts_blk_dev,
                                  int nranks, int64_t k0, int64_t k1, int64_t block_nodes, void* block_dev) {
+    MVS_TRACE();
     int rc = ready(h, p, false);
     if (rc) return rc;
     if (!records_blk_dev || !counts_blk_dev || !block_dev || nranks < 1 || k0 < 0 || k1 < k0 || k1 > h->K || block_nodes < k1 - k0) {
@@ -1077,6 +1120,7 @@ int mvs_deform_assoc_merge_block(mvs_deform_t h, const mvs_deform_params* p, con
 // ... and every rank installs the all-gathered blocks (what mvs_deform_assoc_merge would have left) before _solve: node k
 // is entry k % block_nodes of block k / block_nodes
 int mvs_deform_set_node_targets_dev(mvs_deform_t h, const void* blocks_dev, int nblocks, int64_t block_nodes, int64_t block_stride_bytes) {
+    MVS_TRACE();
     if (!h || !blocks_dev || nblocks < 1 || block_nodes < 1) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     if (h->K == 0) { mvs_set_error("no nodes"); return MVS_E_STATE; }
     if ((int64_t)nblocks * block_nodes < h->K || block_stride_bytes < block_nodes * 25) {
@@ -1087,6 +1131,7 @@ int mvs_deform_set_node_targets_dev(mvs_deform_t h, const void* blocks_dev, int 
     return mvs_check_hip(hipGetLastError(), "set_node_targets");
 }
 int mvs_deform_solve(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stats* stats) {
+    MVS_TRACE();
     int rc = ready(h, p, false);
     if (rc) return rc;
     if (h->cg_iters > 0) {              // calibrated: stay at most THROTTLE_LAG passes ahead of the device and follow the residual ring
@@ -1101,12 +1146,14 @@ int mvs_deform_solve(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stat
     return harvest(h, *p, cg, stats, nullptr);
 }
 int mvs_deform_collect(mvs_deform_t h, const mvs_deform_params* p, mvs_deform_stats* stats) {
+    MVS_TRACE();
     int rc = ready(h, p, false);
     if (rc) return rc;
     if (h->cg_iters <= 0) { mvs_set_error("nothing enqueued: the first mvs_deform_iterate / _solve of a handle runs synchronously"); return MVS_E_STATE; }
     return harvest(h, *p, probe_cg(h, *p), stats, nullptr);
 }
 int mvs_deform_arap(mvs_deform_t h, const mvs_deform_params* p, const double* ctrl_targets, mvs_deform_stats* stats) {
+    MVS_TRACE();
     int rc = ready(h, p, false);
     if (rc) return rc;
     if (!ctrl_targets) return MVS_E_INVALID_ARG;
@@ -1126,11 +1173,13 @@ int mvs_deform_solver_info(mvs_deform_t h, const mvs_deform_params* p, int32_t* 
     return MVS_OK;
 }
 int mvs_deform_sync(mvs_deform_t h) {
+    MVS_TRACE();
     if (!h) return MVS_E_INVALID_ARG;
     return mvs_check_hip(hipStreamSynchronize(h->stream), "sync");
 }
 void* mvs_deform_stream(mvs_deform_t h) { return h ? (void*)h->stream : nullptr; }
 int mvs_deform_set_stream(mvs_deform_t h, void* hip_stream) {
+    MVS_TRACE();
     if (!h) return MVS_E_INVALID_ARG;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1150,6 +1199,7 @@ int mvs_deform_get_normals(mvs_deform_t h, double* n) { return download(h, n, h 
 int mvs_deform_get_rotations(mvs_deform_t h, double* R) { return download(h, R, h ? h->d_rot : nullptr, h ? sizeof(double) * h->V * 9 : 0); }
 int mvs_deform_get_node_targets(mvs_deform_t h, int smoothed, double* controls, uint8_t* valid, float* d2min, int32_t* counts,
                                 int64_t* top_idx) {
+    MVS_TRACE();
     if (!h || !controls) return MVS_E_INVALID_ARG;
     const size_t K = (size_t)h->K;
     int rc = download(h, controls, smoothed ? h->d_ctrl_final : h->d_ctrl_raw, sizeof(double) * K * 3);
@@ -1160,11 +1210,13 @@ int mvs_deform_get_node_targets(mvs_deform_t h, int smoothed, double* controls, 
     return rc;
 }
 int mvs_deform_get_node_graph(mvs_deform_t h, int32_t* nbr) {
+    MVS_TRACE();
     if (!h || !nbr) return MVS_E_INVALID_ARG;
     if (!h->d_nbr || h->nbr_k == 0) { mvs_set_error("node graph not built yet"); return MVS_E_STATE; }
     return download(h, nbr, h->d_nbr, sizeof(int32_t) * (size_t)h->K * h->nbr_k);
 }
 int mvs_deform_compute_normals(mvs_deform_t h, double* normals) {
+    MVS_TRACE();
     if (!h || !normals) return MVS_E_INVALID_ARG;
     HIPCHK(hipSetDevice(h->device));
     double* d = nullptr;
@@ -1177,6 +1229,7 @@ int mvs_deform_compute_normals(mvs_deform_t h, double* normals) {
 }
 
 int mvs_knn_points(const double* pts, int64_t n, int k, int32_t* out_idx) {
+    MVS_TRACE();
     if (!pts || !out_idx || n <= 0 || k < 1 || k > 64 || n > 0x7ffffff0LL) { mvs_set_error("bad arguments (k 1..64)"); return MVS_E_INVALID_ARG; }
     int rc = need_device();
     if (rc) return rc;

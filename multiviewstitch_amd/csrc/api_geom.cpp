@@ -2,6 +2,7 @@
 // mvs_depth_*, mvs_srt_*).  Drop-in for SRTSolver (R/Solver/SRTSolver.h:8-39), the
 // Depth2Model / Image3D back-projection and the SRT glue of Processor.
 #include "engine.h"
+#include "trace.h"
 #include "geom.h"
 #include <cmath>
 #include <cstring>
@@ -37,6 +38,7 @@ extern "C" {
 int mvs_depth_to_model_dev(const float* inv_depth_dev, const mvs_camera* cam, double min_dsp, double max_dsp,
                            double smooth, int64_t* n_points, int64_t* n_faces, double* out_points_dev,
                            double* out_normals_dev, int32_t* out_tex_index_dev, int32_t* out_faces_dev) {
+    MVS_TRACE();
     if (!inv_depth_dev || !cam_ok(cam) || !n_points || !n_faces) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     int rc = need_device();
     if (rc) return rc;
@@ -47,6 +49,7 @@ int mvs_depth_to_model_dev(const float* inv_depth_dev, const mvs_camera* cam, do
 int mvs_depth_to_model(const float* inv_depth, const mvs_camera* cam, double min_dsp, double max_dsp, double smooth,
                        int64_t* n_points, int64_t* n_faces, double* out_points, double* out_normals,
                        int32_t* out_tex_index, int32_t* out_faces) {
+    MVS_TRACE();
     if (!inv_depth || !cam_ok(cam) || !n_points || !n_faces) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     int rc = need_device();
     if (rc) return rc;
@@ -75,6 +78,7 @@ int mvs_depth_to_model(const float* inv_depth, const mvs_camera* cam, double min
 
 int mvs_depth_unproject(const float* inv_depth, const mvs_camera* cam, double min_dsp, double max_dsp,
                         double* out_points, uint8_t* out_valid) {
+    MVS_TRACE();
     if (!inv_depth || !cam_ok(cam) || !out_points || !out_valid) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     int rc = need_device();
     if (rc) return rc;
@@ -109,6 +113,7 @@ int mvs_srt_make_triples(int64_t n, int iters, uint32_t* state, int32_t* triples
 
 int mvs_srt_fit(const double* matches, int64_t n, const mvs_camera* cam1, const mvs_camera* cam2, int mode,
                 const int32_t* triples, int iters, uint32_t seed, double* scale, double* R, double* t, double* residual) {
+    MVS_TRACE();
     if (!matches || !scale || !R || !t || (mode != MVS_SRT_CLOSED_FORM && mode != MVS_SRT_RANSAC)) {
         mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG;
     }
@@ -148,6 +153,7 @@ int mvs_srt_fit(const double* matches, int64_t n, const mvs_camera* cam1, const 
 
 int mvs_srt_residual(const double* matches, int64_t n, const mvs_camera* cam1, const mvs_camera* cam2, double scale,
                      const double* R, const double* t, double* mean_err, double* per_match) {
+    MVS_TRACE();
     if (!matches || !cam1 || !cam2 || !R || !t || n < 1 || (!mean_err && !per_match)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     int rc = need_device();
     if (rc) return rc;
@@ -173,6 +179,7 @@ int mvs_srt_residual(const double* matches, int64_t n, const mvs_camera* cam1, c
 int mvs_srt_remove_outliers(const double* matches, int64_t n, const mvs_camera* cam1, const mvs_camera* cam2, int iters,
                             double pixel_err, double adapt_ratio, uint32_t* rand_state, uint8_t* keep, int64_t* n_keep,
                             double* err_out) {
+    MVS_TRACE();
     // Processor::RemoveOutliers, R/Processor/Processor.cpp:193-259.  The RANSAC fits and the
     // per-match pixel errors run on the GPU; the (tiny) list compaction stays on the host.
     if (!matches || !cam1 || !cam2 || !rand_state || !keep || !n_keep || !err_out || n < 0 || iters < 1) {
@@ -227,6 +234,7 @@ int mvs_select_keyframe_pair(int32_t n1, int32_t n2, const mvs_camera* cams1, co
                              const double* matches, int32_t min_match_count, int iters, double pixel_err, double adapt_ratio,
                              uint32_t* rand_state, int32_t* frm_idx1, int32_t* frm_idx2, double* err_out, uint8_t* keep,
                              int64_t* n_keep, double* pair_err) {
+    MVS_TRACE();
     if (n1 < 1 || n2 < 1 || !cams1 || !cams2 || !match_offsets || !rand_state || !frm_idx1 || !frm_idx2 || !err_out || iters < 1 ||
         (int64_t)n1 * n2 > 1000000) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     const int np = n1 * n2;
@@ -388,6 +396,7 @@ int mvs_srt_relative(double s_k0, const double* R_k0, const double* t_k0, double
 
 int mvs_srt_apply_dev(const double* pts_dev, const double* normals_dev, int64_t P, double s, const double* R,
                       const double* t, int inverse, double* out_pts_dev, double* out_normals_dev, void* hip_stream) {
+    MVS_TRACE();
     if (P < 0 || (P > 0 && (!pts_dev || !out_pts_dev)) || !R || !t || (normals_dev && !out_normals_dev)) {
         mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG;
     }
@@ -399,6 +408,7 @@ int mvs_srt_apply_dev(const double* pts_dev, const double* normals_dev, int64_t 
 
 int mvs_srt_apply(const double* pts, const double* normals, int64_t P, double s, const double* R, const double* t,
                   int inverse, double* out_pts, double* out_normals) {
+    MVS_TRACE();
     if (P < 0 || (P > 0 && (!pts || !out_pts)) || !R || !t || (normals && !out_normals)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     int rc = need_device();
     if (rc) return rc;

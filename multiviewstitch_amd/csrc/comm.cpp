@@ -5,6 +5,7 @@
 // it is the reference's own C++): libmvs_hip.so has no link-time dependency on it and single-GPU hosts never load it.
 // The collectives run on the handle's stream, so they order with the engine kernels without host synchronisation.
 #include "engine.h"
+#include "trace.h"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <cstring>
@@ -73,6 +74,7 @@ struct mvs_comm_s {
 extern "C" {
 
 int mvs_comm_unique_id(uint8_t* id /*MVS_COMM_ID_BYTES*/) {
+    MVS_TRACE();
     if (!id) return MVS_E_INVALID_ARG;
     int rc = load_rccl();
     if (rc) return rc;
@@ -84,6 +86,7 @@ int mvs_comm_unique_id(uint8_t* id /*MVS_COMM_ID_BYTES*/) {
 }
 
 int mvs_comm_init(int rank, int nranks, const uint8_t* id, mvs_comm_t* out) {
+    MVS_TRACE();
     if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     *out = nullptr;
     if (mvs_device_count() == 0) { mvs_set_error("no HIP device: the MI355X engine has no CPU fallback"); return MVS_E_NO_DEVICE; }
@@ -101,6 +104,7 @@ int mvs_comm_init(int rank, int nranks, const uint8_t* id, mvs_comm_t* out) {
 }
 
 int mvs_comm_destroy(mvs_comm_t c) {
+    MVS_TRACE();
     if (!c) return MVS_OK;
     int rc = MVS_OK;
     if (c->comm && g_rccl.CommDestroy) rc = check_nccl(g_rccl.CommDestroy(c->comm), "ncclCommDestroy");
@@ -110,6 +114,7 @@ int mvs_comm_destroy(mvs_comm_t c) {
 }
 
 int mvs_comm_reduce(void* ctx, double* v, int n, int op) {
+    MVS_TRACE();
     mvs_comm_t c = (mvs_comm_t)ctx;
     if (!c || !v || n < 1 || n > 16 || (op != 0 && op != 1)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     if (c->nranks == 1) return MVS_OK;
@@ -149,6 +154,7 @@ int mvs_comm_set_exchange(mvs_comm_t c, int mode) {
 //     (tests/test_gpu_scale.py with one rank through this very code; four emulated shards and world-2 gloo through dist.py).
 // then the replicated solve.  UNVERIFIED ON HARDWARE with more than one rank: this pool gives one GPU per box.
 int mvs_deform_iterate_sharded(mvs_deform_t h, mvs_comm_t c, const mvs_deform_params* p, int n_outer, mvs_deform_stats* stats) {
+    MVS_TRACE();
     if (!h || !c || !p || n_outer < 0) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     int64_t K = 0;
     int rc = mvs_deform_sizes(h, nullptr, nullptr, &K, nullptr);

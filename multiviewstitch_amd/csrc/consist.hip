@@ -7,6 +7,7 @@
 // INTEGER pixels; otherwise it becomes 0.  Traffic: 4 B read + 4 B written per pixel and one 4-byte gather per
 // reference (neighbouring pixels land on neighbouring reference pixels, so the gathers coalesce): HBM-bound.
 #include "engine.h"
+#include "trace.h"
 #include "dev_common.h"
 #include "geom.h"
 #include "camera_dev.h"
@@ -100,6 +101,7 @@ extern "C" {
 
 int mvs_check_consistency_seq_dev(int32_t n_frames, const float* depths_dev, const mvs_camera* cams, double min_dsp, double max_dsp,
                                   int32_t reproj_err, float* out_dev, void* hip_stream) {
+    MVS_TRACE();
     if (n_frames <= 0 || !depths_dev || !cams || !out_dev || depths_dev == out_dev) { mvs_set_error("mvs_check_consistency_seq: bad arguments"); return MVS_E_INVALID_ARG; }
     for (int f = 0; f < n_frames; ++f)
         if (!cam_fine(cams + f) || cams[f].w != cams[0].w || cams[f].h != cams[0].h) {
@@ -122,6 +124,7 @@ int mvs_check_consistency_seq_dev(int32_t n_frames, const float* depths_dev, con
 
 int mvs_check_consistency_seq(int32_t n_frames, const float* depths, const mvs_camera* cams, double min_dsp, double max_dsp,
                               int32_t reproj_err, float* out) {
+    MVS_TRACE();
     if (n_frames <= 0 || !depths || !cams || !out || !cam_fine(cams)) { mvs_set_error("mvs_check_consistency_seq: bad arguments"); return MVS_E_INVALID_ARG; }
     int rc = have_device();
     if (rc) return rc;
@@ -136,6 +139,7 @@ int mvs_check_consistency_seq(int32_t n_frames, const float* depths, const mvs_c
 
 int mvs_check_consistency(const float* depth, const mvs_camera* cur, int32_t n_ref, const float* const* ref_depths,
                           const mvs_camera* ref_cams, double min_dsp, double max_dsp, int32_t reproj_err, float* out) {
+    MVS_TRACE();
     if (!depth || !cam_fine(cur) || n_ref < 0 || n_ref > MAXREF || (n_ref && (!ref_depths || !ref_cams)) || !out) {
         mvs_set_error("mvs_check_consistency: bad arguments (at most %d reference frames)", MAXREF); return MVS_E_INVALID_ARG;
     }

@@ -10,6 +10,7 @@
 
 #include "../../include/mvs_io.h"
 #include "engine.h"
+#include "trace.h"
 
 namespace {
 
@@ -86,6 +87,7 @@ extern "C" {
 
 int mvs_obj_read(const char* path, int64_t* n_vertices, int64_t* n_normals, int64_t* n_faces, double* points, double* normals,
                  int32_t* faces) {
+    MVS_TRACE();
     if (!path || !n_vertices || !n_normals || !n_faces) { mvs_set_error("mvs_obj_read: null argument"); return MVS_E_INVALID_ARG; }
     errno = 0;
     std::string text;
@@ -134,6 +136,7 @@ int mvs_obj_read(const char* path, int64_t* n_vertices, int64_t* n_normals, int6
 
 int mvs_obj_write(const char* path, int64_t n_vertices, const double* points, const double* normals, int64_t n_faces,
                   const int32_t* faces) {
+    MVS_TRACE();
     if (!path || n_vertices < 0 || n_faces < 0 || (n_vertices && !points) || (n_faces && !faces)) {
         mvs_set_error("mvs_obj_write: bad arguments"); return MVS_E_INVALID_ARG;
     }
@@ -168,6 +171,7 @@ int mvs_obj_write(const char* path, int64_t n_vertices, const double* points, co
 }
 
 int mvs_npts_read(const char* path, int64_t* n, double* points, double* normals) {
+    MVS_TRACE();
     if (!path || !n) { mvs_set_error("mvs_npts_read: null argument"); return MVS_E_INVALID_ARG; }
     errno = 0;
     std::string text;
@@ -189,6 +193,7 @@ int mvs_npts_read(const char* path, int64_t* n, double* points, double* normals)
 }
 
 int mvs_npts_write(const char* path, int64_t n, const double* points, const double* normals) {
+    MVS_TRACE();
     if (!path || n < 0 || (n && (!points || !normals))) { mvs_set_error("mvs_npts_write: bad arguments"); return MVS_E_INVALID_ARG; }
     std::string o;
     o.reserve((size_t)n * 72);
@@ -202,6 +207,7 @@ int mvs_npts_write(const char* path, int64_t n, const double* points, const doub
 }
 
 int mvs_srt_txt_read(const char* path, int64_t n_seq, double* scales, double* R, double* t) {
+    MVS_TRACE();
     if (!path || n_seq < 0 || (n_seq && (!scales || !R || !t))) { mvs_set_error("mvs_srt_txt_read: bad arguments"); return MVS_E_INVALID_ARG; }
     errno = 0;
     std::string text;
@@ -217,6 +223,7 @@ int mvs_srt_txt_read(const char* path, int64_t n_seq, double* scales, double* R,
 }
 
 int mvs_srt_txt_write(const char* path, int64_t n_seq, const double* scales, const double* R, const double* t) {
+    MVS_TRACE();
     if (!path || n_seq < 0 || (n_seq && (!scales || !R || !t))) { mvs_set_error("mvs_srt_txt_write: bad arguments"); return MVS_E_INVALID_ARG; }
     std::string o;
     for (int64_t k = 0; k < n_seq; ++k) {
@@ -230,6 +237,7 @@ int mvs_srt_txt_write(const char* path, int64_t n_seq, const double* scales, con
 }
 
 int mvs_depth_raw_read(const char* path, int32_t w, int32_t h, float* raster) {
+    MVS_TRACE();
     if (!path || w <= 0 || h <= 0 || !raster) { mvs_set_error("mvs_depth_raw_read: bad arguments"); return MVS_E_INVALID_ARG; }
     errno = 0;
     File fp(path, "rb");
@@ -240,6 +248,7 @@ int mvs_depth_raw_read(const char* path, int32_t w, int32_t h, float* raster) {
 }
 
 int mvs_depth_raw_write(const char* path, int64_t n, const double* raster) {
+    MVS_TRACE();
     if (!path || n < 0 || (n && !raster)) { mvs_set_error("mvs_depth_raw_write: bad arguments"); return MVS_E_INVALID_ARG; }
     std::vector<float> f((size_t)n);
     for (int64_t i = 0; i < n; ++i) f[i] = (float)raster[i];
@@ -250,6 +259,7 @@ int mvs_depth_raw_write(const char* path, int64_t n, const double* raster) {
 }
 
 int mvs_parts_read(const char* path, int64_t n_vertices, int32_t* labels) {
+    MVS_TRACE();
     if (!path || n_vertices < 0 || (n_vertices && !labels)) { mvs_set_error("mvs_parts_read: bad arguments"); return MVS_E_INVALID_ARG; }
     errno = 0;
     std::string text;
@@ -284,6 +294,7 @@ int mvs_parts_read(const char* path, int64_t n_vertices, int32_t* labels) {
 
 int mvs_processor_deform(const char* model_obj, const char* template_obj, const char* parts_path, const double cam_R[9],
                          double dist_thres, const mvs_deform_params* params, const char* out_obj, mvs_deform_stats* stats) {
+    MVS_TRACE();
     if (!model_obj || !template_obj || !parts_path || !cam_R || !out_obj) { mvs_set_error("mvs_processor_deform: null argument"); return MVS_E_INVALID_ARG; }
     int rc;
     int64_t nt, ntn, ntf, ns, nsn, nsf;

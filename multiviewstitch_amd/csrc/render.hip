@@ -15,6 +15,7 @@
 // eye plane are dropped.  Parity with a particular GL driver is therefore unpinned by construction; parity with the
 // oracle is bit-exact.
 #include "engine.h"
+#include "trace.h"
 #include "dev_common.h"
 #include "geom.h"
 #include <algorithm>
@@ -132,6 +133,7 @@ extern "C" {
 
 int mvs_render_depth_dev(const double* pts_dev, int64_t V, const int32_t* faces_dev, int64_t F, const mvs_camera* cam, float znear,
                          float zfar, float* out_dev, void* hip_stream) {
+    MVS_TRACE();
     if (!pts_dev || V <= 0 || F < 0 || (F && !faces_dev) || !cam || cam->w <= 0 || cam->h <= 0 || !(znear > 0) || !(zfar > znear) ||
         !out_dev || cam->cx == 0.0 || cam->cy == 0.0) { mvs_set_error("mvs_render_depth: bad arguments"); return MVS_E_INVALID_ARG; }
     int n = 0;
@@ -153,6 +155,7 @@ int mvs_render_depth_dev(const double* pts_dev, int64_t V, const int32_t* faces_
 
 int mvs_render_depth(const double* pts, int64_t V, const int32_t* faces, int64_t F, const mvs_camera* cam, float znear, float zfar,
                      float* out) {
+    MVS_TRACE();
     if (!pts || V <= 0 || F < 0 || (F && !faces) || !cam || !out) { mvs_set_error("mvs_render_depth: bad arguments"); return MVS_E_INVALID_ARG; }
     for (int64_t k = 0; k < 3 * F; ++k)
         if (faces[k] < 0 || faces[k] >= V) { mvs_set_error("mvs_render_depth: facet index out of range"); return MVS_E_BAD_MESH; }

@@ -96,3 +96,29 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not pat.search(src), f"{f} references the oracle"
+
+
+def test_trace_callback_sees_every_entry():
+    """mvs_set_trace (SURVEY §8b "optional callback for tracing"): entered / left with the entry's name and its host time —
+    also when the entry fails (here, without a GPU, with MVS_E_NO_DEVICE)."""
+    import ctypes as C
+    from multiviewstitch_amd import _lib, srt
+    seen = []
+    CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_int, C.c_double)
+    cb = CB(lambda ctx, name, phase, ms: seen.append((name.decode(), phase, ms)))
+    L = _lib.lib()
+    assert L.mvs_set_trace(C.cast(cb, C.c_void_p), None) == 0
+    try:
+        try:
+            srt.apply(np.zeros((4, 3)), None, 1.0, np.eye(3), np.zeros(3))
+        except _lib.MvsError:
+            pass
+    finally:
+        assert L.mvs_set_trace(None, None) == 0
+    assert [(n, p) for n, p, _ in seen] == [("mvs_srt_apply", 0), ("mvs_srt_apply", 1)] and seen[1][2] >= 0.0
+    n = len(seen)
+    try:
+        srt.apply(np.zeros((4, 3)), None, 1.0, np.eye(3), np.zeros(3))
+    except _lib.MvsError:
+        pass
+    assert len(seen) == n                                   # switched off
