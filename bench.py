@@ -46,6 +46,8 @@ def parse_args(argv=None):
     ap.add_argument("--config", type=int, default=3, help="scene config (multiviewstitch_amd/scene.py); 3 = metric workload")
     ap.add_argument("--phases", action="store_true", help="extra instrumented pass: per-phase HIP-event times to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-solver", action="store_true", help="skip the comparison run with the one-kernel-per-iteration CG (profiles of the default solver alone)")
+    ap.add_argument("--only-alt-solver", action="store_true", help="time the CG solver as the main run (profiles of the CG path alone)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "all_gather", "owner"],
                     help="N > 1: how the ranks' best-8 records meet (auto: owner-merges from 4 ranks on, DESIGN.md §6)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
@@ -196,6 +198,9 @@ def main():
     sc = scene_mod.make_scene(args.config, device=device, views=set(my_views))
     log(f"[bench r{rank}] scene config {args.config}: V={len(sc.verts)} F={len(sc.faces)} views={my_views} ({time.time()-t0:.1f}s)")
     d = deformation.Deformation(sc.verts, sc.normals, sc.faces, device=dev_id)
+    if args.only_alt_solver:
+        d.params.solver = 1
+        args.no_alt_solver = True
     t1 = time.time()
     K = d.UniformSampling(16)
     tp, tn = build_target(torch, srt_mod, scene_mod, sc, my_views, device)
@@ -296,8 +301,8 @@ def main():
         log(f"[bench r{rank}] warmup done: solver iterations={st['cg_iters']} arap_iters_run={st['arap_iters_run']} "
             f"n_valid={st['n_valid']} worst rel residual of the warm-up batch={st['worst_rel_residual_in_batch']:.2e}")
     worst.update(rel=0.0, missed=0, solves=0, status=0)
-    d.enable_timing(3)                      # HIP events around the global-solve launch groups of every 4th pass (+1 % on the step;
-    fence()                                 # around every solve they cost 5 %: scripts/timing_overhead.py)
+    d.enable_timing(3)                      # HIP events around the planned sweeps of the solves of every 8th pass (around every
+    fence()                                 # solve they cost 5 % of the step: scripts/timing_overhead.py)
     tb = time.perf_counter()
     st = run(args.steps)
     fence()
@@ -309,6 +314,13 @@ def main():
         elapsed = float(tmax.item())
     cg_ms, cg_launches = d.kernel_time("cg")
     d.enable_timing(0)
+    tail_ms, tail_launches = 0.0, 0
+    if world == 1:                          # the last launch of every solve (decides; ARAP local step): events in a pass of its own, outside the timed region
+        d.enable_timing(2)
+        run(4)
+        fence()
+        tail_ms, tail_launches = d.kernel_time("tail")
+        d.enable_timing(0)
     timed = dict(worst)
     log(f"[bench r{rank}] timed batch: worst true relative residual {timed['rel']:.2e} over {timed['solves']} solves, "
         f"{timed['missed']} above cg_tol, status {timed['status']}")
@@ -353,15 +365,23 @@ def main():
         # launches that found all three right-hand sides converged degenerate into a copy of the owned rows (patch
         # sweeps) or exit after the scalar preamble (CG): only the active ones count as algorithmic traffic (stats of
         # the last step; every step launches the same plan)
-        active_frac = st["cg_active"] / max(1, st["cg_launches"])
+        # the "cg" timer brackets the planned sweeps of a solve WITHOUT its last launch (patch solver: that one decides, and in fused
+        # mode performs the ARAP local step — timed as "tail"); in the steady state every active sweep is one of the former
+        n_last = st["arap_iters_run"] if info["kind"] == "patch" else 0
+        active_frac = min(1.0, st["cg_active"] / max(1, st["cg_launches"] - n_last))
         avg_s = 1e-3 * cg_ms / cg_launches
         ach = active_frac * solve_bytes / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "frac": round(ach / 8000.0, 4),
+                    "frac_active": round(solve_bytes / avg_s / 1e9 / 8000.0, 4) if active_frac > 0 else None,
+                    "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": solve_bytes,
                     "avg_launch_us": round(1e6 * avg_s, 3), "launches": int(cg_launches), "active_fraction": round(active_frac, 3),
-                    "launches_per_step": int(st["cg_launches"]), "timed_sample": "the solver launches of every 4th outer iteration of the timed region",
-                    "share_of_step": round(1e3 * avg_s * st["cg_launches"] / ms_per_step, 3)}
+                    "launches_per_step": int(st["cg_launches"]), "timed_sample": "the planned sweep launches of every 8th outer iteration of the timed region",
+                    "share_of_step": round(1e3 * (avg_s * (st["cg_launches"] - n_last) + (1e-3 * tail_ms / tail_launches * n_last if tail_launches else 0.0)) / ms_per_step, 3)}
+        if tail_launches:
+            roofline["last_launch_of_a_solve"] = {"kernel": "k_ras_sweep<W, 2> (decides the solve; ARAP local step on the owned rows)",
+                                                  "avg_launch_us": round(1e3 * tail_ms / tail_launches, 3), "per_step": int(n_last)}
         if info["kind"] == "patch":
             roofline["note"] = ("LDS-resident local iterations: the launch is bound by its dependent load chain and workgroup "
                                 "barriers, not by HBM bytes; local Chebyshev steps per active launch = "
@@ -441,7 +461,7 @@ def main():
             roofline["copy_ceiling_GBps"] = round(copy_gbps, 1)
             roofline["frac_of_copy_ceiling"] = round(roofline["achieved"] / copy_gbps, 4)
         run(1)                                # launch plan back on the 5-iteration schedule
-        if info["kind"] == "patch":
+        if info["kind"] == "patch" and not args.no_alt_solver:
             # the same step with the one-kernel-per-iteration CG (params.solver = MVS_SOLVER_CG), for comparison: its
             # kernel moves more bytes per second, the step takes twice as long
             d.params.solver = 1
@@ -475,7 +495,7 @@ def main():
         fence()
         collectives = {"backend": args.backend, "steps": min(args.steps, 10)}
         # what sharding buys: every rank's association time (its own views only) next to its replicated solve
-        mine = torch.tensor([d.kernel_time("assoc")[0], d.kernel_time("cg")[0] + d.kernel_time("rhs")[0] + d.kernel_time("local")[0]],
+        mine = torch.tensor([d.kernel_time("assoc")[0], d.kernel_time("cg")[0] + d.kernel_time("tail")[0] + d.kernel_time("rhs")[0] + d.kernel_time("local")[0]],
                             dtype=torch.float64, device=device) / min(args.steps, 10)
         every = torch.zeros(2 * world, dtype=torch.float64, device=device)
         dist.all_gather_into_tensor(every, mine)
@@ -500,7 +520,7 @@ def main():
         run(args.steps)
         fence()
         tot = 0.0
-        for name in ("assoc", "graph", "smooth", "weights", "rhs", "cg", "local", "finalize"):
+        for name in ("assoc", "graph", "smooth", "weights", "rhs", "cg", "tail", "local", "finalize"):
             ms, n = d.kernel_time(name)
             tot += ms
             log(f"[phases r{rank}] {name:9s} {ms/args.steps:9.4f} ms/step  {n/args.steps:7.1f} launches/step")
