@@ -385,6 +385,27 @@ def test_an_abandoned_tail_loop_is_unanimous_and_reported(eng):
     assert seen_warning, "a one-poll wait never expired: the abandoned path was not exercised"
 
 
+def test_node_graph_matches_oracle(eng, oracle):
+    """KNearestNeighbor(8) (Deformation.cpp:108-153): the 9-NN graph of the nodes (self included), found in the association
+    launch by a wave per query on the grid of the node positions (knn_dev.h) — exact, ties to the lower index."""
+    sc, tp, tn, _ = scene_and_target(2)
+    d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    K = d.UniformSampling(16)
+    assert K >= 1024                                        # (below that the graph is a brute-force launch)
+    nodes = d.nodes()
+    d.set_target(tp, tn)
+    d.iterate(1)
+    assert np.array_equal(d.node_graph(), oracle.knn_points(sc.verts[nodes], 9))
+    before = d.vertices()[nodes]                            # the second pass searches the moved nodes
+    d.iterate(1)
+    assert np.array_equal(d.node_graph(), oracle.knn_points(before, 9))
+    for gk in (3, 15):                                      # other list lengths
+        d.params.graph_k = gk
+        before = d.vertices()[nodes]
+        d.iterate(1)
+        assert np.array_equal(d.node_graph(), oracle.knn_points(before, gk + 1))
+
+
 def test_a_handle_is_reused_for_the_next_fit(eng):
     """mvs_deform_set_vertices: the template's rest pose again (same topology) — the second fit on the handle gives what a fresh
     handle gives (both solves end within cg_tol of the same systems: 1e-7 on the vertices, the same valid nodes), against
