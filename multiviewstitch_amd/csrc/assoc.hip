@@ -21,6 +21,7 @@
 // round-robin, the 16 top-k lists merged in LDS).  A single-rank run fuses dmin + select into k_assoc_local.
 #include "engine.h"
 #include "knobs.h"
+#include <vector>
 #include "dev_common.h"
 #include "grid_dev.h"
 #include "knn_dev.h"
@@ -30,6 +31,7 @@
 namespace {
 
 #ifdef MVS_STAMPS
+__device__ unsigned long long g_wave_stamps[8 * 20000];       // k_assoc_local: start / end of every one-wave workgroup
 __device__ unsigned long long g_assoc_cycles[2 * 16384];      // per node: cycles of k_assoc_dmin, k_assoc_select
 __device__ unsigned long long g_dmin_shell[16384 * 8];          // per node: cycles at the end of coarse shells 0..5, cycles at the start of the coarse walk
 #define ASTAMP_BEGIN unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory")
@@ -831,6 +833,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                                                      int32_t* __restrict__ counts, int32_t* __restrict__ heavy, int heavy_cap, LocalMerge lm,
                                                      int32_t* __restrict__ heavy_next, int assoc_blocks, int nn, const NgGeom* __restrict__ geo,
                                                      const int* __restrict__ ng_cs, const float4* __restrict__ ng_sorted, int32_t* __restrict__ nbr) {
+#ifdef MVS_STAMPS
+    unsigned long long tw0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tw0_) :: "memory");
+    struct WaveStamp { unsigned long long t0; int b; __device__ ~WaveStamp() { unsigned long long t1_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory");
+                                                                                 /* one 64-byte line per workgroup (entries of several XCDs on one line overwrite each other at write-back); the XCD's id travels along: every XCD has its own clock */
+                                                                                 unsigned xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+                                                                                 if ((threadIdx.x & 63) == 0 && b < 20000) { g_wave_stamps[8 * b] = t0; g_wave_stamps[8 * b + 1] = t1_; g_wave_stamps[8 * b + 2] = xcc_ & 0xf; unsigned hw_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); g_wave_stamps[8 * b + 3] = hw_; } } } ws_{tw0_, (int)blockIdx.x};
+#endif
     if (blockIdx.x == 0 && threadIdx.x == 0) heavy_next[0] = 0;       // the list of the NEXT outer iteration (they alternate): no memset launch
     if ((int)blockIdx.x >= assoc_blocks) {
         // passengers: the 9-NN graph queries of the nodes (a wave each, like the nodes' own searches; the grid of the node
@@ -1015,6 +1024,13 @@ __global__ __launch_bounds__(256) void k_assoc_merge(const double* __restrict__ 
 #ifdef MVS_STAMPS
 extern "C" int mvs_debug_dmin_shells(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dmin_shell), sizeof(unsigned long long) * n);
+}
+extern "C" int mvs_debug_wave_stamps_clear() {
+    static std::vector<unsigned long long> z(8 * 20000, 0ull);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_stamps), z.data(), sizeof(unsigned long long) * z.size());
+}
+extern "C" int mvs_debug_wave_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_stamps), sizeof(unsigned long long) * n);
 }
 extern "C" int mvs_debug_assoc_cycles(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_assoc_cycles), sizeof(unsigned long long) * n);
