@@ -42,6 +42,15 @@ def _meshes(oracle):
     pts, nrm, _, faces = oracle.depth_to_model(sc2.depth[0], sc2.cams[0], S.MIN_DSP, S.MAX_DSP, 1.0)
     pts, nrm, faces = oracle.retain_connect_region(pts, nrm, faces)
     yield "open depth-map mesh, degree 3..8", pts, nrm, faces
+    # a fan: one hub of degree 200 (25 passes of its ELL-8 row group), boundary everywhere; below 2048 vertices: no patches
+    n = 200
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    fan = np.concatenate([[[0.0, 0.0, 0.1]], np.stack([np.cos(ang), np.sin(ang), np.zeros(n)], 1)])
+    ff = np.array([[0, 1 + k, 1 + (k + 1) % n] for k in range(n)], np.int32)
+    yield "fan, hub of degree 200", fan, np.tile([0.0, 0.0, 1.0], (n + 1, 1)), ff
+    # the smallest closed mesh
+    tet = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], float)
+    yield "tetrahedron", tet, tet / np.maximum(np.linalg.norm(tet, axis=1, keepdims=True), 1), np.array([[0, 2, 1], [0, 1, 3], [0, 3, 2], [1, 2, 3]], np.int32)
 
 
 def test_device_built_tables_match_a_numpy_rebuild(oracle):
@@ -63,7 +72,7 @@ def test_device_built_tables_match_a_numpy_rebuild(oracle):
         assert bool(single) == bool(deg.max() <= 8)
         for i in range(0, V, max(1, V // 4000)):                       # a few thousand rows, spread over the mesh
             g, r = divmod(i, 8)
-            passes = (so[g + 1] - so[g]) // 64
+            passes = int(so[g + 1] - so[g]) // 64
             for k in range(passes * 8):
                 e = so[g] + (8 * (k // 8) + r) * 8 + k % 8
                 if k < deg[i]:
@@ -76,7 +85,11 @@ def test_device_built_tables_match_a_numpy_rebuild(oracle):
         assert vfp[0] == 0 and vfp[-1] == 3 * len(faces)
         for i in range(0, V, max(1, V // 4000)):
             assert list(vf[vfp[i]:vfp[i + 1]]) == sorted(vf_ref[i]), (name, i)
-        # ---- patches
+        # ---- patches (meshes of 2048 vertices and more, degree <= 16)
+        if V < 2048:
+            assert has == 0, name
+            d.close()
+            continue
         assert has == 1, name
         pnloc, pown, pnh = (_table(d, k, np.int32) for k in (7, 8, 9))
         l2g, hl2g = _table(d, 10, np.int32).reshape(NP, LS), _table(d, 11, np.int32).reshape(NP, LS)
