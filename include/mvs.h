@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MVS_ABI_VERSION 2
+#define MVS_ABI_VERSION 3   /* 3: tracing hook, mvs_comm_set_exchange, view-sharded RemoveGround / LocalAlignmentCore (additive) */
 
 enum mvs_status {
     MVS_OK            =  0,
