@@ -127,3 +127,45 @@ def test_enqueued_parts_give_the_bits_of_the_synchronous_path():
     assert np.array_equal(runs[0][0], runs[1][0])
     for a, b in zip(runs[0][1], runs[1][1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_abandoned_tail_loops_of_concurrent_parts_are_reported():
+    """several part handles sweeping at once (config 5's pattern) with every solve capped at ONE launch
+    — all further sweeps run inside it, behind the device-wide barrier — and a barrier wait of one poll.  A tail loop whose
+    wait expires is abandoned for EVERY workgroup of its launch at the same sweep and the part's call reports
+    MVS_W_UNCONVERGED; a part none of whose solves was abandoned has exactly the bits of the undisturbed run."""
+    import ctypes as C
+    from multiviewstitch_amd import _lib as L
+
+    def debug_tail(maxspin, cap):
+        fn = L.lib().mvs_debug_tail
+        fn.restype, fn.argtypes = C.c_int, [C.c_int, C.c_int]
+        L.check(fn(maxspin, cap))
+
+    sc, tp, tn, _ = scene_and_target(2)                          # four parts of ~3.3 K vertices: the patch solver runs
+    labels = PW.sector_labels(sc.verts, 4)
+    tl = PW.sector_labels(tp, 4)
+    runs = []
+    try:
+        for disturbed in (False, True):
+            pd = PW.PartwiseDeformation(sc.verts, sc.normals, sc.faces, labels, 4)
+            pd.UniformSampling(16)
+            pd.set_target(tp, tn, tl)
+            assert all(h.solver_info()["kind"] == "patch" for _, h in pd.live)
+            pd.iterate(1)                                        # calibration, part after part, undisturbed
+            if disturbed:
+                debug_tail(1, 1)
+            stats = pd.iterate(2)                                # all parts enqueued, then collected
+            debug_tail(0, 0)
+            runs.append(([h.vertices() for _, h in pd.live], stats))
+            pd.close()
+    finally:
+        debug_tail(0, 0)
+    assert all(s["status"] == 0 for s in runs[0][1])
+    for v_ref, v, s in zip(runs[0][0], runs[1][0], runs[1][1]):
+        assert s["status"] in (0, 1)
+        if s["status"] == 0:
+            assert np.array_equal(v, v_ref)
+        else:
+            assert s["unconverged_solves"] >= 1
