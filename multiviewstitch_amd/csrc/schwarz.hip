@@ -304,24 +304,10 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
             }
         }
     };
-    if (sweep > 0 && slot_prev[3 * NPpad + 6] != 0.0) {
-        if (p == 0 && row == 0) { slot_cur[3 * NPpad + 6] = 1.0; slot_cur[3 * NPpad + 7] = slot_prev[3 * NPpad + 7]; }
-        if (p == 0 && row < 3) slot_cur[3 * NPpad + 3 + row] = slot_prev[3 * NPpad + 3 + row];      // (the right-hand side's norms: the harvest reads them from a solve's last slot)
-        if (row == 0) iters_cur[p] = 0;
-        if constexpr (MODE == 2) {
-            // the solve ended in an earlier launch (both buffers hold the result everywhere): only the local step is left — unless
-            // the reference's energy stop rule had ended the ARAP iterations before this one
-            if (row == 0) s_done = arap_done_before(ered + EFIN, it, arap_tol) ? 1 : 0;
-            const int nown_ = R.pown[p], g_ = R.l2g[base + row];
-            __syncthreads();
-            if (!s_done) local_step(xa, nown_, g_, false);
-        }
-        return;
-    }
+    // ---- operand loads that need nothing but the patch number, issued IN FRONT of the skip test (its scalar load is a memory
+    //      round trip of its own: behind it, every active sweep paid that trip before its first operand load was even issued; a
+    //      launch that skips leaves these few loads unused): row tables, then — below — this row's x, b, diagonal
     const int nloc = R.pnloc[p], nown = R.pown[p];
-    RSTAMP(0);
-    // ---- operand loads, issued before the convergence scalars are known (a frozen sweep wastes them, a planned one
-    //      overlaps them with the fold of the previous sweep's partials): tables, then this row's x, b, diagonal
     const int g = R.l2g[base + row];                                   // (padding rows: vertex 0, pd = 0 -> inert)
     const int nh = R.pnh[p];
     const int gh = R.hl2g[base + row];                                 // the halo vertex this thread fetches (columns outside the patch);
@@ -336,14 +322,30 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
         for (int e = 0; e < W; ++e) {                  // entry-major inside the patch: consecutive rows, consecutive addresses
             lc[e] = (int)lcol[e * LS + row];
             w2[e] = pwp[e * LS + row];
-            if (lc[e] < 0) { lc[e] = row; w2[e] = 0.0; }              // padding entries
         }
     }
+    const double dd = pd[base + row];
+    const double skip_flag = sweep > 0 ? slot_prev[3 * NPpad + 6] : 0.0;
+    if (skip_flag != 0.0) {
+        if (p == 0 && row == 0) { slot_cur[3 * NPpad + 6] = 1.0; slot_cur[3 * NPpad + 7] = slot_prev[3 * NPpad + 7]; }
+        if (p == 0 && row < 3) slot_cur[3 * NPpad + 3 + row] = slot_prev[3 * NPpad + 3 + row];      // (the right-hand side's norms: the harvest reads them from a solve's last slot)
+        if (row == 0) iters_cur[p] = 0;
+        if constexpr (MODE == 2) {
+            // the solve ended in an earlier launch (both buffers hold the result everywhere): only the local step is left — unless
+            // the reference's energy stop rule had ended the ARAP iterations before this one
+            if (row == 0) s_done = arap_done_before(ered + EFIN, it, arap_tol) ? 1 : 0;
+            __syncthreads();
+            if (!s_done) local_step(xa, nown, g, false);
+        }
+        return;
+    }
+    RSTAMP(0);
+#pragma unroll
+    for (int e = 0; e < W; ++e) if (lc[e] < 0) { lc[e] = row; w2[e] = 0.0; }              // padding entries
     const double* xin = xa;
     double* xout = xb;
     d3 xi = ld3(xin + 3 * (int64_t)g);
     d3 xh = ld3(xin + 3 * (int64_t)gh);                                // frozen at the previous sweep's value for this sweep
-    const double dd = pd[base + row];
     const bool fixed = dd == 0.0;
     const d3 rhs = ld3(bvec + 3 * (int64_t)g);                         // (b is 0 on control rows; padding rows are fixed)
     // MODE 2: the last planned launch of a solve is normally the one that finds it finished — its input is then the result and
