@@ -474,6 +474,10 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
         // missed cg_tol (MVS_CTL_ESC) — the launch plan of a batch is fixed on the host, the strength of the local solves is not.
         const ChebCoef& ck = strong ? cc_strong : cc;
         const int m = strong ? cheb_m_strong : cheb_m;
+        // the step coefficients as floats in the lanes of two registers (lane k: step k), read per step with v_readlane: as
+        // scalar loads from the kernel arguments inside the loop they sat on the same wait counter as the step's LDS gathers
+        // (s_waitcnt lgkmcnt(0) waited for both) and were converted from fp64 every step
+        const float c1v = (float)ck.c1[lane & 31], c2v = (float)ck.c2[lane & 31];
         float ex = 0.f, ey = 0.f, ez = 0.f;
         float rx = (float)r.x, ry = (float)r.y, rz = (float)r.z;
         const float c0f = (float)ck.c0 * inv_d_f;
@@ -499,7 +503,8 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
                 if (fixed) { ax = 0.f; ay = 0.f; az = 0.f; }
                 ex += dx; ey += dy; ez += dz;
                 rx -= ax; ry -= ay; rz -= az;
-                const float c1 = (float)ck.c1[k & 31], c2 = (float)ck.c2[k & 31] * inv_d_f;
+                const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c1v), k & 31));
+                const float c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2v), k & 31)) * inv_d_f;
                 dx = __builtin_fmaf(c1, dx, c2 * rx); dy = __builtin_fmaf(c1, dy, c2 * ry); dz = __builtin_fmaf(c1, dz, c2 * rz);
             }
         }
