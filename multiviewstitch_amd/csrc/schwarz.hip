@@ -50,6 +50,14 @@ __device__ unsigned long long g_tail_stamps[256 * 8];
 #endif
 constexpr int RTPB = 1024;          // threads per workgroup = max local rows of a patch
 
+// two floats -> two bfloat16 in one word (lo in bits 0..15), round to nearest even: v_cvt_pk_bf16_f32 on gfx950
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
 // uniform double from lane `l` of the wave (two v_readlane: no LDS crossbar as __shfl would use)
 __device__ inline double lane_bcast(double v, int l) {
     const long long b = __double_as_longlong(v);
@@ -431,11 +439,12 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
     const double inv_d = 1.0 / di;
     const int nw = (nloc + 63) >> 6;                                   // waves that hold rows
     const float di_f = (float)di, inv_d_f = (float)inv_d;
-    float w2f[W];
+    // (a fixed row — control vertex — has residual 0 and keeps direction 0: with its matrix row zeroed the step needs no select)
+    float w2s[W];
 #pragma unroll
-    for (int q = 0; q < W; ++q) w2f[q] = (float)w2[q];
+    for (int q = 0; q < W; ++q) w2s[q] = fixed ? 0.f : (float)w2[q];
+    const float di_s = fixed ? 0.f : di_f;
     uint2* hb = reinterpret_cast<uint2*>(smem);
-    auto to_bf16 = [](float v) -> unsigned { const unsigned u = __float_as_uint(v); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
     bool strong = s_esc || s_slow[0] == 1 || s_slow[1] == 1 || s_slow[2] == 1;
 
     // One sweep of this patch: xs holds x of the local rows and the halo (fp64); residual of that input on the local rows, its
@@ -488,25 +497,31 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
         // what a NEIGHBOUR contributes to an inexact local solve costs no sweep (own direction, residual and correction stay
         // float32; the residual that decides convergence is fp64).
         if (row < nh) { hb[LS + row] = make_uint2(0u, 0u); hb[RTPB + LS + row] = make_uint2(0u, 0u); }
-        for (int k = 0; k < m; ++k) {
-            uint2* buf = hb + (k & 1) * RTPB;
-            buf[row] = make_uint2(to_bf16(dx) | (to_bf16(dy) << 16), to_bf16(dz));
+        // One step; B = which of the two direction buffers it publishes in (a compile-time constant: the gathers then carry the
+        // buffer as an immediate offset of ds_read_b64 and the row addresses are formed once, not per step).  Word 0 of a row:
+        // bf16(dx) | bf16(dy) << 16, word 1: bf16(dz) << 16 (v_cvt_pk_bf16_f32 rounds to nearest even, as the sum did before).
+        auto step = [&](const int k, auto B) {
+            uint2* buf = hb + decltype(B)::value * RTPB;
+            buf[row] = make_uint2(pk_bf16(dx, dy), pk_bf16(0.f, dz));
             __syncthreads();
             if (wv < nw) {
-                float ax = di_f * dx, ay = di_f * dy, az = di_f * dz;
+                float ax = di_s * dx, ay = di_s * dy, az = di_s * dz;
 #pragma unroll
                 for (int q = 0; q < W; ++q) {
                     const uint2 t = buf[lc[q]];
-                    const float tx = __uint_as_float(t.x << 16), ty = __uint_as_float(t.x & 0xffff0000u), tz = __uint_as_float(t.y << 16);
-                    ax = __builtin_fmaf(-w2f[q], tx, ax); ay = __builtin_fmaf(-w2f[q], ty, ay); az = __builtin_fmaf(-w2f[q], tz, az);
+                    const float tx = __uint_as_float(t.x << 16), ty = __uint_as_float(t.x & 0xffff0000u), tz = __uint_as_float(t.y);
+                    ax = __builtin_fmaf(-w2s[q], tx, ax); ay = __builtin_fmaf(-w2s[q], ty, ay); az = __builtin_fmaf(-w2s[q], tz, az);
                 }
-                if (fixed) { ax = 0.f; ay = 0.f; az = 0.f; }
                 ex += dx; ey += dy; ez += dz;
                 rx -= ax; ry -= ay; rz -= az;
                 const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c1v), k & 31));
                 const float c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2v), k & 31)) * inv_d_f;
                 dx = __builtin_fmaf(c1, dx, c2 * rx); dy = __builtin_fmaf(c1, dy, c2 * ry); dz = __builtin_fmaf(c1, dz, c2 * rz);
             }
+        };
+        for (int k = 0; k < m; k += 2) {
+            step(k, std::integral_constant<int, 0>{});
+            if (k + 1 < m) step(k + 1, std::integral_constant<int, 1>{});
         }
         RSTAMP(4);
         xi = xi + mk3((double)ex, (double)ey, (double)ez);
