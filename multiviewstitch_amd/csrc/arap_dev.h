@@ -97,7 +97,11 @@ __device__ inline double fold_partials(const double* __restrict__ part, int nb) 
     const int lane = threadIdx.x & 63;
     double t[NBMAX / 64];
 #pragma unroll
-    for (int u = 0; u < NBMAX / 64; ++u) { const int k = lane + 64 * u; t[u] = k < nb ? part[k] : 0.0; }
+    for (int u = 0; u < NBMAX / 64; ++u) {     // clamped address + select, not a guarded load: as branches the compiler put the wait
+        const int k = lane + 64 * u;           // for the first load in front of the issue of the others (two memory round trips)
+        const double x = part[k < nb ? k : 0];
+        t[u] = k < nb ? x : 0.0;
+    }
     double v = 0.0;
 #pragma unroll
     for (int u = 0; u < NBMAX / 64; ++u) v += t[u];
@@ -108,7 +112,11 @@ __device__ inline void fold_partials2(const double* __restrict__ pa, const doubl
     const int lane = threadIdx.x & 63;
     double t[NBMAX / 64], u_[NBMAX / 64];
 #pragma unroll
-    for (int u = 0; u < NBMAX / 64; ++u) { const int k = lane + 64 * u; t[u] = k < nb ? pa[k] : 0.0; u_[u] = k < nb ? pb[k] : 0.0; }
+    for (int u = 0; u < NBMAX / 64; ++u) {
+        const int k = lane + 64 * u, kc = k < nb ? k : 0;
+        const double x = pa[kc], y = pb[kc];
+        t[u] = k < nb ? x : 0.0; u_[u] = k < nb ? y : 0.0;
+    }
     double va = 0.0, vb = 0.0;
 #pragma unroll
     for (int u = 0; u < NBMAX / 64; ++u) { va += t[u]; vb += u_[u]; }

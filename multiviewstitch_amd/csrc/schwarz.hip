@@ -99,6 +99,7 @@ __device__ inline double fast_inv(double x) {
 }
 
 // fold n partial sums by one wave, every lane gets the total; loads of a chunk are issued together
+template <bool GUARDED = true>
 __device__ inline double fold_n(const double* __restrict__ part, int n) {
     const int lane = threadIdx.x & 63;
     double v = 0.0;
@@ -107,11 +108,16 @@ __device__ inline double fold_n(const double* __restrict__ part, int n) {
         // chunks of 256 the four round trips ran one after the other, on the critical path of every sweep's preamble (same
         // order of additions as the loop: same bits)
         double t[16];
+        if (GUARDED) {      // MODE 2 (256 registers, all in use): the clamped form below costs it 2 us per launch
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int k = 256 * (u >> 2) + lane + 64 * (u & 3); t[u] = k < n ? part[k] : 0.0; }
+            for (int u = 0; u < 16; ++u) { const int k = 256 * (u >> 2) + lane + 64 * (u & 3); t[u] = k < n ? part[k] : 0.0; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int k = 256 * (u >> 2) + lane + 64 * (u & 3); const double x = part[k < n ? k : 0]; t[u] = k < n ? x : 0.0; }
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) v += (t[4 * c] + t[4 * c + 1]) + (t[4 * c + 2] + t[4 * c + 3]);
-        return wave_total(v);
+        return wave_sum_u(v);      // (the additions of wave_total in the same order, the four row sums combined through scalar registers instead of LDS)
     }
     for (int base = 0; base < n; base += 256) {
         double t[4];
@@ -266,6 +272,7 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
                                                     double* __restrict__ ctl, double* __restrict__ slot_prev,
                                                     double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur, RasTail tail, RasLocal loc) {
     constexpr bool TAIL = MODE >= 1;
+    constexpr bool FOLD_GUARDED = MODE == 2;                           // (fold_n: which form of the partial loads this instantiation affords)
     // LDS: fp64 x of the local rows and the halo while the residual is formed (24 KB), then the correction directions as
     // bfloat16 triples, double-buffered (2 x 8 KB of the same array).  The neighbours' directions only steer the inexact
     // local solve; the residual that decides convergence and the solution stay fp64.
@@ -364,11 +371,12 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
     if constexpr (MODE == 2) { if (row < nown) local_fetch_a(loc.m, loc.pts, xin, loc.bpure, g, Epre); }
     // ---- preamble: waves 0..2 fold the residual partials of the previous sweep, waves 3..5 the bnorm partials of the rhs kernel
     if (wv < 3) {
-        const double gam = sweep > 0 ? fold_n(slot_prev + wv * NPpad, R.NP * 4) : INFINITY;
+        const double gam2_early = sweep > 1 ? (slot_prev - ras_slot_doubles(NPpad))[3 * NPpad + wv] : INFINITY;   // (issued with the fold's loads, not behind its reduction)
+        const double gam = sweep > 0 ? fold_n<FOLD_GUARDED>(slot_prev + wv * NPpad, R.NP * 4) : INFINITY;
         // in-solve adaptation: the sweep before the previous one left the residual of ITS input in its slot (reduced by the
         // previous sweep); when the previous sweep cut the residual by less than SLOW, a mode sits below the bracket of the
         // local solves (the mesh deforms, the weights move) — this sweep then takes the strong coefficient set
-        const double gam2 = sweep > 1 ? (slot_prev - ras_slot_doubles(NPpad))[3 * NPpad + wv] : INFINITY;
+        const double gam2 = gam2_early;
         // s_slow: 1 = the previous sweep converged slowly (strong coefficient set), 2 = its rate is not known yet (sweeps 0, 1)
         if (lane == 0) { s_gam[wv] = gam; s_gam2[wv] = gam2; s_slow[wv] = sweep > 1 ? ((gam > slow2 * gam2) ? 1 : 0) : 2; }
     } else if (wv < 6) {
@@ -379,11 +387,13 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
         if (lane == 0) {
             s_done = done ? 1 : 0;
             s_esc = ctl[MVS_CTL_ESC] != 0.0 ? 1 : 0;                   // a solve missed cg_tol since the last harvest: strong local solves
-            s_psafe = fmax(1.0, ctl[MVS_CTL_PSAFE]);                   // (true / predicted)^2 of the predicted stops so far
+            s_psafe = fmax(1.0, ctl[MVS_CTL_PSAFE]);                   // (true / predicted)^2 of the predicted stops so far                                // (true / predicted)^2 of the predicted stops so far
         }
     }
+    RSTAMP(6);
     xs[row] = make_double4(xi.x, xi.y, xi.z, 0.0);
     if (row < nh) xs[LS + row] = make_double4(xh.x, xh.y, xh.z, 0.0);
+    RSTAMP(7);
     __syncthreads();
     RSTAMP(1);
     const double bn[3] = {s_bn[0], s_bn[1], s_bn[2]};
@@ -546,7 +556,7 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
         if (!tail_barrier(tail.bar, (unsigned)(extra + 1), tail.maxspin)) { abandoned = true; break; }     // not every workgroup came in time: every patch stops HERE
         TSTAMP(1);
         if (wv < 3) {
-            const double gam = fold_n(slot_k + wv * NPpad, R.NP * 4);
+            const double gam = fold_n<FOLD_GUARDED>(slot_k + wv * NPpad, R.NP * 4);
             if (lane == 0) s_gam[wv] = gam;
         }
         __syncthreads();

@@ -29,3 +29,11 @@ for k in range(1, 6):
     v = (t[:, k] - t[:, 0])[t[:, k] > 0]
     if len(v):
         print(f"entry -> {names[k]:22s} min {v.min():7d} p10 {int(np.percentile(v, 10)):7d} p50 {int(np.median(v)):7d} p90 {int(np.percentile(v, 90)):7d} max {v.max():7d} (n={len(v)})")
+
+# per wave index: the wave's own preamble work (stamp 6), its x in LDS (7), the barrier passed (1)
+w = np.arange(len(buf) // 8) % 16
+w = w[buf.reshape(-1, 8)[:, 0] > 0]
+for wi in range(8):
+    m = (w == wi) & (t[:, 6] > 0)
+    if m.any():
+        print(f"wave {wi}: own preamble work {int(np.median(t[m, 6] - t[m, 0])):6d}  x in LDS {int(np.median(t[m, 7] - t[m, 0])):6d}  barrier passed {int(np.median(t[m, 1] - t[m, 0])):6d}")
