@@ -1287,6 +1287,15 @@ int mvs_debug_mesh_table(mvs_deform_t h, int what, void* out, int64_t* bytes) {
     HIPCHK(hipSetDevice(h->device));
     const RasDev& R = h->ras;
     const int64_t rows = h->has_ras ? (int64_t)R.NP * R.LS : 0, ent = rows * R.W, ne = h->n_entries, ns = h->sell.nslices;
+#ifdef MVS_EXPERIMENTS
+    if (what >= 112 && what <= 114) {      // experiments (scripts/slot_assign_ab.py): overwrite an entry table of the patches
+        if (!h->has_ras || !out) return MVS_E_STATE;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        void* dst = what == 112 ? (void*)R.lcol : what == 113 ? (void*)R.gent : (void*)R.gcol;
+        HIPCHK(hipMemcpy(dst, out, (size_t)((what == 112 ? 2 : 4) * ent), hipMemcpyHostToDevice));
+        return MVS_OK;
+    }
+#endif
     const void* src = nullptr;
     int64_t n = 0;
     int64_t dims[8] = {h->has_ras ? R.NP : 0, h->has_ras ? R.LS : 0, h->has_ras ? R.W : 0, ns, ne, h->sell.single_pass, h->has_ras ? 1 : 0, h->ras_rows};
