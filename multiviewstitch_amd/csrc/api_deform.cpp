@@ -237,6 +237,12 @@ struct RasPlan {                     // sweeps per ARAP iteration of the patch s
 // host look at the residual after each (five synchronisations per solve, 8 ms for the first outer iteration)
 constexpr int RAS_FIRST_PLAN = 8;
 constexpr int RAS_MAX_SWEEPS = 128;
+// A solve whose plan has grown to this many launches has stalled sweeps behind it (healthy solves take 3-5 sweeps): its planned
+// sweeps are launched as the mixing instantiation (schwarz.hip, RasMix).  A function of the plan, i.e. of the call sequence.
+// Sticky: a mixing solve needs 7-9 launches, the same solve without mixing 17-36 — the switch goes on at RAS_MIX_PLAN and off only
+// when the plan is back at a healthy solve's length.
+#define RAS_MIX_PLAN ((int)MVS_KNOB("MVS_MIX_PLAN", 9, 2, 128))
+constexpr int RAS_MIX_OFF = 5;
 
 int g_dbg_plan_cap = 0;              // tests (mvs_debug_tail): at most this many launches per solve, the rest of its sweeps run in the last one
 RasPlan probe_ras(const mvs_deform_s* h) {
@@ -384,6 +390,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     const int demand_local = (fused && !safe_local) ? 1 : 0;          // the judge of a solve insists that its fused local step ran
     const double* prev_scal = nullptr;   // the 8 scalars of the last sweep slot of the previous solve (idle flag, sweeps that ran)
     for (int it = 0; ras && it < p.arap_iters; ++it) {
+        if (rp.n[it] >= RAS_MIX_PLAN) h->ras_mix_on[it] = 1; else if (rp.n[it] <= RAS_MIX_OFF) h->ras_mix_on[it] = 0;
         {
             Tic t = tic(h, "rhs");
             launch_arap_rhs(h->sell, h->d_pts, x_cur, h->d_rot, it, p.arap_tol, h->d_energy, nullptr, nullptr, h->d_ras_b, p.cg_tol, h->d_ctl, slot, prev_scal, h->d_bar, h->d_bpure, s,
@@ -399,7 +406,8 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
                 // the last planned sweep of a solve is a TAIL launch: should the plan turn out too short it keeps sweeping in
                 // the kernel (its extra sweeps' partial sums go to the solve's tail slots)
                 launch_ras_sweep(h, h->d_ras_b, x_cur, x_next, it, p.arap_tol, i, p.cg_tol, STOP_AT, i > 0 ? cur - ss : nullptr, cur,
-                                 h->d_ras_iters + (size_t)ras_slot * h->ras.NP, s, last ? h->d_ras_tail + (size_t)it * RAS_TAIL_MAX * ss : nullptr, fused);
+                                 h->d_ras_iters + (size_t)ras_slot * h->ras.NP, s, last ? h->d_ras_tail + (size_t)it * RAS_TAIL_MAX * ss : nullptr, fused,
+                                 h->ras_mix_on[it] != 0);
                 x_cur = x_next;
                 ++ras_slot;
             };
@@ -716,7 +724,9 @@ int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* s
             int most = ran + (idle ? 0 : 1);
             for (int q = 0; q < jd.rows; ++q) most = std::max(most, jd.used[q][it]);
             h->ras_plan[it] = std::min(RAS_MAX_SWEEPS, most + ras_spares(most));
-            worst_first = std::max(worst_first, ran - 1);
+            // (a mixing solve's 7-9 sweeps say nothing about the bracket: its stalled mode lies below any bracket and is taken
+            //  out by the mixing — it neither lowers the bracket nor keeps it from drifting back to the default)
+            if (!h->ras_mix_on[it]) worst_first = std::max(worst_first, ran - 1);
         }
         if (mvs_debug_level()) {
             fprintf(stderr, "[mvs] arap it %d: %d of %d planned sweeps ran%s (true final residual %.3e) -> plan %d\n", it, ran, n, idle ? "" : " — no spare left",
@@ -862,7 +872,7 @@ static int install_nodes(mvs_deform_s* h, const int32_t* vertex_idx, int64_t K) 
     if (K) HIPCHK(hipMemcpyAsync(h->d_ctrl_raw, h->d_node_pts, sizeof(double) * K * 3, hipMemcpyDeviceToDevice, h->stream));
     h->d_ctrl_final = h->d_ctrl_raw;
     h->cg_iters = 0;                                  // new node set: every launch plan and the solver bracket start over
-    for (int i = 0; i < 8; ++i) { h->cg_plan[i] = 0; h->ras_plan[i] = 0; h->bump_seq[i] = 0; h->ras_hist_n[i] = 0; }
+    for (int i = 0; i < 8; ++i) { h->cg_plan[i] = 0; h->ras_plan[i] = 0; h->bump_seq[i] = 0; h->ras_hist_n[i] = 0; h->ras_mix_on[i] = 0; }
     HIPCHK(hipMemsetAsync(h->d_ctl, 0, sizeof(double) * 4, h->stream));     // verdicts of the old node set say nothing about the new one
     h->ras_a = 0.0; h->ras_m = 0;
     return MVS_OK;

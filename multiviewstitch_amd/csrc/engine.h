@@ -175,6 +175,9 @@ struct mvs_deform_s {
     size_t sh_off_recin = 0, sh_off_cntin = 0, sh_off_tblk = 0, sh_off_tall = 0;      // owner-merges: records / counts of the owned block from every rank, merged targets
     double* d_bpure = nullptr;      // [V*3] right-hand side without its Dirichlet share (k_arap_rhs -> k_arap_local's true residual)
     double* d_ras_tail = nullptr;   // [8][RAS_TAIL_MAX] sweep slots of the in-kernel sweeps of TAIL launches
+    int ras_mix_on[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per ARAP iteration: its solve's planned sweeps are the mixing instantiation (sticky: enqueue_solve)
+    double* d_ras_mixf = nullptr;   // [V][3] the correction a mixing sweep applied to its (owned) rows: f_k = G(y_k) - y_k
+    double* d_ras_mixp = nullptr;   // [2][6][NPpad] partial sums of <f_k, f_k - f_(k-1)> and |f_k - f_(k-1)|^2 per coordinate, by sweep parity
     volatile double* h_ctl = nullptr;
     int ras_hist[8][4] = {};        // sweeps each solve ran in the last four passes the host has looked at (peek_ring), oldest first
     int ras_hist_n[8] = {};
@@ -289,7 +292,8 @@ int  ras_steps_for(double a);
 #define RAS_TAIL_MAX 32      /* in-kernel sweeps a TAIL launch may add to a solve whose plan was too short */
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, double* xout, int it, double arap_tol, int sweep,
                       double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots = nullptr,
-                      bool with_local = false /*last launch of a solve: also the ARAP local step on every patch's owned rows (when ras_can_fuse_local)*/);
+                      bool with_local = false /*last launch of a solve: also the ARAP local step on every patch's owned rows (when ras_can_fuse_local)*/,
+                      bool mixing_solve = false /*the solve's plan is long: its planned sweeps can mix (RasMix, schwarz.hip)*/);
 bool ras_can_fuse_local(const mvs_deform_s* h);   // patches <= MVS_NBMAX and workgroups <= 512 threads
 int  ras_local_parts(const mvs_deform_s* h);      // partial sums per reduction the local step leaves (what its consumers fold)
 void ras_set_tail_maxspin(int n);                 // tests: polls at the tail barrier before a workgroup abandons the solve (<= 0: default)

@@ -663,10 +663,11 @@ int mesh_build(mvs_deform_s* h, const double* points, const double* normals, con
             ff_bytes = a.off - ff_off;
             h->d_ras_pw = a.take<double>(rows * W); h->d_ras_pd = a.take<double>(rows);
             const int NPpad = (4 * NP + 63) / 64 * 64;
-            const size_t ss = (size_t)3 * NPpad + 8;                    // ras_slot_doubles
+            const size_t ss = (size_t)3 * NPpad + 16;                   // ras_slot_doubles
             h->d_ras_slots = a.take<double>((size_t)128 * 8 * ss);      // RAS_MAX_SWEEPS sweeps of each of <= 8 ARAP iterations
             h->d_ras_iters = a.take<int32_t>((size_t)128 * 8 * NP);
             h->d_ras_tail = a.take<double>((size_t)8 * RAS_TAIL_MAX * ss);
+            h->d_ras_mixf = a.take<double>((size_t)3 * V); h->d_ras_mixp = a.take<double>((size_t)2 * 6 * NPpad);
         }
     };
     {

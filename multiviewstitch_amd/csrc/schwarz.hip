@@ -130,7 +130,8 @@ __device__ inline double fold_n(const double* __restrict__ part, int n) {
 
 // slot of one sweep: part[3][NPpad] | gamma[3] bn[3] idle-flag active-count.  Partials: one per (patch, wave 0..3) — the owned rows of a
 // patch (<= 256) sit in its first four waves, so no workgroup-level reduction is needed for the residual norm.
-__host__ __device__ inline int ras_slot_doubles(int NPpad) { return 3 * NPpad + 8; }
+// [8]: mixing state the sweep leaves (0 none, 1 its correction stored, 2 also the sums for the next sweep's coefficient)
+__host__ __device__ inline int ras_slot_doubles(int NPpad) { return 3 * NPpad + 16; }
 
 struct ChebCoef { double c0, c1[32], c2[32]; };      // d_0 = c0 D^-1 r ;  d_{k+1} = c1[k] d_k + c2[k] D^-1 r_{k+1}
 
@@ -253,6 +254,20 @@ struct RasTail {              // the last planned launch of a solve (MODE >= 1)
     int max_extra;            // in-kernel sweeps after this launch's own one
     int maxspin;              // polls a workgroup waits at the barrier before it abandons the solve
 };
+// Mixing of successive sweeps (MODE 3).  When a solve's sweeps stall — two or three healthy sweeps, then a few per cent per
+// sweep: ONE mode of the sweep operator with an eigenvalue near 1, the signature of sliver triangles after hundreds of outer
+// iterations (EXPERIMENTS.md, "late regime") — the planned sweeps switch to Anderson mixing of depth one, per coordinate:
+//     y_(k+1) = G(y_k) - gamma_k (G(y_k) - G(y_(k-1))),  gamma_k = <f_k, f_k - f_(k-1)> / |f_k - f_(k-1)|^2,  f_k = G(y_k) - y_k
+// G(y_k) and G(y_(k-1)) are what the two solution buffers hold when sweep k+1 starts; the sums come from sweep k's owned rows
+// (per-wave partials like the residual's, folded in sweep k+1's preamble), f_(k-1) from `F`.  A stalled mode at 0.92 per sweep is
+// removed by one mixed sweep (offline: scripts/mixing_offline.py, 31 sweeps -> 8).  The residual that decides convergence is
+// still the true fp64 residual of every sweep's (mixed) input; the result of a solve is still G(an input measured at cg_tol).
+struct RasMix {
+    double* F;                // [V][3]
+    double* part;             // [2][6][NPpad]
+    double cap;               // |gamma| <= cap; 0: mixing off
+    int normal_set;           // the sweeps of a mixing solve keep the planned coefficient set (default; 0: the strong set, experiments)
+};
 struct RasLocal {             // MODE == 2: the launch also performs the ARAP local step of the solve's result on its owned rows
     SellDev m;
     const double* pts;        // rest positions
@@ -261,7 +276,8 @@ struct RasLocal {             // MODE == 2: the launch also performs the ARAP lo
     int nfold;                // partials per sum the consumers fold (>= patches: the slots beyond them are zero-filled here)
 };
 
-// MODE 0: a planned sweep.  MODE 1: the last planned launch of a solve — should the plan turn out too short it keeps sweeping
+// MODE 0: a planned sweep.  MODE 3: a planned sweep of a solve whose plan is long (the host's sign of stalled sweeps): it can mix
+// (RasMix) — a separate instantiation, the healthy regime's sweeps stay as lean as they were.  MODE 1: the last planned launch of a solve — should the plan turn out too short it keeps sweeping
 // behind the device-wide barrier.  MODE 2: MODE 1 and, once the solve has ended, the ARAP local step on the patch's owned rows
 // (workgroups of <= 512 threads: the local step wants ~210 VGPRs, k_arap_local's budget).
 template <int W, int MODE>
@@ -270,8 +286,9 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
                                                     double* __restrict__ ered, int nb_rhs, int sweep, double cg_tol, double stop_margin, double slow2,
                                                     double predict2, ChebCoef cc, int cheb_m, ChebCoef cc_strong, int cheb_m_strong,
                                                     double* __restrict__ ctl, double* __restrict__ slot_prev,
-                                                    double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur, RasTail tail, RasLocal loc) {
-    constexpr bool TAIL = MODE >= 1;
+                                                    double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur, RasTail tail, RasLocal loc, RasMix mix) {
+    constexpr bool TAIL = MODE == 1 || MODE == 2;
+    constexpr bool MIX = MODE == 3;                                     // (the last planned launch of a solve takes the buffer as it is)
     constexpr bool FOLD_GUARDED = MODE == 2;                           // (fold_n: which form of the partial loads this instantiation affords)
     // LDS: fp64 x of the local rows and the halo while the residual is formed (24 KB), then the correction directions as
     // bfloat16 triples, double-buffered (2 x 8 KB of the same array).  The neighbours' directions only steer the inexact
@@ -280,6 +297,7 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
     __shared__ double s_gam[3], s_gam2[3], s_bn[3], s_psafe;
     __shared__ int s_done, s_esc, s_slow[3];
     __shared__ double s_loc[4][4];                                      // (MODE 2: the local step's wave sums)
+    __shared__ double s_mix[6];                                         // (MODE 3: the folded sums of the previous sweep's mixing partials)
     double4* xs = reinterpret_cast<double4*>(smem);                    // 32-byte records: two 16-byte LDS accesses per gather instead of three 8-byte ones
     // workgroup -> patch, XCD-aware: consecutive workgroup ids go round the eight XCDs, and consecutive PATCHES are neighbours on the
     // mesh (recursive bisection) — each XCD takes a contiguous block of 32 patches, so the overlap and halo rows two neighbouring
@@ -341,6 +359,7 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
     }
     const double dd = pd[base + row];
     const double skip_flag = sweep > 0 ? slot_prev[3 * NPpad + 6] : 0.0;
+    const double mix_prev = (sweep > 0 && mix.cap > 0.0) ? slot_prev[3 * NPpad + 8] : 0.0;      // (same round trip as the skip flag)
     if (skip_flag != 0.0) {
         if (p == 0 && row == 0) { slot_cur[3 * NPpad + 6] = 1.0; slot_cur[3 * NPpad + 7] = slot_prev[3 * NPpad + 7]; }
         if (p == 0 && row < 3) slot_cur[3 * NPpad + 3 + row] = slot_prev[3 * NPpad + 3 + row];      // (the right-hand side's norms: the harvest reads them from a solve's last slot)
@@ -363,6 +382,10 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
     d3 xh = ld3(xin + 3 * (int64_t)gh);                                // frozen at the previous sweep's value for this sweep
     const bool fixed = dd == 0.0;
     const d3 rhs = ld3(bvec + 3 * (int64_t)g);                         // (b is 0 on control rows; padding rows are fixed)
+    // mixing: the previous sweep left sums -> this sweep's input is a combination of the two buffers (the other one fetched here)
+    const bool mixing = MIX && mix_prev >= 2.0;
+    d3 xi_o = mk3(0, 0, 0), xh_o = mk3(0, 0, 0);
+    if (mixing) { xi_o = ld3(xout + 3 * (int64_t)g); xh_o = ld3(xout + 3 * (int64_t)gh); }
     // MODE 2: the last planned launch of a solve is normally the one that finds it finished — its input is then the result and
     // all that is left is the local step: the first hop of its fetches (own operands, weights, neighbour indices: ~40 registers)
     // is issued HERE, beside the operand loads and the fold of the previous sweep's partials; a launch that has to sweep after
@@ -391,8 +414,15 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
         }
     }
     RSTAMP(6);
-    xs[row] = make_double4(xi.x, xi.y, xi.z, 0.0);
-    if (row < nh) xs[LS + row] = make_double4(xh.x, xh.y, xh.z, 0.0);
+    if (mixing) {                                                      // (uniform) waves 0..5: one of the six sums each
+        if (wv < 6) {
+            const double t = fold_n<FOLD_GUARDED>(mix.part + ((size_t)((sweep - 1) & 1) * 6 + wv) * NPpad, R.NP * 4);
+            if (lane == 0) s_mix[wv] = t;
+        }
+    } else {
+        xs[row] = make_double4(xi.x, xi.y, xi.z, 0.0);
+        if (row < nh) xs[LS + row] = make_double4(xh.x, xh.y, xh.z, 0.0);
+    }
     RSTAMP(7);
     __syncthreads();
     RSTAMP(1);
@@ -401,7 +431,7 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
     // it could not know) has improved it by another 7x at least when the sweeps converge healthily (rate below RAS_SLOW) — and
     // at stop_margin * cg_tol (0.5) when they do not or the rate is not known yet: near convergence of an ill-conditioned
     // system the f32 / bf16 local corrections make the residual history noisy and a sweep may give some of it back.
-    const bool healthy = s_slow[0] == 0 && s_slow[1] == 0 && s_slow[2] == 0;
+    const bool healthy = s_slow[0] == 0 && s_slow[1] == 0 && s_slow[2] == 0 && !(mix_prev >= 1.0);      // (a solve that mixes stays careful)
     const double stop = healthy ? cg_tol : stop_margin * cg_tol;
     bool frozen = sweep > 0;
 #pragma unroll
@@ -437,6 +467,7 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
         slot_cur[3 * NPpad + 6] = idle ? 1.0 : 0.0;
         slot_cur[3 * NPpad + 7] = idle ? ran_before : ran_before + 1.0;
     }
+    if (MIX && (s_done || frozen) && p == 0 && row == 4) slot_cur[3 * NPpad + 8] = 0.0;
     if (s_done || frozen) {
         // nothing to solve: keep the ping-pong buffers consistent, carry the converged partials forward
         if (row < nown) st3(xout + 3 * (int64_t)g, xi);
@@ -455,7 +486,37 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
     for (int q = 0; q < W; ++q) w2s[q] = fixed ? 0.f : (float)w2[q];
     const float di_s = fixed ? 0.f : di_f;
     uint2* hb = reinterpret_cast<uint2*>(smem);
-    bool strong = s_esc || s_slow[0] == 1 || s_slow[1] == 1 || s_slow[2] == 1;
+    const bool slow_now = s_slow[0] == 1 || s_slow[1] == 1 || s_slow[2] == 1;
+    // mixing mode: entered when a sweep is found slow (sweep >= 2: the rate is known), kept to the end of the solve.  The planned
+    // sweeps of a mixing solve all use ONE coefficient set — the f_k that enter a coefficient must come from the same operator — and
+    // that is the planned set: the stalled mode lies far below any bracket, the strong set's 2-3x longer sweeps do not reach it either
+    // (measured, scripts/soak.py: 0.69-0.78 ms per outer iteration against 0.73-0.80; offline 8 sweeps with either set)
+    const bool mixmode = MIX && mix.cap > 0.0 && sweep >= 2 && (mix_prev >= 1.0 || slow_now);
+    bool strong = (MIX && mix.normal_set) ? (s_esc != 0) : (s_esc || slow_now || mixmode);
+    d3 f_prev = mk3(0, 0, 0);
+    if constexpr (MIX) {
+        if (mixing) {
+            double gm[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double s1 = s_mix[c], s2 = s_mix[3 + c];
+                double gq = s2 > 0.0 ? s1 / s2 : 0.0;
+                if (!(gq == gq) || !(fabs(s1) < INFINITY)) gq = 0.0;
+                gm[c] = fmin(mix.cap, fmax(-mix.cap, gq));
+            }
+            xi = mk3(xi.x - gm[0] * (xi.x - xi_o.x), xi.y - gm[1] * (xi.y - xi_o.y), xi.z - gm[2] * (xi.z - xi_o.z));
+            xh = mk3(xh.x - gm[0] * (xh.x - xh_o.x), xh.y - gm[1] * (xh.y - xh_o.y), xh.z - gm[2] * (xh.z - xh_o.z));
+            xs[row] = make_double4(xi.x, xi.y, xi.z, 0.0);
+            if (row < nh) xs[LS + row] = make_double4(xh.x, xh.y, xh.z, 0.0);
+            __syncthreads();
+        }
+        // f of the sweep before: stored by it when it was a mixing sweep; else (this sweep is the one that found the solve slow) its
+        // input was the buffer this sweep overwrites and its output is this sweep's input — same coefficient set on both sides
+        if (mixmode && row < nown) {
+            if (mix_prev >= 1.0) f_prev = ld3(mix.F + 3 * (int64_t)g);                          // (in flight during the local solve)
+            else if (mix.normal_set) { const d3 xo_ = ld3(xout + 3 * (int64_t)g); f_prev = mk3(xi.x - xo_.x, xi.y - xo_.y, xi.z - xo_.z); }
+        }
+    }
 
     // One sweep of this patch: xs holds x of the local rows and the halo (fp64); residual of that input on the local rows, its
     // owned part into `slot`, the Chebyshev correction, new x of the owned rows into `xo`.
@@ -536,6 +597,22 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
         RSTAMP(4);
         xi = xi + mk3((double)ex, (double)ey, (double)ez);
         if (row < nown) st3(xo + 3 * (int64_t)g, xi);
+        if constexpr (MIX) {
+            if (mixmode) {                                                 // this sweep's f on the owned rows, and — when the
+                const bool own = row < nown;                               // sweep before left its f — the sums of the coefficient
+                const double f0 = own ? (double)ex : 0.0, f1 = own ? (double)ey : 0.0, f2 = own ? (double)ez : 0.0;
+                const bool have_prev = mix_prev >= 1.0 || mix.normal_set != 0;
+                if (wv < 4 && have_prev) {
+                    const double d0 = f0 - f_prev.x, d1 = f1 - f_prev.y, d2 = f2 - f_prev.z;
+                    const double q0 = wave_sum_u(f0 * d0), q1 = wave_sum_u(f1 * d1), q2 = wave_sum_u(f2 * d2);
+                    const double q3 = wave_sum_u(d0 * d0), q4 = wave_sum_u(d1 * d1), q5 = wave_sum_u(d2 * d2);
+                    if (lane < 6) mix.part[((size_t)(sweep & 1) * 6 + lane) * NPpad + 4 * p + wv] =
+                        lane == 0 ? q0 : lane == 1 ? q1 : lane == 2 ? q2 : lane == 3 ? q3 : lane == 4 ? q4 : q5;
+                }
+                if (own) st3(mix.F + 3 * (int64_t)g, mk3(f0, f1, f2));
+            }
+            if (p == 0 && row == 4) slot[3 * NPpad + 8] = mixmode ? ((mix_prev >= 1.0 || mix.normal_set) ? 2.0 : 1.0) : 0.0;
+        }
         return m;
     };
     int steps = sweep_body(slot_cur, xout);
@@ -564,11 +641,12 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
         const bool known = g_before[0] < INFINITY;                     // (the rate of the sweep before the one just done)
 #pragma unroll
         for (int c = 0; c < 3; ++c) if (s_gam[c] > slow2 * g_before[c]) slow = true;      // the same rules a planned sweep applies in its
-        const double stop_k = (known && !slow) ? cg_tol : stop_margin * cg_tol;           // preamble: what a sweep computes does not depend
+        const bool careful = mix_prev >= 1.0;                                              // (the solve has been mixing: no geometric history)
+        const double stop_k = (known && !slow && !careful) ? cg_tol : stop_margin * cg_tol;    // preamble: what a sweep computes does not depend
 #pragma unroll
         for (int c = 0; c < 3; ++c)                                                        // on where the plan ended
             if (!(s_gam[c] <= stop_k * stop_k * bn[c])) conv = false;
-        if (!conv && known && !slow && predict2 > 0.0 && !s_esc) {                         // (predicted stop: the output just written)
+        if (!conv && known && !slow && !careful && predict2 > 0.0 && !s_esc) {             // (predicted stop: the output just written)
             conv = true;
             double prel2 = 0.0;
 #pragma unroll
@@ -668,7 +746,7 @@ int ras_local_parts(const mvs_deform_s* h) { return ras_can_fuse_local(h) ? std:
 
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, double* xout, int it, double arap_tol, int sweep,
                       double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots,
-                      bool with_local) {
+                      bool with_local, bool mixing_solve) {
     const RasDev& R = h->ras;
     const int nb = arap_grid_blocks(h->sell);
     // Chebyshev parameters: the bracket's lower end `a` and the step count live in the handle — initialised from the density
@@ -696,11 +774,15 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, doubl
     const dim3 grid(R.NP), blk(h->ras_block);     // as many waves as the largest patch has rows (idle waves only add barrier cost)
     const RasTail tail{h->d_bar, tail_slots, RAS_TAIL_MAX, g_tail_maxspin};
     const RasLocal loc{h->sell, h->d_pts, h->d_rot, h->d_bpure, ras_local_parts(h)};
-    const int mode = !tail_slots ? 0 : ((with_local && ras_can_fuse_local(h)) ? 2 : 1);
+    // mixing_solve: every planned sweep of this solve is the mixing instantiation (a solve is all lean or all mixing: the state in
+    // the sweep slots is only kept by the latter, and cap = 0 tells every launch of a lean solve not to look at it)
+    const RasMix mix{h->d_ras_mixf, h->d_ras_mixp, (mixing_solve && MVS_KNOB("MVS_MIX", 1, 0, 1) != 0.0) ? MVS_KNOB("MVS_MIX_CAP", 200.0, 1.0, 1e6) : 0.0,
+                     (int)MVS_KNOB("MVS_MIX_SET", 1, 0, 1)};
+    const int mode = !tail_slots ? (mix.cap > 0.0 ? 3 : 0) : ((with_local && ras_can_fuse_local(h)) ? 2 : 1);
 #define MVS_SWEEP(W, T) k_ras_sweep<W, T><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, stop_margin, \
-                                                              RAS_SLOW * RAS_SLOW, RAS_PREDICT * RAS_PREDICT, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur, tail, loc)
+                                                              RAS_SLOW * RAS_SLOW, RAS_PREDICT * RAS_PREDICT, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur, tail, loc, mix)
 #define MVS_SWEEP_W(T) do { if (R.W == 6) MVS_SWEEP(6, T); else if (R.W == 8) MVS_SWEEP(8, T); else if (R.W == 12) MVS_SWEEP(12, T); else MVS_SWEEP(16, T); } while (0)
-    if (mode == 2) MVS_SWEEP_W(2); else if (mode == 1) MVS_SWEEP_W(1); else MVS_SWEEP_W(0);
+    if (mode == 2) MVS_SWEEP_W(2); else if (mode == 1) MVS_SWEEP_W(1); else if (mode == 3) MVS_SWEEP_W(3); else MVS_SWEEP_W(0);
 #undef MVS_SWEEP_W
 #undef MVS_SWEEP
 }

@@ -385,6 +385,29 @@ def test_an_abandoned_tail_loop_is_unanimous_and_reported(eng):
     assert seen_warning, "a one-poll wait never expired: the abandoned path was not exercised"
 
 
+def test_stalled_sweeps_are_mixed(eng):
+    """The late regime of a long fit (config 3 past outer iteration ~170: sliver triangles of the 200-times re-deformed template
+    give the sweep operator a mode with an eigenvalue near 1 — two or three healthy sweeps, then 8-13 % per sweep, 16-35 sweeps
+    per solve).  A solve whose plan has grown long runs its planned sweeps as the mixing instantiation (schwarz.hip, RasMix):
+    Anderson mixing of depth one takes the stalled mode out, 6-9 sweeps per solve; every solve is still judged by its true
+    residual."""
+    import torch
+    import bench
+    from multiviewstitch_amd import scene as S, srt as srt_mod
+    dev = torch.device("cuda", 0)
+    sc = S.make_scene(3, device=dev)
+    d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    d.UniformSampling(16)
+    tp, tn = bench.build_target(torch, srt_mod, S, sc, range(8), dev)
+    d.set_target_dev(tp.data_ptr(), tn.data_ptr(), tp.shape[0], 0)
+    for _ in range(10):
+        st = d.iterate(25)
+        assert st["unconverged_solves"] == 0 and st["worst_rel_residual_in_batch"] <= 1.5 * d.params.cg_tol, st
+    # passes 226-250: deep in the regime
+    assert st["arap_iters_run"] == 5 and st["cg_active"] <= 12 * st["arap_iters_run"], st
+    d.close()
+
+
 def test_node_graph_matches_oracle(eng, oracle):
     """KNearestNeighbor(8) (Deformation.cpp:108-153): the 9-NN graph of the nodes (self included), found in the association
     launch by a wave per query on the grid of the node positions (knn_dev.h) — exact, ties to the lower index."""
