@@ -239,15 +239,32 @@ constexpr int RAS_FIRST_PLAN = 8;
 constexpr int RAS_MAX_SWEEPS = 128;
 // A solve whose plan has grown to this many launches has stalled sweeps behind it (healthy solves take 3-5 sweeps): its planned
 // sweeps are launched as the mixing instantiation (schwarz.hip, RasMix).  A function of the plan, i.e. of the call sequence.
-// Sticky: a mixing solve needs 7-9 launches, the same solve without mixing 17-36 — the switch goes on at RAS_MIX_PLAN and off only
-// when the plan is back at a healthy solve's length.
+// Per HANDLE and sticky: in the regime where solves stall, WHICH of the five solves of a pass stalls changes from pass to pass (the
+// later ARAP iterations start closer to their solution and often finish before the stalled mode matters); a solve that stalls
+// with a short plan runs its extra sweeps in the last launch, unmixed, 15 us each (17-21 of them: 0.3 ms for one solve).  So once
+// any plan reaches RAS_MIX_PLAN every solve of the handle gets mixing sweeps and a plan of at least RAS_MIX_PLAN launches (the
+// ones a solve does not need return after one load, ~4 us each); back to lean sweeps after RAS_MIX_CALM passes in which every
+// solve's need stayed at a healthy solve's length.
 #define RAS_MIX_PLAN ((int)MVS_KNOB("MVS_MIX_PLAN", 9, 2, 128))
-constexpr int RAS_MIX_OFF = 5;
+constexpr int RAS_MIX_OFF = 5, RAS_MIX_CALM = 64;
+void update_mix_state(mvs_deform_s* h, int arap_iters) {
+    bool any_long = false, all_short = true;
+    for (int it = 0; it < arap_iters; ++it) {
+        if (h->ras_plan[it] >= RAS_MIX_PLAN) any_long = true;
+        if (h->ras_plan[it] > RAS_MIX_OFF) all_short = false;
+    }
+    if (any_long) { h->ras_mix_any = 1; h->ras_mix_calm = 0; }
+    else if (h->ras_mix_any) {
+        if (!all_short) h->ras_mix_calm = 0;
+        else if (++h->ras_mix_calm >= RAS_MIX_CALM) { h->ras_mix_any = 0; h->ras_mix_calm = 0; }
+    }
+}
 
 int g_dbg_plan_cap = 0;              // tests (mvs_debug_tail): at most this many launches per solve, the rest of its sweeps run in the last one
 RasPlan probe_ras(const mvs_deform_s* h) {
     RasPlan r;
     for (int i = 0; i < 8; ++i) r.n[i] = h->ras_plan[i] > 0 ? h->ras_plan[i] : RAS_FIRST_PLAN;
+    if (h->ras_mix_any) for (int i = 0; i < 8; ++i) r.n[i] = std::max(r.n[i], RAS_MIX_PLAN);      // (update_mix_state)
     // experiment (scripts/host_bound.py): at most this many LAUNCHES per solve — the rest of the sweeps run inside the last one
     const int cap = g_dbg_plan_cap > 0 ? g_dbg_plan_cap : (int)MVS_KNOB("MVS_RAS_PLAN_CAP", 0, 0, 128);
     if (cap > 0) for (int i = 0; i < 8; ++i) r.n[i] = std::min(r.n[i], cap);
@@ -366,6 +383,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     }
     if (!last_sweep.out) h->d_ctrl_final = const_cast<double*>(ctrl);
     const bool ras = use_ras(h, p);
+    if (ras) update_mix_state(h, p.arap_iters);
     const RasPlan rp = probe_ras(h);
     int rc = ras ? ensure_ras_slots(h, p.arap_iters, rp) : ensure_slots(h, p.arap_iters, plan);
     if (rc) return rc;
@@ -390,7 +408,6 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     const int demand_local = (fused && !safe_local) ? 1 : 0;          // the judge of a solve insists that its fused local step ran
     const double* prev_scal = nullptr;   // the 8 scalars of the last sweep slot of the previous solve (idle flag, sweeps that ran)
     for (int it = 0; ras && it < p.arap_iters; ++it) {
-        if (rp.n[it] >= RAS_MIX_PLAN) h->ras_mix_on[it] = 1; else if (rp.n[it] <= RAS_MIX_OFF) h->ras_mix_on[it] = 0;
         {
             Tic t = tic(h, "rhs");
             launch_arap_rhs(h->sell, h->d_pts, x_cur, h->d_rot, it, p.arap_tol, h->d_energy, nullptr, nullptr, h->d_ras_b, p.cg_tol, h->d_ctl, slot, prev_scal, h->d_bar, h->d_bpure, s,
@@ -407,7 +424,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
                 // the kernel (its extra sweeps' partial sums go to the solve's tail slots)
                 launch_ras_sweep(h, h->d_ras_b, x_cur, x_next, it, p.arap_tol, i, p.cg_tol, STOP_AT, i > 0 ? cur - ss : nullptr, cur,
                                  h->d_ras_iters + (size_t)ras_slot * h->ras.NP, s, last ? h->d_ras_tail + (size_t)it * RAS_TAIL_MAX * ss : nullptr, fused,
-                                 h->ras_mix_on[it] != 0);
+                                 h->ras_mix_any != 0);
                 x_cur = x_next;
                 ++ras_slot;
             };
@@ -726,7 +743,7 @@ int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* s
             h->ras_plan[it] = std::min(RAS_MAX_SWEEPS, most + ras_spares(most));
             // (a mixing solve's 7-9 sweeps say nothing about the bracket: its stalled mode lies below any bracket and is taken
             //  out by the mixing — it neither lowers the bracket nor keeps it from drifting back to the default)
-            if (!h->ras_mix_on[it]) worst_first = std::max(worst_first, ran - 1);
+            if (!h->ras_mix_any) worst_first = std::max(worst_first, ran - 1);
         }
         if (mvs_debug_level()) {
             fprintf(stderr, "[mvs] arap it %d: %d of %d planned sweeps ran%s (true final residual %.3e) -> plan %d\n", it, ran, n, idle ? "" : " — no spare left",
@@ -872,7 +889,8 @@ static int install_nodes(mvs_deform_s* h, const int32_t* vertex_idx, int64_t K) 
     if (K) HIPCHK(hipMemcpyAsync(h->d_ctrl_raw, h->d_node_pts, sizeof(double) * K * 3, hipMemcpyDeviceToDevice, h->stream));
     h->d_ctrl_final = h->d_ctrl_raw;
     h->cg_iters = 0;                                  // new node set: every launch plan and the solver bracket start over
-    for (int i = 0; i < 8; ++i) { h->cg_plan[i] = 0; h->ras_plan[i] = 0; h->bump_seq[i] = 0; h->ras_hist_n[i] = 0; h->ras_mix_on[i] = 0; }
+    for (int i = 0; i < 8; ++i) { h->cg_plan[i] = 0; h->ras_plan[i] = 0; h->bump_seq[i] = 0; h->ras_hist_n[i] = 0; }
+    h->ras_mix_any = 0; h->ras_mix_calm = 0;
     HIPCHK(hipMemsetAsync(h->d_ctl, 0, sizeof(double) * 4, h->stream));     // verdicts of the old node set say nothing about the new one
     h->ras_a = 0.0; h->ras_m = 0;
     return MVS_OK;

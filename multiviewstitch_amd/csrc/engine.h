@@ -175,7 +175,7 @@ struct mvs_deform_s {
     size_t sh_off_recin = 0, sh_off_cntin = 0, sh_off_tblk = 0, sh_off_tall = 0;      // owner-merges: records / counts of the owned block from every rank, merged targets
     double* d_bpure = nullptr;      // [V*3] right-hand side without its Dirichlet share (k_arap_rhs -> k_arap_local's true residual)
     double* d_ras_tail = nullptr;   // [8][RAS_TAIL_MAX] sweep slots of the in-kernel sweeps of TAIL launches
-    int ras_mix_on[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per ARAP iteration: its solve's planned sweeps are the mixing instantiation (sticky: enqueue_solve)
+    int ras_mix_any = 0, ras_mix_calm = 0;          // the handle's solves stall (late regime): planned sweeps are the mixing instantiation, plans keep a floor (update_mix_state)
     double* d_ras_mixf = nullptr;   // [V][3] the correction a mixing sweep applied to its (owned) rows: f_k = G(y_k) - y_k
     double* d_ras_mixp = nullptr;   // [2][6][NPpad] partial sums of <f_k, f_k - f_(k-1)> and |f_k - f_(k-1)|^2 per coordinate, by sweep parity
     volatile double* h_ctl = nullptr;
