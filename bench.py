@@ -47,6 +47,7 @@ def parse_args(argv=None):
     ap.add_argument("--phases", action="store_true", help="extra instrumented pass: per-phase HIP-event times to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-solver", action="store_true", help="skip the comparison run with the one-kernel-per-iteration CG (profiles of the default solver alone)")
+    ap.add_argument("--no-single-solve", action="store_true", help="skip the run with one global solve per outer iteration (kernel-trace profiles: launches per outer iteration then count the metric's schedule only)")
     ap.add_argument("--only-alt-solver", action="store_true", help="time the CG solver as the main run (profiles of the CG path alone)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "all_gather", "owner"],
                     help="N > 1: how the ranks' best-8 records meet (auto: owner-merges from 4 ranks on, DESIGN.md §6)")
@@ -435,16 +436,17 @@ def main():
     copy_gbps = None
     alt = None
     if world == 1:
-        keep = d.params.arap_iters
-        d.params.arap_iters = 1
-        run(max(args.warmup, 1))
-        fence()
-        ta = time.perf_counter()
-        run(args.steps)
-        fence()
-        el1 = time.perf_counter() - ta
-        d.params.arap_iters = keep
-        single = {"ms_per_step": round(1e3 * el1 / args.steps, 4), "iter_per_s": round(args.steps / el1, 2)}
+        if not args.no_single_solve:
+            keep = d.params.arap_iters
+            d.params.arap_iters = 1
+            run(max(args.warmup, 1))
+            fence()
+            ta = time.perf_counter()
+            run(args.steps)
+            fence()
+            el1 = time.perf_counter() - ta
+            d.params.arap_iters = keep
+            single = {"ms_per_step": round(1e3 * el1 / args.steps, 4), "iter_per_s": round(args.steps / el1, 2)}
         a = torch.empty(1 << 27, dtype=torch.float64, device=device).normal_()        # 1 GiB each way
         b = torch.empty_like(a)
         for _ in range(3):

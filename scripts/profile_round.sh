@@ -11,7 +11,8 @@ TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 bench.py --no-cpu-baseline --no-alt-solver > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err || exit 1
+rm -rf /tmp/prof_$TAG /tmp/prof_cg_$TAG /tmp/pmcf_$TAG /tmp/pmcw_$TAG /tmp/prof_rows_$TAG      # (a box may be reused: stale traces would make the copies below ambiguous)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 bench.py --no-cpu-baseline --no-alt-solver --no-single-solve > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err || exit 1
 cp /tmp/prof_$TAG/*/*_kernel_stats.csv $OUT/kernel_stats_all.csv
 # the same command with the alternative solver (one kernel per CG iteration) as the main run: its own table
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_cg_$TAG -- python3 bench.py --no-cpu-baseline --only-alt-solver > $OUT/bench_cg_under_rocprof.json 2> $OUT/bench_cg_under_rocprof.err || exit 1

@@ -31,8 +31,8 @@ steps = None
 for name, r in rows.items():
     if name.endswith("k_arap_finalize"):
         steps = int(r["Calls"])
-print(f"## Hot path, config 3 (P = {P}, K = {K}, V = {V}), one MI355X — rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu-baseline --no-alt-solver`\n")
-print(f"bench line under the profiler: {b['ms_per_step']} ms per step; {steps} outer iterations in the trace (warm-up, timed region, single-solve and reference-schedule runs)\n")
+print(f"## Hot path, config 3 (P = {P}, K = {K}, V = {V}), one MI355X — rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu-baseline --no-alt-solver --no-single-solve`\n")
+print(f"bench line under the profiler: {b['ms_per_step']} ms per step; {steps} outer iterations in the trace (warm-up, timed region, event-timing and reference-schedule runs; the first iterations of every fresh handle are in the averages)\n")
 print("| kernel | launches / outer iteration | avg us | algorithmic bytes / launch | GB/s | of 8 TB/s | what the bytes are |\n|---|---|---|---|---|---|---|")
 for key, (nbytes, note) in alg.items():
     hit = [r for n, r in rows.items() if n.endswith(key) or n == key]
