@@ -156,10 +156,17 @@ __global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, doubl
             const int i = c - 1;
             const double w = 1.0 / sm.nn;
             d3 acc = mk3(0, 0, 0);
-            for (int j = 0; j < sm.nn; ++j) {
-                const int idx = sm.nbr[(int64_t)i * sm.nn + j];
-                if (idx < 0) continue;
-                acc = acc + w * (ld3(ctrl + 3 * idx) - ld3(sm.orig + 3 * idx));
+            // eight neighbours at a time: their indices together, then their operands together (one after the other, every
+            // neighbour was two dependent memory round trips on the critical path of the launch); same order of additions
+            for (int j0 = 0; j0 < sm.nn; j0 += 8) {
+                int idx[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) idx[u] = j0 + u < sm.nn ? sm.nbr[(int64_t)i * sm.nn + j0 + u] : -1;
+                d3 cv[8], ov[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int q = idx[u] < 0 ? 0 : idx[u]; cv[u] = ld3(ctrl + 3 * q); ov[u] = ld3(sm.orig + 3 * q); }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (idx[u] >= 0) acc = acc + w * (cv[u] - ov[u]);
             }
             x = ld3(sm.orig + 3 * i) + acc;
             st3(sm.out + 3 * i, x);
@@ -176,12 +183,17 @@ __global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, doubl
     const int32_t* gent = R.gent + (int64_t)base * W;
     const int32_t* gcol = R.gcol + (int64_t)base * W;
     double* o = pw + (int64_t)base * W;
+    // (all entry ids and columns first, then all weights and control flags: clamped addresses + selects, no guarded loads — entry
+    //  by entry the launch paid three dependent round trips per entry: 14.8 us)
+    int ge[W], gc[W];
 #pragma unroll
-    for (int e = 0; e < W; ++e) {
-        const int ge = gent[e * LS + row], gc = gcol[e * LS + row];
-        const double w = ge >= 0 ? m.w[ge] : 0.0;
-        o[e * LS + row] = (ge >= 0 && !fixed && !m.is_ctrl[gc]) ? 2.0 * w : 0.0;
-    }
+    for (int e = 0; e < W; ++e) { ge[e] = gent[e * LS + row]; gc[e] = gcol[e * LS + row]; }
+    double we[W];
+    int cj[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) { we[e] = m.w[ge[e] < 0 ? 0 : ge[e]]; cj[e] = m.is_ctrl[gc[e] < 0 ? 0 : gc[e]]; }
+#pragma unroll
+    for (int e = 0; e < W; ++e) o[e * LS + row] = (ge[e] >= 0 && !fixed && !cj[e]) ? 2.0 * we[e] : 0.0;
 }
 
 // ---- device-wide barrier of the tail loop (bounded spin).  A kernel boundary is the cheaper device-wide barrier — which is
