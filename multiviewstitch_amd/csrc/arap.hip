@@ -119,12 +119,20 @@ __global__ void k_smooth(const double* __restrict__ orig, const double* __restri
     if (i >= K) return;
     const double w = 1.0 / nn;
     d3 acc = mk3(0, 0, 0);
-    for (int j = 0; j < nn; ++j) {
-        const int idx = nbr[(int64_t)i * nn + j];
-        if (idx < 0) continue;
-        acc = acc + w * (ld3(cur + 3 * idx) - ld3(orig + 3 * idx));
+    const d3 oi = ld3(orig + 3 * i);
+    // eight neighbours at a time: indices together, then operands together (one neighbour after the other = two dependent round
+    // trips each); the additions in the neighbours' order, as before
+    for (int j0 = 0; j0 < nn; j0 += 8) {
+        int idx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int v = nbr[(int64_t)i * nn + (j0 + u < nn ? j0 + u : nn - 1)]; idx[u] = j0 + u < nn ? v : -1; }
+        d3 cv[8], ov[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int q = idx[u] < 0 ? 0 : idx[u]; cv[u] = ld3(cur + 3 * q); ov[u] = ld3(orig + 3 * q); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (idx[u] >= 0) acc = acc + w * (cv[u] - ov[u]);
     }
-    st3(out + 3 * i, ld3(orig + 3 * i) + acc);
+    st3(out + 3 * i, oi + acc);
 }
 
 

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, doubl
             for (int j0 = 0; j0 < sm.nn; j0 += 8) {
                 int idx[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) idx[u] = j0 + u < sm.nn ? sm.nbr[(int64_t)i * sm.nn + j0 + u] : -1;
+                for (int u = 0; u < 8; ++u) { const int v = sm.nbr[(int64_t)i * sm.nn + (j0 + u < sm.nn ? j0 + u : sm.nn - 1)]; idx[u] = j0 + u < sm.nn ? v : -1; }
                 d3 cv[8], ov[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { const int q = idx[u] < 0 ? 0 : idx[u]; cv[u] = ld3(ctrl + 3 * q); ov[u] = ld3(sm.orig + 3 * q); }
