@@ -281,6 +281,114 @@ __global__ __launch_bounds__(TPB) void k_rcb_split(const RcbSeg* __restrict__ se
     }
 }
 
+// A level whose segments hold at most RCB_WG_MAX vertices, one workgroup per segment, in ONE launch: the widest axis, the eight
+// digit passes of the selection (histograms in LDS, keys in registers) and the partition.  The same keys, ranks and pivots as
+// k_rcb_axis / k_rcb_hist x 8 / k_rcb_split, which remain for the upper levels (a segment of the first three levels spans
+// many workgroups): the bisection of a 55 K-vertex mesh was 88 dependent launches, 55 of them for these levels (0.3 ms of the
+// 0.7 ms mesh_build spends on the device).  A segment with nl < 0 is a finished part: copied through.
+constexpr int RCB_WG_PT = 8, RCB_WG_MAX = 1024 * RCB_WG_PT;
+__global__ __launch_bounds__(1024) void k_rcb_level_wg(const RcbSeg* __restrict__ segs, const int32_t* __restrict__ order,
+                                                       const double* __restrict__ pts, int32_t* __restrict__ order_out) {
+    __shared__ double sm[6][16];
+    __shared__ int s_ax, s_h[256], s_k, s_cur[2];
+    __shared__ unsigned long long s_pre;
+    const RcbSeg s = segs[blockIdx.x];
+    const int t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (s.nl < 0) { for (int q = s.lo + t; q < s.hi; q += 1024) order_out[q] = order[q]; return; }
+    int v[RCB_WG_PT];
+    double x[RCB_WG_PT][3];
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int j = 0; j < RCB_WG_PT; ++j) {
+        const int q = s.lo + t + 1024 * j;
+        v[j] = q < s.hi ? order[q] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < RCB_WG_PT; ++j) {
+        const int vv = v[j] < 0 ? 0 : v[j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[j][c] = pts[3 * (int64_t)vv + c];
+    }
+#pragma unroll
+    for (int j = 0; j < RCB_WG_PT; ++j)
+        if (v[j] >= 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { mn[c] = fmin(mn[c], x[j][c]); mx[c] = fmax(mx[c], x[j][c]); }
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double a = mn[c], b = mx[c];
+        for (int o = 32; o > 0; o >>= 1) { a = fmin(a, __shfl_xor(a, o, 64)); b = fmax(b, __shfl_xor(b, o, 64)); }
+        if (lane == 0) { sm[c][wv] = a; sm[3 + c][wv] = b; }
+    }
+    if (t < 2) s_cur[t] = 0;
+    __syncthreads();
+    if (t == 0) {
+        double ext[3];
+        for (int c = 0; c < 3; ++c) {
+            double a = sm[c][0], b = sm[3 + c][0];
+            for (int w = 1; w < 16; ++w) { a = fmin(a, sm[c][w]); b = fmax(b, sm[3 + c][w]); }
+            ext[c] = b - a;
+        }
+        int ax = 0;
+        for (int c = 1; c < 3; ++c) if (ext[c] > ext[ax]) ax = c;
+        s_ax = ax; s_k = s.nl; s_pre = 0ull;
+    }
+    __syncthreads();
+    const int ax = s_ax;
+    unsigned long long key[RCB_WG_PT];
+#pragma unroll
+    for (int j = 0; j < RCB_WG_PT; ++j) {
+        const float c = (float)(ax == 0 ? x[j][0] : (ax == 1 ? x[j][1] : x[j][2])) + 0.0f;      // rcb_key
+        unsigned u = __float_as_uint(c);
+        u = (u >> 31) ? ~u : (u | 0x80000000u);
+        key[j] = ((unsigned long long)u << 32) | (unsigned)v[j];
+    }
+    for (int pass = 0; pass < 8; ++pass) {
+        if (t < 256) s_h[t] = 0;
+        __syncthreads();
+        const unsigned long long pre = s_pre;
+#pragma unroll
+        for (int j = 0; j < RCB_WG_PT; ++j)
+            if (v[j] >= 0 && (pass == 0 || (key[j] >> (64 - 8 * pass)) == pre)) atomicAdd(&s_h[(int)((key[j] >> (56 - 8 * pass)) & 255ull)], 1);
+        __syncthreads();
+        if (t < 64) {                                                  // (rcb_select's step on the LDS histogram)
+            int k = s_k;
+            const int c0 = s_h[4 * lane], c1 = s_h[4 * lane + 1], c2 = s_h[4 * lane + 2], c3 = s_h[4 * lane + 3];
+            const int sum = c0 + c1 + c2 + c3;
+            int incl = sum;
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+            const int excl = incl - sum;
+            const bool mine = excl <= k && k < incl;
+            const unsigned long long m = __ballot(mine);
+            const int L = m ? (int)__builtin_ctzll(m) : 63;
+            int bin = 0, below = excl;
+            if (k >= below + c0) { below += c0; bin = 1; if (k >= below + c1) { below += c1; bin = 2; if (k >= below + c2) { below += c2; bin = 3; } } }
+            bin = __shfl(4 * lane + bin, L, 64);
+            k -= __shfl(below, L, 64);
+            if (t == 0) { s_pre = (pre << 8) | (unsigned)bin; s_k = k; }
+        }
+        __syncthreads();
+    }
+    const unsigned long long pivot = s_pre;
+#pragma unroll
+    for (int j = 0; j < RCB_WG_PT; ++j) {
+        const bool live = v[j] >= 0, left = live && key[j] < pivot;
+        const unsigned long long mL = __ballot(left), mR = __ballot(live && !left);
+        int bL = 0, bR = 0;
+        if (lane == 0) {
+            if (mL) bL = atomicAdd(&s_cur[0], __popcll(mL));
+            if (mR) bR = atomicAdd(&s_cur[1], __popcll(mR));
+        }
+        bL = __shfl(bL, 0, 64); bR = __shfl(bR, 0, 64);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (live) {
+            if (left) order_out[s.lo + bL + __popcll(mL & below)] = v[j];
+            else order_out[s.lo + s.nl + bR + __popcll(mR & below)] = v[j];
+        }
+    }
+}
+
 __global__ void k_iota(int32_t* __restrict__ a, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = i;
@@ -465,7 +573,8 @@ int device_cus(int device) {
 // the bisection tree depends on V and NP alone: per level the segments to split and the 256-element tiles of `order`
 struct RcbPlan {
     std::vector<int32_t> part_begin;                    // NP + 1
-    struct Level { std::vector<RcbSeg> segs; std::vector<int32_t> tile_seg, tile_pos, tile_end; };
+    struct Level { std::vector<RcbSeg> segs; std::vector<int32_t> tile_seg, tile_pos, tile_end;
+                   std::vector<RcbSeg> wg_segs; };      // wg_segs: EVERY node of the level (finished parts with nl = -1) when all fit one workgroup, else empty
     std::vector<Level> levels;
     int max_segs = 0, max_tiles = 0;
 };
@@ -491,6 +600,15 @@ RcbPlan rcb_plan(int V, int NP) {
                 nxt.push_back({n.lo + nl, n.hi, n.p0 + pl_, n.parts - pl_});
             } else nxt.push_back(n);
             for (int q = n.lo; q < n.hi; q += TPB) { L.tile_seg.push_back(sg); L.tile_pos.push_back(q); L.tile_end.push_back(std::min(n.hi, q + TPB)); }
+        }
+        {
+            int longest = 0;
+            for (const Node& n : cur) longest = std::max(longest, n.hi - n.lo);
+            if (longest <= RCB_WG_MAX)
+                for (const Node& n : cur) {
+                    const int pl_ = n.parts / 2;
+                    L.wg_segs.push_back(RcbSeg{n.lo, n.hi, n.parts > 1 ? (int)((int64_t)(n.hi - n.lo) * pl_ / n.parts) : -1, 0});
+                }
         }
         pl.max_segs = std::max(pl.max_segs, (int)L.segs.size());
         pl.max_tiles = std::max(pl.max_tiles, (int)L.tile_seg.size());
@@ -528,7 +646,7 @@ int mesh_build(mvs_deform_s* h, const double* points, const double* normals, con
     if (NP > 0) plan = rcb_plan(V, NP);
     // host -> device tables of the plan, one block: part_begin | per level: segs, tile_seg, tile_pos, tile_end
     std::vector<int32_t> ptab;
-    std::vector<size_t> lvl_off;
+    std::vector<size_t> lvl_off, wg_off;
     if (NP > 0) {
         ptab.insert(ptab.end(), plan.part_begin.begin(), plan.part_begin.end());
         for (const auto& L : plan.levels) {
@@ -538,6 +656,9 @@ int mesh_build(mvs_deform_s* h, const double* points, const double* normals, con
             ptab.insert(ptab.end(), L.tile_seg.begin(), L.tile_seg.end());
             ptab.insert(ptab.end(), L.tile_pos.begin(), L.tile_pos.end());
             ptab.insert(ptab.end(), L.tile_end.begin(), L.tile_end.end());
+            while (ptab.size() & 3) ptab.push_back(0);
+            wg_off.push_back(ptab.size());
+            for (const RcbSeg& sg : L.wg_segs) { ptab.push_back(sg.lo); ptab.push_back(sg.hi); ptab.push_back(sg.nl); ptab.push_back(0); }
         }
     }
 
@@ -615,6 +736,11 @@ int mesh_build(mvs_deform_s* h, const double* points, const double* normals, con
             const RcbSeg* segs = reinterpret_cast<const RcbSeg*>(w.ptab + lvl_off[l]);
             const int32_t* tseg = w.ptab + lvl_off[l] + 4 * (size_t)nseg;
             const int32_t *tpos = tseg + ntile, *tend = tpos + ntile;
+            if (!L.wg_segs.empty()) {
+                k_rcb_level_wg<<<dim3((unsigned)L.wg_segs.size()), dim3(1024), 0, s>>>(reinterpret_cast<const RcbSeg*>(w.ptab + wg_off[l]), w.order[cur], h->d_pts, w.order[cur ^ 1]);
+                cur ^= 1;
+                continue;
+            }
             HIPCHK(hipMemsetAsync(w.hist, 0, sizeof(int32_t) * ((size_t)plan.max_segs * 2048 + (size_t)plan.max_segs * 2), s));
             k_rcb_axis<<<dim3(nseg), dim3(L.segs[0].hi - L.segs[0].lo > 4096 ? 1024 : 256), 0, s>>>(segs, w.order[cur], h->d_pts, w.axis);
             for (int pass = 0; pass < 8; ++pass)
