@@ -268,7 +268,9 @@ struct RasPlan {                     // sweeps per ARAP iteration of the patch s
 // run at the usual node density, the launches left over return after one scalar load, and should the eight not suffice the
 // last one keeps sweeping in the kernel (TAIL) — the DEVICE decides; round 2 probed such a solve in chunks of sweeps with a
 // host look at the residual after each (five synchronisations per solve, 8 ms for the first outer iteration)
-constexpr int RAS_FIRST_PLAN = 8;
+// (The later ARAP iterations of a pass start from the solution of the one before and need fewer sweeps: 6 5 4 4 4 ran of 8 8 8 8 8
+//  on the metric workload's first pass with eight launches each, twelve of which returned at once.)
+constexpr int RAS_FIRST_PLANS[8] = {7, 6, 5, 5, 5, 5, 5, 5};
 constexpr int RAS_MAX_SWEEPS = 128;
 // A solve whose plan has grown to this many launches has stalled sweeps behind it (healthy solves take 3-5 sweeps): its planned
 // sweeps are launched as the mixing instantiation (schwarz.hip, RasMix).  A function of the plan, i.e. of the call sequence.
@@ -296,7 +298,7 @@ void update_mix_state(mvs_deform_s* h, int arap_iters) {
 int g_dbg_plan_cap = 0;              // tests (mvs_debug_tail): at most this many launches per solve, the rest of its sweeps run in the last one
 RasPlan probe_ras(const mvs_deform_s* h) {
     RasPlan r;
-    for (int i = 0; i < 8; ++i) r.n[i] = h->ras_plan[i] > 0 ? h->ras_plan[i] : RAS_FIRST_PLAN;
+    for (int i = 0; i < 8; ++i) r.n[i] = h->ras_plan[i] > 0 ? h->ras_plan[i] : RAS_FIRST_PLANS[i];
     if (h->ras_mix_any) for (int i = 0; i < 8; ++i) r.n[i] = std::max(r.n[i], RAS_MIX_PLAN);      // (update_mix_state)
     // experiment (scripts/host_bound.py): at most this many LAUNCHES per solve — the rest of the sweeps run inside the last one
     const int cap = g_dbg_plan_cap > 0 ? g_dbg_plan_cap : (int)MVS_KNOB("MVS_RAS_PLAN_CAP", 0, 0, 128);
