@@ -23,12 +23,13 @@ __device__ inline void local_fetch_a(const SellDev& m, const double* __restrict_
     E.passes = m.single_pass ? 1 : (m.slice_off[g + 1] - E.off) >> 6;
     E.pi = ld3(pts + 3 * i); E.qi = ld3(sol + 3 * i);
     E.judge = bvec != nullptr && m.is_ctrl[i] == 0;
+    // (weights and columns of the eight entries together, then the select: as "col only where w != 0" the compiler waited for
+    //  every weight before it issued the guarded column load — sixteen dependent accesses in a row)
+    int cj[8];
 #pragma unroll
-    for (int l = 0; l < 8; ++l) {
-        const int e = E.off + r * 8 + l;
-        E.w0[l] = m.w[e];
-        E.j0[l] = E.w0[l] == 0.0 ? i : m.col[e];
-    }
+    for (int l = 0; l < 8; ++l) { const int e = E.off + r * 8 + l; E.w0[l] = m.w[e]; cj[l] = m.col[e]; }
+#pragma unroll
+    for (int l = 0; l < 8; ++l) E.j0[l] = E.w0[l] == 0.0 ? i : cj[l];
 }
 // second hop: the neighbours' positions
 __device__ inline void local_fetch_b(const double* __restrict__ pts, const double* __restrict__ sol, LocalEdges& E) {
