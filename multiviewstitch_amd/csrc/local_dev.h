@@ -13,7 +13,7 @@ namespace {
 
 // the first eight edges of a vertex (all of them when the degree is <= 8): weights, neighbours, then the edge vectors of the rest
 // and the current pose
-struct LocalEdges { int off, passes; d3 pi, qi; double w0[8]; int j0[8]; d3 pp0[8], qq0[8]; bool judge; };
+struct LocalEdges { int off, passes; d3 pi, qi; double w0[8]; int j0[8]; d3 pp0[8], qq0[8]; bool judge; d3 bi; double di; };
 
 // first hop: the vertex's own operands, its weights and neighbour indices (needs nothing but the vertex number)
 __device__ inline void local_fetch_a(const SellDev& m, const double* __restrict__ pts, const double* __restrict__ sol,
@@ -32,14 +32,19 @@ __device__ inline void local_fetch_a(const SellDev& m, const double* __restrict_
     for (int l = 0; l < 8; ++l) E.j0[l] = E.w0[l] == 0.0 ? i : cj[l];
 }
 // second hop: the neighbours' positions
-__device__ inline void local_fetch_b(const double* __restrict__ pts, const double* __restrict__ sol, LocalEdges& E) {
+// (+ the row's right-hand side and diagonal for the judge: with the neighbours' loads, not as a round trip of their own behind
+//  the covariance)
+__device__ inline void local_fetch_b(const SellDev& m, const double* __restrict__ pts, const double* __restrict__ sol,
+                                     const double* __restrict__ bvec, int i, LocalEdges& E) {
+    E.bi = mk3(0, 0, 0); E.di = 1.0;
+    if (E.judge) { E.bi = ld3(bvec + 3 * (int64_t)i); E.di = m.diag[i]; }
 #pragma unroll
     for (int l = 0; l < 8; ++l) { E.pp0[l] = E.pi - ld3(pts + 3 * E.j0[l]); E.qq0[l] = E.qi - ld3(sol + 3 * E.j0[l]); }
 }
 __device__ inline void local_fetch(const SellDev& m, const double* __restrict__ pts, const double* __restrict__ sol,
                                    const double* __restrict__ bvec, int i, LocalEdges& E) {
     local_fetch_a(m, pts, sol, bvec, i, E);
-    local_fetch_b(pts, sol, E);
+    local_fetch_b(m, pts, sol, bvec, i, E);
 }
 
 // rotation of vertex i -> rot; its energy term added to e_acc; with E.judge the squared true residual of row i (M^-1 norm)
@@ -80,8 +85,8 @@ __device__ inline void local_vertex(const SellDev& m, const double* __restrict__
             c[6] += w * (pp.z * qq.x); c[7] += w * (pp.z * qq.y); c[8] += w * (pp.z * qq.z);
         }
     if (judge) {
-        const d3 res = ld3(bvec + 3 * (int64_t)i) - ax;
-        const double inv_d = 1.0 / m.diag[i];
+        const d3 res = E.bi - ax;
+        const double inv_d = 1.0 / E.di;
         g0 += res.x * res.x * inv_d; g1 += res.y * res.y * inv_d; g2 += res.z * res.z * inv_d;
     }
     double R[9];

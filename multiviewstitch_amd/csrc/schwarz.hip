@@ -329,7 +329,7 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
             double e_acc = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
             if (row < nown_) {
                 if (!fetched) local_fetch_a(loc.m, loc.pts, xfin, loc.bpure, g_, Epre);
-                local_fetch_b(loc.pts, xfin, Epre);
+                local_fetch_b(loc.m, loc.pts, xfin, loc.bpure, g_, Epre);
                 local_vertex(loc.m, loc.pts, xfin, loc.bpure, g_, Epre, loc.rot, e_acc, g0, g1, g2);
             }
             if (wv < 4) {                                              // (owned rows <= 256: the first four waves)
