@@ -202,19 +202,25 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
     const int G4 = blockIdx.x * NW + (threadIdx.x >> 6), r16 = (threadIdx.x & 63) >> 2, q4 = threadIdx.x & 3;
     const int row4 = 16 * G4 + r16;
     const bool live4 = four_lanes && G4 < ngroups16 && row4 < m.V;
-    const bool free4 = live4 && !m.is_ctrl[row4];
-    d3 pi4 = mk3(0, 0, 0);
-    double ri4[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, w4[2] = {0.0, 0.0};
-    int j4[2] = {0, 0};
-    if (free4) {
-        pi4 = ld3(pts + 3 * row4);
-        const double* Ri = rot + 9 * (int64_t)row4;
+    // every operand that needs only the row number in ONE round trip, fetched whether or not the row turns out to be a free one
+    // (clamped addresses for the lanes without a row): behind the control flag they were a second trip, and the diagonal and x_i
+    // of the row — needed at the very end — a fourth
+    const int rowc = live4 ? row4 : 0;
+    const int isc4 = m.is_ctrl[rowc];
+    d3 pi4 = ld3(pts + 3 * rowc);
+    double ri4[9], w4[2];
+    int j4[2];
+    {
+        const double* Ri = rot + 9 * (int64_t)rowc;
 #pragma unroll
         for (int c = 0; c < 9; ++c) ri4[c] = Ri[c];
-        const int e0 = 64 * (2 * G4 + (r16 >> 3)) + (r16 & 7) * 8 + q4;
+        const int e0 = live4 ? 64 * (2 * G4 + (r16 >> 3)) + (r16 & 7) * 8 + q4 : q4;
 #pragma unroll
         for (int u = 0; u < 2; ++u) { w4[u] = m.w[e0 + 4 * u]; j4[u] = m.col[e0 + 4 * u]; }
     }
+    const double di4 = m.diag[rowc], sx4 = sol[3 * rowc + (q4 < 3 ? q4 : 0)];
+    const bool free4 = live4 && !isc4;
+    if (!free4) { w4[0] = 0.0; w4[1] = 0.0; j4[0] = 0; j4[1] = 0; }
     if (threadIdx.x < 64) {                      // wave 0 decides
         bool done = arap_done_before(efin, it - 1, tol);
         if (it >= 1) {
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
                 xj[u] = mk3(0, 0, 0); pj[u] = pi; cj[u] = 0;
 #pragma unroll
                 for (int c = 0; c < 9; ++c) rj[u][c] = 0.0;
-                if (w[u] != 0.0) {
+                {   // (unguarded: a padded entry's column is the row itself)
                     const double* Rj = rot + 9 * (int64_t)j[u];
 #pragma unroll
                     for (int c = 0; c < 9; ++c) rj[u][c] = Rj[c];
@@ -270,9 +276,9 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
             double res = 0.0;
             if (bpure) bpure[3 * row + q] = freerow ? (q == 0 ? bb.x - bd.x : (q == 1 ? bb.y - bd.y : bb.z - bd.z)) : 0.0;
             if (freerow) {
-                const double di = m.diag[row];
+                const double di = di4;
                 const double b_c = q == 0 ? bb.x : (q == 1 ? bb.y : bb.z);
-                const double a_c = (q == 0 ? ax.x : (q == 1 ? ax.y : ax.z)) + di * sol[3 * row + q];
+                const double a_c = (q == 0 ? ax.x : (q == 1 ? ax.y : ax.z)) + di * sx4;
                 res = b_c - a_c;
                 bn_acc += b_c * b_c / di;
             }
