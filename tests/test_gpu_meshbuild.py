@@ -34,6 +34,29 @@ def _adjacency(V, faces):
     return [sorted((j, sorted(o)) for j, o in r.items()) for r in nb], vf
 
 
+def _rcb(pts, parts):
+    """recursive coordinate bisection as meshbuild.hip specifies it: the widest axis of the segment's bounding box (ties: the
+    lower axis), vertices ordered by (float32 coordinate with -0 = +0, vertex index), the first n * (k // 2) // k of them to the left"""
+    out = []
+
+    def rec(idx, k):
+        if k == 1:
+            out.append(np.sort(idx))
+            return
+        p = pts[idx]
+        ext = p.max(0) - p.min(0)
+        ax = int(np.argmax(ext))                              # (first maximum)
+        key = p[:, ax].astype(np.float32) + np.float32(0.0)
+        o = np.lexsort((idx, key))
+        kl = k // 2
+        nl = len(idx) * kl // k
+        rec(idx[o[:nl]], kl)
+        rec(idx[o[nl:]], k - kl)
+
+    rec(np.arange(len(pts)), parts)
+    return out
+
+
 def _meshes(oracle):
     from multiviewstitch_amd import scene as S
     sc1, _, _, _ = scene_and_target(1)
@@ -97,6 +120,9 @@ def test_device_built_tables_match_a_numpy_rebuild(oracle):
         gent, gcol = _table(d, 13, np.int32).reshape(NP, W, LS), _table(d, 14, np.int32).reshape(NP, W, LS)
         assert W == (6 if deg.max() <= 6 else 8 if deg.max() <= 8 else 12 if deg.max() <= 12 else 16)
         assert pnloc.sum() == total_rows and pnloc.max() <= LS <= 1024 and LS % 64 == 0 and (LS + pnh.max()) <= 1024
+        parts = _rcb(np.asarray(verts, np.float64), int(NP))       # the bisection itself: every patch owns exactly the specified part
+        for p in range(NP):
+            assert np.array_equal(l2g[p, :pown[p]], parts[p]), (name, p)
         owner = np.full(V, -1)
         for p in range(NP):
             own = l2g[p, :pown[p]]
