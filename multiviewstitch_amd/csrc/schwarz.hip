@@ -23,6 +23,8 @@
 // gamma <= cg_tol^2 * bnorm for all three right-hand sides, degenerates into a copy of the owned rows (and so do all
 // later sweeps).  The host plans the number of sweeps per ARAP iteration from the previous harvest.
 #include "engine.h"
+#include <mutex>
+#include <vector>
 #include "dev_common.h"
 #include "arap_dev.h"
 #include "svd3_dev.h"
@@ -288,18 +290,20 @@ struct RasLocal {             // MODE == 2: the launch also performs the ARAP lo
     int nfold;                // partials per sum the consumers fold (>= patches: the slots beyond them are zero-filled here)
 };
 
+// (MODE 1 is compiled for workgroups of <= 512 threads like MODE 2 — under the 128-register cap of a 1024-thread workgroup its
+// tail loop spilled 324 bytes per thread — MODE 4 is the same code for the meshes whose patches need more than 512 threads.)
 // MODE 0: a planned sweep.  MODE 3: a planned sweep of a solve whose plan is long (the host's sign of stalled sweeps): it can mix
 // (RasMix) — a separate instantiation, the healthy regime's sweeps stay as lean as they were.  MODE 1: the last planned launch of a solve — should the plan turn out too short it keeps sweeping
 // behind the device-wide barrier.  MODE 2: MODE 1 and, once the solve has ended, the ARAP local step on the patch's owned rows
 // (workgroups of <= 512 threads: the local step wants ~210 VGPRs, k_arap_local's budget).
 template <int W, int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, const double* __restrict__ pw, const double* __restrict__ pd,
+__global__ __launch_bounds__((MODE == 2 || MODE == 1) ? 512 : RTPB) void k_ras_sweep(RasDev R, const double* __restrict__ pw, const double* __restrict__ pd,
                                                     const double* __restrict__ bvec, double* xa, double* xb, int it, double arap_tol,
                                                     double* __restrict__ ered, int nb_rhs, int sweep, double cg_tol, double stop_margin, double slow2,
                                                     double predict2, ChebCoef cc, int cheb_m, ChebCoef cc_strong, int cheb_m_strong,
                                                     double* __restrict__ ctl, double* __restrict__ slot_prev,
                                                     double* __restrict__ slot_cur, int32_t* __restrict__ iters_cur, RasTail tail, RasLocal loc, RasMix mix) {
-    constexpr bool TAIL = MODE == 1 || MODE == 2;
+    constexpr bool TAIL = MODE == 1 || MODE == 2 || MODE == 4;         // (MODE 4 = MODE 1 for workgroups above 512 threads: 128 registers)
     constexpr bool MIX = MODE == 3;                                     // (the last planned launch of a solve takes the buffer as it is)
     constexpr bool FOLD_GUARDED = MODE == 2;                           // (fold_n: which form of the partial loads this instantiation affords)
     // LDS: fp64 x of the local rows and the halo while the residual is formed (24 KB), then the correction directions as
@@ -629,7 +633,10 @@ __global__ __launch_bounds__(MODE == 2 ? 512 : RTPB) void k_ras_sweep(RasDev R, 
     };
     int steps = sweep_body(slot_cur, xout);
     RSTAMP(5);
-    if (!TAIL) { if (row == 0) iters_cur[p] = steps; return; }
+    // (max_extra < 0: the launcher found that the workgroups of this launch cannot all be resident at once — the tail loop's
+    //  device-wide barrier would wait for workgroups that cannot start — so the last planned launch is an ordinary sweep; a solve
+    //  whose plan was too short is then a miss of the judge, and the plan grows)
+    if (!TAIL || tail.max_extra < 0) { if (row == 0) iters_cur[p] = steps; return; }
 
     // ---- TAIL: this is the last planned sweep of the solve and its input had not converged.  Whether its result has is
     //      known only after a device-wide reduction: instead of leaving the solve short, the launch keeps sweeping — barrier,
@@ -753,9 +760,37 @@ int ras_steps_for(double a) {
 // RAS_TAIL_MAX more) until the solve has converged, should the plan have been too short.
 static int g_tail_maxspin = 1 << 16;      // polls at the tail loop's barrier before a workgroup abandons the solve (tests lower it: mvs_debug_tail)
 void ras_set_tail_maxspin(int n) { g_tail_maxspin = n > 0 ? n : (1 << 16); }
-bool ras_can_fuse_local(const mvs_deform_s* h) { return h->has_ras && h->ras.NP <= MVS_NBMAX && h->ras_block <= 512; }
+static int ras_device_cus(int device);
+// (the fused instantiation takes every register of a CU: one 512-thread workgroup each — its tail loop needs NP <= CUs)
+bool ras_can_fuse_local(const mvs_deform_s* h) { return h->has_ras && h->ras.NP <= MVS_NBMAX && h->ras_block <= 512 && h->ras.NP <= ras_device_cus(h->device); }
 int ras_local_parts(const mvs_deform_s* h) { return ras_can_fuse_local(h) ? std::max(h->ras.NP, arap_grid_blocks(h->sell)) : arap_grid_blocks(h->sell); }
 
+template <int T> static const void* ras_sweep_fn(int W) {
+    return W == 6 ? (const void*)k_ras_sweep<6, T> : W == 8 ? (const void*)k_ras_sweep<8, T> : W == 12 ? (const void*)k_ras_sweep<12, T> : (const void*)k_ras_sweep<16, T>;
+}
+static int ras_device_cus(int device);
+// can all `np` workgroups of `block` threads of this instantiation be resident at once?  (asked once per instantiation and shape)
+static bool ras_tail_resident(int mode, int W, int block, int np, int device) {
+    struct Key { int mode, W, block, device, per_cu; };
+    static std::vector<Key> cache;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Key& k : cache) if (k.mode == mode && k.W == W && k.block == block && k.device == device) return (int64_t)k.per_cu * ras_device_cus(device) >= np;
+    int per_cu = 0;
+    const void* fn = mode == 2 ? ras_sweep_fn<2>(W) : mode == 1 ? ras_sweep_fn<1>(W) : ras_sweep_fn<4>(W);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, 0) != hipSuccess) per_cu = 0;
+    cache.push_back({mode, W, block, device, per_cu});
+    return (int64_t)per_cu * ras_device_cus(device) >= np;
+}
+static int ras_device_cus(int device) {
+    static int cached_dev = -1, cached = 256;
+    if (cached_dev != device) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) cached = n;
+        cached_dev = device;
+    }
+    return cached;
+}
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, double* xout, int it, double arap_tol, int sweep,
                       double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots,
                       bool with_local, bool mixing_solve) {
@@ -784,17 +819,20 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, doubl
     const ChebCoef cc2 = coefs(strong_a);
     const int m2 = ras_steps_for(strong_a);
     const dim3 grid(R.NP), blk(h->ras_block);     // as many waves as the largest patch has rows (idle waves only add barrier cost)
-    const RasTail tail{h->d_bar, tail_slots, RAS_TAIL_MAX, g_tail_maxspin};
+    RasTail tail{h->d_bar, tail_slots, RAS_TAIL_MAX, g_tail_maxspin};
     const RasLocal loc{h->sell, h->d_pts, h->d_rot, h->d_bpure, ras_local_parts(h)};
     // mixing_solve: every planned sweep of this solve is the mixing instantiation (a solve is all lean or all mixing: the state in
     // the sweep slots is only kept by the latter, and cap = 0 tells every launch of a lean solve not to look at it)
     const RasMix mix{h->d_ras_mixf, h->d_ras_mixp, (mixing_solve && MVS_KNOB("MVS_MIX", 1, 0, 1) != 0.0) ? MVS_KNOB("MVS_MIX_CAP", 200.0, 1.0, 1e6) : 0.0,
                      (int)MVS_KNOB("MVS_MIX_SET", 1, 0, 1)};
-    const int mode = !tail_slots ? (mix.cap > 0.0 ? 3 : 0) : ((with_local && ras_can_fuse_local(h)) ? 2 : 1);
+    const int mode = !tail_slots ? (mix.cap > 0.0 ? 3 : 0) : ((with_local && ras_can_fuse_local(h)) ? 2 : ((h->ras_block <= 512 && (R.NP <= ras_device_cus(h->device) || MVS_KNOB("MVS_FORCE_MODE1", 0, 0, 1) != 0.0)) ? 1 : 4));
+    // (MODE 1's 200 registers allow ONE 512-thread workgroup per CU: with more patches than CUs the tail loop's device-wide barrier
+    //  would wait for workgroups that cannot start — config 4's 512 patches abandoned their solves — so those take MODE 4)
+    if ((mode == 1 || mode == 4) && !ras_tail_resident(mode, R.W, h->ras_block, R.NP, h->device)) tail.max_extra = -1;
 #define MVS_SWEEP(W, T) k_ras_sweep<W, T><<<grid, blk, 0, s>>>(R, h->d_ras_pw, h->d_ras_pd, b, xin, xout, it, arap_tol, h->d_energy, nb, sweep, cg_tol, stop_margin, \
                                                               RAS_SLOW * RAS_SLOW, RAS_PREDICT * RAS_PREDICT, cc, cheb_m, cc2, m2, h->d_ctl, slot_prev, slot_cur, iters_cur, tail, loc, mix)
 #define MVS_SWEEP_W(T) do { if (R.W == 6) MVS_SWEEP(6, T); else if (R.W == 8) MVS_SWEEP(8, T); else if (R.W == 12) MVS_SWEEP(12, T); else MVS_SWEEP(16, T); } while (0)
-    if (mode == 2) MVS_SWEEP_W(2); else if (mode == 1) MVS_SWEEP_W(1); else if (mode == 3) MVS_SWEEP_W(3); else MVS_SWEEP_W(0);
+    if (mode == 2) MVS_SWEEP_W(2); else if (mode == 1) MVS_SWEEP_W(1); else if (mode == 4) MVS_SWEEP_W(4); else if (mode == 3) MVS_SWEEP_W(3); else MVS_SWEEP_W(0);
 #undef MVS_SWEEP_W
 #undef MVS_SWEEP
 }
