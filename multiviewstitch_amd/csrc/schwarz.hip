@@ -376,19 +376,9 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 1) ? 512 : RTPB) void k_ras_s
     const double dd = pd[base + row];
     const double skip_flag = sweep > 0 ? slot_prev[3 * NPpad + 6] : 0.0;
     const double mix_prev = (sweep > 0 && mix.cap > 0.0) ? slot_prev[3 * NPpad + 8] : 0.0;      // (same round trip as the skip flag)
-    if (skip_flag != 0.0) {
-        if (p == 0 && row == 0) { slot_cur[3 * NPpad + 6] = 1.0; slot_cur[3 * NPpad + 7] = slot_prev[3 * NPpad + 7]; }
-        if (p == 0 && row < 3) slot_cur[3 * NPpad + 3 + row] = slot_prev[3 * NPpad + 3 + row];      // (the right-hand side's norms: the harvest reads them from a solve's last slot)
-        if (row == 0) iters_cur[p] = 0;
-        if constexpr (MODE == 2) {
-            // the solve ended in an earlier launch (both buffers hold the result everywhere): only the local step is left — unless
-            // the reference's energy stop rule had ended the ARAP iterations before this one
-            if (row == 0) s_done = arap_done_before(ered + EFIN, it, arap_tol) ? 1 : 0;
-            __syncthreads();
-            if (!s_done) local_step(xa, nown, g, false);
-        }
-        return;
-    }
+    const double* xfin = nullptr;                                      // (MODE 2) the buffer that holds the solve's result everywhere,
+    bool do_local = false, lfetched = false;                           // whether the local step is due, whether its first hop is in Epre
+    auto rest = [&]() {
     RSTAMP(0);
 #pragma unroll
     for (int e = 0; e < W; ++e) if (lc[e] < 0) { lc[e] = row; w2[e] = 0.0; }              // padding entries
@@ -489,7 +479,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 1) ? 512 : RTPB) void k_ras_s
         if (row < nown) st3(xout + 3 * (int64_t)g, xi);
         if (row < 12) slot_cur[(row >> 2) * NPpad + 4 * p + (row & 3)] = (frozen && !s_done) ? slot_prev[(row >> 2) * NPpad + 4 * p + (row & 3)] : 0.0;
         if (row == 0) iters_cur[p] = 0;
-        if (MODE == 2 && !s_done) local_step(xin, nown, g, true);      // this launch decided: the input is the result (complete since the last launch)
+        if (MODE == 2 && !s_done) { xfin = xin; do_local = true; lfetched = true; }      // this launch decided: the input is the result (complete since the last launch)
         return;
     }
     const double di = fixed ? 1.0 : dd;
@@ -711,7 +701,23 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 1) ? 512 : RTPB) void k_ras_s
         slot_cur[3 * NPpad + 7] = ran_before + 1.0 + (double)extra;
     }
     if (row == 0) iters_cur[p] = steps;
-    if (MODE == 2 && !abandoned) local_step(xout, nown, g, false);
+    if (MODE == 2 && !abandoned) { xfin = xout; do_local = true; lfetched = false; }
+    };
+    if (skip_flag != 0.0) {
+        if (p == 0 && row == 0) { slot_cur[3 * NPpad + 6] = 1.0; slot_cur[3 * NPpad + 7] = slot_prev[3 * NPpad + 7]; }
+        if (p == 0 && row < 3) slot_cur[3 * NPpad + 3 + row] = slot_prev[3 * NPpad + 3 + row];      // (the right-hand side's norms: the harvest reads them from a solve's last slot)
+        if (row == 0) iters_cur[p] = 0;
+        if constexpr (MODE == 2) {
+            // the solve ended in an earlier launch (both buffers hold the result everywhere): only the local step is left — unless
+            // the reference's energy stop rule had ended the ARAP iterations before this one
+            if (row == 0) s_done = arap_done_before(ered + EFIN, it, arap_tol) ? 1 : 0;
+            __syncthreads();
+            if (!s_done) { xfin = xa; do_local = true; }
+        }
+    } else rest();
+    // ONE call site of the local step for the three ways that lead to it (solve finished in an earlier launch / found finished by
+    // this one / finished inside this one): inlined three times the fused instantiation was 13 K instructions
+    if constexpr (MODE == 2) { if (do_local) local_step(xfin, nown, g, lfetched); }
 }
 
 }  // namespace
