@@ -851,6 +851,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     }
     const int node = blockIdx.x * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (node >= K) return;
+    // ONE copy of the nearest-distance search and ONE of the selection in this kernel: with a second pair for "the heavy list is
+    // full" (which cannot happen: the list has room for every node, each node appends at most once) it was 12.7 K instructions,
+    // twice the instruction cache, for waves that are all at different places of it
     bool deferred = false;
     const float best = dmin_node(g, node_pts, node, INFINITY, heavy ? &deferred : nullptr);
     if ((threadIdx.x & 63) == 0) d2min[node] = best;         // (deferred: the best of the fine shells, an upper bound)
@@ -859,10 +862,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
         int slot = 0;
         if ((threadIdx.x & 63) == 0) slot = atomicAdd(&heavy[0], 1);
         slot = rl_i(slot, 0);
-        if (slot < heavy_cap) { if ((threadIdx.x & 63) == 0) heavy[1 + slot] = node | HEAVY_DMIN_FLAG; return; }
-        const float full = dmin_node(g, node_pts, node);     // (list full: cannot happen with heavy_cap = K)
-        if ((threadIdx.x & 63) == 0) d2min[node] = full;
-        select_node<1>(g, node_pts, node_nrm, node, top_k, full, rec, counts, nullptr, 0, nullptr, lm);
+        if ((threadIdx.x & 63) == 0 && slot < heavy_cap) heavy[1 + slot] = node | HEAVY_DMIN_FLAG;
         return;
     }
     select_node<1>(g, node_pts, node_nrm, node, top_k, best, rec, counts, heavy, heavy_cap, nullptr, lm);
