@@ -55,6 +55,28 @@ __device__ inline void ng_knn_query(int q, const double* __restrict__ pts, int n
         const int cx = ng_axis(qx, g.minx, g.inv_h, g.nx), cy = ng_axis(qy, g.miny, g.inv_h, g.ny), cz = ng_axis(qz, g.minz, g.inv_h, g.nz);
         float m = fminf(fminf(fminf(fx - cx, cx + 1 - fx), fminf(fy - cy, cy + 1 - fy)), fminf(fz - cz, cz + 1 - fz));
         m = fmaxf(m, 0.0f);
+        // the lanes' candidates (has: this lane holds one) into the wave-resident sorted list
+        auto insert = [&](bool has, float d, int j) {
+            unsigned long long pend = __ballot(has && (len < k || dl_less(d, j, t_d, t_i)));
+            while (pend) {
+                const int src = __ffsll((long long)pend) - 1;
+                const float c_d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), src));
+                const int c_i = __builtin_amdgcn_readlane(j, src);
+                const bool less = lane < len && dl_less(L_d, L_i, c_d, c_i);
+                const int pos = __popcll(__ballot(less));
+                const float u_d = __int_as_float(wave_shr1(__float_as_int(L_d)));
+                const int u_i = wave_shr1(L_i);
+                if (lane > pos && lane <= len && lane < k) { L_d = u_d; L_i = u_i; }
+                else if (lane == pos) { L_d = c_d; L_i = c_i; }
+                len = min(len + 1, k);
+                if (len == k) {
+                    t_d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L_d), k - 1));
+                    t_i = __builtin_amdgcn_readlane(L_i, k - 1);
+                }
+                if (lane == src) has = false;
+                pend = __ballot(has && (len < k || dl_less(d, j, t_d, t_i)));
+            }
+        };
         auto scan = [&](int A, int B) {
             for (int cb = A; cb < B; cb += 64) {
                 const int i = cb + lane;
@@ -66,25 +88,7 @@ __device__ inline void ng_knn_query(int q, const double* __restrict__ pts, int n
                     j = __float_as_int(p.w);
                     has = !(d != d);
                 }
-                unsigned long long pend = __ballot(has && (len < k || dl_less(d, j, t_d, t_i)));
-                while (pend) {
-                    const int src = __ffsll((long long)pend) - 1;
-                    const float c_d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), src));
-                    const int c_i = __builtin_amdgcn_readlane(j, src);
-                    const bool less = lane < len && dl_less(L_d, L_i, c_d, c_i);
-                    const int pos = __popcll(__ballot(less));
-                    const float u_d = __int_as_float(wave_shr1(__float_as_int(L_d)));
-                    const int u_i = wave_shr1(L_i);
-                    if (lane > pos && lane <= len && lane < k) { L_d = u_d; L_i = u_i; }
-                    else if (lane == pos) { L_d = c_d; L_i = c_i; }
-                    len = min(len + 1, k);
-                    if (len == k) {
-                        t_d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L_d), k - 1));
-                        t_i = __builtin_amdgcn_readlane(L_i, k - 1);
-                    }
-                    if (lane == src) has = false;
-                    pend = __ballot(has && (len < k || dl_less(d, j, t_d, t_i)));
-                }
+                insert(has, d, j);
             }
         };
         const int smax = max(g.nx, max(g.ny, g.nz));
@@ -107,12 +111,33 @@ __device__ inline void ng_knn_query(int q, const double* __restrict__ pts, int n
                         }
                     }
                 }
-                unsigned long long mask = __ballot(b0 > a0 || b1 > a1);
+                // The ranges of a node grid hold a handful of points each: EIGHT ranges per load, lane = (range, point) — range
+                // after range, every occupied row of a shell was a memory round trip of its own (~30 per query).  Range slot
+                // 2 r + w of this pass = range w of the row lane r holds; points beyond the eighth of a range follow the plain way.
+                const int nslots = 2 * min(64, nrows - base);
+                for (int s0 = 0; s0 < nslots; s0 += 8) {
+                    const int slot = s0 + (lane >> 3), src = slot >> 1;
+                    const int ra0 = __shfl(a0, src, 64), rb0 = __shfl(b0, src, 64), ra1 = __shfl(a1, src, 64), rb1 = __shfl(b1, src, 64);
+                    const int A = (slot & 1) ? ra1 : ra0, B = (slot & 1) ? rb1 : rb0;
+                    const int i = A + (lane & 7);
+                    float d = INFINITY; int j = -1;
+                    bool has = false;
+                    if (slot < nslots && i < B) {
+                        const float4 p = sorted[i];
+                        d = d2f(qx, qy, qz, p.x, p.y, p.z);
+                        j = __float_as_int(p.w);
+                        has = !(d != d);
+                    }
+                    insert(has, d, j);
+                }
+                unsigned long long mask = __ballot(b0 - a0 > 8 || b1 - a1 > 8);
                 while (mask) {
                     const int l = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
-                    scan(__builtin_amdgcn_readlane(a0, l), __builtin_amdgcn_readlane(b0, l));
-                    scan(__builtin_amdgcn_readlane(a1, l), __builtin_amdgcn_readlane(b1, l));
+                    const int A0 = __builtin_amdgcn_readlane(a0, l), B0 = __builtin_amdgcn_readlane(b0, l);
+                    const int A1 = __builtin_amdgcn_readlane(a1, l), B1 = __builtin_amdgcn_readlane(b1, l);
+                    if (B0 - A0 > 8) scan(A0 + 8, B0);
+                    if (B1 - A1 > 8) scan(A1 + 8, B1);
                 }
             }
             const float bound = ((float)s + m - 0.01f) * g.h;
