@@ -634,7 +634,8 @@ __global__ void k_arap_finalize(SellDev m, int iters, double tol, int nb, double
                         for (int t = 0; t < MVS_CTL_SEQ; ++t) host_ctl[t] = ctl[t];
                         __threadfence_system();
                         host_ctl[MVS_CTL_SEQ] = ctl[MVS_CTL_SEQ];                 // last: a row is complete when its sequence number shows
-                        __threadfence_system();
+                        // (no second fence: nothing follows the sequence number, and the end of the kernel releases it — the fence
+                        //  was a PCIe round trip at the end of the launch's longest chain)
                     }
                 }
             }
