@@ -214,7 +214,7 @@ def test_patch_solver_adapts_to_the_node_density(eng, oracle, stride):
     ref = oracle.arap(sc.verts, sc.faces, nodes, tg, 5, 1e-4)
     assert st["arap_iters_run"] == ref["iters"] and st["cg_rel_residual"] <= 1.5 * d.params.cg_tol
     assert rms(d.vertices(), ref["pts"]) <= 1e-6
-    # the first call ran the short uncalibrated plan (8 launches per solve, the rest of the sweeps inside the last one);
+    # the first call ran the short uncalibrated plan (7 6 5 5 5 launches for the five solves, the rest of the sweeps inside the last one);
     # the second runs the plan the harvest made of it: what the solves used plus the spares
     st2 = d.arap(tg)
     assert st2["cg_rel_residual"] <= 1.5 * d.params.cg_tol and st2["status"] == 0
