@@ -152,16 +152,33 @@ __device__ inline float dmin_node(const GridDev& g, const double* __restrict__ n
         for (int s = 0; s <= 1 && !found; ++s) {
             const int side = 2 * s + 1, nrows = side * side;     // <= 9 rows: one pass
             int a0 = 0, b0 = 0, a1 = 0, b1 = 0;
+            // (shell 1 after a shell 0 that found points: only the cells a CLOSER point could lie in — lower bound of the cell's box,
+            //  the slack of axis_gap included, against the best distance so far.  A node on the surface has its nearest point a fraction
+            //  of a cell away: of the 26 neighbour cells two or three remain, and with them one group of loads instead of five.)
+            const float lim = best * g.inv_h * g.inv_h;                          // (inf while nothing has been seen: every cell stays)
             if (lane < nrows) {
                 const int dy = lane / side - s, dz = lane % side - s;
                 const int y = c.cy + dy, z = c.cz + dz;
                 if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
-                    if (abs(dy) == s || abs(dz) == s) {          // face rows of the shell: whole x run
-                        const int x0 = max(c.cx - s, 0), x1 = min(c.cx + s, g.nx - 1);
-                        if (x0 <= x1) run2(y, z, x0, x1, a0, b0, a1, b1);
-                    } else {                                      // interior row: the two end cells
-                        if (c.cx - s >= 0) { const int64_t i0 = grid_index(g.NX, g.NY, c.cx - s, y, z); a0 = cs[i0]; b0 = cs[i0 + 1]; }
-                        if (c.cx + s < g.nx) { const int64_t i1 = grid_index(g.NX, g.NY, c.cx + s, y, z); a1 = cs[i1]; b1 = cs[i1 + 1]; }
+                    const float ey = axis_gap(c.fy, (float)y, (float)y + 1.0f), ez = axis_gap(c.fz, (float)z, (float)z + 1.0f);
+                    const float rem = lim - (ey * ey + ez * ez);                 // what is left for the x gap
+                    if (rem >= 0.0f) {
+                        if (abs(dy) == s || abs(dz) == s) {      // face rows of the shell: whole x run
+                            int x0 = max(c.cx - s, 0), x1 = min(c.cx + s, g.nx - 1);
+                            // (the end cells of the run only if their x gap fits; the query's own column always does)
+                            if (x0 < c.cx) { const float ex = axis_gap(c.fx, (float)x0, (float)x0 + 1.0f); if (ex * ex > rem) ++x0; }
+                            if (x1 > c.cx) { const float ex = axis_gap(c.fx, (float)x1, (float)x1 + 1.0f); if (ex * ex > rem) --x1; }
+                            if (x0 <= x1) run2(y, z, x0, x1, a0, b0, a1, b1);
+                        } else {                                  // interior row: the two end cells
+                            if (c.cx - s >= 0) {
+                                const float ex = axis_gap(c.fx, (float)(c.cx - s), (float)(c.cx - s) + 1.0f);
+                                if (ex * ex <= rem) { const int64_t i0 = grid_index(g.NX, g.NY, c.cx - s, y, z); a0 = cs[i0]; b0 = cs[i0 + 1]; }
+                            }
+                            if (c.cx + s < g.nx) {
+                                const float ex = axis_gap(c.fx, (float)(c.cx + s), (float)(c.cx + s) + 1.0f);
+                                if (ex * ex <= rem) { const int64_t i1 = grid_index(g.NX, g.NY, c.cx + s, y, z); a1 = cs[i1]; b1 = cs[i1 + 1]; }
+                            }
+                        }
                     }
                 }
             }
