@@ -279,9 +279,10 @@ constexpr int RAS_MAX_SWEEPS = 128;
 // with a short plan runs its extra sweeps in the last launch, unmixed, 15 us each (17-21 of them: 0.3 ms for one solve).  So once
 // any plan reaches RAS_MIX_PLAN every solve of the handle gets mixing sweeps and a plan of at least RAS_MIX_PLAN launches (the
 // ones a solve does not need return after one load, ~4 us each); back to lean sweeps after RAS_MIX_CALM passes in which every
-// solve's need stayed at a healthy solve's length.
+// solve's need stayed at a healthy solve's length (<= RAS_MIX_OFF launches).
 #define RAS_MIX_PLAN ((int)MVS_KNOB("MVS_MIX_PLAN", 9, 2, 128))
-constexpr int RAS_MIX_OFF = 5, RAS_MIX_CALM = 64;
+constexpr int RAS_MIX_OFF = 7, RAS_MIX_CALM = 16;      // (healthy plans are 4-7 launches, a mixing solve's 8-12, a stalled one's 17+: config 4 went
+                                                        //  on at a transient and, with "<= 5 for 64 passes", never came back: 45 launches for 20 sweeps)
 void update_mix_state(mvs_deform_s* h, int arap_iters) {
     bool any_long = false, all_short = true;
     for (int it = 0; it < arap_iters; ++it) {
