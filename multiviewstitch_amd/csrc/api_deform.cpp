@@ -350,8 +350,14 @@ void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
     const int nn = p.graph_k + 1;
     const bool graph_here = defer && ensure_nbr(h, nn) == MVS_OK;
     if (graph_here) knn_grid_build(h->d_node_pts, K, h->d_knn_ws, h->stream);
+    // The first association of a fit meets the template far from the scan: a third of the nodes have balls wider than 25 grid rows
+    // (2 664 of 8 142 on the metric workload, ten rounds of the workgroup-per-node pass: 276 us) — up to 64 rows a single wave still
+    // copes (one row per lane); from the second pass on ~220 nodes are left and the lower threshold keeps the slowest wave short
+    // (0.7 % of a steady step).  Same results either way.
+    const int heavy_rows = h->assoc_passes == 0 ? 64 : 0;
+    h->assoc_passes++;
     launch_assoc_local(h->grid, h->d_node_pts, h->d_node_nrm, K, p, h->d_d2min, h->d_records, h->d_counts, cur, nxt, K, h->d_ctrl_raw,
-                       h->d_valid, h->d_top_idx, h->stream, defer, nn, h->d_nbr, graph_here ? h->d_knn_ws : nullptr);
+                       h->d_valid, h->d_top_idx, h->stream, defer, nn, h->d_nbr, graph_here ? h->d_knn_ws : nullptr, heavy_rows);
     h->graph_in_local = graph_here;
     h->heavy_pending = defer ? cur : nullptr;
     toc(t, defer ? 1 : 2);
@@ -926,7 +932,7 @@ static int install_nodes(mvs_deform_s* h, const int32_t* vertex_idx, int64_t K) 
     h->d_ctrl_final = h->d_ctrl_raw;
     h->cg_iters = 0;                                  // new node set: every launch plan and the solver bracket start over
     for (int i = 0; i < 8; ++i) { h->cg_plan[i] = 0; h->ras_plan[i] = 0; h->bump_seq[i] = 0; h->ras_hist_n[i] = 0; }
-    h->ras_mix_any = 0; h->ras_mix_calm = 0;
+    h->ras_mix_any = 0; h->ras_mix_calm = 0; h->assoc_passes = 0;
     HIPCHK(hipMemsetAsync(h->d_ctl, 0, sizeof(double) * 4, h->stream));     // verdicts of the old node set say nothing about the new one
     h->ras_a = 0.0; h->ras_m = 0;
     return MVS_OK;

@@ -390,6 +390,7 @@ struct LocalMerge {
     double* controls; uint8_t* valid; int64_t* top_idx;      // controls == NULL: sharded run, the lists go to k_assoc_merge
     double proj_len_err, proj_dist_err, min_cos;
     int max_result;
+    int heavy_rows;           // rows of a ball's bounding box above which the node is deferred (0: HEAVY_ROWS)
 };
 
 template <int PARTS>
@@ -505,7 +506,7 @@ __device__ inline void select_node(const GridDev& g, const double* __restrict__ 
             const int z0 = (int)fmaxf(lz, 0.f), z1 = (int)fminf(hz, (float)(g.nz - 1));
             const int ny_ = y1 - y0 + 1, nrows = ny_ * (z1 - z0 + 1);
             // a ball wider than a few cells goes to the workgroup-per-node kernel (one wave would need > 100 K cycles)
-            if (PARTS == 1 && heavy && nrows > HEAVY_ROWS) {
+            if (PARTS == 1 && heavy && nrows > (lm.heavy_rows > 0 ? lm.heavy_rows : HEAVY_ROWS)) {
                 int slot = 0;
                 if (lane == 0) slot = atomicAdd(&heavy[0], 1);
                 slot = rl_i(slot, 0);
@@ -1072,9 +1073,9 @@ void launch_assoc_select(const GridDev& g, const double* node_pts, const double*
 // ... and the merge: with one rank a node's list is final, its wave writes the node target itself
 void launch_assoc_local(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, float* d2min,
                         mvs_cand* rec, int32_t* counts, int32_t* heavy, int32_t* heavy_next, int heavy_cap, double* controls, uint8_t* valid,
-                        int64_t* top_idx, hipStream_t s, bool defer_heavy, int nn, int32_t* nbr, void* knn_ws) {
+                        int64_t* top_idx, hipStream_t s, bool defer_heavy, int nn, int32_t* nbr, void* knn_ws, int heavy_rows) {
     if (K <= 0) return;
-    const LocalMerge lm{controls, valid, top_idx, p.proj_len_err, p.proj_dist_err, p.min_cos, p.max_result};
+    const LocalMerge lm{controls, valid, top_idx, p.proj_len_err, p.proj_dist_err, p.min_cos, p.max_result, heavy_rows};
     // knn_ws != NULL: the grid of the node positions has been built in it (knn_grid_build, same stream): the node-graph queries
     // share the launch, nbr[K * nn] = each node's nn nearest nodes, itself included
     const void *geo = nullptr, *sorted = nullptr;
@@ -1096,7 +1097,7 @@ void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const doub
                             double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s,
                             const SellDev* mesh, const double* mesh_pts, int cot_blocks, bool with_knn) {
     if (K <= 0) return;
-    const LocalMerge lm{controls, valid, top_idx, p.proj_len_err, p.proj_dist_err, p.min_cos, p.max_result};
+    const LocalMerge lm{controls, valid, top_idx, p.proj_len_err, p.proj_dist_err, p.min_cos, p.max_result, 0};
     const void *geo, *sorted;
     const int* cs;
     knn_grid_views(knn_ws, K, &geo, &cs, &sorted);

@@ -175,6 +175,7 @@ struct mvs_deform_s {
     size_t sh_off_recin = 0, sh_off_cntin = 0, sh_off_tblk = 0, sh_off_tall = 0;      // owner-merges: records / counts of the owned block from every rank, merged targets
     double* d_bpure = nullptr;      // [V*3] right-hand side without its Dirichlet share (k_arap_rhs -> k_arap_local's true residual)
     double* d_ras_tail = nullptr;   // [8][RAS_TAIL_MAX] sweep slots of the in-kernel sweeps of TAIL launches
+    int assoc_passes = 0;                           // associations since the node set / target was installed (the first one defers fewer nodes)
     int ras_mix_any = 0, ras_mix_calm = 0;          // the handle's solves stall (late regime): planned sweeps are the mixing instantiation, plans keep a floor (update_mix_state)
     double* d_ras_mixf = nullptr;   // [V][3] the correction a mixing sweep applied to its (owned) rows: f_k = G(y_k) - y_k
     double* d_ras_mixp = nullptr;   // [2][6][NPpad] partial sums of <f_k, f_k - f_(k-1)> and |f_k - f_(k-1)|^2 per coordinate, by sweep parity
@@ -221,7 +222,7 @@ void launch_assoc_select(const GridDev& g, const double* node_pts, const double*
 void launch_assoc_local(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, float* d2min,
                         mvs_cand* rec, int32_t* counts, int32_t* heavy /*counter already 0*/, int32_t* heavy_next /*reset for the next call*/,
                         int heavy_cap, double* controls, uint8_t* valid, int64_t* top_idx, hipStream_t s, bool defer_heavy = false,
-                        int nn = 0, int32_t* nbr = nullptr, void* knn_ws = nullptr /* != NULL: the node-graph queries share the launch (grid built in it) */);
+                        int nn = 0, int32_t* nbr = nullptr, void* knn_ws = nullptr /* != NULL: the node-graph queries share the launch (grid built in it) */, int heavy_rows = 0 /*rows of a ball's bounding box above which the node goes to the heavy pass (0: default)*/);
 void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
                             float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, int heavy_cap,
                             double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s,

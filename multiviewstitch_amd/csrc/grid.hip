@@ -167,6 +167,7 @@ GridGeom make_geom(const float mn[3], const float mx[3], float h) {
 // (Round 2: 11 hipMallocs, 7 hipFrees — each a device synchronisation — and 5 stream synchronisations: 1.3 ms at config 3.)
 int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* nrm_dev, int64_t index_base) {
     hipStream_t s = h->stream;
+    h->assoc_passes = 0;
     h->prev_valid = false;                              // a new target: the remembered nearest distances say nothing about it
     h->has_target = false;
     h->P = P;
