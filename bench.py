@@ -290,8 +290,8 @@ def main():
         torch.cuda.synchronize(device)
 
     # ------------------------------------------------------------ warmup + timed ----
-    # the first outer iteration of a fresh handle calibrates the launch plan (sweeps go out in chunks with a host look at
-    # the residual): timed on its own, reported in "regime"
+    # the first outer iteration of a fresh handle runs fixed first plans (7 6 5 5 5 launches per solve, trimmed or extended by the
+    # device) and harvests them into the handle's launch plan: timed on its own, reported in "regime"
     fence()
     tf = time.perf_counter()
     run(1)
@@ -313,7 +313,11 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    # (sampled passes bracket the planned sweeps of a solve in two groups — "cg": the launches expected to do work, "cgB": the
+    #  spares behind them — and the idle flags those very launches left are read back: "cg_idle" / "cgB_idle" carry the counts)
     cg_ms, cg_launches = d.kernel_time("cg")
+    cgb_ms, cgb_launches = d.kernel_time("cgB")
+    idle_a, idle_b = d.kernel_time("cg_idle")[1], d.kernel_time("cgB_idle")[1]
     d.enable_timing(0)
     tail_ms, tail_launches = 0.0, 0
     if world == 1:                          # the last launch of every solve (decides; ARAP local step): events in a pass of its own, outside the timed region
@@ -362,23 +366,48 @@ def main():
         except Exception:
             pass
     active_per_step = st["cg_active"]
-    if cg_launches > 0 and cg_ms > 0:
-        # launches that found all three right-hand sides converged degenerate into a copy of the owned rows (patch
-        # sweeps) or exit after the scalar preamble (CG): only the active ones count as algorithmic traffic (stats of
-        # the last step; every step launches the same plan)
-        # the "cg" timer brackets the planned sweeps of a solve WITHOUT its last launch (patch solver: that one decides, and in fused
-        # mode performs the ARAP local step — timed as "tail"); in the steady state every active sweep is one of the former
+    timed_launches = int(cg_launches + cgb_launches)
+    if timed_launches > 0 and cg_ms + cgb_ms > 0:
+        # launches that found all three right-hand sides converged degenerate into a copy of the owned rows (the first one) or
+        # return after one scalar load (the others): only the active ones move the algorithmic bytes.  Active and idle launches
+        # are counted among the TIMED launches themselves (device flags), and their average durations separated from the two
+        # brackets' totals: T_cg = a * active_cg + b * idle_cg, T_cgB = a * active_cgB + b * idle_cgB.
         n_last = st["arap_iters_run"] if info["kind"] == "patch" else 0
-        active_frac = min(1.0, st["cg_active"] / max(1, st["cg_launches"] - n_last))
-        avg_s = 1e-3 * cg_ms / cg_launches
+        n_idle = int(idle_a + idle_b)
+        n_active = timed_launches - n_idle
+        act_a, act_b = cg_launches - idle_a, cgb_launches - idle_b
+        t_all = 1e-3 * (cg_ms + cgb_ms)
+        avg_s = t_all / timed_launches
+        a_s, b_s, how = None, None, None
+        det = act_a * idle_b - act_b * idle_a
+        if n_idle == 0:
+            a_s, how = avg_s, "no idle launch in the sample"
+        elif n_active == 0:
+            b_s, how = avg_s, "no active launch in the sample"
+        elif abs(det) >= 1 and min(cg_launches, cgb_launches) > 0:
+            a_s = 1e-3 * (cg_ms * idle_b - cgb_ms * idle_a) / det
+            b_s = 1e-3 * (cgb_ms * act_a - cg_ms * act_b) / det
+            how = "2x2 solve over the two brackets"
+        if a_s is None or b_s is None or a_s <= 0 or (b_s is not None and b_s < 0):
+            if n_active and n_idle:      # brackets of one composition: the idle launches at the kernel's shortest profiled duration
+                b_s = 2.5e-6
+                a_s = (t_all - n_idle * b_s) / n_active
+                how = "idle launches priced at 2.5 us (rocprofv3 minimum of the kernel)"
+        active_frac = n_active / timed_launches
         ach = active_frac * solve_bytes / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(ach / 8000.0, 4),
-                    "frac_active": round(solve_bytes / avg_s / 1e9 / 8000.0, 4) if active_frac > 0 else None,
+                    "frac_active": round(solve_bytes / a_s / 1e9 / 8000.0, 4) if a_s else None,
                     "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": solve_bytes,
-                    "avg_launch_us": round(1e6 * avg_s, 3), "launches": int(cg_launches), "active_fraction": round(active_frac, 3),
-                    "launches_per_step": int(st["cg_launches"]), "timed_sample": "the planned sweep launches of every 8th outer iteration of the timed region",
+                    "avg_launch_us": round(1e6 * avg_s, 3), "launches": timed_launches, "active_fraction": round(active_frac, 3),
+                    "active_launches": n_active, "avg_active_launch_us": round(1e6 * a_s, 3) if a_s else None,
+                    "idle_launches": n_idle, "avg_idle_launch_us": round(1e6 * b_s, 3) if b_s is not None else None,
+                    "brackets": {"cg": {"ms": round(cg_ms, 5), "launches": int(cg_launches), "idle": int(idle_a)},
+                                 "cgB": {"ms": round(cgb_ms, 5), "launches": int(cgb_launches), "idle": int(idle_b)}, "separation": how},
+                    "launches_per_step": int(st["cg_launches"]),
+                    "timed_sample": "the planned sweep launches of every 8th outer iteration of the timed region (HIP events on the engine's "
+                                    "stream); active / idle counted from the idle flags those launches left on the device",
                     "share_of_step": round(1e3 * (avg_s * (st["cg_launches"] - n_last) + (1e-3 * tail_ms / tail_launches * n_last if tail_launches else 0.0)) / ms_per_step, 3)}
         if tail_launches:
             roofline["last_launch_of_a_solve"] = {"kernel": "k_ras_sweep<W, 2> (decides the solve; ARAP local step on the owned rows)",
@@ -620,8 +649,9 @@ def main():
             "regime": {"timed": f"outer iterations {args.warmup}..{args.warmup + args.steps - 1} of a fresh fit from the template pose",
                        "first_outer_iteration_ms": round(first_ms, 3),
                        "note": "fewer than half of the nodes hold a correspondence in this regime (the reference rejects nodes whose "
-                               "mean direction is nearly tangential, |cos| < 0.1); after ~150 outer iterations the system's "
-                               "conditioning degrades and a step costs 2-4x (scripts/soak.py, DESIGN.md §4)"},
+                               "mean direction is nearly tangential, |cos| < 0.1); past ~170 outer iterations of a fit (which the reference "
+                               "never runs: counter = 1) one sliver triangle stalls the sweeps and the solver switches to Anderson-mixed "
+                               "sweeps: 0.63-0.68 ms per step (profiles/r03/soak_400_outer.log, DESIGN.md §5)"},
             "solver": {"worst_rel_residual_timed": timed["rel"], "solves_timed": timed["solves"],
                        "unconverged_solves_timed": timed["missed"], "status": timed["status"], "cg_tol": d.params.cg_tol},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,

@@ -498,9 +498,10 @@ int mvs_comm_destroy(mvs_comm_t c);
 /* an mvs_reduce_fn over a communicator (ctx = the mvs_comm_t): n <= 16 host doubles, op 0 = sum, 1 = min */
 int mvs_comm_reduce(void* comm, double* v, int n, int op);
 int mvs_comm_info(mvs_comm_t c, int* rank, int* nranks);
-/* How the ranks' best-8 records meet in mvs_deform_iterate_sharded: AUTO = all-gather up to 3 ranks, owner-merges from 4 on
- * (every rank receives and merges only the node block it owns: K * 392 bytes into a rank instead of N * K * 392, then one
- * all-gather of 25 bytes per node); the result is the same bits either way. */
+/* How the ranks' best-8 records meet in mvs_deform_iterate_sharded: AUTO = ALL_GATHER at every rank count; OWNER (on request)
+ * = every rank receives and merges only the node block it owns (K * 392 bytes into a rank instead of N * K * 392, then one
+ * all-gather of 25 bytes per node); the result is the same bits either way.  OWNER has run with one rank only on hardware
+ * (the point-to-point step is then a device copy): AUTO does not select it until a multi-GPU run has pinned it. */
 enum { MVS_EXCHANGE_AUTO = 0, MVS_EXCHANGE_ALL_GATHER = 1, MVS_EXCHANGE_OWNER = 2 };
 int mvs_comm_set_exchange(mvs_comm_t c, int mode);
 int mvs_deform_iterate_sharded(mvs_deform_t h, mvs_comm_t c, const mvs_deform_params* p, int n_outer, mvs_deform_stats* stats);
@@ -537,7 +538,10 @@ int mvs_deform_arap(mvs_deform_t h, const mvs_deform_params* p,
  * hipEvents on the handle's stream (bench.py's roofline object).  names:
  * "assoc", "graph", "smooth", "weights", "rhs", "cg", "local", "finalize". */
 int mvs_deform_kernel_time(mvs_deform_t h, const char* name, double* total_ms, int64_t* launches);
-/* on: 0 off, 1 every phase, 2 only the "cg" groups (two events per global solve), 3 the "cg" groups of every fourth pass. */
+/* on: 0 off, 1 every phase, 2 only the "cg" / "tail" groups (two events per global solve), 3 the planned sweeps of every eighth
+ * pass in two brackets — "cg" (the launches expected to do work) and "cgB" (the spare launches behind them) — with the idle
+ * flags those launches left on the device read back: the `launches` field of "cg_idle" / "cgB_idle" counts the bracketed
+ * launches that found their solve already finished. */
 int mvs_deform_enable_timing(mvs_deform_t h, int on);
 
 #ifdef __cplusplus

@@ -4,6 +4,7 @@
 #include "engine.h"
 #include "trace.h"
 #include "knobs.h"
+#include "../../include/mvs_test.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -193,7 +194,7 @@ struct Tic { mvs_deform_s* h; const char* name; hipEvent_t a; };
 // of every EIGHTH pass (what bench.py keeps on inside its timed region — the sampled passes hold the same launch mix as the others)
 bool timed(const mvs_deform_s* h, const char* name) {
     if (h->timing == 1) return true;
-    const bool cg = std::strcmp(name, "cg") == 0, tail = std::strcmp(name, "tail") == 0;
+    const bool cg = std::strcmp(name, "cg") == 0 || std::strcmp(name, "cgB") == 0, tail = std::strcmp(name, "tail") == 0;
     if (!cg && !tail) return false;
     // (an event pair costs ~4 us of stream time — the marker packets break the back-to-back dispatch of the launches around them:
     //  bench.py's timed region keeps only the pair around the planned sweeps of every EIGHTH pass, ~0.2 % of a step)
@@ -221,6 +222,18 @@ void collect_timers(mvs_deform_s* h) {
     h->pending.clear();
     for (auto& kv : h->pending_launches) h->timers[kv.first].launches += kv.second;
     h->pending_launches.clear();
+    // (mode 3) how many launches of the sampled brackets found their solve finished: "cg_idle" / "cgB_idle" carry the counts in
+    // their launch fields (the stream has been synchronised: the flag copies have landed)
+    for (size_t q = 0; q < h->sample_off.size(); ++q) {
+        const double* F = h->h_sample + h->sample_off[q];
+        const size_t s0 = (size_t)h->sample_pass_first[q], s1 = q + 1 < h->sample_off.size() ? (size_t)h->sample_pass_first[q + 1] : h->samples.size();
+        for (size_t k = s0; k < s1; ++k) {
+            const mvs_deform_s::SweepSample& sm = h->samples[k];
+            for (int i = 0; i < sm.n_a; ++i) if (F[(size_t)(sm.first + i) * 8 + 6] != 0.0) h->timers["cg_idle"].launches++;
+            for (int i = 0; i < sm.n_b; ++i) if (F[(size_t)(sm.first + sm.n_a + i) * 8 + 6] != 0.0) h->timers["cgB_idle"].launches++;
+        }
+    }
+    h->samples.clear(); h->sample_off.clear(); h->sample_pass_first.clear(); h->sample_used = 0;
 }
 
 void free_nodes(mvs_deform_s* h) {
@@ -296,13 +309,12 @@ void update_mix_state(mvs_deform_s* h, int arap_iters) {
     }
 }
 
-int g_dbg_plan_cap = 0;              // tests (mvs_debug_tail): at most this many launches per solve, the rest of its sweeps run in the last one
 RasPlan probe_ras(const mvs_deform_s* h) {
     RasPlan r;
     for (int i = 0; i < 8; ++i) r.n[i] = h->ras_plan[i] > 0 ? h->ras_plan[i] : RAS_FIRST_PLANS[i];
     if (h->ras_mix_any) for (int i = 0; i < 8; ++i) r.n[i] = std::max(r.n[i], RAS_MIX_PLAN);      // (update_mix_state)
     // experiment (scripts/host_bound.py): at most this many LAUNCHES per solve — the rest of the sweeps run inside the last one
-    const int cap = g_dbg_plan_cap > 0 ? g_dbg_plan_cap : (int)MVS_KNOB("MVS_RAS_PLAN_CAP", 0, 0, 128);
+    const int cap = h->dbg_plan_cap > 0 ? h->dbg_plan_cap : (int)MVS_KNOB("MVS_RAS_PLAN_CAP", 0, 0, 128);
     if (cap > 0) for (int i = 0; i < 8; ++i) r.n[i] = std::min(r.n[i], cap);
     return r;
 }
@@ -335,6 +347,17 @@ static int ensure_nbr(mvs_deform_s* h, int nn) {
     if (!h->d_nbr || nn < 1 || nn > 64) { mvs_set_error("no node set / graph_k out of range"); return MVS_E_STATE; }
     h->nbr_k = nn;
     return MVS_OK;
+}
+
+// (timing mode 3) room for one more sampled pass's slot scalars in the pinned buffer?  Allocated at the first sampled pass.
+bool sample_room(mvs_deform_s* h, int64_t nslots) {
+    if (!h->h_sample) {
+        void* hp = nullptr;
+        const size_t cap = (size_t)64 * 8 * 64;                              // 64 passes of 64 slots (a pass holds 20-40)
+        if (hipHostMalloc(&hp, cap * sizeof(double), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+        h->h_sample = (double*)hp; h->sample_cap = cap; h->sample_used = 0;
+    }
+    return h->sample_used + (size_t)nslots * 8 <= h->sample_cap;
 }
 
 void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
@@ -449,6 +472,8 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     const int nl = ras ? ras_local_parts(h) : 0;
     const int demand_local = (fused && !safe_local) ? 1 : 0;          // the judge of a solve insists that its fused local step ran
     const double* prev_scal = nullptr;   // the 8 scalars of the last sweep slot of the previous solve (idle flag, sweeps that ran)
+    const bool sampling = ras && h->timing == 3 && timed(h, "cg") && sample_room(h, rp.total(p.arap_iters));
+    if (sampling) h->sample_pass_first.push_back((int)h->samples.size());
     for (int it = 0; ras && it < p.arap_iters; ++it) {
         {
             Tic t = tic(h, "rhs");
@@ -471,8 +496,23 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
                 ++ras_slot;
             };
             // ("cg" = the planned sweeps, "tail" = the solve's last launch — in fused mode the deciding launch + the local step)
-            for (int i = 0; i + 1 < rp.n[it]; ++i) sweep(i, false);
-            toc(t, rp.n[it] - 1);
+            // Sampled passes of timing mode 3 bracket the planned sweeps in two groups: "cg" = as many launches as the solve
+            // ran sweeps the last time the host looked (they do work), "cgB" = the spare launches behind them (they find the
+            // solve finished: one copy, then returns after one load).  Which launches were idle is READ BACK (sample_flags).
+            const int planned = rp.n[it] - 1;
+            int n_a = planned;
+            if (sampling) {
+                const int ran = h->ras_hist_n[it] > 0 ? h->ras_hist[it][h->ras_hist_n[it] - 1] : planned;
+                n_a = std::max(0, std::min(planned, ran));
+                h->samples.push_back({(int)ras_slot, n_a, planned - n_a});
+            }
+            for (int i = 0; i < n_a; ++i) sweep(i, false);
+            toc(t, n_a);
+            if (n_a < planned) {
+                Tic tb = tic(h, "cgB");
+                for (int i = n_a; i < planned; ++i) sweep(i, false);
+                toc(tb, planned - n_a);
+            }
             Tic tl = tic(h, "tail");
             sweep(rp.n[it] - 1, true);
             toc(tl, 1);
@@ -507,14 +547,22 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
     Tic t = tic(h, "finalize");
     int n = 1;
     if (p.update_normals) {              // the node normals change too: separate gather after the normals kernel
-        launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, nullptr, nullptr, nullptr, p.cg_tol, h->d_ctl, slot, host_ctl, prev_scal, s, nl, demand_local);   // :400
+        launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, nullptr, nullptr, nullptr, p.cg_tol, h->d_ctl, slot, host_ctl, prev_scal, s, nl, demand_local, (double)(h->seq_enqueued + 1));   // :400
         launch_vertex_normals(h->d_pts, h->d_faces, h->d_vf_ptr, h->d_vf, V, h->d_nrm, s);
         launch_gather_nodes(h->d_pts, h->d_nrm, h->d_nodes, K, h->d_node_pts, h->d_node_nrm, s);
         n = 3;
     } else {
-        launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, h->d_nrm, h->d_node_pts, h->d_node_nrm, p.cg_tol, h->d_ctl, slot, host_ctl, prev_scal, s, nl, demand_local);
+        launch_arap_finalize(h->sell, p.arap_iters, p.arap_tol, h->d_energy, x_cur, h->d_pts, h->d_info, h->d_nrm, h->d_node_pts, h->d_node_nrm, p.cg_tol, h->d_ctl, slot, host_ctl, prev_scal, s, nl, demand_local, (double)(h->seq_enqueued + 1));
     }
     toc(t, n);
+    if (sampling) {      // the 8 scalars of every sweep slot of this pass -> pinned memory (a few KB, every eighth pass)
+        const int ss = ras_slot_size(h);
+        const size_t nslots = (size_t)rp.total(p.arap_iters);
+        h->sample_off.push_back(h->sample_used);
+        (void)hipMemcpy2DAsync(h->h_sample + h->sample_used, 8 * sizeof(double), h->d_ras_slots + 3 * (size_t)h->ras.NPpad, (size_t)ss * sizeof(double),
+                               8 * sizeof(double), nslots, hipMemcpyDeviceToHost, s);
+        h->sample_used += nslots * 8;
+    }
     (void)V;
     h->graph_ready_nn = 0; h->weights_ready = false;     // the nodes have moved
     h->seq_enqueued++;
@@ -892,6 +940,7 @@ int mvs_deform_destroy(mvs_deform_t h) {
     dfree(h->d_slots);
     if (h->d_sh) { (void)hipFree(h->d_sh); h->d_sh = nullptr; }
     if (h->h_ctl) { (void)hipHostFree((void*)h->h_ctl); h->h_ctl = nullptr; }
+    if (h->h_sample) { (void)hipHostFree(h->h_sample); h->h_sample = nullptr; }
     for (auto& pr : h->pending) { (void)hipEventDestroy(pr.second.first); (void)hipEventDestroy(pr.second.second); }
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     if (h->own_stream) stream_release(h->device, h->own_stream);
@@ -1341,9 +1390,9 @@ int mvs_knn_points(const double* pts, int64_t n, int k, int32_t* out_idx) {
     return rc;
 }
 
-// diagnostics (scripts/assoc_debug.py; not part of the ABI): the heavy list of the last association — entries, and how many of
-// them had their coarse nearest-distance walk deferred
-int mvs_debug_heavy_count(mvs_deform_t h, int* n, int* flagged) {
+// ---- test hooks (include/mvs_test.h; not part of the ABI of include/mvs.h): all state they set lives in the handle ----
+// the heavy list of the last association — entries, and how many of them had their coarse nearest-distance walk deferred
+int mvs_test_heavy_count(mvs_deform_t h, int* n, int* flagged) {
     if (!h || !h->d_heavy) return MVS_E_INVALID_ARG;
     HIPCHK(hipStreamSynchronize(h->stream));
     const int32_t* cur = h->heavy_flip ? h->d_heavy : h->d_heavy2;      // (the list the LAST association filled)
@@ -1356,19 +1405,32 @@ int mvs_debug_heavy_count(mvs_deform_t h, int* n, int* flagged) {
     return MVS_OK;
 }
 
-// diagnostics (tests; not part of the ABI): maxspin = polls a workgroup waits at the tail loop's device-wide barrier before it
-// abandons the solve (<= 0: default); plan_cap = at most this many launches per solve, the remaining sweeps run inside the last
-// one (0: no cap).  Process-wide.
-int mvs_debug_tail(int maxspin, int plan_cap) {
-    ras_set_tail_maxspin(maxspin);
-    g_dbg_plan_cap = plan_cap > 0 ? plan_cap : 0;
+// maxspin = polls a workgroup waits at the tail loop's device-wide barrier before it abandons the solve (<= 0: default);
+// plan_cap = at most this many launches per solve, the remaining sweeps run inside the last one (0: no cap); skip_wg = the
+// workgroup of every tail launch that never arrives at the barrier, so that the wait of every other one expires (-1: none).
+// State of THIS handle only.
+int mvs_test_tail(mvs_deform_t h, int maxspin, int plan_cap, int skip_wg) {
+    if (!h) return MVS_E_INVALID_ARG;
+    h->dbg_maxspin = maxspin > 0 ? maxspin : 0;
+    h->dbg_plan_cap = plan_cap > 0 ? plan_cap : 0;
+    h->dbg_skip_wg = skip_wg >= 0 ? skip_wg : -1;
     return MVS_OK;
 }
 
-// diagnostics (tests/test_gpu_meshbuild.py; not part of the ABI): the tables the device build left, copied to the host.
+// Chebyshev steps every patch ran in the launch of sweep slot `slot` of the handle's last pass (slots are numbered through the
+// pass: solve 0's launches first) -> out[NP].  A tail launch that swept k times in the kernel reports k * steps-per-sweep.
+int mvs_test_sweep_steps(mvs_deform_t h, int slot, int32_t* out) {
+    if (!h || !out || !h->has_ras || slot < 0 || (int64_t)slot >= h->ras_slots_cap) return MVS_E_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->d_ras_iters + (size_t)slot * h->ras.NP, sizeof(int32_t) * h->ras.NP, hipMemcpyDeviceToHost));
+    return MVS_OK;
+}
+
+// (tests/test_gpu_meshbuild.py) the tables the device build left, copied to the host.
 // what = 0: dims as int64[8] {NP, LS, W, nslices, ne, single_pass, has_patches, total local rows}; 1 slice_off, 2 col, 3 opp0,
 // 4 opp1, 5 vf_ptr, 6 vf, 7 pnloc, 8 pown, 9 pnh, 10 l2g, 11 hl2g, 12 lcol (int16), 13 gent, 14 gcol.  out == NULL: only *bytes.
-int mvs_debug_mesh_table(mvs_deform_t h, int what, void* out, int64_t* bytes) {
+int mvs_test_mesh_table(mvs_deform_t h, int what, void* out, int64_t* bytes) {
     if (!h || !bytes) return MVS_E_INVALID_ARG;
     HIPCHK(hipSetDevice(h->device));
     const RasDev& R = h->ras;
@@ -1416,6 +1478,7 @@ int mvs_deform_enable_timing(mvs_deform_t h, int on) {
     if (!h) return MVS_E_INVALID_ARG;
     h->timing = on;
     h->timers.clear();
+    h->samples.clear(); h->sample_off.clear(); h->sample_pass_first.clear(); h->sample_used = 0;
     return MVS_OK;
 }
 int mvs_deform_kernel_time(mvs_deform_t h, const char* name, double* total_ms, int64_t* launches) {

@@ -602,9 +602,17 @@ __global__ void k_arap_finalize(SellDev m, int iters, double tol, int nb, double
                                 const double* __restrict__ sol, double* __restrict__ pts, int32_t* __restrict__ info,
                                 const double* __restrict__ nrm, double* __restrict__ node_pts, double* __restrict__ node_nrm,
                                 double cg_tol, double* __restrict__ ctl, int ring_slot, double* __restrict__ host_ctl,
-                                const double* __restrict__ last_scal, int nl, int fused_local) {
+                                const double* __restrict__ last_scal, int nl, int fused_local, double pass1) {
     // assign_solution + overwrite_initial_geometry (Deformation.cpp:398-400)
     double* efin = ered + EFIN;
+    // A fused solve whose tail loop was abandoned (schwarz.hip) skipped its local step: the iterations after it ran on the
+    // rotations and energies of the iteration before and their result is not the ARAP iterate of anything.  Such a pass leaves
+    // the geometry and the nodes as they were (it is reported as MVS_W_UNCONVERGED by the judge; from the next harvest on the
+    // handle keeps a local-step launch of its own behind every solve).  pass1 = this pass's number + 1, from the host: the
+    // device's own counter is advanced by this kernel's last block.
+    bool broken = false;
+    if (fused_local && ctl)
+        for (int t = 0; t < iters; ++t) if (ctl[MVS_CTL_GAVEUP + t] == pass1) broken = true;
     if (blockIdx.x == gridDim.x - 1) {           // the extra block: stop-rule bookkeeping, the last solve's verdict, the host mirror
         // the last iteration's energy is only meaningful if that iteration ran (its kernels exit once the rule fired)
         const bool done = arap_done_before(efin, iters - 1, tol);
@@ -643,7 +651,7 @@ __global__ void k_arap_finalize(SellDev m, int iters, double tol, int nb, double
         return;
     }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m.V) {
+    if (i < m.V && !broken) {
         const d3 x = ld3(sol + 3 * i);
         st3(pts + 3 * i, x);
         const int c = node_pts ? m.is_ctrl[i] : 0;                     // node k sits at its vertex: refresh the node arrays too
@@ -716,9 +724,9 @@ void launch_arap_local(const SellDev& m, const double* pts, const double* sol, i
 void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered, const double* sol,
                           double* pts, int32_t* info, const double* nrm, double* node_pts, double* node_nrm,
                           double cg_tol, double* ctl, int ring_slot, double* host_ctl, const double* last_solve_scalars, hipStream_t s,
-                          int nfold_local, int fused_local) {
+                          int nfold_local, int fused_local, double pass1) {
     k_arap_finalize<<<dim3((m.V + 255) / 256 + 1), dim3(256), 0, s>>>(m, iters, tol, arap_grid_blocks(m), ered, sol, pts, info, nrm, node_pts, node_nrm,
-                                                                  cg_tol, ctl, ring_slot, host_ctl, last_solve_scalars, nfold_local, fused_local);
+                                                                  cg_tol, ctl, ring_slot, host_ctl, last_solve_scalars, nfold_local, fused_local, pass1);
 }
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf, int V,
                            double* out, hipStream_t s) {

@@ -68,6 +68,8 @@ struct mvs_comm_s {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1, device = 0;
     double* scratch = nullptr;               // 16 doubles on the device (mvs_comm_reduce)
+    double* hscratch = nullptr;              // ... and their pinned host side
+    hipStream_t stream = nullptr;            // the communicator's own stream (mvs_comm_reduce): never the legacy default stream
     int exchange = 0;                        // MVS_EXCHANGE_AUTO / _ALL_GATHER / _OWNER (mvs_comm_set_exchange)
 };
 
@@ -109,6 +111,8 @@ int mvs_comm_destroy(mvs_comm_t c) {
     int rc = MVS_OK;
     if (c->comm && g_rccl.CommDestroy) rc = check_nccl(g_rccl.CommDestroy(c->comm), "ncclCommDestroy");
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->hscratch) (void)hipHostFree(c->hscratch);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return rc;
 }
@@ -119,12 +123,17 @@ int mvs_comm_reduce(void* ctx, double* v, int n, int op) {
     if (!c || !v || n < 1 || n > 16 || (op != 0 && op != 1)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     if (c->nranks == 1) return MVS_OK;
     HIPCHK(hipSetDevice(c->device));
+    if (!c->stream) HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (!c->scratch) HIPCHK(hipMalloc(&c->scratch, sizeof(double) * 16));
-    HIPCHK(hipMemcpy(c->scratch, v, sizeof(double) * n, hipMemcpyHostToDevice));
-    int rc = check_nccl(g_rccl.AllReduce(c->scratch, c->scratch, (size_t)n, ncclFloat64, op == 0 ? ncclSum : ncclMin, c->comm, nullptr), "ncclAllReduce");
+    if (!c->hscratch) HIPCHK(hipHostMalloc((void**)&c->hscratch, sizeof(double) * 16, hipHostMallocDefault));
+    // upload, all-reduce and download are ordered on the communicator's own stream; only that stream is waited for
+    std::memcpy(c->hscratch, v, sizeof(double) * n);
+    HIPCHK(hipMemcpyAsync(c->scratch, c->hscratch, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    int rc = check_nccl(g_rccl.AllReduce(c->scratch, c->scratch, (size_t)n, ncclFloat64, op == 0 ? ncclSum : ncclMin, c->comm, c->stream), "ncclAllReduce");
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(nullptr));
-    HIPCHK(hipMemcpy(v, c->scratch, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(c->hscratch, c->scratch, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::memcpy(v, c->hscratch, sizeof(double) * n);
     return MVS_OK;
 }
 
@@ -146,8 +155,8 @@ int mvs_comm_set_exchange(mvs_comm_t c, int mode) {
 
 // n_outer passes of the view-sharded body (mvs.h: mvs_deform_assoc_* comment) on the handle's stream.  Per pass ONE
 // all-reduce(MIN) of K floats, then the ranks' best-8 records meet in one of two ways:
-//   all-gather (up to 3 ranks): ONE all-gather of K * 392 bytes per rank, the identical merge of all K nodes on every rank;
-//   owner-merges (from 4 ranks on, or on request): rank r owns the node block [r * ceil(K / N), (r + 1) * ceil(K / N)); grouped
+//   all-gather (the default at every rank count): ONE all-gather of K * 392 bytes per rank, the identical merge of all K nodes on every rank;
+//   owner-merges (on request, MVS_EXCHANGE_OWNER): rank r owns the node block [r * ceil(K / N), (r + 1) * ceil(K / N)); grouped
 //     ncclSend / ncclRecv move every rank's records and counts of a block to its owner (K * 392 bytes INTO a rank instead of
 //     N * K * 392), the owner merges its block with the same kernel and total order (1 / N of the merge), ONE all-gather brings
 //     the 25 bytes per node of merged targets back and a small kernel installs them.  Same bits as the all-gather form
@@ -163,7 +172,11 @@ int mvs_deform_iterate_sharded(mvs_deform_t h, mvs_comm_t c, const mvs_deform_pa
     HIPCHK(hipSetDevice(c->device));
     const int N = c->nranks;
     const bool p2p = g_rccl.Send && g_rccl.Recv && g_rccl.GroupStart && g_rccl.GroupEnd;
-    const bool owner = c->exchange == MVS_EXCHANGE_OWNER || (c->exchange == MVS_EXCHANGE_AUTO && N >= 4 && p2p);
+    // MVS_EXCHANGE_AUTO = the all-gather form at every rank count: the owner-merges exchange has never run with more than one
+    // rank on hardware (this pool gives one GPU per box) and this entry, unlike bench.py, does not cross-check it against the
+    // all-gather form before trusting it — it runs only on request (MVS_EXCHANGE_OWNER), once a multi-GPU run has pinned it.
+    if (c->exchange == MVS_EXCHANGE_OWNER && N > 1 && !p2p) { mvs_set_error("this RCCL has no point-to-point calls: the owner-merges exchange is not available"); return MVS_E_STATE; }
+    const bool owner = c->exchange == MVS_EXCHANGE_OWNER;
     const size_t RECB = sizeof(mvs_cand);
     const size_t rec_bytes = (size_t)K * 8 * RECB, blk = rec_bytes + (size_t)K * 2 * sizeof(int32_t);
     // owner-merges layout: block_nodes = ceil(K / N); this rank owns [k0, k1)
@@ -203,18 +216,22 @@ int mvs_deform_iterate_sharded(mvs_deform_t h, mvs_comm_t c, const mvs_deform_pa
             if (N > 1) {
                 // every rank's records / counts of block r go to rank r; from every rank come those of this rank's block
                 if ((rc = check_nccl(g_rccl.GroupStart(), "ncclGroupStart"))) return rc;
-                for (int r = 0; r < N; ++r) {
+                // (a failing Send / Recv must not leave the group open on the communicator: the group is always closed, the
+                //  first error wins)
+                for (int r = 0; r < N && !rc; ++r) {
                     const int64_t a = blk0(r), n = blk0(r + 1) - a;
                     if (n > 0) {
-                        if ((rc = check_nccl(g_rccl.Send(rec + (size_t)a * 8 * RECB, (size_t)n * 8 * RECB, ncclUint8, r, c->comm, s), "ncclSend(records)"))) return rc;
-                        if ((rc = check_nccl(g_rccl.Send(cnt + (size_t)a * 2 * sizeof(int32_t), (size_t)n * 2 * sizeof(int32_t), ncclUint8, r, c->comm, s), "ncclSend(counts)"))) return rc;
+                        rc = check_nccl(g_rccl.Send(rec + (size_t)a * 8 * RECB, (size_t)n * 8 * RECB, ncclUint8, r, c->comm, s), "ncclSend(records)");
+                        if (!rc) rc = check_nccl(g_rccl.Send(cnt + (size_t)a * 2 * sizeof(int32_t), (size_t)n * 2 * sizeof(int32_t), ncclUint8, r, c->comm, s), "ncclSend(counts)");
                     }
-                    if (mine > 0) {
-                        if ((rc = check_nccl(g_rccl.Recv(rec_in + (size_t)r * mine * 8 * RECB, (size_t)mine * 8 * RECB, ncclUint8, r, c->comm, s), "ncclRecv(records)"))) return rc;
-                        if ((rc = check_nccl(g_rccl.Recv(cnt_in + (size_t)r * mine * 2 * sizeof(int32_t), (size_t)mine * 2 * sizeof(int32_t), ncclUint8, r, c->comm, s), "ncclRecv(counts)"))) return rc;
+                    if (mine > 0 && !rc) {
+                        rc = check_nccl(g_rccl.Recv(rec_in + (size_t)r * mine * 8 * RECB, (size_t)mine * 8 * RECB, ncclUint8, r, c->comm, s), "ncclRecv(records)");
+                        if (!rc) rc = check_nccl(g_rccl.Recv(cnt_in + (size_t)r * mine * 2 * sizeof(int32_t), (size_t)mine * 2 * sizeof(int32_t), ncclUint8, r, c->comm, s), "ncclRecv(counts)");
                     }
                 }
-                if ((rc = check_nccl(g_rccl.GroupEnd(), "ncclGroupEnd"))) return rc;
+                const int rc_end = check_nccl(g_rccl.GroupEnd(), "ncclGroupEnd");
+                if (rc) return rc;
+                if (rc_end) return rc_end;
             } else {
                 HIPCHK(hipMemcpyAsync(rec_in, rec, (size_t)mine * 8 * RECB, hipMemcpyDeviceToDevice, s));
                 HIPCHK(hipMemcpyAsync(cnt_in, cnt, (size_t)mine * 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));

@@ -193,6 +193,15 @@ struct mvs_deform_s {
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
     std::vector<hipEvent_t> event_pool;
     std::map<std::string, int64_t> pending_launches;
+    // timing mode 3: the idle flags of the sweep launches the sampled event pairs bracket (every sweep leaves "found the solve
+    // finished" in its slot, schwarz.hip) are copied out behind each sampled pass — which of the TIMED launches did work is
+    // then counted from the device's own record, not inferred from another pass
+    struct SweepSample { int first, n_a, n_b; };      // slots [first, first + n_a) = bracket "cg", the next n_b = bracket "cgB"
+    std::vector<SweepSample> samples;                 // one per sampled solve, in the order of the copies
+    std::vector<size_t> sample_off;                   // where each sampled pass's flags start in h_sample (doubles)
+    std::vector<int> sample_pass_first;               // index into `samples` of each sampled pass's first solve
+    double* h_sample = nullptr;                       // pinned: [8] scalars per sweep slot of the sampled passes
+    size_t sample_cap = 0, sample_used = 0;           // doubles
     mvs_deform_stats last{};
     // device memory: one allocation per lifetime (meshbuild.hip, api_deform.cpp, grid.hip); every d_* pointer above points
     // into one of these, nothing is freed piecewise
@@ -205,6 +214,10 @@ struct mvs_deform_s {
     size_t arena_probe_bytes = 0;
     bool saw_abandon = false;       // a tail loop of this handle was abandoned at its barrier: keep a local-step launch behind every solve
     double gaveup_seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // test hooks (include/mvs_test.h, mvs_test_tail): per handle, never process-wide
+    int dbg_maxspin = 0;            // polls a workgroup waits at the tail loop's barrier before it abandons the solve (0: default)
+    int dbg_plan_cap = 0;           // at most this many launches per solve, the rest of its sweeps run inside the last one (0: no cap)
+    int dbg_skip_wg = -1;           // the workgroup that never arrives at the tail loop's barrier (-1: none)
     int32_t* d_deg = nullptr;       // [V] vertex degree (device build; the ELL-8 tables pad every row to a multiple of 8)
 };
 
@@ -272,7 +285,7 @@ void launch_arap_local(const SellDev& m, const double* pts, const double* sol, i
 void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered, const double* sol,
                           double* pts, int32_t* info, const double* nrm, double* node_pts, double* node_nrm,
                           double cg_tol, double* ctl, int ring_slot, double* host_ctl, const double* last_solve_scalars, hipStream_t s,
-                          int nfold_local = 0, int fused_local = 0);
+                          int nfold_local = 0, int fused_local = 0, double pass1 = 0.0 /*this pass's number + 1 (fused_local: a pass with an abandoned solve keeps the old geometry)*/);
 int  arap_grid_blocks(const SellDev& m);
 // schwarz.hip
 // meshbuild.hip — row a16 on the device (Deformation.cpp:29-46, Deformation.h:51-84): validity of the facet list, ELL-8
@@ -297,7 +310,7 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, doubl
                       bool mixing_solve = false /*the solve's plan is long: its planned sweeps can mix (RasMix, schwarz.hip)*/);
 bool ras_can_fuse_local(const mvs_deform_s* h);   // patches <= MVS_NBMAX and workgroups <= 512 threads
 int  ras_local_parts(const mvs_deform_s* h);      // partial sums per reduction the local step leaves (what its consumers fold)
-void ras_set_tail_maxspin(int n);                 // tests: polls at the tail barrier before a workgroup abandons the solve (<= 0: default)
+int  mvs_device_cus(int device);                  // compute units of a device (mutex-guarded table, one entry per device)
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf,
                            int V, double* out, hipStream_t s);
 

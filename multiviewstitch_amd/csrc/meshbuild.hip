@@ -560,15 +560,7 @@ __global__ __launch_bounds__(RTPB) void k_patch_tables(int LS, int W, const int3
 }
 
 // ------------------------------------------------------------------ host ----
-int device_cus(int device) {
-    static int cached_dev = -1, cached = 256;
-    if (cached_dev != device) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cached = prop.multiProcessorCount;
-        cached_dev = device;
-    }
-    return cached;
-}
+int device_cus(int device) { return mvs_device_cus(device); }      // (schwarz.hip: mutex-guarded table, one entry per device)
 
 // the bisection tree depends on V and NP alone: per level the segments to split and the 256-element tiles of `order`
 struct RcbPlan {

@@ -215,9 +215,24 @@ __global__ __launch_bounds__(RTPB) void k_ras_prepare(SellDev m, RasDev R, doubl
 // Words (MVS_BAR_STRIDE apart, k_arap_rhs zeroes them before every solve): [0] root counter, [1] dec, [2 + g] arrivals of group g,
 // [2 + GROUPS + g] release word of group g.
 constexpr unsigned TAIL_ABANDONED = 0xffffffffu;
-__device__ inline bool tail_barrier(unsigned* bar, unsigned gen /* 1, 2, ... : the barrier's number within this solve */, int maxspin) {
+__device__ inline bool tail_barrier(unsigned* bar, unsigned gen /* 1, 2, ... : the barrier's number within this solve */, int maxspin, int skip_wg) {
     __shared__ int s_ok;
     __syncthreads();                                                   // (every wave's stores have been issued and waited for)
+    if (threadIdx.x == 0 && (int)blockIdx.x == skip_wg) {
+        // test hook (mvs_test_tail): this workgroup NEVER arrives, so the bounded wait of every other workgroup must expire and
+        // one of them abandons the solve; it leaves with their verdict (its own bound only guards against a lost launch)
+        unsigned* dec = bar + MVS_BAR_STRIDE;
+        int spin = 0;
+        while (__hip_atomic_load(dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != TAIL_ABANDONED) {
+            if (++spin > (1 << 22)) {
+                unsigned expect = gen - 1u;
+                (void)__hip_atomic_compare_exchange_strong(dec, &expect, TAIL_ABANDONED, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        s_ok = 0;
+    } else
     if (threadIdx.x == 0) {
         int ok = 1;
         unsigned* dec = bar + MVS_BAR_STRIDE;
@@ -267,6 +282,7 @@ struct RasTail {              // the last planned launch of a solve (MODE >= 1)
     double* slots;            // max_extra further sweep slots (partials of the in-kernel sweeps)
     int max_extra;            // in-kernel sweeps after this launch's own one
     int maxspin;              // polls a workgroup waits at the barrier before it abandons the solve
+    int skip_wg;              // test hook: the workgroup that never arrives at the barrier (-1: none)
 };
 // Mixing of successive sweeps (MODE 3).  When a solve's sweeps stall — two or three healthy sweeps, then a few per cent per
 // sweep: ONE mode of the sweep operator with an eigenvalue near 1, the signature of sliver triangles after hundreds of outer
@@ -639,7 +655,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 1) ? 512 : RTPB) void k_ras_s
     double g_before[3] = {s_gam[0], s_gam[1], s_gam[2]};               // residual of the input of the sweep BEFORE the one done last
     for (;;) {
         TSTAMP(0);
-        if (!tail_barrier(tail.bar, (unsigned)(extra + 1), tail.maxspin)) { abandoned = true; break; }     // not every workgroup came in time: every patch stops HERE
+        if (!tail_barrier(tail.bar, (unsigned)(extra + 1), tail.maxspin, tail.skip_wg)) { abandoned = true; break; }     // not every workgroup came in time: every patch stops HERE
         TSTAMP(1);
         if (wv < 3) {
             const double gam = fold_n<FOLD_GUARDED>(slot_k + wv * NPpad, R.NP * 4);
@@ -764,39 +780,51 @@ int ras_steps_for(double a) {
 // one sweep of ARAP iteration `it`: slot_prev / slot_cur are the slots of sweeps (sweep-1) / sweep.  tail_slots != NULL: this
 // is the last planned sweep of the solve — the launch keeps sweeping (device-wide barrier between sweeps, at most
 // RAS_TAIL_MAX more) until the solve has converged, should the plan have been too short.
-static int g_tail_maxspin = 1 << 16;      // polls at the tail loop's barrier before a workgroup abandons the solve (tests lower it: mvs_debug_tail)
-void ras_set_tail_maxspin(int n) { g_tail_maxspin = n > 0 ? n : (1 << 16); }
-static int ras_device_cus(int device);
-// (the fused instantiation takes every register of a CU: one 512-thread workgroup each — its tail loop needs NP <= CUs)
-bool ras_can_fuse_local(const mvs_deform_s* h) { return h->has_ras && h->ras.NP <= MVS_NBMAX && h->ras_block <= 512 && h->ras.NP <= ras_device_cus(h->device); }
-int ras_local_parts(const mvs_deform_s* h) { return ras_can_fuse_local(h) ? std::max(h->ras.NP, arap_grid_blocks(h->sell)) : arap_grid_blocks(h->sell); }
+constexpr int RAS_TAIL_MAXSPIN = 1 << 16;   // polls at the tail loop's barrier before a workgroup abandons the solve (tests lower it per handle: mvs_test_tail)
+// CUs of a device: one mutex-guarded table for the process (a handle per device per thread is the library's contract, mvs.h)
+int mvs_device_cus(int device) {
+    static std::mutex mu;
+    static std::vector<std::pair<int, int>> table;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto& e : table) if (e.first == device) return e.second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    table.push_back({device, n});
+    return n;
+}
+static int ras_device_cus(int device) { return mvs_device_cus(device); }
 
 template <int T> static const void* ras_sweep_fn(int W) {
     return W == 6 ? (const void*)k_ras_sweep<6, T> : W == 8 ? (const void*)k_ras_sweep<8, T> : W == 12 ? (const void*)k_ras_sweep<12, T> : (const void*)k_ras_sweep<16, T>;
 }
-static int ras_device_cus(int device);
 // can all `np` workgroups of `block` threads of this instantiation be resident at once?  (asked once per instantiation and shape)
 static bool ras_tail_resident(int mode, int W, int block, int np, int device) {
     struct Key { int mode, W, block, device, per_cu; };
     static std::vector<Key> cache;
     static std::mutex mu;
-    std::lock_guard<std::mutex> lk(mu);
-    for (const Key& k : cache) if (k.mode == mode && k.W == W && k.block == block && k.device == device) return (int64_t)k.per_cu * ras_device_cus(device) >= np;
-    int per_cu = 0;
-    const void* fn = mode == 2 ? ras_sweep_fn<2>(W) : mode == 1 ? ras_sweep_fn<1>(W) : ras_sweep_fn<4>(W);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, 0) != hipSuccess) per_cu = 0;
-    cache.push_back({mode, W, block, device, per_cu});
+    int per_cu = -1;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Key& k : cache) if (k.mode == mode && k.W == W && k.block == block && k.device == device) per_cu = k.per_cu;
+    }
+    if (per_cu < 0) {
+        per_cu = 0;
+        const void* fn = mode == 2 ? ras_sweep_fn<2>(W) : mode == 1 ? ras_sweep_fn<1>(W) : ras_sweep_fn<4>(W);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+        std::lock_guard<std::mutex> lk(mu);
+        cache.push_back({mode, W, block, device, per_cu});
+    }
     return (int64_t)per_cu * ras_device_cus(device) >= np;
 }
-static int ras_device_cus(int device) {
-    static int cached_dev = -1, cached = 256;
-    if (cached_dev != device) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) cached = n;
-        cached_dev = device;
-    }
-    return cached;
+// (the fused instantiation takes every register of a CU: one 512-thread workgroup each — its tail loop needs every workgroup of
+//  the launch resident at once: the runtime is asked, as for the unfused tail instantiations; a handle that fails the test runs
+//  the unfused last launch + k_arap_local)
+bool ras_can_fuse_local(const mvs_deform_s* h) {
+    return h->has_ras && h->ras.NP <= MVS_NBMAX && h->ras_block <= 512 && h->ras.NP <= ras_device_cus(h->device) &&
+           ras_tail_resident(2, h->ras.W, h->ras_block, h->ras.NP, h->device);
 }
+int ras_local_parts(const mvs_deform_s* h) { return ras_can_fuse_local(h) ? std::max(h->ras.NP, arap_grid_blocks(h->sell)) : arap_grid_blocks(h->sell); }
+
 void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, double* xout, int it, double arap_tol, int sweep,
                       double cg_tol, double stop_margin, double* slot_prev, double* slot_cur, int32_t* iters_cur, hipStream_t s, double* tail_slots,
                       bool with_local, bool mixing_solve) {
@@ -825,7 +853,7 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, doubl
     const ChebCoef cc2 = coefs(strong_a);
     const int m2 = ras_steps_for(strong_a);
     const dim3 grid(R.NP), blk(h->ras_block);     // as many waves as the largest patch has rows (idle waves only add barrier cost)
-    RasTail tail{h->d_bar, tail_slots, RAS_TAIL_MAX, g_tail_maxspin};
+    RasTail tail{h->d_bar, tail_slots, RAS_TAIL_MAX, h->dbg_maxspin > 0 ? h->dbg_maxspin : RAS_TAIL_MAXSPIN, h->dbg_skip_wg};
     const RasLocal loc{h->sell, h->d_pts, h->d_rot, h->d_bpure, ras_local_parts(h)};
     // mixing_solve: every planned sweep of this solve is the mixing instantiation (a solve is all lean or all mixing: the state in
     // the sweep slots is only kept by the latter, and cap = 0 tells every launch of a lean solve not to look at it)

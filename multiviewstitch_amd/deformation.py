@@ -251,7 +251,9 @@ class Deformation:
         return {"kind": "patch" if kind.value else "cg", "patches": patches.value, "local_rows": rows.value, "width": width.value}
 
     def enable_timing(self, on: int = 1):
-        """0 off, 1 every phase, 2 only the "cg" groups, 3 the "cg" groups of every fourth pass (mvs_deform_enable_timing)."""
+        """0 off, 1 every phase, 2 only the "cg" / "tail" groups, 3 the planned sweeps of every eighth pass in two brackets ("cg": launches
+        expected to do work, "cgB": the spares behind them) with the idle flags of exactly those launches read back into the launch
+        counts of "cg_idle" / "cgB_idle" (mvs_deform_enable_timing)."""
         L.check(L.lib().mvs_deform_enable_timing(self._h, int(on)))
 
     def kernel_time(self, name: str):

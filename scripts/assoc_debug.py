@@ -25,6 +25,6 @@ import ctypes as C
 from multiviewstitch_amd import _lib as L
 for it in range(3):
     n, f = C.c_int(), C.c_int()
-    L.lib().mvs_debug_heavy_count.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    print("heavy list after pass", it, ":", L.lib().mvs_debug_heavy_count(d._h, C.byref(n), C.byref(f)), n.value, "entries,", f.value, "with the coarse walk deferred")
+    L.lib().mvs_test_heavy_count.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    print("heavy list after pass", it, ":", L.lib().mvs_test_heavy_count(d._h, C.byref(n), C.byref(f)), n.value, "entries,", f.value, "with the coarse walk deferred")
     d.iterate(1)

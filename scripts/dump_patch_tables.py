@@ -10,7 +10,7 @@ from multiviewstitch_amd import _lib as L, deformation, scene as S
 
 
 def table(d, what, dtype):
-    fn = L.lib().mvs_debug_mesh_table
+    fn = L.lib().mvs_test_mesh_table
     fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     n = C.c_int64()
     L.check(fn(d._h, what, None, C.byref(n)))

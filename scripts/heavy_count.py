@@ -9,7 +9,7 @@ tp, tn = bench.build_target(torch, srt_mod, S, sc, range(8), dev)
 d = deformation.Deformation(sc.verts, sc.normals, sc.faces)
 d.UniformSampling(16)
 d.set_target_dev(tp.data_ptr(), tn.data_ptr(), tp.shape[0], 0)
-fn = L.lib().mvs_debug_heavy_count
+fn = L.lib().mvs_test_heavy_count
 fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]
 for k in range(6):
     d.iterate(1)

@@ -1,6 +1,6 @@
 """Experiment (EXPERIMENTS build): does assigning a row's matrix entries to the ELL slots so that the 32-lane groups of the
 Chebyshev step's LDS gathers meet few bank conflicts pay?  A fresh handle per variant (a long fit drifts into the late regime:
-the same passes must be compared), the entry tables permuted per row on the host and written back (mvs_debug_mesh_table 112-114)."""
+the same passes must be compared), the entry tables permuted per row on the host and written back (mvs_test_mesh_table 112-114)."""
 import ctypes as C
 import itertools
 import sys
@@ -16,7 +16,7 @@ import bench
 dev = torch.device("cuda", 0)
 sc = S.make_scene(3, device=dev)
 tp, tn = bench.build_target(torch, srt_mod, S, sc, range(8), dev)
-fn = L.lib().mvs_debug_mesh_table
+fn = L.lib().mvs_test_mesh_table
 fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
 rng = np.random.default_rng(1)
 

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 def _table(d, what, dtype):
     from multiviewstitch_amd import _lib as L
-    fn = L.lib().mvs_debug_mesh_table
+    fn = L.lib().mvs_test_mesh_table
     fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     n = C.c_int64()
     L.check(fn(d._h, what, None, C.byref(n)))

@@ -138,30 +138,27 @@ def test_abandoned_tail_loops_of_concurrent_parts_are_reported():
     import ctypes as C
     from multiviewstitch_amd import _lib as L
 
-    def debug_tail(maxspin, cap):
-        fn = L.lib().mvs_debug_tail
-        fn.restype, fn.argtypes = C.c_int, [C.c_int, C.c_int]
-        L.check(fn(maxspin, cap))
+    def test_tail(pd, maxspin, cap):                          # include/mvs_test.h: per handle
+        fn = L.lib().mvs_test_tail
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        for _, h in pd.live:
+            L.check(fn(h._h, maxspin, cap, -1))
 
     sc, tp, tn, _ = scene_and_target(2)                          # four parts of ~3.3 K vertices: the patch solver runs
     labels = PW.sector_labels(sc.verts, 4)
     tl = PW.sector_labels(tp, 4)
     runs = []
-    try:
-        for disturbed in (False, True):
-            pd = PW.PartwiseDeformation(sc.verts, sc.normals, sc.faces, labels, 4)
-            pd.UniformSampling(16)
-            pd.set_target(tp, tn, tl)
-            assert all(h.solver_info()["kind"] == "patch" for _, h in pd.live)
-            pd.iterate(1)                                        # calibration, part after part, undisturbed
-            if disturbed:
-                debug_tail(1, 1)
-            stats = pd.iterate(2)                                # all parts enqueued, then collected
-            debug_tail(0, 0)
-            runs.append(([h.vertices() for _, h in pd.live], stats))
-            pd.close()
-    finally:
-        debug_tail(0, 0)
+    for disturbed in (False, True):
+        pd = PW.PartwiseDeformation(sc.verts, sc.normals, sc.faces, labels, 4)
+        pd.UniformSampling(16)
+        pd.set_target(tp, tn, tl)
+        assert all(h.solver_info()["kind"] == "patch" for _, h in pd.live)
+        pd.iterate(1)                                        # calibration, part after part, undisturbed
+        if disturbed:
+            test_tail(pd, 1, 1)
+        stats = pd.iterate(2)                                # all parts enqueued, then collected
+        runs.append(([h.vertices() for _, h in pd.live], stats))
+        pd.close()
     assert all(s["status"] == 0 for s in runs[0][1])
     for v_ref, v, s in zip(runs[0][0], runs[1][0], runs[1][1]):
         assert s["status"] in (0, 1)
