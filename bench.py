@@ -313,11 +313,16 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    # (sampled passes bracket the planned sweeps of a solve in two groups — "cg": the launches expected to do work, "cgB": the
-    #  spares behind them — and the idle flags those very launches left are read back: "cg_idle" / "cgB_idle" carry the counts)
+    # (sampled passes bracket the planned sweeps of each solve; the idle flags those very launches left are read back: "cg_idle"
+    #  counts them, and every bracket is filed under its composition "cg:a<active>:i<idle>")
     cg_ms, cg_launches = d.kernel_time("cg")
-    cgb_ms, cgb_launches = d.kernel_time("cgB")
-    idle_a, idle_b = d.kernel_time("cg_idle")[1], d.kernel_time("cgB_idle")[1]
+    idle_n = d.kernel_time("cg_idle")[1]
+    brackets = []                               # (active, idle, brackets of this composition, their total ms)
+    for na in range(0, 17):
+        for ni in range(0, 17):
+            ms_c, n_c = d.kernel_time(f"cg:a{na}:i{ni}")
+            if n_c:
+                brackets.append((na, ni, int(n_c), ms_c))
     d.enable_timing(0)
     tail_ms, tail_launches = 0.0, 0
     if world == 1:                          # the last launch of every solve (decides; ARAP local step): events in a pass of its own, outside the timed region
@@ -366,33 +371,36 @@ def main():
         except Exception:
             pass
     active_per_step = st["cg_active"]
-    timed_launches = int(cg_launches + cgb_launches)
-    if timed_launches > 0 and cg_ms + cgb_ms > 0:
+    timed_launches = int(cg_launches)
+    if timed_launches > 0 and cg_ms > 0:
         # launches that found all three right-hand sides converged degenerate into a copy of the owned rows (the first one) or
         # return after one scalar load (the others): only the active ones move the algorithmic bytes.  Active and idle launches
-        # are counted among the TIMED launches themselves (device flags), and their average durations separated from the two
-        # brackets' totals: T_cg = a * active_cg + b * idle_cg, T_cgB = a * active_cgB + b * idle_cgB.
+        # are counted among the TIMED launches themselves (device flags); their costs are separated by least squares over the
+        # brackets, T = a * active + b * idle + c (c = what an event pair adds to the stream, ~4 us).
         n_last = st["arap_iters_run"] if info["kind"] == "patch" else 0
-        n_idle = int(idle_a + idle_b)
+        n_idle = int(idle_n)
         n_active = timed_launches - n_idle
-        act_a, act_b = cg_launches - idle_a, cgb_launches - idle_b
-        t_all = 1e-3 * (cg_ms + cgb_ms)
+        t_all = 1e-3 * cg_ms
         avg_s = t_all / timed_launches
-        a_s, b_s, how = None, None, None
-        det = act_a * idle_b - act_b * idle_a
-        if n_idle == 0:
-            a_s, how = avg_s, "no idle launch in the sample"
-        elif n_active == 0:
-            b_s, how = avg_s, "no active launch in the sample"
-        elif abs(det) >= 1 and min(cg_launches, cgb_launches) > 0:
-            a_s = 1e-3 * (cg_ms * idle_b - cgb_ms * idle_a) / det
-            b_s = 1e-3 * (cgb_ms * act_a - cg_ms * act_b) / det
-            how = "2x2 solve over the two brackets"
-        if a_s is None or b_s is None or a_s <= 0 or (b_s is not None and b_s < 0):
-            if n_active and n_idle:      # brackets of one composition: the idle launches at the kernel's shortest profiled duration
-                b_s = 2.5e-6
-                a_s = (t_all - n_idle * b_s) / n_active
-                how = "idle launches priced at 2.5 us (rocprofv3 minimum of the kernel)"
+        a_s, b_s, c_s, how = None, None, None, None
+        if brackets:
+            A = np.array([[na, ni, 1.0] for na, ni, _, _ in brackets], dtype=np.float64)
+            w = np.sqrt(np.array([n_c for _, _, n_c, _ in brackets], dtype=np.float64))
+            y = np.array([1e-3 * ms_c / n_c for _, _, n_c, ms_c in brackets], dtype=np.float64)      # mean bracket time per composition
+            for cols in ((0, 1, 2), (0, 2), (0, 1), (0,)):                  # the fullest model the sample supports
+                M = A[:, cols]
+                if len(brackets) < len(cols) or np.linalg.matrix_rank(M) < len(cols):
+                    continue
+                sol, *_ = np.linalg.lstsq(M * w[:, None], y * w, rcond=None)
+                coef = dict(zip(cols, (float(v) for v in sol)))
+                if coef[0] > 0 and coef.get(1, 0.0) >= 0 and coef.get(2, 0.0) >= 0:
+                    a_s, b_s, c_s = coef[0], coef.get(1), coef.get(2)
+                    how = (f"weighted least squares over {len(brackets)} bracket compositions ({int((w * w).sum())} brackets): "
+                           "T = " + " + ".join(t for t, k in (("a*active", 0), ("b*idle", 1), ("c", 2)) if k in cols))
+                    break
+        if a_s is None or not (a_s > 0):
+            a_s, how = (t_all - n_idle * 2.5e-6) / max(1, n_active), "idle launches priced at 2.5 us (rocprofv3 minimum of the kernel)"
+            b_s, c_s = 2.5e-6, None
         active_frac = n_active / timed_launches
         ach = active_frac * solve_bytes / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
@@ -403,8 +411,9 @@ def main():
                     "avg_launch_us": round(1e6 * avg_s, 3), "launches": timed_launches, "active_fraction": round(active_frac, 3),
                     "active_launches": n_active, "avg_active_launch_us": round(1e6 * a_s, 3) if a_s else None,
                     "idle_launches": n_idle, "avg_idle_launch_us": round(1e6 * b_s, 3) if b_s is not None else None,
-                    "brackets": {"cg": {"ms": round(cg_ms, 5), "launches": int(cg_launches), "idle": int(idle_a)},
-                                 "cgB": {"ms": round(cgb_ms, 5), "launches": int(cgb_launches), "idle": int(idle_b)}, "separation": how},
+                    "bracket_overhead_us": round(1e6 * c_s, 3) if c_s is not None else None,
+                    "brackets": [{"active": na, "idle": ni, "n": n_c, "mean_us": round(1e3 * ms_c / n_c, 3)} for na, ni, n_c, ms_c in brackets],
+                    "separation": how,
                     "launches_per_step": int(st["cg_launches"]),
                     "timed_sample": "the planned sweep launches of every 8th outer iteration of the timed region (HIP events on the engine's "
                                     "stream); active / idle counted from the idle flags those launches left on the device",

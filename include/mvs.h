@@ -538,10 +538,10 @@ int mvs_deform_arap(mvs_deform_t h, const mvs_deform_params* p,
  * hipEvents on the handle's stream (bench.py's roofline object).  names:
  * "assoc", "graph", "smooth", "weights", "rhs", "cg", "local", "finalize". */
 int mvs_deform_kernel_time(mvs_deform_t h, const char* name, double* total_ms, int64_t* launches);
-/* on: 0 off, 1 every phase, 2 only the "cg" / "tail" groups (two events per global solve), 3 the planned sweeps of every eighth
- * pass in two brackets — "cg" (the launches expected to do work) and "cgB" (the spare launches behind them) — with the idle
- * flags those launches left on the device read back: the `launches` field of "cg_idle" / "cgB_idle" counts the bracketed
- * launches that found their solve already finished. */
+/* on: 0 off, 1 every phase, 2 only the "cg" / "tail" groups (two events per global solve), 3 the planned sweeps ("cg") of
+ * every eighth pass, with the idle flags those very launches left on the device read back: the `launches` field of "cg_idle"
+ * counts the bracketed launches that found their solve already finished, and every bracket is also filed under its
+ * composition, "cg:a<active>:i<idle>" (total ms, number of such brackets). */
 int mvs_deform_enable_timing(mvs_deform_t h, int on);
 
 #ifdef __cplusplus

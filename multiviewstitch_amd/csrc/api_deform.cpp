@@ -194,7 +194,7 @@ struct Tic { mvs_deform_s* h; const char* name; hipEvent_t a; };
 // of every EIGHTH pass (what bench.py keeps on inside its timed region — the sampled passes hold the same launch mix as the others)
 bool timed(const mvs_deform_s* h, const char* name) {
     if (h->timing == 1) return true;
-    const bool cg = std::strcmp(name, "cg") == 0 || std::strcmp(name, "cgB") == 0, tail = std::strcmp(name, "tail") == 0;
+    const bool cg = std::strcmp(name, "cg") == 0, tail = std::strcmp(name, "tail") == 0;
     if (!cg && !tail) return false;
     // (an event pair costs ~4 us of stream time — the marker packets break the back-to-back dispatch of the launches around them:
     //  bench.py's timed region keeps only the pair around the planned sweeps of every EIGHTH pass, ~0.2 % of a step)
@@ -213,26 +213,32 @@ void toc(Tic& t, int launches) {
     t.h->pending_launches[t.name] += launches;
 }
 void collect_timers(mvs_deform_s* h) {
+    // (mode 3) the k-th "cg" bracket of the pending list is the k-th sampled solve: its launches that found the solve finished are
+    // counted from the flags copied out behind its pass (the stream has been synchronised: the copies have landed), and the
+    // bracket is also filed under its composition — "cg:a<active>:i<idle>": total ms, number of brackets — so that a caller
+    // can separate the cost of an active launch from that of an idle one and from the bracket's own overhead (bench.py)
+    size_t k_cg = 0, q = 0;
     for (auto& pr : h->pending) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, pr.second.first, pr.second.second) == hipSuccess) h->timers[pr.first].total_ms += ms;
+        const bool okms = hipEventElapsedTime(&ms, pr.second.first, pr.second.second) == hipSuccess;
+        if (okms) h->timers[pr.first].total_ms += ms;
+        if (h->timing == 3 && pr.first == "cg" && k_cg < h->samples.size()) {
+            while (q + 1 < h->sample_off.size() && (size_t)h->sample_pass_first[q + 1] <= k_cg) ++q;
+            const mvs_deform_s::SweepSample& sm = h->samples[k_cg++];
+            const double* F = h->h_sample + h->sample_off[q];
+            int idle = 0;
+            for (int i = 0; i < sm.n_a; ++i) if (F[(size_t)(sm.first + i) * 8 + 6] != 0.0) ++idle;
+            h->timers["cg_idle"].launches += idle;
+            char key[48];
+            snprintf(key, sizeof key, "cg:a%d:i%d", sm.n_a - idle, idle);
+            if (okms) { h->timers[key].total_ms += ms; h->timers[key].launches += 1; }
+        }
         h->event_pool.push_back(pr.second.first);
         h->event_pool.push_back(pr.second.second);
     }
     h->pending.clear();
     for (auto& kv : h->pending_launches) h->timers[kv.first].launches += kv.second;
     h->pending_launches.clear();
-    // (mode 3) how many launches of the sampled brackets found their solve finished: "cg_idle" / "cgB_idle" carry the counts in
-    // their launch fields (the stream has been synchronised: the flag copies have landed)
-    for (size_t q = 0; q < h->sample_off.size(); ++q) {
-        const double* F = h->h_sample + h->sample_off[q];
-        const size_t s0 = (size_t)h->sample_pass_first[q], s1 = q + 1 < h->sample_off.size() ? (size_t)h->sample_pass_first[q + 1] : h->samples.size();
-        for (size_t k = s0; k < s1; ++k) {
-            const mvs_deform_s::SweepSample& sm = h->samples[k];
-            for (int i = 0; i < sm.n_a; ++i) if (F[(size_t)(sm.first + i) * 8 + 6] != 0.0) h->timers["cg_idle"].launches++;
-            for (int i = 0; i < sm.n_b; ++i) if (F[(size_t)(sm.first + sm.n_a + i) * 8 + 6] != 0.0) h->timers["cgB_idle"].launches++;
-        }
-    }
     h->samples.clear(); h->sample_off.clear(); h->sample_pass_first.clear(); h->sample_used = 0;
 }
 
@@ -242,6 +248,8 @@ void free_nodes(mvs_deform_s* h) {
     h->d_ctrl_a = nullptr; h->d_ctrl_b = nullptr; h->d_valid = nullptr; h->d_d2min = nullptr; h->d_counts = nullptr;
     h->d_records = nullptr; h->d_top_idx = nullptr; h->d_heavy = nullptr; h->d_heavy2 = nullptr;
     h->d_prev_d2 = nullptr; h->d_prev_node = nullptr; h->d_knn_ws = nullptr;
+    h->d_near_prev = nullptr; h->d_lim = nullptr; h->d_mid = nullptr; h->d_mid2 = nullptr;
+    h->near_ready = false; h->graph_prev_nn = 0;
     h->prev_valid = false;
     h->d_ctrl_final = nullptr; h->K = 0; h->nbr_k = 0; h->h_nodes.clear();
     h->graph_ready_nn = 0; h->weights_ready = false; h->heavy_pending = nullptr;
@@ -365,7 +373,31 @@ void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
     const int K = (int)h->K;
     int32_t* cur = h->heavy_flip ? h->d_heavy2 : h->d_heavy;
     int32_t* nxt = h->heavy_flip ? h->d_heavy : h->d_heavy2;
+    int32_t* mcur = h->heavy_flip ? h->d_mid2 : h->d_mid;
+    int32_t* mnxt = h->heavy_flip ? h->d_mid : h->d_mid2;
     h->heavy_flip ^= 1;
+    if (h->near_ready && h->grid.P > 0 && K > 0 && p.graph_k + 1 <= 16 && MVS_KNOB("MVS_ASSOC_BOUNDED", 1, 0, 1) != 0.0) {
+        // Bounded pass (assoc.hip): the last association of this node set against this target left every node's nearest distance
+        // (d_d2min) and position (d_near_prev).  Two launches: bounds + classes (+ the node grid of the graph search in the same
+        // launch's first workgroup), then heavy / mid / near nodes, the graph queries and the cotangent weights side by side.
+        const int nn = p.graph_k + 1;
+        const bool graph_here = h->d_knn_ws != nullptr && knn_grid_is_single(K) && ensure_nbr(h, nn) == MVS_OK;
+        const bool bounded_graph = graph_here && h->graph_prev_nn == nn && K >= nn;
+        const bool w = graph_here && use_ras(h, p);
+        launch_assoc_prep(h->grid, h->d_node_pts, K, h->d_d2min, h->d_near_prev, h->d_lim, cur, mcur, graph_here ? h->d_knn_ws : nullptr, h->stream);
+        launch_assoc_all(h->grid, h->d_node_pts, h->d_node_nrm, K, p, h->d_lim, h->d_d2min, h->d_records, h->d_counts, cur, mcur, nxt, mnxt, h->d_ctrl_raw,
+                         h->d_valid, h->d_top_idx, nn, h->d_nbr, graph_here ? h->d_knn_ws : nullptr, bounded_graph, w ? &h->sell : nullptr, h->d_pts,
+                         arap_grid_blocks(h->sell), h->stream);
+        h->assoc_passes++;
+        h->graph_in_local = false; h->heavy_pending = nullptr;
+        if (graph_here) { h->graph_ready_nn = nn; h->weights_ready = w; h->graph_prev_nn = nn; }
+        toc(t, 2);
+        return;
+    }
+    // unbounded pass (the first association of a fit): what the bounded passes start from is recorded behind it
+    (void)hipMemsetAsync(mcur, 0, sizeof(int32_t), h->stream); (void)hipMemsetAsync(mnxt, 0, sizeof(int32_t), h->stream);
+    if (K > 0) (void)hipMemcpyAsync(h->d_near_prev, h->d_node_pts, sizeof(double) * 3 * (size_t)K, hipMemcpyDeviceToDevice, h->stream);
+    h->near_ready = K > 0 && h->grid.P > 0;
     // the heavy-node pass shares a launch with the node-graph search of enqueue_solve when that search runs on the grid
     const bool defer = h->d_knn_ws != nullptr && p.graph_k + 1 <= 64;
     // the 9-NN graph of the nodes needs only their positions: its grid is built first and the queries ride with the nodes' own
@@ -431,6 +463,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
                 toc(t, knn_grid_launches(K));
             } else { launch_knn(h->d_node_pts, K, nn, h->d_nbr, s); toc(t, 1); }
         }
+        h->graph_prev_nn = nn;               // d_nbr holds this pass's complete graph: the bound of the next pass's graph queries
         Tic t = tic(h, "smooth");
         double* bufs[2] = {h->d_ctrl_a, h->d_ctrl_b};
         // (patch-solver iteration: the last sweep is done by k_ras_prepare, node by node, as it starts the solve)
@@ -482,7 +515,7 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
             toc(t, 1);
         }
         {
-            Tic t = tic(h, "cg");
+            Tic t = (h->timing == 3 && !sampling) ? Tic{h, "cg", nullptr} : tic(h, "cg");      // (mode 3 times exactly the sampled brackets)
             const int ss = ras_slot_size(h);
             auto sweep = [&](int i, bool last) {
                 double* x_next = x_cur == h->d_sol ? h->d_ras_x2 : h->d_sol;
@@ -496,23 +529,12 @@ int enqueue_solve(mvs_deform_s* h, const mvs_deform_params& p, const double* ctr
                 ++ras_slot;
             };
             // ("cg" = the planned sweeps, "tail" = the solve's last launch — in fused mode the deciding launch + the local step)
-            // Sampled passes of timing mode 3 bracket the planned sweeps in two groups: "cg" = as many launches as the solve
-            // ran sweeps the last time the host looked (they do work), "cgB" = the spare launches behind them (they find the
-            // solve finished: one copy, then returns after one load).  Which launches were idle is READ BACK (sample_flags).
+            // Sampled passes of timing mode 3: which of the bracketed launches did work is READ BACK (the idle flags of this pass's
+            // sweep slots are copied out behind the pass); collect_timers files every bracket under its composition.
             const int planned = rp.n[it] - 1;
-            int n_a = planned;
-            if (sampling) {
-                const int ran = h->ras_hist_n[it] > 0 ? h->ras_hist[it][h->ras_hist_n[it] - 1] : planned;
-                n_a = std::max(0, std::min(planned, ran));
-                h->samples.push_back({(int)ras_slot, n_a, planned - n_a});
-            }
-            for (int i = 0; i < n_a; ++i) sweep(i, false);
-            toc(t, n_a);
-            if (n_a < planned) {
-                Tic tb = tic(h, "cgB");
-                for (int i = n_a; i < planned; ++i) sweep(i, false);
-                toc(tb, planned - n_a);
-            }
+            if (sampling) h->samples.push_back({(int)ras_slot, planned, 0});
+            for (int i = 0; i < planned; ++i) sweep(i, false);
+            toc(t, planned);
             Tic tl = tic(h, "tail");
             sweep(rp.n[it] - 1, true);
             toc(tl, 1);
@@ -962,6 +984,8 @@ static int install_nodes(mvs_deform_s* h, const int32_t* vertex_idx, int64_t K) 
         h->d_ctrl_raw = a.take<double>((size_t)K * 3); h->d_ctrl_a = a.take<double>((size_t)K * 3); h->d_ctrl_b = a.take<double>((size_t)K * 3);
         h->d_d2min = a.take<float>(K); h->d_counts = a.take<int32_t>((size_t)K * 2);
         h->d_prev_d2 = a.take<float>(K); h->d_prev_node = a.take<double>((size_t)K * 3);
+        h->d_near_prev = a.take<double>((size_t)K * 3); h->d_lim = a.take<float>(K);
+        h->d_mid = a.take<int32_t>((size_t)K + 1); h->d_mid2 = a.take<int32_t>((size_t)K + 1);
         h->d_records = a.take<mvs_cand>((size_t)K * 8); h->d_top_idx = a.take<int64_t>((size_t)K * 8);
         h->d_nbr = a.take<int32_t>((size_t)K * 64);                            // graph_k <= 63
         h->d_knn_ws = ws_bytes ? (void*)a.take<char>(ws_bytes) : nullptr;
@@ -972,6 +996,7 @@ static int install_nodes(mvs_deform_s* h, const int32_t* vertex_idx, int64_t K) 
         Arena b; b.base = (char*)h->arena_nodes; lay(b);
     }
     HIPCHK(hipMemsetAsync(h->d_heavy, 0, sizeof(int32_t), h->stream)); HIPCHK(hipMemsetAsync(h->d_heavy2, 0, sizeof(int32_t), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_mid, 0, sizeof(int32_t), h->stream)); HIPCHK(hipMemsetAsync(h->d_mid2, 0, sizeof(int32_t), h->stream));
     HIPCHK(hipMemsetAsync(h->d_valid, 0, (size_t)std::max<int64_t>(K, 1), h->stream));
     h->heavy_flip = 0;
     HIPCHK(hipMemsetAsync(h->d_is_ctrl, 0, sizeof(int32_t) * h->V, h->stream));
@@ -1018,6 +1043,7 @@ int mvs_deform_set_vertices(mvs_deform_t h, const double* points, const double* 
         h->d_ctrl_final = h->d_ctrl_raw;
     }
     h->graph_ready_nn = 0; h->weights_ready = false; h->heavy_pending = nullptr; h->graph_in_local = false;
+    h->near_ready = false;                                   // a new fit: its first association searches unbounded
     HIPCHK(hipStreamSynchronize(h->stream));                 // (the host arrays may be released on return)
     return mvs_check_hip(hipGetLastError(), "set_vertices");
 }
@@ -1185,6 +1211,7 @@ int mvs_deform_assoc_dmin(mvs_deform_t h, const mvs_deform_params* p, float* d2m
     int rc = ready(h, p, true);
     if (rc) return rc;
     if (!d2min_dev) return MVS_E_INVALID_ARG;
+    h->near_ready = false;              // (the sharded step keeps its own bound, d_prev_d2 / d_prev_node)
     Tic t = tic(h, "assoc");
     launch_assoc_dmin(h->grid, h->d_node_pts, (int)h->K, d2min_dev, h->stream, h->prev_valid ? h->d_prev_d2 : nullptr, h->d_prev_node);
     toc(t, 1);
@@ -1196,6 +1223,7 @@ int mvs_deform_assoc_select(mvs_deform_t h, const mvs_deform_params* p, const fl
     int rc = ready(h, p, true);
     if (rc) return rc;
     if (!d2min_dev || !records_dev || !counts_dev) return MVS_E_INVALID_ARG;
+    h->near_ready = false;
     Tic t = tic(h, "assoc");
     // The heavy-node pass shares its launch with two pieces of the solve that need nothing from the exchange: the node
     // graph and (patch solver) the cotangent weights — they then overlap with the heavy nodes instead of following the

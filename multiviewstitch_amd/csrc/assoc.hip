@@ -329,7 +329,9 @@ constexpr int HEAVY_DMIN_FLAG = 0x40000000;                 // heavy-list entry:
 // shells are taken in batches (0-3, 4-5, then one by one) with the waves' minima joined through LDS after each batch.
 // `best` = distance to a point already seen (stage A), INFINITY if none.  The result is the exact nearest distance: which
 // cells are skipped depends on the order of the search, the minimum does not.
-__device__ inline float dmin_coarse_wg(const GridDev& g, const double* __restrict__ node_pts, int node, float best, HeavyLds* lds) {
+// s_first: shells 0..s_first go through in the FIRST batch (a caller that knows an upper bound of the result — `best` is then
+// that bound, not a distance already seen — passes the shell the bound reaches: one batch, no barrier per shell).
+__device__ inline float dmin_coarse_wg(const GridDev& g, const double* __restrict__ node_pts, int node, float best, HeavyLds* lds, int s_first = 3) {
     const int lane = threadIdx.x & 63, part = (int)(threadIdx.x >> 6);
     const float qx = (float)node_pts[3 * node], qy = (float)node_pts[3 * node + 1], qz = (float)node_pts[3 * node + 2];
     const QCell c = query_cell(g, qx, qy, qz);
@@ -340,7 +342,7 @@ __device__ inline float dmin_coarse_wg(const GridDev& g, const double* __restric
     Mc = fmaxf(Mc, 0.0f);
     const int SmaxC = max(g.NX, max(g.NY, g.NZ));
     for (int s_lo = 0; s_lo <= SmaxC;) {
-        const int s_hi = s_lo == 0 ? min(3, SmaxC) : (s_lo == 4 ? min(5, SmaxC) : s_lo);
+        const int s_hi = s_lo == 0 ? min(max(3, s_first), SmaxC) : (s_lo == 4 ? min(5, SmaxC) : s_lo);
         int grp = 0;
         for (int S = s_lo; S <= s_hi; ++S) {
             const int n = 2 * S + 1, total = S == 0 ? 1 : 6 * n * n - 12 * n + 8;
@@ -889,14 +891,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 // one heavy-list entry by one 16-wave workgroup: the deferred coarse walk first when the entry asks for it, then the ball query
 __device__ inline void heavy_entry(const GridDev& g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm, int entry,
                                    int top_k, float* __restrict__ d2min, mvs_cand* __restrict__ rec, int32_t* __restrict__ counts,
-                                   HeavyLds* lds, const LocalMerge& lm) {
+                                   HeavyLds* lds, const LocalMerge& lm, const float* __restrict__ bound2 = nullptr) {
     const int node = entry & ~HEAVY_DMIN_FLAG;
-    float dm = d2min[node];
+    // bound2 (bounded association, k_assoc_all): an upper bound of the node's squared nearest distance from the previous pass —
+    // the walk prunes against it from its first cell on and takes every shell it reaches in one batch
+    float dm = bound2 ? bound2[node] : d2min[node];
+    int s_first = 3;
+    if (bound2 && dm < INFINITY) s_first = (int)fminf(1.0e6f, ceilf(sqrtf(dm) * g.inv_h * 0.125f)) + 1;
     if (entry & HEAVY_DMIN_FLAG) {
 #ifdef MVS_STAMPS
         unsigned long long tc0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc0_) :: "memory");
 #endif
-        dm = dmin_coarse_wg(g, node_pts, node, dm, lds);
+        dm = dmin_coarse_wg(g, node_pts, node, dm, lds, s_first);
 #ifdef MVS_STAMPS
         { unsigned long long tc1_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc1_) :: "memory");
           if (threadIdx.x == 0 && node < 16384) g_dmin_shell[8 * node + 7] = tc1_ - tc0_; }
@@ -950,6 +956,469 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_heavy_knn(GridDev g,
     }
     const int q = ((int)blockIdx.x - heavy_blocks) * HEAVY_WAVES + (int)(threadIdx.x >> 6);
     if (q < K) ng_knn_query(q, node_pts, K, nn, geo, cs, sorted, nbr, nullptr, nullptr);
+}
+
+// =================================================================== bounded association (round 4) ====
+// From the second association of a fit on, every node comes with a bound: the target has not changed, the node has moved by
+// `delta`, so its new nearest distance is at most sqrt(d2min of the last pass) + delta (triangle inequality; slack for the
+// float32 roundings as in k_assoc_dmin).  The ball the reference queries (radius^2 = 2 d2min, Deformation.cpp:288) then lies
+// inside the CANDIDATE sphere of radius^2 2 * limit2, which is known BEFORE the search: no shell walk, one look-up of the cells
+// the sphere touches, one pass over their points (nearest distance) and one over the same points again (ball members; cache
+// hits).  On the metric workload the candidate sphere of 99.5 % of the nodes is a fraction of a grid cell wide (scripts/
+// stream_stats.py: median radius 0.15 cells, 1-4 ball members) — 16 LANES take such a node, four nodes to a wave; the search
+// is four dependent memory round trips (node, cell table, points, normals + positions of the members) instead of the nine or
+// more of the unbounded walk.  The results are the same bits: the nearest distance is a minimum over a superset of the points
+// that can attain it, the ball and the total order of its members do not depend on how they were found.
+//   k_assoc_prep : [block 0: the node grid of the graph search (knn_dev.h)] + a thread per node: bound, class, lists
+//   k_assoc_all  : heavy nodes (workgroup each, bounded coarse walk) | mid nodes (wave each, the unbounded code with the bound as
+//                  its limit) | near nodes (16 lanes each) | 9-NN graph queries bounded by the previous neighbour list
+//                  (16 lanes each) | cotangent weights of the template
+constexpr int CLS_NEAR = 0, CLS_MID = 1, CLS_HEAVY = 2;
+struct NearBox { int x0, x1, y0, z0, ny_, npx, R; };
+
+__device__ inline float temporal_limit2(float prev_d2, d3 prev, d3 cur) {
+    const double dx = cur.x - prev.x, dy = cur.y - prev.y, dz = cur.z - prev.z;
+    // the search runs on float32-rounded coordinates: both roundings (previous and current query) enter the radius (k_assoc_dmin)
+    const double ulp = 4.0 * 1.1920929e-7 * (fabs(cur.x) + fabs(cur.y) + fabs(cur.z));
+    const double r = sqrt((double)prev_d2) + sqrt(dx * dx + dy * dy + dz * dz) + ulp;
+    const double l2 = r * r * 1.001 + 1e-12;
+    return (l2 == l2 && l2 < 3.0e38) ? (float)l2 : INFINITY;
+}
+
+// class of a node from its bound; NEAR: the cells of the candidate sphere's bounding box are at most 16 contiguous ranges of
+// the cell-sorted points (rows (y,z) x the one or two coarse columns its x run crosses) — one per lane of the node's group
+__device__ inline int near_classify(const GridDev& g, const QCell& c, float limit2, NearBox* B) {
+    if (!(limit2 < INFINITY)) return CLS_MID;                // no bound: the unbounded search of one wave
+    const float rc = sqrtf(2.0f * limit2) * g.inv_h + 0.01f; // candidate radius in fine cells (+ rounding guard, as select_node)
+    const float lx = floorf(c.fx - rc), hx = floorf(c.fx + rc);
+    const float ly = floorf(c.fy - rc), hy = floorf(c.fy + rc);
+    const float lz = floorf(c.fz - rc), hz = floorf(c.fz + rc);
+    const bool any = hx >= 0.f && lx <= (float)(g.nx - 1) && hy >= 0.f && ly <= (float)(g.ny - 1) && hz >= 0.f && lz <= (float)(g.nz - 1);
+    if (!any) return CLS_MID;
+    const int x0 = (int)fmaxf(lx, 0.f), x1 = (int)fminf(hx, (float)(g.nx - 1));
+    const int y0 = (int)fmaxf(ly, 0.f), y1 = (int)fminf(hy, (float)(g.ny - 1));
+    const int z0 = (int)fmaxf(lz, 0.f), z1 = (int)fminf(hz, (float)(g.nz - 1));
+    const int ny_ = y1 - y0 + 1, nz_ = z1 - z0 + 1;
+    if (ny_ > 64 || nz_ > 64) return CLS_HEAVY;
+    const int rows = ny_ * nz_, npx = (x1 >> 3) - (x0 >> 3) + 1;
+    if (x1 - x0 < 8 && rows * npx <= 16) {
+        B->x0 = x0; B->x1 = x1; B->y0 = y0; B->z0 = z0; B->ny_ = ny_; B->npx = npx; B->R = rows * npx;
+        return CLS_NEAR;
+    }
+    return rows <= HEAVY_ROWS ? CLS_MID : CLS_HEAVY;
+}
+
+// a thread per node: the bound for this pass, where the node stands (for the next pass's bound), the lists of the nodes the
+// 16-lane search does not take
+__device__ inline void classify_node(const GridDev& g, const double* __restrict__ node_pts, int node, const float* __restrict__ d2min_prev,
+                                     double* __restrict__ prev_node, float* __restrict__ lim_out, int32_t* __restrict__ heavy,
+                                     int32_t* __restrict__ mid) {
+    const d3 cur = ld3(node_pts + 3 * (int64_t)node), prv = ld3(prev_node + 3 * (int64_t)node);
+    const float lim = temporal_limit2(d2min_prev[node], prv, cur);
+    st3(prev_node + 3 * (int64_t)node, cur);
+    lim_out[node] = lim;
+    const QCell c = query_cell(g, (float)cur.x, (float)cur.y, (float)cur.z);
+    NearBox B;
+    const int cls = near_classify(g, c, lim, &B);
+    if (cls == CLS_MID) mid[1 + atomicAdd(&mid[0], 1)] = node;
+    else if (cls == CLS_HEAVY) heavy[1 + atomicAdd(&heavy[0], 1)] = node | HEAVY_DMIN_FLAG;
+}
+
+__global__ __launch_bounds__(1024) void k_assoc_prep(GridDev g, const double* __restrict__ node_pts, int K, const float* __restrict__ d2min_prev,
+                                                     double* __restrict__ prev_node, float* __restrict__ lim_out, int32_t* __restrict__ heavy,
+                                                     int32_t* __restrict__ mid, int with_grid, int NC, NgGeom* __restrict__ geo,
+                                                     int* __restrict__ ng_start, float4* __restrict__ ng_sorted) {
+    if (with_grid && blockIdx.x == 0) { ng_build1_body(node_pts, K, NC, geo, ng_start, ng_sorted); return; }
+    const int node = ((int)blockIdx.x - (with_grid ? 1 : 0)) * 1024 + (int)threadIdx.x;
+    if (node < K) classify_node(g, node_pts, node, d2min_prev, prev_node, lim_out, heavy, mid);
+}
+
+// ---- 16-lane row helpers (DPP: row_shr:n = 0x110 + n with zero fill, row_ror:n = 0x120 + n)
+__device__ inline int row_incl_scan_i(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    return v;
+}
+template <int N> __device__ inline int row_ror(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x120 + N, 0xf, 0xf, false); }
+__device__ inline float row_min_f(float v) {
+    v = fminf(v, __int_as_float(row_ror<8>(__float_as_int(v)))); v = fminf(v, __int_as_float(row_ror<4>(__float_as_int(v))));
+    v = fminf(v, __int_as_float(row_ror<2>(__float_as_int(v)))); v = fminf(v, __int_as_float(row_ror<1>(__float_as_int(v))));
+    return v;
+}
+__device__ inline float row_max_f(float v) {      // NaN-propagating: a NaN in any lane gives NaN
+    float t;
+    t = __int_as_float(row_ror<8>(__float_as_int(v))); v = (v != v || t != t) ? NAN : fmaxf(v, t);
+    t = __int_as_float(row_ror<4>(__float_as_int(v))); v = (v != v || t != t) ? NAN : fmaxf(v, t);
+    t = __int_as_float(row_ror<2>(__float_as_int(v))); v = (v != v || t != t) ? NAN : fmaxf(v, t);
+    t = __int_as_float(row_ror<1>(__float_as_int(v))); v = (v != v || t != t) ? NAN : fmaxf(v, t);
+    return v;
+}
+__device__ inline int row_sum_i(int v) { v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v); return v; }
+// LDS written by some lanes of this wave, read by others of the same wave: the LDS executes a wave's accesses in order; the
+// fences keep the compiler from moving them across
+__device__ inline void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+struct NearSlots {            // one per 16-lane group
+    double pd[16], pl[16], x[16], y[16], z[16]; long long idx[16];            // candidates (ball members that face the node)
+    double s_pd[8], s_pl[8], s_x[8], s_y[8], s_z[8]; long long s_idx[8];      // the node's list, best first
+};
+
+// the item (point) numbers l, l+16, l+32, l+48 of a round of 64 over the concatenated ranges of a group: range of each item by
+// counting the inclusive prefixes at or below it (the ranges are few: Rw = the most any group of this wave holds)
+__device__ inline void near_items(int r0, int l, int rb, int Rw, int a, int off, int inc, int T, bool act, int (&idx)[4], bool (&ok)[4]) {
+    int jr[4] = {0, 0, 0, 0};
+    for (int j = 0; j < Rw; ++j) {
+        const int oj = __shfl(inc, rb | j, 64);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) jr[k] += (r0 + l + 16 * k >= oj) ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = r0 + l + 16 * k, j = min(jr[k], 15);
+        const int aj = __shfl(a, rb | j, 64), oj = __shfl(off, rb | j, 64);
+        ok[k] = act && t < T;
+        idx[k] = ok[k] ? aj + (t - oj) : 0;
+    }
+}
+
+// Four nodes by one wave, 16 lanes each: node = node_base + (lane >> 4).  A node whose class is not NEAR is left alone (its
+// list entry is taken by the heavy / mid sections of the same launch).
+__device__ inline void near_nodes(const GridDev& g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm, int K, int top_k,
+                                  const float* __restrict__ lim_in, float* __restrict__ d2min, mvs_cand* __restrict__ rec,
+                                  int32_t* __restrict__ counts, const LocalMerge& lm, NearSlots* wave_slots, int node_base) {
+    const int lane = threadIdx.x & 63, l = lane & 15, rb = lane & 48;
+    NearSlots* S = wave_slots + (lane >> 4);
+    const int node = node_base + (lane >> 4);
+    bool act = node < K;
+    const int nd = act ? node : 0;
+    const d3 orig = ld3(node_pts + 3 * (int64_t)nd), nn = ld3(node_nrm + 3 * (int64_t)nd);
+    const float lim2 = lim_in[nd];
+    const float qx = (float)orig.x, qy = (float)orig.y, qz = (float)orig.z;
+    const QCell c = query_cell(g, qx, qy, qz);
+    NearBox B{0, 0, 0, 0, 1, 1, 0};
+    act = act && near_classify(g, c, lim2, &B) == CLS_NEAR;
+    // ---- the ranges: lane l takes range l = (row, coarse column) of the box
+    int a = 0, n = 0;
+    if (act && l < B.R) {
+        const int row = B.npx == 2 ? (l >> 1) : l, piece = B.npx == 2 ? (l & 1) : 0;
+        const int zq = (int)(((float)row + 0.5f) * (1.0f / (float)B.ny_));           // row / ny_ (exact at these sizes)
+        const int y = B.y0 + (row - zq * B.ny_), z = B.z0 + zq, X = (B.x0 >> 3) + piece;
+        const int64_t base = grid_rowbase(g.NX, g.NY, X, y, z);
+        a = g.cell_start[base + (max(B.x0, 8 * X) & 7)];
+        n = g.cell_start[base + (min(B.x1, 8 * X + 7) & 7) + 1] - a;
+    }
+    const int inc = row_incl_scan_i(n), off = inc - n;
+    const int T = __shfl(inc, rb | 15, 64);
+    const int Ract = act ? B.R : 0;
+    const int Rw = max(max(__builtin_amdgcn_readlane(Ract, 0), __builtin_amdgcn_readlane(Ract, 16)),
+                       max(__builtin_amdgcn_readlane(Ract, 32), __builtin_amdgcn_readlane(Ract, 48)));
+    // ---- pass 1: the nearest distance (the points of the first round stay in registers for pass 2)
+    float best = INFINITY;
+    float4 P0[4];
+    int I0[4]; bool V0[4];
+    for (int r0 = 0;; r0 += 64) {
+        if (!__ballot(act && r0 < T)) break;                                         // (wave-uniform)
+        int I[4]; bool V[4];
+        near_items(r0, l, rb, Rw, a, off, inc, T, act, I, V);
+        float4 P[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) P[k] = g.spos[I[k]];                             // (clamped address 0 for lanes without an item)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (V[k]) best = fminf(best, d2f(qx, qy, qz, P[k].x, P[k].y, P[k].z));
+        if (r0 == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { P0[k] = P[k]; I0[k] = I[k]; V0[k] = V[k]; }
+        }
+    }
+    const float dm = row_min_f(best);
+    // ---- pass 2: the ball d2 <= 2 d2min (:288), normal filter (:304-315), keys (:330-335), the best top_k by the total order
+    const float r2 = dm * 2.0f;
+    const double nlen = norm3(nn);
+    const bool sel = act && dm < INFINITY;
+    int n_ball = 0, n_pass = 0, cnt = 0;
+    // all `cnt` candidates ranked by (projDist, |projLen|, index): the ones with fewer than 8 predecessors ARE the list
+    auto rank_slots = [&]() {
+        wave_lds_fence();
+        const bool mine = sel && l < cnt;
+        double m_pd = 0, m_pl = 0; long long m_i = 0;
+        if (mine) { m_pd = S->pd[l]; m_pl = S->pl[l]; m_i = S->idx[l]; }
+        int rank = 0;
+        for (int cidx = 0; cidx < 16; ++cidx) {
+            if (!__ballot(sel && cidx < cnt)) break;
+            if (mine && cidx < cnt && key_less(S->pd[cidx], fabs(S->pl[cidx]), S->idx[cidx], m_pd, fabs(m_pl), m_i)) ++rank;
+        }
+        if (mine && rank < 8) { S->s_pd[rank] = m_pd; S->s_pl[rank] = m_pl; S->s_x[rank] = S->x[l]; S->s_y[rank] = S->y[l]; S->s_z[rank] = S->z[l]; S->s_idx[rank] = m_i; }
+        wave_lds_fence();
+    };
+    auto push = [&](bool has, double pd, double pl, d3 tp, long long gi) {
+        bool pending = has;
+        while (__ballot(pending)) {
+            const int f = pending ? 1 : 0, ic = row_incl_scan_i(f), ex = ic - f;
+            const int tot = __shfl(ic, rb | 15, 64), room = 16 - cnt;
+            if (pending && ex < room) {
+                const int sl = cnt + ex;
+                S->pd[sl] = pd; S->pl[sl] = pl; S->x[sl] = tp.x; S->y[sl] = tp.y; S->z[sl] = tp.z; S->idx[sl] = gi;
+                pending = false;
+            }
+            cnt += min(tot, room);
+            if (__ballot(tot > room)) {                                              // a group's 16 slots are full: keep its best 8
+                const bool full = tot > room;                                        // (the other groups of the wave idle through this)
+                const int keep_cnt = cnt;
+                if (!full) cnt = 0;                                                  // (rank_slots looks at `cnt` slots: none for them)
+                rank_slots();
+                if (full && l < 8) { S->pd[l] = S->s_pd[l]; S->pl[l] = S->s_pl[l]; S->x[l] = S->s_x[l]; S->y[l] = S->s_y[l]; S->z[l] = S->s_z[l]; S->idx[l] = S->s_idx[l]; }
+                wave_lds_fence();
+                cnt = full ? 8 : keep_cnt;
+            }
+        }
+    };
+    for (int r0 = 0;; r0 += 64) {
+        if (!__ballot(sel && r0 < T)) break;
+        float4 P[4]; int I[4]; bool V[4];
+        if (r0 == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { P[k] = P0[k]; I[k] = I0[k]; V[k] = V0[k]; }
+        } else {
+            near_items(r0, l, rb, Rw, a, off, inc, T, act, I, V);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) P[k] = g.spos[I[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool member = sel && V[k] && d2f(qx, qy, qz, P[k].x, P[k].y, P[k].z) <= r2;
+            if (!__ballot(member)) continue;                                          // (wave-uniform)
+            bool has = false;
+            double pd = 0, pl = 0; d3 tp = mk3(0, 0, 0); long long gi = 0;
+            if (member) {
+                ++n_ball;
+                const d3 tn = ld3(g.tnrm + 3 * (int64_t)I[k]);
+                tp = ld3(g.tpos + 3 * (int64_t)I[k]);                                 // (issued with the normal: one round trip)
+                if (dot3(nn, tn) > 0) {                                               // :307
+                    ++n_pass;
+                    const d3 dir = tp - orig;                                         // :331
+                    pl = dot3(dir, nn) / nlen;                                        // :332
+                    const double x = sqn3(dir) - pl * pl;
+                    pd = sqrt((0.0 < x) ? x : 0.0);                                   // :334, clamped (Appendix A.2)
+                    gi = g.index_base + (long long)__float_as_int(P[k].w);
+                    has = true;
+                }
+            }
+            push(has, pd, pl, tp, gi);
+        }
+    }
+    n_ball = row_sum_i(n_ball);
+    n_pass = row_sum_i(n_pass);
+    rank_slots();
+    const int len = min(cnt, min(top_k, 8));
+    if (!act) return;
+    // ---- what select_node writes for a single-rank run, same operations in the same order
+    if (l < 8) {
+        mvs_cand* o = rec + (int64_t)node * 8 + l;
+        const bool live = l < len;
+        o->proj_dist = live ? S->s_pd[l] : 0.0;
+        o->proj_len = live ? S->s_pl[l] : 0.0;
+        o->pos[0] = live ? S->s_x[l] : 0.0; o->pos[1] = live ? S->s_y[l] : 0.0; o->pos[2] = live ? S->s_z[l] : 0.0;
+        o->index = live ? S->s_idx[l] : -1;
+    }
+    if (l == 0) { counts[2 * (int64_t)node] = n_ball; counts[2 * (int64_t)node + 1] = n_pass; d2min[node] = dm; }
+    if (lm.controls) {
+        bool ok = n_ball < lm.max_result && len > 0;
+        d3 mp = orig;
+        double m_pl = 0, m_pd = 0;
+        d3 acc = mk3(0, 0, 0);
+        for (int sidx = 0; sidx < len; ++sidx) {                                      // :341-346, best first
+            m_pl += S->s_pl[sidx]; m_pd += S->s_pd[sidx];
+            acc = acc + mk3(S->s_x[sidx], S->s_y[sidx], S->s_z[sidx]);
+        }
+        if (ok) {
+            const double dn = (double)len;
+            m_pl /= dn; m_pd /= dn; acc = acc / dn;
+            if (m_pl >= lm.proj_len_err || m_pd >= lm.proj_dist_err) ok = false;
+            if (ok) {
+                const d3 dir = acc - orig;
+                if (fabs(dot3(dir, nn) / (norm3(dir) * norm3(nn))) < lm.min_cos) ok = false;
+            }
+            if (ok) mp = acc;
+        }
+        if (lm.top_idx && l < 8) lm.top_idx[(int64_t)node * 8 + l] = (n_ball < lm.max_result && len > 0 && l < len) ? S->s_idx[l] : -1;
+        if (l == 0) { lm.valid[node] = ok ? 1 : 0; st3(lm.controls + 3 * (int64_t)node, mp); }
+    }
+}
+
+// Four graph queries by one wave, 16 lanes each, bounded by the PREVIOUS pass's neighbour list: the k nodes of that list are k
+// distinct points, so the k-th nearest distance now is at most B = the largest of their distances now — every neighbour lies in
+// the cells the sphere of radius sqrt(B) touches.  Their points with d <= B are ranked by (distance, index); the first k are the
+// list, in the order the shell walk of ng_knn_query leaves it.  A query this does not fit (no complete previous list, a box of
+// more than 16 rows, more than 32 points inside B, a NaN) is redone by the whole wave with the walk.
+__device__ inline void graph_queries_bounded(const double* __restrict__ pts, int K, int k, const NgGeom* __restrict__ geo, const int* __restrict__ cs,
+                                             const float4* __restrict__ sorted, int32_t* __restrict__ nbr, unsigned long long (*wave_keys)[32], int q_base) {
+    const int lane = threadIdx.x & 63, l = lane & 15, rb = lane & 48;
+    unsigned long long* keys = wave_keys[lane >> 4];
+    const int q = q_base + (lane >> 4);
+    const bool live = q < K;
+    const int qc = live ? q : 0;
+    const NgGeom g = *geo;
+    const float qx = (float)pts[3 * (int64_t)qc], qy = (float)pts[3 * (int64_t)qc + 1], qz = (float)pts[3 * (int64_t)qc + 2];
+    // the bound: distances NOW to the nodes of the previous list
+    float dprev = 0.0f;
+    bool complete = live;
+    if (live && l < k) {
+        const int j = nbr[(int64_t)q * k + l];
+        if (j < 0 || j >= K) complete = false;
+        else dprev = d2f(qx, qy, qz, (float)pts[3 * (int64_t)j], (float)pts[3 * (int64_t)j + 1], (float)pts[3 * (int64_t)j + 2]);
+    }
+    const float B2 = row_max_f(dprev);
+    const int incomplete = row_sum_i(complete ? 0 : 1);                                // (cross-lane: outside any short-circuit)
+    bool fit = live && !(B2 != B2) && B2 < INFINITY && incomplete == 0;
+    int x0 = 0, x1 = 0, y0 = 0, z0 = 0, ny_ = 1, rows = 0;
+    if (fit) {
+        const float fx = (qx - g.minx) * g.inv_h, fy = (qy - g.miny) * g.inv_h, fz = (qz - g.minz) * g.inv_h;
+        const float rc = sqrtf(B2) * g.inv_h + 0.01f;
+        const float lx = floorf(fx - rc), hx = floorf(fx + rc), ly = floorf(fy - rc), hy = floorf(fy + rc), lz = floorf(fz - rc), hz = floorf(fz + rc);
+        x0 = (int)fmaxf(lx, 0.f); x1 = (int)fminf(hx, (float)(g.nx - 1));
+        y0 = (int)fmaxf(ly, 0.f); const int y1 = (int)fminf(hy, (float)(g.ny - 1));
+        z0 = (int)fmaxf(lz, 0.f); const int z1 = (int)fminf(hz, (float)(g.nz - 1));
+        ny_ = y1 - y0 + 1;
+        const int nz_ = z1 - z0 + 1;
+        rows = (ny_ > 0 && nz_ > 0 && x0 <= x1 && ny_ <= 16 && nz_ <= 16) ? ny_ * nz_ : 17;
+        if (rows > 16) { fit = false; rows = 0; }
+    }
+    int a = 0, n = 0;
+    if (fit && l < rows) {
+        const int zq = (int)(((float)l + 0.5f) * (1.0f / (float)ny_));
+        const int y = y0 + (l - zq * ny_), z = z0 + zq;
+        const int rbase = (z * g.ny + y) * g.nx;
+        a = cs[rbase + x0];
+        n = cs[rbase + x1 + 1] - a;
+    }
+    const int inc = row_incl_scan_i(n), off = inc - n;
+    const int T = __shfl(inc, rb | 15, 64);
+    const int Ract = fit ? rows : 0;
+    const int Rw = max(max(__builtin_amdgcn_readlane(Ract, 0), __builtin_amdgcn_readlane(Ract, 16)),
+                       max(__builtin_amdgcn_readlane(Ract, 32), __builtin_amdgcn_readlane(Ract, 48)));
+    int cnt = 0;
+    for (int r0 = 0;; r0 += 64) {
+        if (!__ballot(fit && r0 < T)) break;
+        int I[4]; bool V[4];
+        near_items(r0, l, rb, Rw, a, off, inc, T, fit, I, V);
+        float4 P[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) P[kk] = sorted[I[kk]];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float d = d2f(qx, qy, qz, P[kk].x, P[kk].y, P[kk].z);
+            const bool in = fit && V[kk] && d <= B2;                                   // (a NaN distance never enters, as in the walk)
+            if (!__ballot(in)) continue;
+            const int f = in ? 1 : 0, ic = row_incl_scan_i(f), sl = cnt + ic - f;
+            if (in && sl < 32) keys[sl] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(P[kk].w);
+            cnt += __shfl(ic, rb | 15, 64);
+        }
+    }
+    if (cnt > 32 || cnt < k) fit = false;            // (cnt < k cannot happen with a complete list; the walk decides then)
+    wave_lds_fence();
+    if (fit) {
+        // non-negative float bits order like the floats: key order = (distance, index) order
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int sl = l + 16 * h2;
+            if (sl < cnt) {
+                const unsigned long long mk = keys[sl];
+                int rank = 0;
+                for (int cidx = 0; cidx < cnt; ++cidx) rank += keys[cidx] < mk ? 1 : 0;
+                if (rank < k) nbr[(int64_t)q * k + rank] = (int)(unsigned)(mk & 0xffffffffull);
+            }
+        }
+    }
+    // the queries the bound did not serve: the shell walk, a wave each
+    unsigned long long redo = __ballot(live && !fit && l == 0);
+    while (redo) {
+        const int src = __ffsll((long long)redo) - 1;
+        redo &= redo - 1;
+        ng_knn_query(__builtin_amdgcn_readlane(q, src), pts, K, k, geo, cs, sorted, nbr, nullptr, nullptr);
+    }
+}
+
+struct NearLdsAll { NearSlots g[16][4]; };
+struct GraphLds { unsigned long long key[16][4][32]; };
+union AllLds { HeavyLds heavy; NearLdsAll near; GraphLds graph; };
+
+// ONE launch for everything the association and the start of the solve need from the node positions (bounded passes):
+//   blocks [0, HB): heavy list (a workgroup per node) | [HB, +MB): mid list (a wave per node) | [.., +NB): near nodes (16 lanes per
+//   node) | [.., +GB): node-graph queries (16 lanes each, or a wave each without a previous list) | the rest: cotangent weights
+#ifdef MVS_STAMPS
+__device__ unsigned long long g_all_stamps[4 * 4096];         // k_assoc_all: per workgroup {start, end (100 MHz constant clock), section, work items}
+#endif
+__device__ inline int assoc_all_sections(const GridDev& g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm,
+                                                                int K, int top_k, const float* __restrict__ lim, float* __restrict__ d2min,
+                                                                mvs_cand* __restrict__ rec, int32_t* __restrict__ counts,
+                                                                const int32_t* __restrict__ heavy, const int32_t* __restrict__ mid, LocalMerge lm,
+                                                                int32_t* __restrict__ heavy_next, int32_t* __restrict__ mid_next,
+                                                                int HB, int MB, int NB, int GB, int nn, int graph_bounded,
+                                                                const NgGeom* __restrict__ geo, const int* __restrict__ cs,
+                                                                const float4* __restrict__ sorted, int32_t* __restrict__ nbr, const SellDev& m,
+                                                                const double* __restrict__ mesh_pts, int* items) {
+    __shared__ AllLds lds;
+    const int b = (int)blockIdx.x, wv = (int)(threadIdx.x >> 6);
+    if (b < HB) {
+        const int n = min(heavy[0], K);
+        for (int h = b; h < n; h += HB) {
+            heavy_entry(g, node_pts, node_nrm, heavy[1 + h], top_k, d2min, rec, counts, &lds.heavy, lm, lim);
+            __syncthreads();
+            ++*items;
+        }
+        return 0;
+    }
+    if (b < HB + MB) {
+        if (b == HB && threadIdx.x == 0) { heavy_next[0] = 0; mid_next[0] = 0; }      // the lists of the NEXT pass (they alternate)
+        const int n = min(mid[0], K);
+        for (int e = (b - HB) * HEAVY_WAVES + wv; e < n; e += MB * HEAVY_WAVES) {     // (wave-uniform)
+            const int node = mid[1 + e];
+            const float best = dmin_node(g, node_pts, node, lim[node], nullptr);
+            if ((threadIdx.x & 63) == 0) d2min[node] = best;
+            select_node<1>(g, node_pts, node_nrm, node, top_k, best, rec, counts, nullptr, 0, nullptr, lm);
+            ++*items;
+        }
+        return 1;
+    }
+    if (b < HB + MB + NB) {
+        near_nodes(g, node_pts, node_nrm, K, top_k, lim, d2min, rec, counts, lm, lds.near.g[wv], ((b - HB - MB) * HEAVY_WAVES + wv) * 4);
+        return 2;
+    }
+    if (b < HB + MB + NB + GB) {
+        const int w = (b - HB - MB - NB) * HEAVY_WAVES + wv;
+        if (graph_bounded) graph_queries_bounded(node_pts, K, nn, geo, cs, sorted, nbr, lds.graph.key[wv], 4 * w);
+        else if (w < K) ng_knn_query(w, node_pts, K, nn, geo, cs, sorted, nbr, nullptr, nullptr);
+        return 3;
+    }
+    cot_weight_rows(m, mesh_pts, b - HB - MB - NB - GB, (int)gridDim.x - HB - MB - NB - GB);
+    return 4;
+}
+__global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_all(GridDev g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm,
+                                                                int K, int top_k, const float* __restrict__ lim, float* __restrict__ d2min,
+                                                                mvs_cand* __restrict__ rec, int32_t* __restrict__ counts,
+                                                                const int32_t* __restrict__ heavy, const int32_t* __restrict__ mid, LocalMerge lm,
+                                                                int32_t* __restrict__ heavy_next, int32_t* __restrict__ mid_next,
+                                                                int HB, int MB, int NB, int GB, int nn, int graph_bounded,
+                                                                const NgGeom* __restrict__ geo, const int* __restrict__ cs,
+                                                                const float4* __restrict__ sorted, int32_t* __restrict__ nbr, SellDev m,
+                                                                const double* __restrict__ mesh_pts) {
+    int items = 0;
+#ifdef MVS_STAMPS
+    unsigned long long t0_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory");
+#endif
+    const int section = assoc_all_sections(g, node_pts, node_nrm, K, top_k, lim, d2min, rec, counts, heavy, mid, lm, heavy_next, mid_next, HB, MB, NB, GB, nn,
+                                           graph_bounded, geo, cs, sorted, nbr, m, mesh_pts, &items);
+    (void)section;
+#ifdef MVS_STAMPS
+    unsigned long long t1_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory");
+    if (threadIdx.x == 0 && blockIdx.x < 4096) { g_all_stamps[4 * blockIdx.x] = t0_; g_all_stamps[4 * blockIdx.x + 1] = t1_; g_all_stamps[4 * blockIdx.x + 2] = (unsigned long long)section; g_all_stamps[4 * blockIdx.x + 3] = (unsigned long long)items; }
+#endif
 }
 
 // ----------------------------------------------------------------- merge ----
@@ -1043,6 +1512,9 @@ __global__ __launch_bounds__(256) void k_assoc_merge(const double* __restrict__ 
 extern "C" int mvs_debug_dmin_shells(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dmin_shell), sizeof(unsigned long long) * n);
 }
+extern "C" int mvs_debug_all_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_all_stamps), sizeof(unsigned long long) * n);
+}
 extern "C" int mvs_debug_wave_stamps_clear() {
     static std::vector<unsigned long long> z(8 * 20000, 0ull);
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_stamps), z.data(), sizeof(unsigned long long) * z.size());
@@ -1134,4 +1606,32 @@ void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, c
     if (cnt_stride == 0) cnt_stride = (int64_t)K * 2 * sizeof(int32_t);
     k_assoc_merge<<<dim3(K), dim3(64), 0, s>>>(node_pts, node_nrm, K, p, rec_all, counts_all, nranks,
                                                              controls, valid, top_idx, rec_stride, cnt_stride, node0);
+}
+
+// ---- bounded association (k_assoc_prep, k_assoc_all): see the comment above near_classify
+void launch_assoc_prep(const GridDev& g, const double* node_pts, int K, const float* d2min_prev, double* prev_node, float* lim, int32_t* heavy,
+                       int32_t* mid, void* knn_ws /*!= NULL: the node grid is built by the launch's first workgroup (knn_grid_is_single(K))*/, hipStream_t s) {
+    if (K <= 0) return;
+    const void *geo = nullptr, *sorted = nullptr;
+    const int* cs = nullptr;
+    if (knn_ws) knn_grid_views(knn_ws, K, &geo, &cs, &sorted);
+    k_assoc_prep<<<dim3((knn_ws ? 1 : 0) + (K + 1023) / 1024), dim3(1024), 0, s>>>(g, node_pts, K, d2min_prev, prev_node, lim, heavy, mid, knn_ws ? 1 : 0,
+                                                                                knn_ws ? knn_grid_cells_per_axis(K) : 0, (NgGeom*)geo, const_cast<int*>(cs),
+                                                                                (float4*)sorted);
+}
+void launch_assoc_all(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, const float* lim,
+                      float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, const int32_t* mid, int32_t* heavy_next, int32_t* mid_next,
+                      double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws /*NULL: no graph section*/,
+                      bool graph_bounded, const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks, hipStream_t s) {
+    if (K <= 0) return;
+    const LocalMerge lm{controls, valid, top_idx, p.proj_len_err, p.proj_dist_err, p.min_cos, p.max_result, 0};
+    const void *geo = nullptr, *sorted = nullptr;
+    const int* cs = nullptr;
+    if (knn_ws) knn_grid_views(knn_ws, K, &geo, &cs, &sorted);
+    const int HB = std::min(K, 256), MB = 16, NB = (K + 63) / 64;
+    const int GB = !knn_ws ? 0 : (graph_bounded ? (K + 63) / 64 : (K + HEAVY_WAVES - 1) / HEAVY_WAVES);
+    const int CB = mesh ? cot_blocks : 0;
+    k_assoc_all<<<dim3(HB + MB + NB + GB + CB), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, K, p.top_k, lim, d2min, rec, counts, heavy, mid, lm,
+                                                                              heavy_next, mid_next, HB, MB, NB, GB, nn, graph_bounded ? 1 : 0, (const NgGeom*)geo, cs,
+                                                                              (const float4*)sorted, nbr, mesh ? *mesh : SellDev{}, mesh_pts);
 }

@@ -134,6 +134,13 @@ struct mvs_deform_s {
     int64_t *d_top_idx = nullptr;
     int32_t *d_heavy = nullptr;       // [1 + K]: nodes deferred to the workgroup-per-node association kernel
     int32_t *d_heavy2 = nullptr;      // second list: single-rank iterations alternate (each resets the other's counter)
+    // bounded association (assoc.hip, k_assoc_prep / k_assoc_all): where every node stood at the last single-rank association
+    // (d_d2min holds what it found), this pass's bounds, the list of the nodes a wave each takes
+    double* d_near_prev = nullptr;     // [K][3]
+    float* d_lim = nullptr;            // [K]
+    int32_t *d_mid = nullptr, *d_mid2 = nullptr;   // [1 + K] each, alternating like d_heavy / d_heavy2
+    bool near_ready = false;           // d_d2min / d_near_prev describe the last association of THIS node set against THIS target
+    int graph_prev_nn = 0;             // d_nbr holds the complete graph of an earlier pass with this many neighbours (the bound of the graph queries)
     float* d_prev_d2 = nullptr;        // sharded step: global nearest distance of every node at the previous association ...
     double* d_prev_node = nullptr;     // ... and where the node stood (bound for the next nearest-distance search)
     bool prev_valid = false;
@@ -196,8 +203,8 @@ struct mvs_deform_s {
     // timing mode 3: the idle flags of the sweep launches the sampled event pairs bracket (every sweep leaves "found the solve
     // finished" in its slot, schwarz.hip) are copied out behind each sampled pass — which of the TIMED launches did work is
     // then counted from the device's own record, not inferred from another pass
-    struct SweepSample { int first, n_a, n_b; };      // slots [first, first + n_a) = bracket "cg", the next n_b = bracket "cgB"
-    std::vector<SweepSample> samples;                 // one per sampled solve, in the order of the copies
+    struct SweepSample { int first, n_a, n_b; };      // slots [first, first + n_a) = the launches of one "cg" bracket
+    std::vector<SweepSample> samples;                 // one per sampled solve, in the order of the brackets
     std::vector<size_t> sample_off;                   // where each sampled pass's flags start in h_sample (doubles)
     std::vector<int> sample_pass_first;               // index into `samples` of each sampled pass's first solve
     double* h_sample = nullptr;                       // pinned: [8] scalars per sweep slot of the sampled passes
@@ -241,6 +248,12 @@ void launch_assoc_heavy_knn(const GridDev& g, const double* node_pts, const doub
                             double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws, hipStream_t s,
                             const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks,
                             bool with_knn = true /*false: the graph came with launch_assoc_local*/);
+void launch_assoc_prep(const GridDev& g, const double* node_pts, int K, const float* d2min_prev, double* prev_node, float* lim, int32_t* heavy,
+                       int32_t* mid, void* knn_ws /*!= NULL: the node grid is built by the launch's first workgroup (knn_grid_is_single(K))*/, hipStream_t s);
+void launch_assoc_all(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, const float* lim,
+                      float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, const int32_t* mid, int32_t* heavy_next, int32_t* mid_next,
+                      double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws /*NULL: no graph section*/,
+                      bool graph_bounded, const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks, hipStream_t s);
 void launch_install_targets(const void* blocks, int K, int block_nodes, int64_t stride_bytes, double* controls, uint8_t* valid, int64_t* top_idx,
                             hipStream_t s);
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,
@@ -254,6 +267,8 @@ size_t knn_grid_ws_bytes(int n);
 int knn_grid_launches(int n);
 void knn_grid_build(const double* pts, int n, void* ws, hipStream_t s);
 void knn_grid_views(void* ws, int n, const void** geo, const int** cs, const void** sorted);
+bool knn_grid_is_single(int n);                   // the build of n points is the one-workgroup launch (knn_dev.h: ng_build1_body)
+int  knn_grid_cells_per_axis(int n);
 void launch_knn_grid(const double* pts, int n, int k, int32_t* out, void* ws, hipStream_t s, const double* smooth_cur = nullptr,
                      double* smooth_out = nullptr);                                           // 5 launches
 // arap.hip

@@ -243,111 +243,10 @@ __global__ void k_ng_scatter(const double* __restrict__ pts, int n, const int* _
     sorted[d] = make_float4((float)pts[3 * i], (float)pts[3 * i + 1], (float)pts[3 * i + 2], __int_as_float(i));
 }
 
-// The whole grid build of a SMALL point set (n <= NG1_MAX: the deformation nodes, a template's vertices) in ONE
-// launch of one workgroup: the points stay in registers (NG1_PPT per thread), the cell counters live in LDS (<= 32^3
-// cells = 128 KB), and the LDS atomic that counts a point also hands it its rank inside the cell, so the scatter
-// needs no second atomic pass.  bbox -> count -> scan -> scatter were four dependent launches (~12 us each) before.
-constexpr int NG1_PPT = 20;
-constexpr int NG1_MAX = 1024 * NG1_PPT;
-constexpr int NG1_NC = 32;
-constexpr int NG1_CELLS = NG1_NC * NG1_NC * NG1_NC;
+// (the build itself lives in knn_dev.h, ng_build1_body: k_assoc_prep of assoc.hip carries it in its first workgroup)
 __global__ __launch_bounds__(1024) void k_ng_build1(const double* __restrict__ pts, int n, int NC, NgGeom* __restrict__ geo,
                                                     int* __restrict__ start, float4* __restrict__ sorted) {
-    __shared__ int cnt[NG1_CELLS];
-    __shared__ float sm[6][16];
-    __shared__ NgGeom sg;
-    __shared__ int wsum[16];
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    float px[NG1_PPT], py[NG1_PPT], pz[NG1_PPT];
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-    for (int j = 0; j < NG1_PPT; ++j) {
-        const int i = t + 1024 * j;
-        px[j] = py[j] = pz[j] = 0.0f;
-        if (i < n) {
-            px[j] = (float)pts[3 * i]; py[j] = (float)pts[3 * i + 1]; pz[j] = (float)pts[3 * i + 2];
-            mn[0] = fminf(mn[0], px[j]); mx[0] = fmaxf(mx[0], px[j]);
-            mn[1] = fminf(mn[1], py[j]); mx[1] = fmaxf(mx[1], py[j]);
-            mn[2] = fminf(mn[2], pz[j]); mx[2] = fmaxf(mx[2], pz[j]);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float a = mn[c], b = mx[c];
-        for (int o = 32; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o, 64)); b = fmaxf(b, __shfl_xor(b, o, 64)); }
-        if (lane == 0) { sm[c][w] = a; sm[3 + c][w] = b; }
-    }
-    for (int i = t; i < NG1_CELLS / 4; i += 1024) reinterpret_cast<int4*>(cnt)[i] = make_int4(0, 0, 0, 0);
-    __syncthreads();
-    if (t == 0) {                                                   // same geometry rule as k_ng_bbox
-        float lo[3], hi[3];
-        for (int c = 0; c < 3; ++c) {
-            lo[c] = sm[c][0]; hi[c] = sm[3 + c][0];
-            for (int ww = 1; ww < 16; ++ww) { lo[c] = fminf(lo[c], sm[c][ww]); hi[c] = fmaxf(hi[c], sm[3 + c][ww]); }
-            if (!(lo[c] <= hi[c])) { lo[c] = 0.f; hi[c] = 0.f; }
-        }
-        float ext = fmaxf(hi[0] - lo[0], fmaxf(hi[1] - lo[1], hi[2] - lo[2]));
-        if (!(ext > 0.f)) ext = 1.f;
-        NgGeom g;
-        g.h = ext / (float)NC * 1.0001f; g.inv_h = 1.0f / g.h;
-        g.minx = lo[0]; g.miny = lo[1]; g.minz = lo[2];
-        g.nx = min(NC, (int)floorf((hi[0] - lo[0]) * g.inv_h) + 1);
-        g.ny = min(NC, (int)floorf((hi[1] - lo[1]) * g.inv_h) + 1);
-        g.nz = min(NC, (int)floorf((hi[2] - lo[2]) * g.inv_h) + 1);
-        *geo = g;
-        sg = g;
-    }
-    __syncthreads();
-    const NgGeom g = sg;
-    const int ncell = g.nx * g.ny * g.nz;
-    int cr[NG1_PPT];                                                // cell (low 15 bits) | rank inside the cell << 15
-#pragma unroll
-    for (int j = 0; j < NG1_PPT; ++j) {
-        cr[j] = 0;
-        if (t + 1024 * j < n) {
-            const int c = (ng_axis(pz[j], g.minz, g.inv_h, g.nz) * g.ny + ng_axis(py[j], g.miny, g.inv_h, g.ny)) * g.nx + ng_axis(px[j], g.minx, g.inv_h, g.nx);
-            cr[j] = c | (atomicAdd(&cnt[c], 1) << 15);
-        }
-    }
-    __syncthreads();
-    // exclusive scan of the counters, in place: wave w owns a contiguous chunk of cells (a multiple of 256), a lane
-    // takes four consecutive cells per step (16-byte LDS accesses), the 64 lane sums are scanned with DPP row shifts
-    const int chunk = ((ncell + 15) / 16 + 255) / 256 * 256, c_lo = w * chunk, c_hi = min((ncell + 3) / 4 * 4, c_lo + chunk);
-    int s_acc = 0;
-    for (int c = c_lo + 4 * lane; c < c_hi; c += 256) { const int4 v = *reinterpret_cast<const int4*>(cnt + c); s_acc += (v.x + v.y) + (v.z + v.w); }
-    for (int o = 32; o > 0; o >>= 1) s_acc += __shfl_xor(s_acc, o, 64);
-    if (lane == 0) wsum[w] = s_acc;
-    __syncthreads();
-    int run = 0;
-    for (int ww = 0; ww < w; ++ww) run += wsum[ww];
-    for (int c0 = c_lo; c0 < c_hi; c0 += 256) {
-        const int c = c0 + 4 * lane;
-        int4 v = make_int4(0, 0, 0, 0);
-        if (c < c_hi) v = *reinterpret_cast<const int4*>(cnt + c);
-        const int own = (v.x + v.y) + (v.z + v.w);
-        int inc = own;                                              // inclusive scan over the wave
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);    // row_shr:1
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);    // row_shr:2
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);    // row_shr:4
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);    // row_shr:8
-        const int r0 = __builtin_amdgcn_readlane(inc, 15), r1 = __builtin_amdgcn_readlane(inc, 31), r2 = __builtin_amdgcn_readlane(inc, 47),
-                  r3 = __builtin_amdgcn_readlane(inc, 63);
-        inc += (lane >= 16 ? r0 : 0) + (lane >= 32 ? r1 : 0) + (lane >= 48 ? r2 : 0);
-        const int e0 = run + inc - own;
-        if (c < c_hi) {
-            const int4 e = make_int4(e0, e0 + v.x, e0 + v.x + v.y, e0 + v.x + v.y + v.z);
-            *reinterpret_cast<int4*>(cnt + c) = e;
-            *reinterpret_cast<int4*>(start + c) = e;
-        }
-        run += ((r0 + r1) + (r2 + r3));
-    }
-    __syncthreads();
-    if (t == 0) start[ncell] = n;                                   // (after the barrier: the padded tail of the last int4 may cover it)
-#pragma unroll
-    for (int j = 0; j < NG1_PPT; ++j) {
-        const int i = t + 1024 * j;
-        if (i < n) sorted[cnt[cr[j] & 32767] + (cr[j] >> 15)] = make_float4(px[j], py[j], pz[j], __int_as_float(i));
-    }
+    ng_build1_body(pts, n, NC, geo, start, sorted);
 }
 
 __global__ __launch_bounds__(256) void k_ng_knn(const double* __restrict__ pts, int n, int k, const NgGeom* __restrict__ geo,
@@ -420,6 +319,10 @@ void knn_grid_build(const double* pts, int n, void* ws, hipStream_t s) {
     ng_scan(w, s);
     k_ng_scatter<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.cell_of, w.start, w.counts, w.sorted);
 }
+// does knn_grid_build(n) consist of the ONE one-workgroup launch (ng_build1_body)?  Then a caller may run that body inside a
+// launch of its own (k_assoc_prep) instead.
+bool knn_grid_is_single(int n) { return n <= NG1_MAX && knn_grid_cap(n) <= NG1_NC; }
+int knn_grid_cells_per_axis(int n) { return knn_grid_cap(n); }
 // where knn_grid_build left the grid inside ws (for the fused heavy-node + node-graph kernel of assoc.hip)
 void knn_grid_views(void* ws, int n, const void** geo, const int** cs, const void** sorted) {
     const NgWs w = ng_carve(ws, n);

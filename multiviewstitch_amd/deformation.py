@@ -251,9 +251,9 @@ class Deformation:
         return {"kind": "patch" if kind.value else "cg", "patches": patches.value, "local_rows": rows.value, "width": width.value}
 
     def enable_timing(self, on: int = 1):
-        """0 off, 1 every phase, 2 only the "cg" / "tail" groups, 3 the planned sweeps of every eighth pass in two brackets ("cg": launches
-        expected to do work, "cgB": the spares behind them) with the idle flags of exactly those launches read back into the launch
-        counts of "cg_idle" / "cgB_idle" (mvs_deform_enable_timing)."""
+        """0 off, 1 every phase, 2 only the "cg" / "tail" groups, 3 the planned sweeps ("cg") of every eighth pass with the idle flags
+        of exactly those launches read back: "cg_idle" counts them, "cg:a<active>:i<idle>" holds the brackets of one composition
+        (mvs_deform_enable_timing)."""
         L.check(L.lib().mvs_deform_enable_timing(self._h, int(on)))
 
     def kernel_time(self, name: str):
@@ -279,7 +279,7 @@ class Comm:
         self.rank, self.nranks = rank, nranks
 
     def set_exchange(self, mode: int):
-        """0 auto (owner-merges from 4 ranks on), 1 all-gather, 2 owner-merges (mvs_comm_set_exchange)"""
+        """0 auto (= all-gather at every rank count), 1 all-gather, 2 owner-merges on request (mvs_comm_set_exchange)"""
         L.check(L.lib().mvs_comm_set_exchange(self._c, int(mode)))
 
     def close(self):

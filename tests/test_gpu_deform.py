@@ -67,6 +67,52 @@ def test_association_matches_oracle(eng, oracle, config):
         assert ref["valid"].sum() > 0.5 * len(nodes)
 
 
+@pytest.mark.parametrize("config", [1, 2])
+def test_bounded_association_and_graph_match_oracle(eng, oracle, config):
+    """From the second association of a fit on the search is BOUNDED by the previous pass (assoc.hip: k_assoc_prep / k_assoc_all —
+    16 lanes per near node, the graph queries bounded by the previous neighbour list).  Pass after pass, at the engine's own
+    node positions, every output of the association (nearest distance, ball counts, best-8 indices, validity, node targets) and
+    the 9-NN node graph must be the oracle's, bit for bit.  Config 1 (512 nodes): brute-force graph; config 2 (2 K nodes): node
+    grid + bounded graph queries.  Between two passes the template is also thrown back to its rest pose (mvs_deform_set_vertices
+    starts a new fit: unbounded first pass) and pushed around without telling the engine's bound anything but the new positions."""
+    sc, tp, tn, _ = scene_and_target(config)
+    nodes = oracle.uniform_sampling(sc.verts, 16)
+    d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+    d.set_nodes(nodes)
+    d.set_target(tp, tn)
+    tgt = oracle.Target(tp, tn)
+    p = oracle.Params.default()
+
+    def one_pass(tag):
+        v, nrm = d.vertices(), d.normals()
+        st = d.iterate(1)
+        assert st["status"] == 0, tag
+        got = d.node_targets(smoothed=False)
+        ref = tgt.associate(v[nodes], nrm[nodes], p)
+        assert np.array_equal(got["d2min"], ref["d2min"]), tag
+        assert counts_match(got["counts"], ref["counts"]), tag
+        assert np.array_equal(got["top_idx"], ref["top_idx"]), tag
+        assert np.array_equal(got["valid"], ref["valid"]), tag
+        assert np.abs(got["controls"] - ref["controls"]).max() <= 1e-12, tag
+        assert np.array_equal(d.node_graph(), oracle.knn_points(v[nodes], p.graph_k + 1)), tag
+        return ref
+
+    for it in range(5):
+        ref = one_pass(f"pass {it}")
+    assert ref["valid"].sum() > 0.3 * len(nodes)
+    # a pass after an ARAP solve the association knows nothing about: the nodes have moved by whole grid cells (the bound
+    # follows from their new positions alone: every class of the bounded search is met)
+    rng = np.random.default_rng(11)
+    tgts = d.vertices()[nodes] + rng.normal(scale=0.03, size=(len(nodes), 3))
+    assert d.arap(tgts)["status"] == 0
+    one_pass("after a foreign ARAP solve")
+    one_pass("and the pass after it")
+    d.set_vertices(sc.verts, sc.normals)
+    one_pass("new fit, first pass")
+    one_pass("new fit, second pass")
+    d.close()
+
+
 @pytest.mark.parametrize("solver", [0, 1])          # MVS_SOLVER_AUTO (overlapping-patch sweeps at this size), MVS_SOLVER_CG
 def test_iterate_matches_oracle(eng, oracle, solver):
     sc, tp, tn, _ = scene_and_target(1)
