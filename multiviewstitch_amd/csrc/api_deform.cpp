@@ -248,8 +248,8 @@ void free_nodes(mvs_deform_s* h) {
     h->d_ctrl_a = nullptr; h->d_ctrl_b = nullptr; h->d_valid = nullptr; h->d_d2min = nullptr; h->d_counts = nullptr;
     h->d_records = nullptr; h->d_top_idx = nullptr; h->d_heavy = nullptr; h->d_heavy2 = nullptr;
     h->d_prev_d2 = nullptr; h->d_prev_node = nullptr; h->d_knn_ws = nullptr;
-    h->d_near_prev = nullptr; h->d_lim = nullptr; h->d_mid = nullptr; h->d_mid2 = nullptr;
-    h->near_ready = false; h->graph_prev_nn = 0;
+    h->d_near_prev = nullptr; h->d_lim = nullptr; h->d_mid = nullptr; h->d_mid2 = nullptr; h->d_ng_sync = nullptr;
+    h->near_age = 0; h->graph_prev_nn = 0;
     h->prev_valid = false;
     h->d_ctrl_final = nullptr; h->K = 0; h->nbr_k = 0; h->h_nodes.clear();
     h->graph_ready_nn = 0; h->weights_ready = false; h->heavy_pending = nullptr;
@@ -376,7 +376,10 @@ void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
     int32_t* mcur = h->heavy_flip ? h->d_mid2 : h->d_mid;
     int32_t* mnxt = h->heavy_flip ? h->d_mid : h->d_mid2;
     h->heavy_flip ^= 1;
-    if (h->near_ready && h->grid.P > 0 && K > 0 && p.graph_k + 1 <= 16 && MVS_KNOB("MVS_ASSOC_BOUNDED", 1, 0, 1) != 0.0) {
+    // (the SECOND association of a fit still searches unbounded: the first deformation has moved the nodes by whole grid cells, the
+    //  bounds are loose — 4 680 of 8 142 nodes of the metric workload came out as heavy, 380 us — while their true nearest points
+    //  are a fraction of a cell away by then, which the shell walk finds at once)
+    if (h->near_age >= 2 && h->grid.P > 0 && K > 0 && p.graph_k + 1 <= 16 && MVS_KNOB("MVS_ASSOC_BOUNDED", 1, 0, 1) != 0.0) {
         // Bounded pass (assoc.hip): the last association of this node set against this target left every node's nearest distance
         // (d_d2min) and position (d_near_prev).  Two launches: bounds + classes (+ the node grid of the graph search in the same
         // launch's first workgroup), then heavy / mid / near nodes, the graph queries and the cotangent weights side by side.
@@ -384,11 +387,14 @@ void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
         const bool graph_here = h->d_knn_ws != nullptr && knn_grid_is_single(K) && ensure_nbr(h, nn) == MVS_OK;
         const bool bounded_graph = graph_here && h->graph_prev_nn == nn && K >= nn;
         const bool w = graph_here && use_ras(h, p);
-        launch_assoc_prep(h->grid, h->d_node_pts, K, h->d_d2min, h->d_near_prev, h->d_lim, cur, mcur, graph_here ? h->d_knn_ws : nullptr, h->stream);
+        // (the node grid: inside the second launch, beside the searches, when one of its workgroups can build it; else by the first)
+        const bool build_in_all = graph_here && assoc_all_builds_grid(K) && MVS_KNOB("MVS_NG_IN_ALL", 1, 0, 1) != 0.0;
+        launch_assoc_prep(h->grid, h->d_node_pts, K, h->d_d2min, h->d_near_prev, h->d_lim, cur, mcur, (graph_here && !build_in_all) ? h->d_knn_ws : nullptr, h->stream);
         launch_assoc_all(h->grid, h->d_node_pts, h->d_node_nrm, K, p, h->d_lim, h->d_d2min, h->d_records, h->d_counts, cur, mcur, nxt, mnxt, h->d_ctrl_raw,
                          h->d_valid, h->d_top_idx, nn, h->d_nbr, graph_here ? h->d_knn_ws : nullptr, bounded_graph, w ? &h->sell : nullptr, h->d_pts,
-                         arap_grid_blocks(h->sell), h->stream);
+                         arap_grid_blocks(h->sell), h->stream, build_in_all ? h->d_ng_sync : nullptr, build_in_all ? ++h->ng_pass : 0);
         h->assoc_passes++;
+        h->near_age++;
         h->graph_in_local = false; h->heavy_pending = nullptr;
         if (graph_here) { h->graph_ready_nn = nn; h->weights_ready = w; h->graph_prev_nn = nn; }
         toc(t, 2);
@@ -397,7 +403,7 @@ void enqueue_assoc_local(mvs_deform_s* h, const mvs_deform_params& p) {
     // unbounded pass (the first association of a fit): what the bounded passes start from is recorded behind it
     (void)hipMemsetAsync(mcur, 0, sizeof(int32_t), h->stream); (void)hipMemsetAsync(mnxt, 0, sizeof(int32_t), h->stream);
     if (K > 0) (void)hipMemcpyAsync(h->d_near_prev, h->d_node_pts, sizeof(double) * 3 * (size_t)K, hipMemcpyDeviceToDevice, h->stream);
-    h->near_ready = K > 0 && h->grid.P > 0;
+    h->near_age = (K > 0 && h->grid.P > 0) ? h->near_age + 1 : 0;
     // the heavy-node pass shares a launch with the node-graph search of enqueue_solve when that search runs on the grid
     const bool defer = h->d_knn_ws != nullptr && p.graph_k + 1 <= 64;
     // the 9-NN graph of the nodes needs only their positions: its grid is built first and the queries ride with the nodes' own
@@ -986,6 +992,7 @@ static int install_nodes(mvs_deform_s* h, const int32_t* vertex_idx, int64_t K) 
         h->d_prev_d2 = a.take<float>(K); h->d_prev_node = a.take<double>((size_t)K * 3);
         h->d_near_prev = a.take<double>((size_t)K * 3); h->d_lim = a.take<float>(K);
         h->d_mid = a.take<int32_t>((size_t)K + 1); h->d_mid2 = a.take<int32_t>((size_t)K + 1);
+        h->d_ng_sync = a.take<unsigned long long>(32);
         h->d_records = a.take<mvs_cand>((size_t)K * 8); h->d_top_idx = a.take<int64_t>((size_t)K * 8);
         h->d_nbr = a.take<int32_t>((size_t)K * 64);                            // graph_k <= 63
         h->d_knn_ws = ws_bytes ? (void*)a.take<char>(ws_bytes) : nullptr;
@@ -997,6 +1004,8 @@ static int install_nodes(mvs_deform_s* h, const int32_t* vertex_idx, int64_t K) 
     }
     HIPCHK(hipMemsetAsync(h->d_heavy, 0, sizeof(int32_t), h->stream)); HIPCHK(hipMemsetAsync(h->d_heavy2, 0, sizeof(int32_t), h->stream));
     HIPCHK(hipMemsetAsync(h->d_mid, 0, sizeof(int32_t), h->stream)); HIPCHK(hipMemsetAsync(h->d_mid2, 0, sizeof(int32_t), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_ng_sync, 0, sizeof(unsigned long long) * 32, h->stream));
+    h->ng_pass = 0;
     HIPCHK(hipMemsetAsync(h->d_valid, 0, (size_t)std::max<int64_t>(K, 1), h->stream));
     h->heavy_flip = 0;
     HIPCHK(hipMemsetAsync(h->d_is_ctrl, 0, sizeof(int32_t) * h->V, h->stream));
@@ -1043,7 +1052,7 @@ int mvs_deform_set_vertices(mvs_deform_t h, const double* points, const double* 
         h->d_ctrl_final = h->d_ctrl_raw;
     }
     h->graph_ready_nn = 0; h->weights_ready = false; h->heavy_pending = nullptr; h->graph_in_local = false;
-    h->near_ready = false;                                   // a new fit: its first association searches unbounded
+    h->near_age = 0;                                   // a new fit: its first association searches unbounded
     HIPCHK(hipStreamSynchronize(h->stream));                 // (the host arrays may be released on return)
     return mvs_check_hip(hipGetLastError(), "set_vertices");
 }
@@ -1211,7 +1220,7 @@ int mvs_deform_assoc_dmin(mvs_deform_t h, const mvs_deform_params* p, float* d2m
     int rc = ready(h, p, true);
     if (rc) return rc;
     if (!d2min_dev) return MVS_E_INVALID_ARG;
-    h->near_ready = false;              // (the sharded step keeps its own bound, d_prev_d2 / d_prev_node)
+    h->near_age = 0;              // (the sharded step keeps its own bound, d_prev_d2 / d_prev_node)
     Tic t = tic(h, "assoc");
     launch_assoc_dmin(h->grid, h->d_node_pts, (int)h->K, d2min_dev, h->stream, h->prev_valid ? h->d_prev_d2 : nullptr, h->d_prev_node);
     toc(t, 1);
@@ -1223,7 +1232,7 @@ int mvs_deform_assoc_select(mvs_deform_t h, const mvs_deform_params* p, const fl
     int rc = ready(h, p, true);
     if (rc) return rc;
     if (!d2min_dev || !records_dev || !counts_dev) return MVS_E_INVALID_ARG;
-    h->near_ready = false;
+    h->near_age = 0;
     Tic t = tic(h, "assoc");
     // The heavy-node pass shares its launch with two pieces of the solve that need nothing from the exchange: the node
     // graph and (patch solver) the cotangent weights — they then overlap with the heavy nodes instead of following the

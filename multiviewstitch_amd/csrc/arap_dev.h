@@ -83,8 +83,8 @@ __device__ inline void cot_weight_row(const SellDev& m, const double* __restrict
     if (r.live && r.l == 0) m.diag[r.row] = diag;
 }
 // all row groups by `vgrid` virtual workgroups of 16 waves (this one is number vblock)
-__device__ inline void cot_weight_rows(const SellDev& m, const double* __restrict__ pts, int vblock, int vgrid) {
-    for (int g = vblock * 16 + (int)(threadIdx.x >> 6); g < m.nslices; g += vgrid * 16) {
+__device__ inline void cot_weight_rows(const SellDev& m, const double* __restrict__ pts, int vblock, int vgrid, int waves = 16 /*per workgroup*/) {
+    for (int g = vblock * waves + (int)(threadIdx.x >> 6); g < m.nslices; g += vgrid * waves) {
         const RowCtx r = row_ctx(m, g);
         cot_weight_row(m, pts, r, r.live ? ld3(pts + 3 * r.row) : mk3(0, 0, 0));
     }

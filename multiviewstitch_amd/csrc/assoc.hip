@@ -27,6 +27,7 @@
 #include "knn_dev.h"
 #include "arap_dev.h"
 #include <algorithm>
+#include <mutex>
 
 namespace {
 
@@ -306,7 +307,10 @@ __global__ __launch_bounds__(256) void k_assoc_dmin(GridDev g, const double* __r
 // One node by one wave (PARTS == 1) or by the PARTS waves of a workgroup (heavy nodes: each wave takes every
 // PARTS-th occupied coarse cell of the ball, the per-wave lists are merged through LDS by wave 0).
 // A PARTS == 1 caller that passes a `heavy` list defers nodes whose ball spans more than 64 grid rows to it.
-constexpr int HEAVY_WAVES = 16;
+#ifndef MVS_HEAVY_WAVES
+#define MVS_HEAVY_WAVES 16
+#endif
+constexpr int HEAVY_WAVES = MVS_HEAVY_WAVES;                // waves of a workgroup that takes a heavy node (16, or 8: two such workgroups to a CU)
 constexpr int HEAVY_RANGES = 2048;
 constexpr int HEAVY_CAND = 10240;                           // members of a ball the workgroup list holds (>= params.max_result = 10000)
 constexpr int HEAVY_PIECE = 256;                            // a listed cell is dealt out in pieces of this many points
@@ -320,7 +324,8 @@ struct HeavyLds { double pd[HEAVY_WAVES][8], pl[HEAVY_WAVES][8], x[HEAVY_WAVES][
                   int cand[HEAVY_CAND];                               // ball members (sorted-order indices) found by phase 1 of the listed pieces
                   int len[HEAVY_WAVES];                               // live entries of each wave's list (rank merge)
                   double r_pd[8], r_pl[8], r_x[8], r_y[8], r_z[8]; long long r_idx[8];   // the merged list, best first
-                  int ball; };                                        // ball members counted so far by all waves (full-result cut-off)
+                  int ball;                                           // ball members counted so far by all waves (full-result cut-off)
+                  unsigned w8[HEAVY_WAVES][8], T; int ovf; };         // bounded pass (heavy_bounded): the waves' smallest keys, the threshold, "does not fit"
 constexpr int HEAVY_DMIN_FLAG = 0x40000000;                 // heavy-list entry: the node's nearest distance is still open (coarse walk deferred)
 
 // The coarse-shell walk of dmin_node (stage B) by ALL waves of a workgroup: a far node (it faces a hole of the scan, its
@@ -951,7 +956,7 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_heavy_knn(GridDev g,
         return;
     }
     if ((int)blockIdx.x >= heavy_blocks + knn_blocks) {      // third passenger: the cotangent weights of the template (rest geometry only)
-        cot_weight_rows(m, mesh_pts, (int)blockIdx.x - heavy_blocks - knn_blocks, (int)gridDim.x - heavy_blocks - knn_blocks);
+        cot_weight_rows(m, mesh_pts, (int)blockIdx.x - heavy_blocks - knn_blocks, (int)gridDim.x - heavy_blocks - knn_blocks, HEAVY_WAVES);
         return;
     }
     const int q = ((int)blockIdx.x - heavy_blocks) * HEAVY_WAVES + (int)(threadIdx.x >> 6);
@@ -1028,7 +1033,11 @@ __global__ __launch_bounds__(1024) void k_assoc_prep(GridDev g, const double* __
                                                      double* __restrict__ prev_node, float* __restrict__ lim_out, int32_t* __restrict__ heavy,
                                                      int32_t* __restrict__ mid, int with_grid, int NC, NgGeom* __restrict__ geo,
                                                      int* __restrict__ ng_start, float4* __restrict__ ng_sorted) {
-    if (with_grid && blockIdx.x == 0) { ng_build1_body(node_pts, K, NC, geo, ng_start, ng_sorted); return; }
+    if (with_grid && blockIdx.x == 0) {
+        __shared__ __attribute__((aligned(16))) int cnt[NG1_CELLS];
+        ng_build1_body<1024>(node_pts, K, NC, geo, ng_start, ng_sorted, cnt);
+        return;
+    }
     const int node = ((int)blockIdx.x - (with_grid ? 1 : 0)) * 1024 + (int)threadIdx.x;
     if (node < K) classify_node(g, node_pts, node, d2min_prev, prev_node, lim_out, heavy, mid);
 }
@@ -1344,13 +1353,312 @@ __device__ inline void graph_queries_bounded(const double* __restrict__ pts, int
     }
 }
 
-struct NearLdsAll { NearSlots g[16][4]; };
-struct GraphLds { unsigned long long key[16][4][32]; };
+// The node grid of the graph queries, built INSIDE k_assoc_all (it needs the node positions only and took 14 us as the first
+// launch of every pass): workgroup 0 builds it while the heavy / near nodes are searched, the graph workgroups — the last of the
+// launch — find it done.  No order of dispatch is assumed: the builder is whoever CLAIMS the build (atomicMax of the pass number
+// on sync[0]); workgroup 0 claims at its start; a graph workgroup that has waited NG_WAIT_POLLS polls for the grid claims it
+// itself if nobody has — a claimant is running by definition, so somebody always makes progress.  Hand-off (cdna_hip_programming
+// Guideline 16): every storing wave waits for its stores, workgroup barrier, one lane: agent-scope release, wait, relaxed store of
+// the pass number to sync[NG_DONE]; a consumer polls relaxed, then one agent-scope acquire + wait + workgroup barrier.
+struct NgBuild { unsigned long long* sync; unsigned long long pass; int NC; NgGeom* geo; int* start; float4* sorted; };
+constexpr int NG_DONE = 16;                                 // (claim and done words on lines of their own)
+constexpr int NG_WAIT_POLLS = 400;
+__device__ inline void ng_build_publish(const double* __restrict__ node_pts, int K, const NgBuild& nb, int* cnt) {
+    ng_build1_body<64 * HEAVY_WAVES>(node_pts, K, nb.NC, nb.geo, nb.start, nb.sorted, cnt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(nb.sync + NG_DONE, nb.pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ inline void ng_build_wait(const double* __restrict__ node_pts, int K, const NgBuild& nb, int* cnt) {
+    __shared__ int s_build;
+    if (threadIdx.x == 0) {
+        int build = 0, spin = 0;
+        while (__hip_atomic_load(nb.sync + NG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nb.pass) {
+            if (++spin > NG_WAIT_POLLS) {
+                if (atomicMax(nb.sync, nb.pass) < nb.pass) { build = 1; break; }          // nobody is building: this workgroup does
+                spin = 0;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!build) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        s_build = build;
+    }
+    __syncthreads();
+    if (s_build) {                                           // (wave-uniform)
+        ng_build_publish(node_pts, K, nb, cnt);
+        __syncthreads();
+        if (threadIdx.x == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __syncthreads();
+    }
+}
+
+struct NearLdsAll { NearSlots g[HEAVY_WAVES][4]; };
+struct GraphLds { unsigned long long key[HEAVY_WAVES][4][32]; };
 union AllLds { HeavyLds heavy; NearLdsAll near; GraphLds graph; };
 
 // ONE launch for everything the association and the start of the solve need from the node positions (bounded passes):
-//   blocks [0, HB): heavy list (a workgroup per node) | [HB, +MB): mid list (a wave per node) | [.., +NB): near nodes (16 lanes per
-//   node) | [.., +GB): node-graph queries (16 lanes each, or a wave each without a previous list) | the rest: cotangent weights
+//   [workgroup 0: the node grid] | heavy list (a workgroup per node) | mid list (a wave per node) | near nodes (16 lanes per
+//   node) | cotangent weights | node-graph queries (16 lanes each, or a wave each without a previous list)
+// ---- a heavy node of a bounded pass, by one workgroup.  The bound is tight in the steady state (the nodes that face a hole of
+// the scan barely move): ONE list of the coarse cells the candidate sphere (radius^2 = 2 limit2) touches serves the nearest
+// distance AND the ball; ONE scan of their points gives the minimum and the candidates (d2 <= 2 limit2 — a superset of the ball
+// d2 <= 2 d2min); the candidates are then tested against the ball exactly, and the top_k of the members that face the node are
+// found through a threshold on their float32 projection distances (per wave: its top_k smallest keys by min-extraction with
+// DPP reductions; wave 0: the top_k-th smallest of those) instead of the unbounded path's radix select — 2 workgroup barriers
+// instead of 13.  The members at or below the threshold are recomputed in fp64 and ranked exactly (total order of select_node).
+// (unbounded path per heavy node on the metric workload: coarse walk 9.5 K cycles + ball query 32 K cycles for a median ball of 34
+//  members, scripts/heavy_bounded_stats.py.)  Returns false — having written nothing — when the node does not fit (list or
+// candidate overflow, more float ties than merge slots): the caller runs the unbounded heavy path.
+__device__ inline unsigned wave_min_u(unsigned v) {
+    v = min(v, (unsigned)row_ror<8>((int)v)); v = min(v, (unsigned)row_ror<4>((int)v));
+    v = min(v, (unsigned)row_ror<2>((int)v)); v = min(v, (unsigned)row_ror<1>((int)v));
+    return min(min((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 16)),
+               min((unsigned)__builtin_amdgcn_readlane((int)v, 32), (unsigned)__builtin_amdgcn_readlane((int)v, 48)));
+}
+__device__ inline int wave_sum_dpp(int v) {
+    v = row_sum_i(v);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+// the `want` (<= 8) smallest of a wave's keys with multiplicity (NK per lane, 0xffffffff = none) -> out[0..7] (unused: 0xffffffff)
+template <int NK>
+__device__ inline void wave_smallest(const unsigned (&key)[NK], int want, unsigned* out) {
+    const int lane = threadIdx.x & 63;
+    if (lane < 8) out[lane] = 0xffffffffu;
+    int taken = 0;
+    unsigned last = 0u;
+    bool first = true;
+    while (taken < want) {                                     // (wave-uniform)
+        unsigned m = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { const unsigned v = key[k]; if ((first || v > last) && v < m) m = v; }
+        m = wave_min_u(m);
+        if (m == 0xffffffffu) break;
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) c += key[k] == m ? 1 : 0;
+        c = wave_sum_dpp(c);
+        if (lane == 0) for (int j = taken; j < min(taken + c, 8); ++j) out[j] = m;
+        taken += c; last = m; first = false;
+    }
+}
+
+template <int PARTS>
+__device__ inline bool heavy_bounded(const GridDev& g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm, int node,
+                                     int top_k, float lim2, float* __restrict__ d2min, mvs_cand* __restrict__ rec, int32_t* __restrict__ counts,
+                                     HeavyLds* lds, const LocalMerge& lm) {
+    const int tid = (int)threadIdx.x, lane = tid & 63, part = tid >> 6;
+    if (!(lim2 < INFINITY) || lm.max_result <= 0 || lm.max_result > HEAVY_CAND || g.P <= 0) return false;      // (uniform)
+    const d3 orig = ld3(node_pts + 3 * (int64_t)node), nn = ld3(node_nrm + 3 * (int64_t)node);
+    const float qx = (float)orig.x, qy = (float)orig.y, qz = (float)orig.z;
+    const QCell c = query_cell(g, qx, qy, qz);
+    const float cand2 = 2.0f * lim2;
+    const float rc = sqrtf(cand2) * g.inv_h + 0.01f, limc = rc * rc;
+    const float lx = floorf(c.fx - rc), hx = floorf(c.fx + rc), ly = floorf(c.fy - rc), hy = floorf(c.fy + rc), lz = floorf(c.fz - rc), hz = floorf(c.fz + rc);
+    if (!(hx >= 0.f && lx <= (float)(g.nx - 1) && hy >= 0.f && ly <= (float)(g.ny - 1) && hz >= 0.f && lz <= (float)(g.nz - 1))) return false;
+    const int X0 = (int)fmaxf(lx, 0.f) >> 3, X1 = (int)fminf(hx, (float)(g.nx - 1)) >> 3;
+    const int Y0 = (int)fmaxf(ly, 0.f) >> 3, Y1 = (int)fminf(hy, (float)(g.ny - 1)) >> 3;
+    const int Z0 = (int)fmaxf(lz, 0.f) >> 3, Z1 = (int)fminf(hz, (float)(g.nz - 1)) >> 3;
+    const int nX = X1 - X0 + 1, nY = Y1 - Y0 + 1, nZ = Z1 - Z0 + 1;
+    if ((int64_t)nX * nY * nZ > 32768) return false;
+    const int ncc = nX * nY * nZ;
+    if (tid == 0) { lds->nr = 0; lds->ball = 0; lds->next = 0; lds->nwin = 0; lds->ovf = 0; }
+    if (tid < PARTS * 8) lds->idx[tid >> 3][tid & 7] = -1;
+    __syncthreads();
+    // ---- the coarse cells the candidate sphere touches, listed in pieces of HEAVY_PIECE points
+    {
+        const float inv_nX = 1.0f / (float)nX, inv_nY = 1.0f / (float)nY;
+        for (int t = tid; t < ncc; t += 64 * PARTS) {
+            const int q1 = div_small(t, nX, inv_nX), X = X0 + (t - q1 * nX);            // (t < 2^15: the float quotient is exact)
+            const int q2 = div_small(q1, nY, inv_nY), Y = Y0 + (q1 - q2 * nY), Z = Z0 + q2;
+            const int64_t C = grid_coarse(g.NX, g.NY, X, Y, Z);
+            const int a0 = g.coarse_start[C], b0 = g.coarse_start[C + 1];
+            if (b0 > a0 && box_lb2(c, 8.f * X, 8.f * X + 8.f, 8.f * Y, 8.f * Y + 8.f, 8.f * Z, 8.f * Z + 8.f) <= limc) {
+                const int np_ = (b0 - a0 + HEAVY_PIECE - 1) / HEAVY_PIECE;
+                const int slot = atomicAdd(&lds->nr, np_);
+                if (slot + np_ <= HEAVY_RANGES) for (int k = 0; k < np_; ++k) { lds->ra[slot + k] = a0 + k * HEAVY_PIECE; lds->rb[slot + k] = min(b0, a0 + (k + 1) * HEAVY_PIECE); }
+                else lds->ovf = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (lds->ovf) { __syncthreads(); return false; }
+    // ---- one scan: the nearest distance, and the candidates of the ball
+    {
+        const int nr = lds->nr;
+        float best = INFINITY;
+        for (;;) {
+            int r = 0;
+            if (lane == 0) r = atomicAdd(&lds->next, 1);
+            r = rl_i(r, 0);
+            if (r >= nr) break;
+            const int A = lds->ra[r], B = lds->rb[r];
+            float4 p4[HEAVY_PIECE / 64];
+#pragma unroll
+            for (int u = 0; u < HEAVY_PIECE / 64; ++u) { const int i = A + 64 * u + lane; p4[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (i < B) p4[u] = g.spos[i]; }
+#pragma unroll
+            for (int u = 0; u < HEAVY_PIECE / 64; ++u) {
+                const int i = A + 64 * u + lane;
+                const float d = d2f(qx, qy, qz, p4[u].x, p4[u].y, p4[u].z);
+                if (i < B) best = fminf(best, d);
+                const bool in = i < B && d <= cand2;
+                const unsigned long long m = __ballot(in);
+                if (m) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&lds->ball, __popcll(m));
+                    base = rl_i(base, 0);
+                    const int my = base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (in) { if (my < HEAVY_CAND) lds->cand[my] = i; else lds->ovf = 1; }
+                }
+            }
+        }
+        best = wave_min_f(best);
+        if (lane == 0) lds->fmin[part] = best;
+    }
+    __syncthreads();
+    if (lds->ovf) { __syncthreads(); return false; }
+    const float dm = wave_min_f(lds->fmin[lane % HEAVY_WAVES]);
+    const int nc = lds->ball;
+    const float r2 = dm * 2.0f;                                  // radiusSearch(..., minDist * 2.0f, ...)  :288
+    const double nlen = norm3(nn);
+    // ---- the candidates against the ball and the normal filter (:304-315); float32 key of the survivors' projection distance
+    constexpr int KMAX = HEAVY_CAND / (64 * PARTS);
+    unsigned ukey[KMAX];
+    int n_ball = 0, n_pass = 0;
+    const int nk = (nc + 64 * PARTS - 1) / (64 * PARTS);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        ukey[k] = 0xffffffffu;
+        const int q = k * 64 * PARTS + tid;
+        if (k < nk && q < nc) {
+            const int i = lds->cand[q];
+            const float4 p = g.spos[i];
+            const d3 tn = ld3(g.tnrm + 3 * (int64_t)i);
+            const d3 tp = ld3(g.tpos + 3 * (int64_t)i);
+            if (d2f(qx, qy, qz, p.x, p.y, p.z) <= r2) {
+                ++n_ball;
+                if (dot3(nn, tn) > 0) {                       // :307
+                    ++n_pass;
+                    const d3 dir = tp - orig;                 // :331
+                    const double pl = dot3(dir, nn) / nlen;   // :332
+                    const double x = sqn3(dir) - pl * pl;
+                    const float f = (float)sqrt((0.0 < x) ? x : 0.0);
+                    ukey[k] = (f == f) ? __float_as_uint(f) : 0x7f800000u;
+                }
+            }
+        }
+    }
+    n_ball = wave_sum_dpp(n_ball);
+    n_pass = wave_sum_dpp(n_pass);
+    if (lane == 0) { lds->nb[part] = n_ball; lds->np[part] = n_pass; }
+    // (a wave whose survivors cannot all be among the node's top_k reports its top_k smallest keys; the usual heavy node — a few
+    //  dozen members — has fewer survivors than merge slots: then no threshold is needed at all, every survivor is ranked exactly)
+    const bool few = nc <= PARTS * 8;                            // (uniform: candidates <= merge slots -> survivors too)
+    if (!few) wave_smallest<KMAX>(ukey, top_k, lds->w8[part]);
+    __syncthreads();
+    if (part == 0) {
+        int tb = 0, tpn = 0;
+        for (int w = 0; w < PARTS; ++w) { tb += lds->nb[w]; tpn += lds->np[w]; }
+        unsigned T = 0xfffffffeu;                                // fewer than top_k survivors, or few candidates: all of them
+        if (tpn > top_k && !few) {
+            constexpr int NK2 = (PARTS * 8 + 63) / 64;
+            unsigned k2[NK2];
+#pragma unroll
+            for (int k = 0; k < NK2; ++k) { const int q = lane + 64 * k; k2[k] = q < PARTS * 8 ? lds->w8[q >> 3][q & 7] : 0xffffffffu; }
+            __shared__ unsigned s_top[8];
+            wave_smallest<NK2>(k2, top_k, s_top);
+            wave_lds_fence();
+            T = s_top[top_k - 1];
+        }
+        if (lane == 0) { lds->T = T; lds->ball = tb; lds->npass = tpn; }
+    }
+    __syncthreads();
+    const unsigned T = lds->T;
+    n_ball = lds->ball; n_pass = lds->npass;
+    // ---- the survivors at or below the threshold, exactly, into the merge slots
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (ukey[k] <= T && ukey[k] != 0xffffffffu) {
+            const int slot = atomicAdd(&lds->nwin, 1);
+            if (slot < PARTS * 8) {
+                const int i = lds->cand[k * 64 * PARTS + tid];
+                const d3 tp = ld3(g.tpos + 3 * (int64_t)i);
+                const d3 dir = tp - orig;                     // :331
+                const double pl = dot3(dir, nn) / nlen;       // :332
+                const double x = sqn3(dir) - pl * pl;
+                lds->pd[slot >> 3][slot & 7] = sqrt((0.0 < x) ? x : 0.0);     // :334, clamped (Appendix A.2)
+                lds->pl[slot >> 3][slot & 7] = pl;
+                lds->x[slot >> 3][slot & 7] = tp.x; lds->y[slot >> 3][slot & 7] = tp.y; lds->z[slot >> 3][slot & 7] = tp.z;
+                lds->idx[slot >> 3][slot & 7] = g.index_base + (long long)__float_as_int(g.spos[i].w);
+            }
+        }
+    }
+    __syncthreads();
+    const int nwin = lds->nwin;
+    if (nwin > PARTS * 8) { __syncthreads(); return false; }      // more float ties than merge slots (degenerate input)
+    // ---- exact ranks among the slots (8 lanes per slot), the first top_k are the list
+    {
+        const int cd = tid >> 3, chunk = tid & 7;                 // PARTS * 64 threads: PARTS * 8 slots x 8 lanes
+        const int cw = cd >> 3, cl = cd & 7;
+        const long long my_i = lds->idx[cw][cl];
+        const double my_pd = lds->pd[cw][cl], my_apl = fabs(lds->pl[cw][cl]);
+        int before = 0;
+        for (int k = 0; k < PARTS; ++k) {
+            const int j = chunk * PARTS + k, jw = j >> 3, jl = j & 7;
+            const long long o_i = lds->idx[jw][jl];
+            if (o_i >= 0 && key_less(lds->pd[jw][jl], fabs(lds->pl[jw][jl]), o_i, my_pd, my_apl, my_i)) ++before;
+        }
+        before += __shfl_xor(before, 1, 64); before += __shfl_xor(before, 2, 64); before += __shfl_xor(before, 4, 64);
+        if (chunk == 0 && my_i >= 0 && before < top_k) {
+            lds->r_pd[before] = my_pd; lds->r_pl[before] = lds->pl[cw][cl];
+            lds->r_x[before] = lds->x[cw][cl]; lds->r_y[before] = lds->y[cw][cl]; lds->r_z[before] = lds->z[cw][cl];
+            lds->r_idx[before] = my_i;
+        }
+    }
+    __syncthreads();
+    if (part != 0) return true;
+    // ---- what select_node writes (wave 0), same operations in the same order
+    const int len = min(nwin, top_k);
+    double L_pd = 0, L_pl = 0, L_x = 0, L_y = 0, L_z = 0;
+    long long L_idx = -1;
+    if (lane < len) { L_pd = lds->r_pd[lane]; L_pl = lds->r_pl[lane]; L_x = lds->r_x[lane]; L_y = lds->r_y[lane]; L_z = lds->r_z[lane]; L_idx = lds->r_idx[lane]; }
+    if (lane < 8) {
+        mvs_cand* o = rec + (int64_t)node * 8 + lane;
+        const bool live = lane < len;
+        o->proj_dist = live ? L_pd : 0.0;
+        o->proj_len = live ? L_pl : 0.0;
+        o->pos[0] = live ? L_x : 0.0; o->pos[1] = live ? L_y : 0.0; o->pos[2] = live ? L_z : 0.0;
+        o->index = live ? L_idx : -1;
+    }
+    if (lane == 0) { counts[2 * (int64_t)node] = n_ball; counts[2 * (int64_t)node + 1] = n_pass; d2min[node] = dm; }
+    if (lm.controls) {
+        bool ok = n_ball < lm.max_result && len > 0;
+        d3 mp = orig;
+        double m_pl = 0, m_pd = 0;
+        d3 acc = mk3(0, 0, 0);
+        for (int sidx = 0; sidx < len; ++sidx) {
+            m_pl += rl_d(L_pl, sidx); m_pd += rl_d(L_pd, sidx);
+            acc = acc + mk3(rl_d(L_x, sidx), rl_d(L_y, sidx), rl_d(L_z, sidx));
+        }
+        if (ok) {
+            const double dn = (double)len;
+            m_pl /= dn; m_pd /= dn; acc = acc / dn;
+            if (m_pl >= lm.proj_len_err || m_pd >= lm.proj_dist_err) ok = false;
+            if (ok) {
+                const d3 dir = acc - orig;
+                if (fabs(dot3(dir, nn) / (norm3(dir) * norm3(nn))) < lm.min_cos) ok = false;
+            }
+            if (ok) mp = acc;
+        }
+        if (lm.top_idx && lane < 8) lm.top_idx[(int64_t)node * 8 + lane] = (n_ball < lm.max_result && len > 0 && lane < len) ? L_idx : -1;
+        if (lane == 0) { lm.valid[node] = ok ? 1 : 0; st3(lm.controls + 3 * (int64_t)node, mp); }
+    }
+    return true;
+}
+
 #ifdef MVS_STAMPS
 __device__ unsigned long long g_all_stamps[4 * 4096];         // k_assoc_all: per workgroup {start, end (100 MHz constant clock), section, work items}
 #endif
@@ -1362,13 +1670,22 @@ __device__ inline int assoc_all_sections(const GridDev& g, const double* __restr
                                                                 int HB, int MB, int NB, int GB, int nn, int graph_bounded,
                                                                 const NgGeom* __restrict__ geo, const int* __restrict__ cs,
                                                                 const float4* __restrict__ sorted, int32_t* __restrict__ nbr, const SellDev& m,
-                                                                const double* __restrict__ mesh_pts, int* items) {
-    __shared__ AllLds lds;
-    const int b = (int)blockIdx.x, wv = (int)(threadIdx.x >> 6);
+                                                                const double* __restrict__ mesh_pts, int* items, AllLds& lds, const NgBuild& nb) {
+    const int wv = (int)(threadIdx.x >> 6);
+    if (nb.sync && blockIdx.x == 0) {                              // the node grid of this pass's graph queries (unless somebody took over)
+        __shared__ int s_mine;
+        if (threadIdx.x == 0) s_mine = atomicMax(nb.sync, nb.pass) < nb.pass ? 1 : 0;
+        __syncthreads();
+        if (s_mine) ng_build_publish(node_pts, K, nb, reinterpret_cast<int*>(&lds));
+        return 5;
+    }
+    const int b = (int)blockIdx.x - (nb.sync ? 1 : 0);
     if (b < HB) {
         const int n = min(heavy[0], K);
         for (int h = b; h < n; h += HB) {
-            heavy_entry(g, node_pts, node_nrm, heavy[1 + h], top_k, d2min, rec, counts, &lds.heavy, lm, lim);
+            const int entry = heavy[1 + h], node = entry & ~HEAVY_DMIN_FLAG;
+            if (!heavy_bounded<HEAVY_WAVES>(g, node_pts, node_nrm, node, top_k, lim[node], d2min, rec, counts, &lds.heavy, lm))
+                heavy_entry(g, node_pts, node_nrm, entry, top_k, d2min, rec, counts, &lds.heavy, lm, lim);
             __syncthreads();
             ++*items;
         }
@@ -1390,16 +1707,20 @@ __device__ inline int assoc_all_sections(const GridDev& g, const double* __restr
         near_nodes(g, node_pts, node_nrm, K, top_k, lim, d2min, rec, counts, lm, lds.near.g[wv], ((b - HB - MB) * HEAVY_WAVES + wv) * 4);
         return 2;
     }
-    if (b < HB + MB + NB + GB) {
-        const int w = (b - HB - MB - NB) * HEAVY_WAVES + wv;
-        if (graph_bounded) graph_queries_bounded(node_pts, K, nn, geo, cs, sorted, nbr, lds.graph.key[wv], 4 * w);
-        else if (w < K) ng_knn_query(w, node_pts, K, nn, geo, cs, sorted, nbr, nullptr, nullptr);
-        return 3;
+    // (the weights before the graph queries: those wait for the node grid workgroup 0 builds meanwhile — as the LAST workgroups
+    //  of the launch they find it done; in front of the weights they spun on a CU each: scripts/assoc_all_timeline.py)
+    const int CB = (int)gridDim.x - (nb.sync ? 1 : 0) - HB - MB - NB - GB;
+    if (b < HB + MB + NB + CB) {
+        cot_weight_rows(m, mesh_pts, b - HB - MB - NB, CB, HEAVY_WAVES);
+        return 4;
     }
-    cot_weight_rows(m, mesh_pts, b - HB - MB - NB - GB, (int)gridDim.x - HB - MB - NB - GB);
-    return 4;
+    if (nb.sync) ng_build_wait(node_pts, K, nb, reinterpret_cast<int*>(&lds));
+    const int w = (b - HB - MB - NB - CB) * HEAVY_WAVES + wv;
+    if (graph_bounded) graph_queries_bounded(node_pts, K, nn, geo, cs, sorted, nbr, lds.graph.key[wv], 4 * w);
+    else if (w < K) ng_knn_query(w, node_pts, K, nn, geo, cs, sorted, nbr, nullptr, nullptr);
+    return 3;
 }
-__global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_all(GridDev g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm,
+__global__ __launch_bounds__(64 * HEAVY_WAVES, 4) void k_assoc_all(GridDev g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm,
                                                                 int K, int top_k, const float* __restrict__ lim, float* __restrict__ d2min,
                                                                 mvs_cand* __restrict__ rec, int32_t* __restrict__ counts,
                                                                 const int32_t* __restrict__ heavy, const int32_t* __restrict__ mid, LocalMerge lm,
@@ -1407,13 +1728,15 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_assoc_all(GridDev g, const
                                                                 int HB, int MB, int NB, int GB, int nn, int graph_bounded,
                                                                 const NgGeom* __restrict__ geo, const int* __restrict__ cs,
                                                                 const float4* __restrict__ sorted, int32_t* __restrict__ nbr, SellDev m,
-                                                                const double* __restrict__ mesh_pts) {
+                                                                const double* __restrict__ mesh_pts, NgBuild nb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char all_dyn[];      // AllLds, or the cell counters of the node grid's builder
+    AllLds& lds = *reinterpret_cast<AllLds*>(all_dyn);
     int items = 0;
 #ifdef MVS_STAMPS
     unsigned long long t0_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory");
 #endif
     const int section = assoc_all_sections(g, node_pts, node_nrm, K, top_k, lim, d2min, rec, counts, heavy, mid, lm, heavy_next, mid_next, HB, MB, NB, GB, nn,
-                                           graph_bounded, geo, cs, sorted, nbr, m, mesh_pts, &items);
+                                           graph_bounded, geo, cs, sorted, nbr, m, mesh_pts, &items, lds, nb);
     (void)section;
 #ifdef MVS_STAMPS
     unsigned long long t1_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory");
@@ -1619,19 +1942,31 @@ void launch_assoc_prep(const GridDev& g, const double* node_pts, int K, const fl
                                                                                 knn_ws ? knn_grid_cells_per_axis(K) : 0, (NgGeom*)geo, const_cast<int*>(cs),
                                                                                 (float4*)sorted);
 }
+bool assoc_all_builds_grid(int K) { return K <= 64 * HEAVY_WAVES * NG1_PPT && knn_grid_cells_per_axis(K) <= NG1_NC; }
 void launch_assoc_all(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, const float* lim,
                       float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, const int32_t* mid, int32_t* heavy_next, int32_t* mid_next,
                       double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws /*NULL: no graph section*/,
-                      bool graph_bounded, const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks, hipStream_t s) {
+                      bool graph_bounded, const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks, hipStream_t s,
+                      unsigned long long* ng_sync /*!= NULL: the launch builds the node grid itself (assoc_all_builds_grid(K))*/, unsigned long long ng_pass) {
     if (K <= 0) return;
     const LocalMerge lm{controls, valid, top_idx, p.proj_len_err, p.proj_dist_err, p.min_cos, p.max_result, 0};
     const void *geo = nullptr, *sorted = nullptr;
     const int* cs = nullptr;
     if (knn_ws) knn_grid_views(knn_ws, K, &geo, &cs, &sorted);
-    const int HB = std::min(K, 256), MB = 16, NB = (K + 63) / 64;
-    const int GB = !knn_ws ? 0 : (graph_bounded ? (K + 63) / 64 : (K + HEAVY_WAVES - 1) / HEAVY_WAVES);
-    const int CB = mesh ? cot_blocks : 0;
-    k_assoc_all<<<dim3(HB + MB + NB + GB + CB), dim3(64 * HEAVY_WAVES), 0, s>>>(g, node_pts, node_nrm, K, p.top_k, lim, d2min, rec, counts, heavy, mid, lm,
+    const int per = 4 * HEAVY_WAVES;                               // near nodes / bounded graph queries per workgroup
+    const int HB = std::min(K, 256), MB = 256 / HEAVY_WAVES, NB = (K + per - 1) / per;
+    const int GB = !knn_ws ? 0 : (graph_bounded ? (K + per - 1) / per : (K + HEAVY_WAVES - 1) / HEAVY_WAVES);
+    const int CB = mesh ? cot_blocks * (16 / HEAVY_WAVES) : 0;
+    const bool build = ng_sync && knn_ws && GB > 0;
+    const int NC = knn_ws ? knn_grid_cells_per_axis(K) : 0;
+    const NgBuild nb{build ? ng_sync : nullptr, ng_pass, NC, (NgGeom*)geo, const_cast<int*>(cs), (float4*)sorted};
+    size_t lds_bytes = sizeof(AllLds);
+    if (build) lds_bytes = std::max(lds_bytes, sizeof(int) * (((size_t)NC * NC * NC + 3) / 4 * 4) + 16);
+    if (lds_bytes > 64 * 1024) {                                   // (above the default limit of dynamic LDS: once per process)
+        static std::once_flag once;
+        std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)k_assoc_all, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); });
+    }
+    k_assoc_all<<<dim3((build ? 1 : 0) + HB + MB + NB + GB + CB), dim3(64 * HEAVY_WAVES), lds_bytes, s>>>(g, node_pts, node_nrm, K, p.top_k, lim, d2min, rec, counts, heavy, mid, lm,
                                                                               heavy_next, mid_next, HB, MB, NB, GB, nn, graph_bounded ? 1 : 0, (const NgGeom*)geo, cs,
-                                                                              (const float4*)sorted, nbr, mesh ? *mesh : SellDev{}, mesh_pts);
+                                                                              (const float4*)sorted, nbr, mesh ? *mesh : SellDev{}, mesh_pts, nb);
 }

@@ -139,7 +139,10 @@ struct mvs_deform_s {
     double* d_near_prev = nullptr;     // [K][3]
     float* d_lim = nullptr;            // [K]
     int32_t *d_mid = nullptr, *d_mid2 = nullptr;   // [1 + K] each, alternating like d_heavy / d_heavy2
-    bool near_ready = false;           // d_d2min / d_near_prev describe the last association of THIS node set against THIS target
+    int near_age = 0;                  // associations of THIS node set against THIS target since d_d2min / d_near_prev were last invalidated
+                                       // (0: they describe nothing; the bounded search runs from the third association of a fit on)
+    unsigned long long* d_ng_sync = nullptr;   // [32] claim / done words of the node grid built inside k_assoc_all
+    unsigned long long ng_pass = 0;    // passes whose node grid was built that way
     int graph_prev_nn = 0;             // d_nbr holds the complete graph of an earlier pass with this many neighbours (the bound of the graph queries)
     float* d_prev_d2 = nullptr;        // sharded step: global nearest distance of every node at the previous association ...
     double* d_prev_node = nullptr;     // ... and where the node stood (bound for the next nearest-distance search)
@@ -253,7 +256,9 @@ void launch_assoc_prep(const GridDev& g, const double* node_pts, int K, const fl
 void launch_assoc_all(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, const float* lim,
                       float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, const int32_t* mid, int32_t* heavy_next, int32_t* mid_next,
                       double* controls, uint8_t* valid, int64_t* top_idx, int nn, int32_t* nbr, void* knn_ws /*NULL: no graph section*/,
-                      bool graph_bounded, const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks, hipStream_t s);
+                      bool graph_bounded, const SellDev* mesh /*NULL: no weights*/, const double* mesh_pts, int cot_blocks, hipStream_t s,
+                      unsigned long long* ng_sync = nullptr /*!= NULL: the launch builds the node grid itself (assoc_all_builds_grid(K))*/, unsigned long long ng_pass = 0);
+bool assoc_all_builds_grid(int K);
 void launch_install_targets(const void* blocks, int K, int block_nodes, int64_t stride_bytes, double* controls, uint8_t* valid, int64_t* top_idx,
                             hipStream_t s);
 void launch_assoc_merge(const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p,

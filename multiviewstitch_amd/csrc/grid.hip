@@ -169,7 +169,7 @@ int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* 
     hipStream_t s = h->stream;
     h->assoc_passes = 0;
     h->prev_valid = false;                              // a new target: the remembered nearest distances say nothing about it
-    h->near_ready = false;
+    h->near_age = 0;
     h->has_target = false;
     h->P = P;
     h->grid = GridDev{};

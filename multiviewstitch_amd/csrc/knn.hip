@@ -246,7 +246,8 @@ __global__ void k_ng_scatter(const double* __restrict__ pts, int n, const int* _
 // (the build itself lives in knn_dev.h, ng_build1_body: k_assoc_prep of assoc.hip carries it in its first workgroup)
 __global__ __launch_bounds__(1024) void k_ng_build1(const double* __restrict__ pts, int n, int NC, NgGeom* __restrict__ geo,
                                                     int* __restrict__ start, float4* __restrict__ sorted) {
-    ng_build1_body(pts, n, NC, geo, start, sorted);
+    __shared__ __attribute__((aligned(16))) int cnt[NG1_CELLS];
+    ng_build1_body(pts, n, NC, geo, start, sorted, cnt);
 }
 
 __global__ __launch_bounds__(256) void k_ng_knn(const double* __restrict__ pts, int n, int k, const NgGeom* __restrict__ geo,

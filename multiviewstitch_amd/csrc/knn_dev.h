@@ -172,18 +172,21 @@ constexpr int NG1_PPT = 20;
 constexpr int NG1_MAX = 1024 * NG1_PPT;
 constexpr int NG1_NC = 32;
 constexpr int NG1_CELLS = NG1_NC * NG1_NC * NG1_NC;
+// cnt: LDS, room for NC^3 cell counters rounded up to a multiple of 4 (<= NG1_CELLS), 16-byte aligned.  T = threads of the
+// workgroup (1024, or 512 inside k_assoc_all's 8-wave workgroups): n <= T * NG1_PPT.
+template <int T = 1024>
 __device__ inline void ng_build1_body(const double* __restrict__ pts, int n, int NC, NgGeom* __restrict__ geo,
-                                                    int* __restrict__ start, float4* __restrict__ sorted) {
-    __shared__ int cnt[NG1_CELLS];
-    __shared__ float sm[6][16];
+                                      int* __restrict__ start, float4* __restrict__ sorted, int* cnt) {
+    constexpr int NWV = T / 64;
+    __shared__ float sm[6][NWV];
     __shared__ NgGeom sg;
-    __shared__ int wsum[16];
+    __shared__ int wsum[NWV];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     float px[NG1_PPT], py[NG1_PPT], pz[NG1_PPT];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int j = 0; j < NG1_PPT; ++j) {
-        const int i = t + 1024 * j;
+        const int i = t + T * j;
         px[j] = py[j] = pz[j] = 0.0f;
         if (i < n) {
             px[j] = (float)pts[3 * i]; py[j] = (float)pts[3 * i + 1]; pz[j] = (float)pts[3 * i + 2];
@@ -198,13 +201,13 @@ __device__ inline void ng_build1_body(const double* __restrict__ pts, int n, int
         for (int o = 32; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o, 64)); b = fmaxf(b, __shfl_xor(b, o, 64)); }
         if (lane == 0) { sm[c][w] = a; sm[3 + c][w] = b; }
     }
-    for (int i = t; i < NG1_CELLS / 4; i += 1024) reinterpret_cast<int4*>(cnt)[i] = make_int4(0, 0, 0, 0);
+    for (int i = t; i < (NC * NC * NC + 3) / 4; i += T) reinterpret_cast<int4*>(cnt)[i] = make_int4(0, 0, 0, 0);
     __syncthreads();
     if (t == 0) {                                                   // same geometry rule as k_ng_bbox
         float lo[3], hi[3];
         for (int c = 0; c < 3; ++c) {
             lo[c] = sm[c][0]; hi[c] = sm[3 + c][0];
-            for (int ww = 1; ww < 16; ++ww) { lo[c] = fminf(lo[c], sm[c][ww]); hi[c] = fmaxf(hi[c], sm[3 + c][ww]); }
+            for (int ww = 1; ww < NWV; ++ww) { lo[c] = fminf(lo[c], sm[c][ww]); hi[c] = fmaxf(hi[c], sm[3 + c][ww]); }
             if (!(lo[c] <= hi[c])) { lo[c] = 0.f; hi[c] = 0.f; }
         }
         float ext = fmaxf(hi[0] - lo[0], fmaxf(hi[1] - lo[1], hi[2] - lo[2]));
@@ -225,7 +228,7 @@ __device__ inline void ng_build1_body(const double* __restrict__ pts, int n, int
 #pragma unroll
     for (int j = 0; j < NG1_PPT; ++j) {
         cr[j] = 0;
-        if (t + 1024 * j < n) {
+        if (t + T * j < n) {
             const int c = (ng_axis(pz[j], g.minz, g.inv_h, g.nz) * g.ny + ng_axis(py[j], g.miny, g.inv_h, g.ny)) * g.nx + ng_axis(px[j], g.minx, g.inv_h, g.nx);
             cr[j] = c | (atomicAdd(&cnt[c], 1) << 15);
         }
@@ -233,7 +236,7 @@ __device__ inline void ng_build1_body(const double* __restrict__ pts, int n, int
     __syncthreads();
     // exclusive scan of the counters, in place: wave w owns a contiguous chunk of cells (a multiple of 256), a lane
     // takes four consecutive cells per step (16-byte LDS accesses), the 64 lane sums are scanned with DPP row shifts
-    const int chunk = ((ncell + 15) / 16 + 255) / 256 * 256, c_lo = w * chunk, c_hi = min((ncell + 3) / 4 * 4, c_lo + chunk);
+    const int chunk = ((ncell + NWV - 1) / NWV + 255) / 256 * 256, c_lo = w * chunk, c_hi = min((ncell + 3) / 4 * 4, c_lo + chunk);
     int s_acc = 0;
     for (int c = c_lo + 4 * lane; c < c_hi; c += 256) { const int4 v = *reinterpret_cast<const int4*>(cnt + c); s_acc += (v.x + v.y) + (v.z + v.w); }
     for (int o = 32; o > 0; o >>= 1) s_acc += __shfl_xor(s_acc, o, 64);
@@ -266,7 +269,7 @@ __device__ inline void ng_build1_body(const double* __restrict__ pts, int n, int
     if (t == 0) start[ncell] = n;                                   // (after the barrier: the padded tail of the last int4 may cover it)
 #pragma unroll
     for (int j = 0; j < NG1_PPT; ++j) {
-        const int i = t + 1024 * j;
+        const int i = t + T * j;
         if (i < n) sorted[cnt[cr[j] & 32767] + (cr[j] >> 15)] = make_float4(px[j], py[j], pz[j], __int_as_float(i));
     }
 }

@@ -19,16 +19,21 @@ K = d.UniformSampling(16)
 tp, tn = bench.build_target(torch, srt_mod, S, sc, range(len(sc.cams)), dev)
 d.set_target_dev(tp.data_ptr(), tn.data_ptr(), tp.shape[0], 0)
 lib = C.CDLL(_lib.LIB_PATH)
-names = ["heavy", "mid", "near", "graph", "cot"]
-for upto in (2, 6, 12):
-    d.iterate(upto - (0 if upto == 2 else {6: 2, 12: 6}[upto]))
+names = ["heavy", "mid", "near", "graph", "cot", "ngbuild"]
+done = 0
+for upto in (3, 6, 12):
+    d.iterate(upto - done)
+    done = upto
     buf = np.zeros(4 * 4096, np.uint64)
     assert lib.mvs_debug_all_stamps(buf.ctypes.data_as(C.c_void_p), len(buf)) == 0
     raw = buf.reshape(-1, 4).astype(np.int64)
     raw = raw[raw[:, 0] != 0]
+    if not len(raw):
+        print(f"--- after {upto} outer iterations: no bounded pass yet")
+        continue
     t0 = raw[:, 0].min()
     print(f"--- after {upto} outer iterations: {len(raw)} workgroups, launch span {(raw[:, 1].max() - t0) / 100:.2f} us")
-    for sct in range(5):
+    for sct in range(6):
         m = raw[:, 2] == sct
         if not m.any():
             continue
