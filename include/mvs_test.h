@@ -9,6 +9,16 @@
 extern "C" {
 #endif
 
+/* The handle's solver control block (csrc/engine.h, MVS_CTL_*): [0..7] escalation flag, worst rel^2, misses, solves, passes
+ * finalized, pending prediction, prediction safety factor; then the ring of the last 32 passes x 8 solves: rel^2 of each solve's
+ * result (-1: did not run), and the sweeps it ran (negative: no spare launch was left; a fractional quarter: it stopped on a
+ * prediction).  n <= 8 + 2 * 256 + 16 doubles. */
+int mvs_test_ctl(mvs_deform_t h, double* out, int n);
+
+/* Cold start: mvs_set_device (or the first entry that needs a device) starts a helper thread that loads the library's code
+ * objects and creates the first stream; this waits for it (measurements of the warm / cold first call). */
+int mvs_test_preload_wait(void);
+
 /* Tail loop of the patch solver's last launch (csrc/schwarz.hip), for THIS handle:
  *   maxspin  : polls a workgroup waits at the device-wide barrier before it abandons the solve (<= 0: default, 65536);
  *   plan_cap : at most this many launches per global solve, its remaining sweeps run inside the last one (0: no cap);

@@ -161,6 +161,8 @@ _SIGS = {
     "mvs_parts_read": (C.c_int, [C.c_char_p, _I64, _VP]),
     "mvs_processor_deform": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _VP, _D, _VP, C.c_char_p, _VP]),
     # include/mvs_test.h (test hooks: per handle, not part of the drop-in ABI)
+    "mvs_test_preload_wait": (C.c_int, []),
+    "mvs_test_ctl": (C.c_int, [_VP, _VP, _I32]),
     "mvs_test_tail": (C.c_int, [_VP, _I32, _I32, _I32]),
     "mvs_test_sweep_steps": (C.c_int, [_VP, _I32, _VP]),
     "mvs_test_heavy_count": (C.c_int, [_VP, _VP, _VP]),

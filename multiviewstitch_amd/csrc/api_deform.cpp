@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <tuple>
 #include <mutex>
+#include <condition_variable>
+#include <thread>
 #include <sched.h>
 #include <dlfcn.h>
 
@@ -33,9 +35,56 @@ int mvs_check_hip(hipError_t e, const char* what) {
     return e == hipErrorOutOfMemory ? MVS_E_OOM : MVS_E_HIP;
 }
 int mvs_current_device() { return g_device; }
+void mvs_preload(int device);
+void mvs_preload_join(int device);
 int mvs_debug_level() {
     static const int level = [] { const char* e = getenv("MVS_DEBUG_CG"); return (e && *e) ? (e[0] == '2' ? 2 : 1) : 0; }();
     return level;
+}
+
+// ---- cold start ----
+// The reference's process calls Processor::Deform ONCE (R/main.cpp:24-25): what a drop-in caller sees is the COLD call.  Two
+// things a first call pays that later ones do not: the runtime loads each translation unit's code object at the first use of one
+// of its kernels (twelve units), and the first stream of a process is a new hardware queue (hipStreamCreate: 5.7 ms, measured).
+// Both need nothing from the caller: a helper thread does them — once per device — as soon as the device is known
+// (mvs_set_device, or the first entry that needs a device), while the host reads its files; the thread is detached and
+// touches only the runtime and the stream pool (mutex).  mvs_preload_wait (mvs_test.h) joins the work, for measurements.
+const void* mvs_tu_probe_grid(); const void* mvs_tu_probe_assoc(); const void* mvs_tu_probe_knn(); const void* mvs_tu_probe_arap();
+const void* mvs_tu_probe_schwarz(); const void* mvs_tu_probe_meshbuild(); const void* mvs_tu_probe_geom(); const void* mvs_tu_probe_srt();
+const void* mvs_tu_probe_align(); const void* mvs_tu_probe_consist(); const void* mvs_tu_probe_render(); const void* mvs_tu_probe_matchfilter();
+void stream_pool_prime(int device);
+// (never destroyed: the helper thread is detached and may outlive the static destructors of an exiting process)
+static std::mutex& g_preload_mu = *new std::mutex;
+static std::condition_variable& g_preload_cv = *new std::condition_variable;
+static std::vector<int>& g_preload_started = *new std::vector<int>;
+static std::vector<int>& g_preload_done = *new std::vector<int>;
+void mvs_preload(int device) {
+    {
+        std::lock_guard<std::mutex> lk(g_preload_mu);
+        for (int d : g_preload_started) if (d == device) return;
+        g_preload_started.push_back(device);
+    }
+    std::thread([device] {
+        if (hipSetDevice(device) == hipSuccess) {
+            // the deformation path first (what mvs_deform_create meets first), then the rest
+            for (const void* k : {mvs_tu_probe_meshbuild(), mvs_tu_probe_knn(), mvs_tu_probe_grid(), mvs_tu_probe_assoc(), mvs_tu_probe_arap(), mvs_tu_probe_schwarz(),
+                                  mvs_tu_probe_geom(), mvs_tu_probe_srt(), mvs_tu_probe_align(), mvs_tu_probe_consist(), mvs_tu_probe_render(), mvs_tu_probe_matchfilter()}) {
+                hipFuncAttributes a;
+                if (hipFuncGetAttributes(&a, k) != hipSuccess) (void)hipGetLastError();
+            }
+            stream_pool_prime(device);
+        }
+        std::lock_guard<std::mutex> lk(g_preload_mu);
+        g_preload_done.push_back(device);
+        g_preload_cv.notify_all();
+    }).detach();
+}
+void mvs_preload_join(int device) {
+    std::unique_lock<std::mutex> lk(g_preload_mu);
+    bool started = false;
+    for (int d : g_preload_started) started = started || d == device;
+    if (!started) return;
+    g_preload_cv.wait(lk, [&] { for (int d : g_preload_done) if (d == device) return true; return false; });
 }
 
 // ---- tracing (trace.h) ----
@@ -79,6 +128,7 @@ int mvs_set_device(int device) {
     if (device < 0 || device >= mvs_device_count()) { mvs_set_error("no such device %d", device); return MVS_E_NO_DEVICE; }
     HIPCHK(hipSetDevice(device));
     g_device = device;
+    mvs_preload(device);
     return MVS_OK;
 }
 int mvs_device_name(char* buf, int buflen) {
@@ -125,6 +175,19 @@ int stream_acquire(int device, hipStream_t* out) {
     }
     return mvs_check_hip(hipStreamCreateWithFlags(out, hipStreamNonBlocking), "hipStreamCreate");
 }
+}  // namespace
+// (cold start: one stream in the pool before the first handle asks for it)
+void stream_pool_prime(int device) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        for (const PooledStream& p : g_pool) if (p.device == device) return;
+    }
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; }
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    g_pool.push_back({device, s});
+}
+namespace {
 void stream_release(int device, hipStream_t s) {
     {
         std::lock_guard<std::mutex> lk(g_pool_mutex);
@@ -168,7 +231,9 @@ void scratch_release(int device, void* p, size_t bytes, bool pinned) {
 
 int need_device() {
     if (mvs_device_count() == 0) { mvs_set_error("no HIP device: the MI355X engine has no CPU fallback"); return MVS_E_NO_DEVICE; }
-    return mvs_check_hip(hipSetDevice(g_device), "hipSetDevice");
+    int rc = mvs_check_hip(hipSetDevice(g_device), "hipSetDevice");
+    if (!rc) mvs_preload(g_device);
+    return rc;
 }
 
 int check_params(const mvs_deform_params* p) {
@@ -1441,6 +1506,18 @@ int mvs_test_heavy_count(mvs_deform_t h, int* n, int* flagged) {
     if (flagged) *flagged = f;
     return MVS_OK;
 }
+
+// the handle's solver control block (engine.h, MVS_CTL_*: verdict ring, sweeps used, prediction safety factor ...) -> out[n], n <= MVS_CTL_SIZE
+int mvs_test_ctl(mvs_deform_t h, double* out, int n) {
+    if (!h || !out || n < 1 || n > MVS_CTL_SIZE) return MVS_E_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->d_ctl, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return MVS_OK;
+}
+
+// waits until the cold-start helper thread of the current device has loaded the code objects and primed the stream pool
+int mvs_test_preload_wait(void) { mvs_preload_join(g_device); return MVS_OK; }
 
 // maxspin = polls a workgroup waits at the tail loop's device-wide barrier before it abandons the solve (<= 0: default);
 // plan_cap = at most this many launches per solve, the remaining sweeps run inside the last one (0: no cap); skip_wg = the

@@ -182,6 +182,7 @@ __device__ inline void judge_solve(const double* __restrict__ ered, int it, int 
         // true / predicted (decaying 6 % per predicted solve) is the safety factor of the next predictions
         const double pr = ctl[MVS_CTL_PRED];
         if (pr > 0.0) {
+            used[it] += used[it] < 0.0 ? -0.25 : 0.25;                    // (diagnostics: a quarter marks a solve that stopped on a prediction; the integer part is what the host plans from)
             if (rel2 < INFINITY) ctl[MVS_CTL_PSAFE] = fmax(rel2 / pr, 0.94 * ctl[MVS_CTL_PSAFE]);
             ctl[MVS_CTL_PRED] = 0.0;
         }

@@ -1970,3 +1970,7 @@ void launch_assoc_all(const GridDev& g, const double* node_pts, const double* no
                                                                               heavy_next, mid_next, HB, MB, NB, GB, nn, graph_bounded ? 1 : 0, (const NgGeom*)geo, cs,
                                                                               (const float4*)sorted, nbr, mesh ? *mesh : SellDev{}, mesh_pts, nb);
 }
+
+// one kernel of this translation unit, for the code-object preload of api_deform.cpp (mvs_set_device): asking the runtime for its
+// attributes loads the unit's code object without launching anything
+const void* mvs_tu_probe_assoc() { return (const void*)k_assoc_prep; }

@@ -192,3 +192,7 @@ void launch_srt_apply(const double* pts, const double* nrm, int64_t P, double sc
     const int64_t blocks = std::min<int64_t>((P + TPB - 1) / TPB, 256 * 16);
     k_srt_apply<<<dim3((unsigned)blocks), dim3(TPB), 0, s>>>(pts, nrm, P, m, out_pts, out_nrm);
 }
+
+// one kernel of this translation unit, for the code-object preload of api_deform.cpp (mvs_set_device): asking the runtime for its
+// attributes loads the unit's code object without launching anything
+const void* mvs_tu_probe_geom() { return (const void*)k_srt_apply; }

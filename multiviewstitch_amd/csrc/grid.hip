@@ -268,3 +268,7 @@ int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* 
     h->has_target = true;
     return mvs_check_hip(hipGetLastError(), "grid_build");
 }
+
+// one kernel of this translation unit, for the code-object preload of api_deform.cpp (mvs_set_device): asking the runtime for its
+// attributes loads the unit's code object without launching anything
+const void* mvs_tu_probe_grid() { return (const void*)k_bbox; }

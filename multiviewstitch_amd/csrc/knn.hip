@@ -488,3 +488,7 @@ void launch_label_nn(const double* tmpl, int V, const int32_t* tmpl_labels, void
     k_label_nn<<<dim3(nb), dim3(256), 0, s>>>(w.geo, w.start, w.sorted, tmpl_labels, pts, P, out, far_list);
     k_label_far<<<dim3((unsigned)std::min<int64_t>((P + 3) / 4, 8192)), dim3(256), 0, s>>>(w.geo, w.start, w.sorted, V, tmpl_labels, pts, far_list, out);   // waves stride over the far list
 }
+
+// one kernel of this translation unit, for the code-object preload of api_deform.cpp (mvs_set_device): asking the runtime for its
+// attributes loads the unit's code object without launching anything
+const void* mvs_tu_probe_knn() { return (const void*)k_ng_build1; }

@@ -820,3 +820,7 @@ int mesh_build(mvs_deform_s* h, const double* points, const double* normals, con
                 NP, (long long)h->ras_rows, V, h->ras_block, W, info.max_nh);
     return MVS_OK;
 }
+
+// one kernel of this translation unit, for the code-object preload of api_deform.cpp (mvs_set_device): asking the runtime for its
+// attributes loads the unit's code object without launching anything
+const void* mvs_tu_probe_meshbuild() { return (const void*)k_iota; }

@@ -173,3 +173,7 @@ int mvs_render_depth(const double* pts, int64_t V, const int32_t* faces, int64_t
 }
 
 }  // extern "C"
+
+// one kernel of this translation unit, for the code-object preload of api_deform.cpp (mvs_set_device): asking the runtime for its
+// attributes loads the unit's code object without launching anything
+const void* mvs_tu_probe_render() { return (const void*)k_rd_project; }

@@ -870,3 +870,7 @@ void launch_ras_sweep(const mvs_deform_s* h, const double* b, double* xin, doubl
 #undef MVS_SWEEP_W
 #undef MVS_SWEEP
 }
+
+// one kernel of this translation unit, for the code-object preload of api_deform.cpp (mvs_set_device): asking the runtime for its
+// attributes loads the unit's code object without launching anything
+const void* mvs_tu_probe_schwarz() { return (const void*)k_ras_prepare<6>; }

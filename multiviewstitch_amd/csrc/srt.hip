@@ -304,3 +304,7 @@ void launch_srt_residual(const double* matches_dev, int64_t n, const CamDev& c1,
     if (n <= 0) return;
     k_srt_residual<<<dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s>>>(matches_dev, n, c1, c2, scale, Rt_dev, per_match_dev);
 }
+
+// one kernel of this translation unit, for the code-object preload of api_deform.cpp (mvs_set_device): asking the runtime for its
+// attributes loads the unit's code object without launching anything
+const void* mvs_tu_probe_srt() { return (const void*)k_srt_closed; }

@@ -1,0 +1,96 @@
+"""The measurement rows BASELINE.md §2 promises beyond the deformation kernels (missing #2): host wall clock
+around each C-ABI entry (best of REPS calls; host-pointer entries include their uploads and downloads — what a drop-in caller
+pays), with the oracle's single-thread time of the same call on the same inputs beside it.
+  * mvs_align and its stages at scan scale: 2.03 M-vertex / 4.05 M-facet scan mesh + 9 K-vertex template (tests/util.py body_scene)
+  * mvs_srt_fit closed form and RANSAC-200, mvs_srt_remove_outliers on 64 and 1 000 matches
+  * mvs_select_keyframe_pair on 8 x 8 frame pairs of 64 matches
+Prints a markdown table; `JSON ` + one line on stderr."""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from multiviewstitch_amd import alignment, scene as S, srt
+from oracle import binding as O
+from tests.util import body_scene
+
+REPS = 3
+rows = []
+
+
+def best(fn, reps=REPS):
+    t = []
+    out = None
+    for _ in range(reps):
+        a = time.perf_counter()
+        out = fn()
+        t.append(time.perf_counter() - a)
+    return 1e3 * min(t), out
+
+
+def row(name, what, gpu_ms, cpu_ms, note=""):
+    rows.append(dict(entry=name, input=what, gpu_ms=round(gpu_ms, 3), oracle_1_thread_ms=round(cpu_ms, 3), ratio=round(cpu_ms / gpu_ms, 1) if gpu_ms > 0 else None, note=note))
+
+
+# ---------------------------------------------------------------- alignment at scan scale
+sc = body_scene(5, 30, 450)
+A = alignment.Alignment()
+Vt, Ft, Vs = len(sc["tgt"]), len(sc["t_faces"]), len(sc["src"])
+scan = f"{Vt} scan vertices, {Ft} facets"
+g, _ = best(lambda: A.RetainConnectRegion(sc["tgt"], sc["t_nrm"], sc["t_faces"]))
+c, _ = best(lambda: O.retain_connect_region(sc["tgt"], sc["t_nrm"], sc["t_faces"]), 1)
+row("mvs_retain_connect_region", scan, g, c, "R/Alignment/Alignment.cpp:618-654")
+g, gr_ = best(lambda: A.RemoveGround(sc["tgt"], sc["t_nrm"], sc["t_faces"], 0.81))
+c, og = best(lambda: O.remove_ground(sc["tgt"], sc["t_nrm"], sc["t_faces"], 0.81), 1)
+row("mvs_remove_ground", scan, g, c, "Alignment.cpp:79-233")
+ogr, op = og[0], og[1]
+g, _ = best(lambda: A.InitAlignment(sc["src"], op, ogr, sc["view_ray"]))
+c, oi = best(lambda: O.init_alignment(sc["src"], op, ogr, sc["view_ray"]), 1)
+row("mvs_init_alignment", f"{Vs} template vertices, {len(op)} scan points", g, c, "Alignment.cpp:235-314")
+moved = oi[2] * sc["src"] @ oi[0].T + oi[1]
+g, _ = best(lambda: alignment.part_recog(moved, sc["s_labels"], op))
+c, tl = best(lambda: O.part_recog(moved, sc["s_labels"], op), 1)
+row("mvs_part_recog", f"{len(op)} scan points x {Vs} template vertices", g, c, "PartRecognition.cpp:50-77")
+g, _ = best(lambda: A.LocalAlignmentCore(moved, sc["s_labels"], op, tl, (1 << 2 | 1 << 3 | 1 << 4), 4))
+c, _ = best(lambda: O.local_alignment_core(moved, sc["s_labels"], op, tl, (1 << 2 | 1 << 3 | 1 << 4), 4), 1)
+row("mvs_local_alignment_core", "left arm of the same pair", g, c, "Alignment.cpp:316-421")
+g, _ = best(lambda: A.Align(sc["src"], sc["s_nrm"], sc["s_labels"], sc["tgt"], sc["t_nrm"], sc["t_faces"], sc["view_ray"], 0.81))
+c, _ = best(lambda: O.align(sc["src"], sc["s_nrm"], sc["s_labels"], sc["tgt"], sc["t_nrm"], sc["t_faces"], sc["view_ray"], 0.81), 1)
+row("mvs_align", scan + f", {Vs} template vertices", g, c, "Alignment::Align, Alignment.cpp:11-76 (host pointers: ~150 MB up, ~140 MB down per call)")
+
+# ---------------------------------------------------------------- SRT fit, RANSAC, RemoveOutliers
+sc0 = S.make_scene(1)
+s0, R0, t0 = sc0.srt[0]
+s1, R1, t1 = sc0.srt[1]
+s01, R01, t01 = s0 / s1, R1.T @ R0, (R1.T @ (t0 - t1)) / s1
+for n in (64, 1000):
+    m = S.make_matches(np.random.default_rng(5 + n), sc0.cams[0], sc0.cams[1], s01, R01, t01, n=n)
+    sol = srt.SRTSolver()
+    sol.SetInput(m, sc0.cams[0], sc0.cams[1])
+    g, _ = best(sol.EstimateTransform, 10)
+    c, _ = best(lambda: O.srt_fit(m, sc0.cams[0], sc0.cams[1], 0), 10)
+    row("mvs_srt_fit (closed form)", f"{n} matches", g, c, "SRTSolver.cpp:6-129,272-275")
+    tri, _ = srt.make_triples(n, 200, 7)
+    sol.SetIterationNum(200)
+    g, _ = best(lambda: sol.EstimateTransformRansac(tri), 10)
+    c, _ = best(lambda: O.srt_fit(m, sc0.cams[0], sc0.cams[1], 1, tri, 200), 10)
+    row("mvs_srt_fit (RANSAC, 200 hypotheses)", f"{n} matches", g, c, "SRTSolver.cpp:131-185")
+    g, _ = best(lambda: srt.remove_outliers(m, sc0.cams[0], sc0.cams[1], 200, 60.0, 0.75, state=7), 10)
+    c, _ = best(lambda: O.srt_remove_outliers(m, sc0.cams[0], sc0.cams[1], 200, 60.0, 0.75, 7), 10)
+    row("mvs_srt_remove_outliers (3 rounds x 200)", f"{n} matches", g, c, "Processor.cpp:177-269")
+
+# ---------------------------------------------------------------- key-frame pair selection, 8 x 8 frames
+rng = np.random.default_rng(8)
+cams1, cams2 = [sc0.cams[0]] * 8, [sc0.cams[1]] * 8
+mm = [[S.make_matches(rng, cams1[i], cams2[j], s01, R01, t01, n=64, outlier_frac=0.2, noise_px=0.3 + 0.1 * ((3 * i + j) % 4)) for j in range(8)] for i in range(8)]
+g, _ = best(lambda: srt.select_keyframe_pair(cams1, cams2, mm, min_match_count=7, iters=200, state=9))
+c, _ = best(lambda: O.select_keyframe_pair(cams1, cams2, mm, min_match_count=7, iters=200, state=9), 1)
+row("mvs_select_keyframe_pair", "8 x 8 frame pairs x 64 matches, 200 hypotheses", g, c, "Processor.cpp:746-765")
+
+print("| entry | input | MI355X, ms (host wall clock per call) | oracle, 1 thread, ms | ratio | reference |")
+print("|---|---|---|---|---|---|")
+for r in rows:
+    print(f"| `{r['entry']}` | {r['input']} | {r['gpu_ms']} | {r['oracle_1_thread_ms']} | {r['ratio']} | {r['note']} |")
+print("JSON " + json.dumps(rows), file=sys.stderr)
