@@ -49,9 +49,10 @@ int mvs_debug_level() {
 // Both need nothing from the caller: a helper thread does them — once per device — as soon as the device is known
 // (mvs_set_device, or the first entry that needs a device), while the host reads its files; the thread is detached and
 // touches only the runtime and the stream pool (mutex).  mvs_preload_wait (mvs_test.h) joins the work, for measurements.
-const void* mvs_tu_probe_grid(); const void* mvs_tu_probe_assoc(); const void* mvs_tu_probe_knn(); const void* mvs_tu_probe_arap();
-const void* mvs_tu_probe_schwarz(); const void* mvs_tu_probe_meshbuild(); const void* mvs_tu_probe_geom(); const void* mvs_tu_probe_srt();
-const void* mvs_tu_probe_align(); const void* mvs_tu_probe_consist(); const void* mvs_tu_probe_render(); const void* mvs_tu_probe_matchfilter();
+const void* const* mvs_tu_kernels_grid(int*); const void* const* mvs_tu_kernels_assoc(int*); const void* const* mvs_tu_kernels_knn(int*);
+const void* const* mvs_tu_kernels_arap(int*); const void* const* mvs_tu_kernels_schwarz(int*); const void* const* mvs_tu_kernels_meshbuild(int*);
+const void* const* mvs_tu_kernels_geom(int*);
+const void* mvs_tu_probe_srt(); const void* mvs_tu_probe_align(); const void* mvs_tu_probe_consist(); const void* mvs_tu_probe_render(); const void* mvs_tu_probe_matchfilter();
 void stream_pool_prime(int device);
 // (never destroyed: the helper thread is detached and may outlive the static destructors of an exiting process)
 static std::mutex& g_preload_mu = *new std::mutex;
@@ -66,13 +67,20 @@ void mvs_preload(int device) {
     }
     std::thread([device] {
         if (hipSetDevice(device) == hipSuccess) {
-            // the deformation path first (what mvs_deform_create meets first), then the rest
-            for (const void* k : {mvs_tu_probe_meshbuild(), mvs_tu_probe_knn(), mvs_tu_probe_grid(), mvs_tu_probe_assoc(), mvs_tu_probe_arap(), mvs_tu_probe_schwarz(),
-                                  mvs_tu_probe_geom(), mvs_tu_probe_srt(), mvs_tu_probe_align(), mvs_tu_probe_consist(), mvs_tu_probe_render(), mvs_tu_probe_matchfilter()}) {
+            // the deformation path first, every kernel of it (a kernel's first launch otherwise pays its own resolution: the first
+            // outer iteration of a fresh process took 5.6-7.5 ms against 0.8 ms warm with only the code objects loaded), in the
+            // order a fit meets the units; then one kernel of each remaining unit
+            stream_pool_prime(device);
+            for (auto unit : {mvs_tu_kernels_meshbuild, mvs_tu_kernels_knn, mvs_tu_kernels_grid, mvs_tu_kernels_assoc, mvs_tu_kernels_arap, mvs_tu_kernels_schwarz,
+                              mvs_tu_kernels_geom}) {
+                int n = 0;
+                const void* const* ks = unit(&n);
+                for (int i = 0; i < n; ++i) { hipFuncAttributes a; if (hipFuncGetAttributes(&a, ks[i]) != hipSuccess) (void)hipGetLastError(); }
+            }
+            for (const void* k : {mvs_tu_probe_srt(), mvs_tu_probe_align(), mvs_tu_probe_consist(), mvs_tu_probe_render(), mvs_tu_probe_matchfilter()}) {
                 hipFuncAttributes a;
                 if (hipFuncGetAttributes(&a, k) != hipSuccess) (void)hipGetLastError();
             }
-            stream_pool_prime(device);
         }
         std::lock_guard<std::mutex> lk(g_preload_mu);
         g_preload_done.push_back(device);
@@ -184,6 +192,27 @@ void stream_pool_prime(int device) {
     }
     hipStream_t s = nullptr;
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; }
+    // the runtime's own fill / copy kernels and staging paths are loaded at their first use too (hipMemsetAsync, device-to-device
+    // and strided device-to-host copies: what a pass and its harvest enqueue): one use of each on a scratch buffer
+    {
+        void *d = nullptr, *hp = nullptr;
+        if (hipMalloc(&d, 1 << 16) == hipSuccess && hipHostMalloc(&hp, 1 << 12, hipHostMallocDefault) == hipSuccess) {
+            (void)hipMemsetAsync(d, 0, 1 << 16, s);
+            (void)hipMemsetAsync((char*)d + 4, 0, 4, s);
+            (void)hipMemcpyAsync((char*)d + (1 << 15), d, 1 << 14, hipMemcpyDeviceToDevice, s);
+            (void)hipMemcpy2DAsync(hp, 64, d, 1024, 64, 32, hipMemcpyDeviceToHost, s);
+            (void)hipMemcpyAsync(hp, d, 256, hipMemcpyDeviceToHost, s);
+            (void)hipMemcpyAsync(d, hp, 256, hipMemcpyHostToDevice, s);
+            char pageable[256] = {0};
+            (void)hipMemcpyAsync(pageable, d, sizeof pageable, hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpyAsync(d, pageable, sizeof pageable, hipMemcpyHostToDevice, s);
+            (void)hipStreamSynchronize(s);
+        }
+        if (d) (void)hipFree(d);
+        if (hp) (void)hipHostFree(hp);
+        (void)hipGetLastError();
+    }
     std::lock_guard<std::mutex> lk(g_pool_mutex);
     g_pool.push_back({device, s});
 }

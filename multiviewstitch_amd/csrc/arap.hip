@@ -736,3 +736,21 @@ void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_
 // one kernel of this translation unit, for the code-object preload of api_deform.cpp (mvs_set_device): asking the runtime for its
 // attributes loads the unit's code object without launching anything
 const void* mvs_tu_probe_arap() { return (const void*)k_smooth; }
+
+// every kernel of this translation unit, for the cold-start preload of api_deform.cpp (mvs_set_device): asking the runtime for a
+// kernel's attributes loads the unit's code object and resolves the kernel without launching anything
+const void* const* mvs_tu_kernels_arap(int* n) {
+    static const void* const ks[] = {
+        (const void*)k_gather_nodes,
+        (const void*)k_smooth,
+        (const void*)k_cot_weights,
+        (const void*)k_cg_coef,
+        (const void*)k_arap_rhs,
+        (const void*)k_cg_w0,
+        (const void*)k_cg_iter,
+        (const void*)k_arap_local,
+        (const void*)k_arap_finalize,
+        (const void*)k_vertex_normals};
+    *n = (int)(sizeof ks / sizeof ks[0]);
+    return ks;
+}

@@ -1974,3 +1974,20 @@ void launch_assoc_all(const GridDev& g, const double* node_pts, const double* no
 // one kernel of this translation unit, for the code-object preload of api_deform.cpp (mvs_set_device): asking the runtime for its
 // attributes loads the unit's code object without launching anything
 const void* mvs_tu_probe_assoc() { return (const void*)k_assoc_prep; }
+
+// every kernel of this translation unit, for the cold-start preload of api_deform.cpp (mvs_set_device): asking the runtime for a
+// kernel's attributes loads the unit's code object and resolves the kernel without launching anything
+const void* const* mvs_tu_kernels_assoc(int* n) {
+    static const void* const ks[] = {
+        (const void*)k_assoc_dmin,
+        (const void*)k_assoc_select,
+        (const void*)k_assoc_local,
+        (const void*)k_assoc_select_heavy,
+        (const void*)k_assoc_heavy_knn,
+        (const void*)k_assoc_prep,
+        (const void*)k_assoc_all,
+        (const void*)k_assoc_merge,
+        (const void*)k_install_targets};
+    *n = (int)(sizeof ks / sizeof ks[0]);
+    return ks;
+}

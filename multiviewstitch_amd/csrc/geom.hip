@@ -196,3 +196,16 @@ void launch_srt_apply(const double* pts, const double* nrm, int64_t P, double sc
 // one kernel of this translation unit, for the code-object preload of api_deform.cpp (mvs_set_device): asking the runtime for its
 // attributes loads the unit's code object without launching anything
 const void* mvs_tu_probe_geom() { return (const void*)k_srt_apply; }
+
+// every kernel of this translation unit, for the cold-start preload of api_deform.cpp (mvs_set_device): asking the runtime for a
+// kernel's attributes loads the unit's code object and resolves the kernel without launching anything
+const void* const* mvs_tu_kernels_geom(int* n) {
+    static const void* const ks[] = {
+        (const void*)k_depth_valid,
+        (const void*)k_quad_count,
+        (const void*)k_depth_emit,
+        (const void*)k_depth_unproject,
+        (const void*)k_srt_apply};
+    *n = (int)(sizeof ks / sizeof ks[0]);
+    return ks;
+}

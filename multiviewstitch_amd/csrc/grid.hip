@@ -272,3 +272,19 @@ int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* 
 // one kernel of this translation unit, for the code-object preload of api_deform.cpp (mvs_set_device): asking the runtime for its
 // attributes loads the unit's code object without launching anything
 const void* mvs_tu_probe_grid() { return (const void*)k_bbox; }
+
+// every kernel of this translation unit, for the cold-start preload of api_deform.cpp (mvs_set_device): asking the runtime for a
+// kernel's attributes loads the unit's code object and resolves the kernel without launching anything
+const void* const* mvs_tu_kernels_grid(int* n) {
+    static const void* const ks[] = {
+        (const void*)k_bbox,
+        (const void*)k_cell_count,
+        (const void*)k_count_nonzero,
+        (const void*)k_scan_block_sums,
+        (const void*)k_scan_sums_serial,
+        (const void*)k_scan_apply,
+        (const void*)k_scatter,
+        (const void*)k_coarse_start};
+    *n = (int)(sizeof ks / sizeof ks[0]);
+    return ks;
+}

@@ -492,3 +492,23 @@ void launch_label_nn(const double* tmpl, int V, const int32_t* tmpl_labels, void
 // one kernel of this translation unit, for the code-object preload of api_deform.cpp (mvs_set_device): asking the runtime for its
 // attributes loads the unit's code object without launching anything
 const void* mvs_tu_probe_knn() { return (const void*)k_ng_build1; }
+
+// every kernel of this translation unit, for the cold-start preload of api_deform.cpp (mvs_set_device): asking the runtime for a
+// kernel's attributes loads the unit's code object and resolves the kernel without launching anything
+const void* const* mvs_tu_kernels_knn(int* n) {
+    static const void* const ks[] = {
+        (const void*)k_knn,
+        (const void*)k_ng_bbox,
+        (const void*)k_ng_count,
+        (const void*)k_ng_scan,
+        (const void*)k_ng_tile_sums,
+        (const void*)k_ng_scan_tiles,
+        (const void*)k_ng_scan_apply,
+        (const void*)k_ng_scatter,
+        (const void*)k_ng_build1,
+        (const void*)k_ng_knn,
+        (const void*)k_label_nn,
+        (const void*)k_label_far};
+    *n = (int)(sizeof ks / sizeof ks[0]);
+    return ks;
+}

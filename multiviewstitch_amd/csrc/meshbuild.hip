@@ -824,3 +824,24 @@ int mesh_build(mvs_deform_s* h, const double* points, const double* normals, con
 // one kernel of this translation unit, for the code-object preload of api_deform.cpp (mvs_set_device): asking the runtime for its
 // attributes loads the unit's code object without launching anything
 const void* mvs_tu_probe_meshbuild() { return (const void*)k_iota; }
+
+// every kernel of this translation unit, for the cold-start preload of api_deform.cpp (mvs_set_device): asking the runtime for a
+// kernel's attributes loads the unit's code object and resolves the kernel without launching anything
+const void* const* mvs_tu_kernels_meshbuild(int* n) {
+    static const void* const ks[] = {
+        (const void*)k_mb_faces,
+        (const void*)k_mb_scatter,
+        (const void*)k_mb_rows,
+        (const void*)k_mb_groups,
+        (const void*)k_mb_vfptr,
+        (const void*)k_mb_ell,
+        (const void*)k_rcb_axis,
+        (const void*)k_rcb_hist,
+        (const void*)k_rcb_split,
+        (const void*)k_rcb_level_wg,
+        (const void*)k_iota,
+        (const void*)k_patch_rows,
+        (const void*)k_patch_tables};
+    *n = (int)(sizeof ks / sizeof ks[0]);
+    return ks;
+}
