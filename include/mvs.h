@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MVS_ABI_VERSION 3   /* 3: tracing hook, mvs_comm_set_exchange, view-sharded RemoveGround / LocalAlignmentCore (additive) */
+#define MVS_ABI_VERSION 4   /* 3: tracing hook, mvs_comm_set_exchange, view-sharded RemoveGround / LocalAlignmentCore; 4: mvs_deform_group_* (additive) */
 
 enum mvs_status {
     MVS_OK            =  0,
@@ -505,6 +505,22 @@ int mvs_comm_info(mvs_comm_t c, int* rank, int* nranks);
 enum { MVS_EXCHANGE_AUTO = 0, MVS_EXCHANGE_ALL_GATHER = 1, MVS_EXCHANGE_OWNER = 2 };
 int mvs_comm_set_exchange(mvs_comm_t c, int mode);
 int mvs_deform_iterate_sharded(mvs_deform_t h, mvs_comm_t c, const mvs_deform_params* p, int n_outer, mvs_deform_stats* stats);
+
+/* ---- groups: several handles on one device stepping in lockstep as ONE sequence of launches ----
+ * BASELINE config 5's per-part deformation graphs (R/PartRecognition/PartRecognition.cpp:50-77 labels, one Deformation per
+ * part): every part is an ordinary handle — its own sub-mesh, nodes, target, control block and verdicts — but sixteen small
+ * launch chains cost sixteen times the launch overhead.  A group launches every kernel of an outer iteration once for all its
+ * handles (grid = workgroups x parts); what a part computes is what its handle computes stepping alone.
+ *   mvs_deform_group_create  : the handles (one device, no duplicates) stay owned by the caller and must outlive the group;
+ *   mvs_deform_group_iterate : n_outer outer iterations of every handle, stats[n] per handle (may be NULL).  Returns
+ *                              MVS_E_STATE having done nothing when the handles cannot step as a group yet — each must have
+ *                              stepped twice on its own (mvs_deform_iterate: the unbounded first passes and the calibration of
+ *                              its launch plan) with the overlapping-patch solver, smooth_sweeps = 2, update_normals = 0 —
+ *                              mvs_last_error says which condition failed; the caller then steps the handles one by one. */
+typedef struct mvs_group_s* mvs_group_t;
+int mvs_deform_group_create(mvs_deform_t* handles, int n, mvs_group_t* out);
+int mvs_deform_group_iterate(mvs_group_t g, const mvs_deform_params* p, int n_outer, mvs_deform_stats* stats /*n, or NULL*/);
+int mvs_deform_group_destroy(mvs_group_t g);
 
 /* Read-back (host buffers). */
 int mvs_deform_get_vertices(mvs_deform_t h, double* pts /*V*3*/);

@@ -135,6 +135,9 @@ _SIGS = {
     "mvs_comm_info": (C.c_int, [_VP, _VP, _VP]),
     "mvs_comm_set_exchange": (C.c_int, [_VP, _I32]),
     "mvs_deform_iterate_sharded": (C.c_int, [_VP, _VP, _VP, _I32, _VP]),
+    "mvs_deform_group_create": (C.c_int, [_VP, _I32, _VP]),
+    "mvs_deform_group_iterate": (C.c_int, [_VP, _VP, _I32, _VP]),
+    "mvs_deform_group_destroy": (C.c_int, [_VP]),
     "mvs_deform_sync": (C.c_int, [_VP]),
     "mvs_deform_stream": (C.c_void_p, [_VP]),
     "mvs_deform_set_stream": (C.c_int, [_VP, _VP]),

@@ -213,8 +213,13 @@ void stream_pool_prime(int device) {
         if (hp) (void)hipHostFree(hp);
         (void)hipGetLastError();
     }
+    // ... and a second stream: a process that holds two handles at once (bench.py's reference-schedule leg beside its main handle)
+    // otherwise meets the 5.7 ms of a new hardware queue at the second handle's creation
+    hipStream_t s2 = nullptr;
+    if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); s2 = nullptr; }
     std::lock_guard<std::mutex> lk(g_pool_mutex);
     g_pool.push_back({device, s});
+    if (s2) g_pool.push_back({device, s2});
 }
 namespace {
 void stream_release(int device, hipStream_t s) {
@@ -395,7 +400,10 @@ constexpr int RAS_MAX_SWEEPS = 128;
 // any plan reaches RAS_MIX_PLAN every solve of the handle gets mixing sweeps and a plan of at least RAS_MIX_PLAN launches (the
 // ones a solve does not need return after one load, ~4 us each); back to lean sweeps after RAS_MIX_CALM passes in which every
 // solve's need stayed at a healthy solve's length (<= RAS_MIX_OFF launches).
-#define RAS_MIX_PLAN ((int)MVS_KNOB("MVS_MIX_PLAN", 9, 2, 128))
+// (11, was 9 through round 3: the first solve of a pass of a small part — config 5's 13 K-vertex sub-meshes — runs 7-8 healthy sweeps,
+//  and once it predicts cautiously in a fit's first passes (schwarz.hip, RAS_YOUNG_PASSES) its plan of "sweeps + spares" reached 9-10:
+//  sixteen healthy handles switched to mixing sweeps and 45 launches per pass, 14 ms per outer iteration instead of 7.5)
+#define RAS_MIX_PLAN ((int)MVS_KNOB("MVS_MIX_PLAN", 11, 2, 128))
 constexpr int RAS_MIX_OFF = 7, RAS_MIX_CALM = 16;      // (healthy plans are 4-7 launches, a mixing solve's 8-12, a stalled one's 17+: config 4 went
                                                         //  on at a transient and, with "<= 5 for 64 passes", never came back: 45 launches for 20 sweeps)
 void update_mix_state(mvs_deform_s* h, int arap_iters) {
@@ -824,7 +832,7 @@ int judged_status(const Judgement& j, const mvs_deform_params& p) {
 }
 
 // after a sync: read the CG slots of the last solve, fill stats, re-calibrate cg_iters
-int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* st, bool* converged);
+int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* st, bool* converged, const RasPlan* used = nullptr);
 
 int harvest(mvs_deform_s* h, const mvs_deform_params& p, const CgPlan& plan, mvs_deform_stats* st, bool* converged) {
     if (use_ras(h, p)) return harvest_ras(h, p, st, converged);
@@ -895,8 +903,9 @@ int harvest(mvs_deform_s* h, const mvs_deform_params& p, const CgPlan& plan, mvs
 
 // patch solver: read the sweep slots of the last solve, fill stats, re-plan the sweep counts.
 // NOTE the plan used by the solve being harvested is probe_ras() of the state BEFORE this call.
-int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* st, bool* converged) {
-    const RasPlan rp = probe_ras(h);
+// used != NULL: the plan the harvested pass ran with (a group's common plan) instead of the handle's own
+int harvest_ras(mvs_deform_s* h, const mvs_deform_params& p, mvs_deform_stats* st, bool* converged, const RasPlan* used) {
+    const RasPlan rp = used ? *used : probe_ras(h);
     const int ss = ras_slot_size(h), NP = h->ras.NP, NPpad = h->ras.NPpad;
     const size_t nslots = (size_t)rp.total(p.arap_iters);
     // per sweep only its 8 scalars (gamma[3] of its input, folded by the following sweep; bn[3]; idle flag; sweeps that ran)
@@ -1060,6 +1069,7 @@ int mvs_deform_destroy(mvs_deform_t h) {
     free_nodes(h);
     for (void* a : {h->arena_mesh, h->arena_tab, h->arena_target, h->arena_probe}) if (a) (void)hipFree(a);
     dfree(h->d_slots);
+    dfree(h->d_cheb);
     if (h->d_sh) { (void)hipFree(h->d_sh); h->d_sh = nullptr; }
     if (h->h_ctl) { (void)hipHostFree((void*)h->h_ctl); h->h_ctl = nullptr; }
     if (h->h_sample) { (void)hipHostFree(h->h_sample); h->h_sample = nullptr; }
@@ -1630,6 +1640,187 @@ int mvs_deform_kernel_time(mvs_deform_t h, const char* name, double* total_ms, i
     if (total_ms) *total_ms = it == h->timers.end() ? 0.0 : it->second.total_ms;
     if (launches) *launches = it == h->timers.end() ? 0 : it->second.launches;
     return MVS_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------- groups ----
+// Several handles on one device stepping in lockstep — BASELINE config 5's sixteen per-part graphs (partwise.py) — as ONE
+// sequence of launches: every kernel of a bounded pass is launched once with grid (x, part) and takes its part's record
+// (engine.h, PartDev).  Sixteen parts cost sixteen launch chains before (~640 launches per outer iteration at the runtime's
+// ~3.3 us per launch: 2.0 ms, whatever the streams and host threads); a group's pass is ~40 launches.  Each part keeps its
+// own control block, verdict ring, energy stop rule and plan history; the arithmetic of a part is what its handle computes
+// alone (the launch plan is the longest of the parts': a part that needs fewer sweeps finds its solve finished and its
+// launches return after one load, as spare launches always do).  Every solve of a group ends with a local-step launch of its
+// own (k_arap_local_multi): the fused deciding launch of a single handle needs a barrier among ONE part's workgroups.
+struct mvs_group_s {
+    std::vector<mvs_deform_s*> h;
+    std::vector<PartDev> host;
+    PartDev* d_parts = nullptr;
+    GroupDims dims{};
+    int device = 0;
+    int flip = 0;                       // which of every handle's two heavy / mid lists the next pass fills
+    unsigned long long ng_pass = 0;
+};
+
+static int group_member_ok(const mvs_deform_s* h, const mvs_deform_params& p, int nn, std::string* why) {
+    auto bad = [&](const char* m) { *why = m; return 0; };
+    if (!h->has_ras || p.solver == MVS_SOLVER_CG) return bad("a part's mesh runs the CG solver");
+    if (h->ras_mix_any) return bad("a part's solves stall (mixing sweeps)");
+    if (h->near_age < 2 || h->cg_iters <= 0) return bad("a part has not stepped twice on its own yet (unbounded first passes, calibration)");
+    if (!h->d_knn_ws || h->graph_prev_nn != nn || h->K < nn || !assoc_all_builds_grid((int)h->K)) return bad("a part's node graph cannot be searched bounded");
+    if (h->grid.P <= 0) return bad("a part has no target points");
+    if (h->timing) return bad("a part has timing enabled");
+    if (h->saw_abandon) return bad("a part has seen an abandoned solve");
+    return 1;
+}
+
+int mvs_deform_group_create(mvs_deform_t* handles, int n, mvs_group_t* out) {
+    MVS_TRACE();
+    if (!handles || n < 1 || n > 1024 || !out) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    *out = nullptr;
+    for (int i = 0; i < n; ++i) {
+        if (!handles[i] || handles[i]->device != handles[0]->device) { mvs_set_error("the handles of a group live on one device"); return MVS_E_INVALID_ARG; }
+        for (int j = 0; j < i; ++j) if (handles[j] == handles[i]) { mvs_set_error("a handle is listed twice"); return MVS_E_INVALID_ARG; }
+    }
+    HIPCHK(hipSetDevice(handles[0]->device));
+    mvs_group_s* g = new mvs_group_s;
+    g->h.assign(handles, handles + n);
+    g->host.resize(n);
+    g->device = handles[0]->device;
+    if (hipMalloc((void**)&g->d_parts, sizeof(PartDev) * n) != hipSuccess) { delete g; mvs_set_error("out of device memory"); return MVS_E_OOM; }
+    *out = g;
+    return MVS_OK;
+}
+
+int mvs_deform_group_destroy(mvs_group_t g) {
+    MVS_TRACE();
+    if (!g) return MVS_OK;
+    (void)hipSetDevice(g->device);
+    if (!g->h.empty() && g->h[0]->stream) (void)hipStreamSynchronize(g->h[0]->stream);
+    if (g->d_parts) (void)hipFree(g->d_parts);
+    delete g;
+    return MVS_OK;
+}
+
+// n_outer outer iterations of every part; stats[n] (may be NULL).  MVS_E_STATE (nothing done) when the parts cannot step as a
+// group yet — mvs_last_error says why; the caller then steps the handles one by one (mvs_deform_iterate).
+int mvs_deform_group_iterate(mvs_group_t g, const mvs_deform_params* pp, int n_outer, mvs_deform_stats* stats) {
+    MVS_TRACE();
+    if (!g || n_outer < 0) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = check_params(pp);
+    if (rc) return rc;
+    const mvs_deform_params& p = *pp;
+    const int n = (int)g->h.size(), nn = p.graph_k + 1;
+    if (p.smooth_sweeps != 2 || p.update_normals || nn > 16) { mvs_set_error("a group steps with smooth_sweeps = 2, update_normals = 0, graph_k <= 15"); return MVS_E_STATE; }
+    HIPCHK(hipSetDevice(g->device));
+    std::string why;
+    for (mvs_deform_s* h : g->h) if (!group_member_ok(h, p, nn, &why)) { mvs_set_error("the handles cannot step as a group yet: %s", why.c_str()); return MVS_E_STATE; }
+    for (mvs_deform_s* h : g->h) if (h->ras.W != g->h[0]->ras.W) { mvs_set_error("the parts' patch tables differ in width"); return MVS_E_STATE; }
+    if (n_outer == 0) return MVS_OK;                          // (a probe: can the handles step as a group?)
+    for (mvs_deform_s* h : g->h) HIPCHK(hipStreamSynchronize(h->stream));
+    hipStream_t s = g->h[0]->stream;
+    int status = MVS_OK;
+    std::vector<mvs_deform_stats> acc(n);
+    std::vector<double> worst(n, 0.0);
+    std::vector<int> solves(n, 0), missed(n, 0), esc(n, 0);
+    for (int done = 0; done < n_outer;) {
+        const int batch = std::min(n_outer - done, MAX_BATCH);
+        // ---- the parts' records (the coefficient sets and the plans move at every harvest) and the launch dimensions
+        GroupDims d{};
+        d.n = n; d.W = g->h[0]->ras.W;
+        RasPlan plan{};
+        for (int i = 0; i < 8; ++i) plan.n[i] = 0;
+        size_t lds = 0;
+        for (int k = 0; k < n; ++k) {
+            mvs_deform_s* h = g->h[k];
+            // (the lists a pass fills alternate: bring every handle's pair into the group's phase)
+            int32_t* hv[2] = {h->heavy_flip ? h->d_heavy2 : h->d_heavy, h->heavy_flip ? h->d_heavy : h->d_heavy2};
+            int32_t* md[2] = {h->heavy_flip ? h->d_mid2 : h->d_mid, h->heavy_flip ? h->d_mid : h->d_mid2};
+            PartDev& P = g->host[k];
+            P.sell = h->sell; P.ras = h->ras; P.grid = h->grid;
+            P.K = (int)h->K; P.V = (int)h->V; P.ras_block = h->ras_block; P.NC = knn_grid_cells_per_axis((int)h->K); P.ss = ras_slot_size(h); P.pad0 = 0;
+            ras_cheb_sets(h, &P.cc, &P.cheb_m, &P.cc2, &P.m2);
+            P.pts = h->d_pts; P.nrm = h->d_nrm; P.sol = h->d_sol; P.x2 = h->d_ras_x2; P.rot = h->d_rot; P.b = h->d_ras_b; P.bpure = h->d_bpure;
+            P.pw = h->d_ras_pw; P.pd = h->d_ras_pd; P.slots = h->d_ras_slots; P.energy = h->d_energy; P.ctl = h->d_ctl; P.host_ctl = const_cast<double*>(h->h_ctl);
+            P.iters = h->d_ras_iters; P.info = h->d_info; P.bar = h->d_bar;
+            P.node_pts = h->d_node_pts; P.node_nrm = h->d_node_nrm; P.ctrl_raw = h->d_ctrl_raw; P.ctrl_a = h->d_ctrl_a; P.ctrl_b = h->d_ctrl_b; P.near_prev = h->d_near_prev;
+            P.d2min = h->d_d2min; P.lim = h->d_lim; P.counts = h->d_counts; P.nbr = h->d_nbr;
+            P.heavy[g->flip] = hv[0]; P.heavy[g->flip ^ 1] = hv[1]; P.mid[g->flip] = md[0]; P.mid[g->flip ^ 1] = md[1];
+            P.rec = h->d_records; P.top_idx = h->d_top_idx; P.valid = h->d_valid;
+            const void *geo, *sorted; const int* cs;
+            knn_grid_views(h->d_knn_ws, (int)h->K, &geo, &cs, &sorted);
+            P.ng_geo = const_cast<void*>(geo); P.ng_start = const_cast<int*>(cs); P.ng_sorted = const_cast<void*>(sorted); P.ng_sync = h->d_ng_sync;
+            g->ng_pass = std::max(g->ng_pass, h->ng_pass);
+            if ((rc = ensure_nbr(h, nn))) return rc;
+            const RasPlan rp = probe_ras(h);
+            if ((rc = ensure_ras_slots(h, p.arap_iters, rp))) return rc;
+            for (int i = 0; i < p.arap_iters; ++i) plan.n[i] = std::max(plan.n[i], rp.n[i]);
+            d.block = std::max(d.block, h->ras_block); d.Kmax = std::max(d.Kmax, (int)h->K); d.Vmax = std::max(d.Vmax, (int)h->V);
+            // (row kernels: with four lanes per row — degree <= 8 — a 16-wave workgroup takes 256 rows; the handle's own grid holds twice
+            //  the workgroups that then have rows, which costs nothing alone and whole rounds of the chip with sixteen parts in one launch)
+            const int row_wgs = h->sell.single_pass ? ((((h->sell.nslices + 1) >> 1) + 15) / 16 + 1) : arap_grid_blocks(h->sell);
+            d.NPmax = std::max(d.NPmax, h->ras.NP); d.Grow = std::max(d.Grow, std::min(row_wgs, arap_grid_blocks(h->sell)));
+            int HB, MB, NB, GB, CB;
+            assoc_all_dims((int)h->K, arap_grid_blocks(h->sell), true, &HB, &MB, &NB, &GB, &CB);
+            HB = std::min(HB, 64); MB = std::min(MB, 4);          // (a part's lists hold a few dozen nodes; the workgroups loop over them)
+            d.HB = std::max(d.HB, HB); d.MB = std::max(d.MB, MB); d.NB = std::max(d.NB, NB); d.GB = std::max(d.GB, GB); d.CB = std::max(d.CB, CB);
+            lds = std::max(lds, assoc_all_lds_bytes((int)h->K, true));
+        }
+        d.lds_all = lds;
+        g->dims = d;
+        HIPCHK(hipMemcpyAsync(g->d_parts, g->host.data(), sizeof(PartDev) * n, hipMemcpyHostToDevice, s));
+        // ---- the passes
+        int last_slot = -1;
+        for (int o = 0; o < batch; ++o) {
+            const int par = g->flip;
+            g->flip ^= 1;
+            launch_group_assoc(g->d_parts, d, par, p, nn, ++g->ng_pass, s);
+            launch_group_smooth(g->d_parts, d, nn, s);                                            // Deformation.cpp:362-381, first sweep
+            launch_group_prepare(g->d_parts, d, nn, s);                                           // ... second sweep, patch matrices, start of the solve
+            int parity = 0, slot = 0, prev_slot = -1;
+            for (int it = 0; it < p.arap_iters; ++it) {
+                launch_group_rhs(g->d_parts, d, parity, it, p.arap_tol, p.cg_tol, prev_slot, s);
+                double predict = 1e300;
+                for (mvs_deform_s* h : g->h) predict = std::min(predict, ras_predict_margin(h, it));
+                for (int i = 0; i < plan.n[it]; ++i) { launch_group_sweep(g->d_parts, d, parity, it, p.arap_tol, i, p.cg_tol, STOP_AT, predict, slot, s); parity ^= 1; ++slot; }
+                prev_slot = slot - 1;
+                launch_group_local(g->d_parts, d, parity, it, p.arap_tol, s);
+            }
+            launch_group_finalize(g->d_parts, d, parity, p.arap_iters, p.arap_tol, p.cg_tol, prev_slot, s);
+            last_slot = prev_slot;
+            for (mvs_deform_s* h : g->h) {
+                h->seq_enqueued++; h->assoc_passes++; h->near_age++;
+                h->heavy_flip ^= 1;
+                h->ng_pass = g->ng_pass;
+                h->graph_prev_nn = nn; h->graph_ready_nn = 0; h->weights_ready = false; h->heavy_pending = nullptr; h->graph_in_local = false;
+                h->d_ctrl_final = h->d_ctrl_b;
+            }
+        }
+        (void)last_slot;
+        HIPCHK(hipStreamSynchronize(s));
+        rc = mvs_check_hip(hipGetLastError(), "group pass");
+        if (rc) return rc;
+        // ---- every part's verdicts and statistics, its plans re-made from what ITS solves ran
+        for (int k = 0; k < n; ++k) {
+            mvs_deform_stats st{};
+            bool conv = true;
+            rc = harvest_ras(g->h[k], p, &st, &conv, &plan);
+            if (rc < 0) return rc;
+            if (rc > 0) status = rc;
+            worst[k] = std::max(worst[k], st.worst_rel_residual_in_batch);
+            solves[k] += st.solves_in_batch; missed[k] += st.unconverged_solves; esc[k] |= st.escalated;
+            acc[k] = st;
+        }
+        done += batch;
+    }
+    for (int k = 0; k < n; ++k) {
+        mvs_deform_stats& st = acc[k];
+        st.outer_done = n_outer;
+        st.worst_rel_residual_in_batch = worst[k]; st.solves_in_batch = solves[k]; st.unconverged_solves = missed[k]; st.escalated = esc[k];
+        g->h[k]->last = st;
+        if (stats) stats[k] = st;
+    }
+    return status;
 }
 
 }  // extern "C"

@@ -112,7 +112,7 @@ __global__ void k_gather_nodes(const double* __restrict__ pts, const double* __r
     st3(node_nrm + 3 * k, ld3(nrm + 3 * v));   // norm = normals[idx]         :304
 }
 
-__global__ void k_smooth(const double* __restrict__ orig, const double* __restrict__ cur,
+__device__ __forceinline__ void smooth_body(const double* __restrict__ orig, const double* __restrict__ cur,
                          const int32_t* __restrict__ nbr, int nn, int K, double* __restrict__ out) {
     // one Jacobi sweep, Deformation.cpp:364-379, w = 1/(K+1) (:143)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -134,6 +134,8 @@ __global__ void k_smooth(const double* __restrict__ orig, const double* __restri
     }
     st3(out + 3 * i, oi + acc);
 }
+__global__ void k_smooth(const double* __restrict__ orig, const double* __restrict__ cur,
+                         const int32_t* __restrict__ nbr, int nn, int K, double* __restrict__ out) { smooth_body(orig, cur, nbr, nn, K, out); }
 
 
 // per entry: w_ij = (cot a + cot b) / 2 clamped per angle; per row: diag = sum_j (wij + wji)
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(TPB) void k_cg_coef(SellDev m, double* __restrict__
 // r0 = b - A x0 on free rows;  b_i = sum_j (wij R_i + wji R_j)(p_i - p_j) (+ Dirichlet columns)
 // state record per vertex: rws[9] = {r.xyz, w.xyz, s.xyz}.
 // Also closes the previous ARAP iteration: folds its energy partials into ered[EFIN + it - 1].
-__global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __restrict__ pts,
+__device__ __forceinline__ void arap_rhs_body(const SellDev& m, const double* __restrict__ pts,
                                                   const double* __restrict__ sol, const double* __restrict__ rot,
                                                   int it, double tol, double* __restrict__ ered,
                                                   double* __restrict__ rws, double* __restrict__ p,
@@ -353,6 +355,13 @@ __global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __res
     for (int c = 0; c < 3; ++c) v[c] = wave_total(l == c ? bn_acc : 0.0);
     block_store_partials<3>(v, ered + it * EIT + NBMAX);
 }
+__global__ __launch_bounds__(TPB) void k_arap_rhs(SellDev m, const double* __restrict__ pts,
+                                                  const double* __restrict__ sol, const double* __restrict__ rot,
+                                                  int it, double tol, double* __restrict__ ered,
+                                                  double* __restrict__ rws, double* __restrict__ p,
+                                                  double* __restrict__ bout, double cg_tol, double* __restrict__ ctl,
+                                                  int ring_slot, const double* __restrict__ prev_scal, unsigned* __restrict__ bar,
+                                                  double* __restrict__ bpure, int nl, int fused_local) { arap_rhs_body(m, pts, sol, rot, it, tol, ered, rws, p, bout, cg_tol, ctl, ring_slot, prev_scal, bar, bpure, nl, fused_local); }
 
 // w0 = A u0, gamma0 = (r0,u0), delta0 = (w0,u0); folds the bnorm partials into slot0
 __global__ __launch_bounds__(TPB) void k_cg_w0(SellDev m, const double* __restrict__ coef, int it, double tol,
@@ -554,7 +563,7 @@ __global__ __launch_bounds__(TPB) void k_cg_iter(SellDev m, const double* __rest
 // the rotation still in registers.  (Three kernels before — 8 lanes per row for the two gathers, a thread per vertex
 // for the Jacobi chain: the gathers were never the cost, the two extra kernel boundaries were.)  The grid is the row
 // kernels' grid so that the energy partials land where their consumers fold them.
-__global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __restrict__ pts, const double* __restrict__ sol,
+__device__ __forceinline__ void arap_local_body(const SellDev& m, const double* __restrict__ pts, const double* __restrict__ sol,
                                                     int it, double tol, double* __restrict__ ered, double* __restrict__ rot,
                                                     const double* __restrict__ bvec, const double* __restrict__ ctl, int nfold) {
     // the stop rule's verdict (one thread: two dependent loads and an fp64 division) travels WITH the first vertex's loads, not in
@@ -597,8 +606,11 @@ __global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __r
             for (int c = 0; c < 3; ++c) ered[it * EIT + (4 + c) * NBMAX + q] = 0.0;
         }
 }
+__global__ __launch_bounds__(256) void k_arap_local(SellDev m, const double* __restrict__ pts, const double* __restrict__ sol,
+                                                    int it, double tol, double* __restrict__ ered, double* __restrict__ rot,
+                                                    const double* __restrict__ bvec, const double* __restrict__ ctl, int nfold) { arap_local_body(m, pts, sol, it, tol, ered, rot, bvec, ctl, nfold); }
 
-__global__ void k_arap_finalize(SellDev m, int iters, double tol, int nb, double* __restrict__ ered,
+__device__ __forceinline__ void arap_finalize_body(const SellDev& m, int iters, double tol, int nb, double* __restrict__ ered,
                                 const double* __restrict__ sol, double* __restrict__ pts, int32_t* __restrict__ info,
                                 const double* __restrict__ nrm, double* __restrict__ node_pts, double* __restrict__ node_nrm,
                                 double cg_tol, double* __restrict__ ctl, int ring_slot, double* __restrict__ host_ctl,
@@ -657,6 +669,34 @@ __global__ void k_arap_finalize(SellDev m, int iters, double tol, int nb, double
         const int c = node_pts ? m.is_ctrl[i] : 0;                     // node k sits at its vertex: refresh the node arrays too
         if (c) { st3(node_pts + 3 * (c - 1), x); st3(node_nrm + 3 * (c - 1), ld3(nrm + 3 * i)); }
     }
+}
+__global__ void k_arap_finalize(SellDev m, int iters, double tol, int nb, double* __restrict__ ered,
+                                const double* __restrict__ sol, double* __restrict__ pts, int32_t* __restrict__ info,
+                                const double* __restrict__ nrm, double* __restrict__ node_pts, double* __restrict__ node_nrm,
+                                double cg_tol, double* __restrict__ ctl, int ring_slot, double* __restrict__ host_ctl,
+                                const double* __restrict__ last_scal, int nl, int fused_local, double pass1) { arap_finalize_body(m, iters, tol, nb, ered, sol, pts, info, nrm, node_pts, node_nrm, cg_tol, ctl, ring_slot, host_ctl, last_scal, nl, fused_local, pass1); }
+
+// ---- group launches (engine.h, PartDev): grid (x, part); the bodies see blockIdx.x / gridDim.x of the x dimension
+__global__ void k_smooth_multi(const PartDev* __restrict__ parts, int nn) {
+    const PartDev& P = parts[blockIdx.y];
+    smooth_body(P.node_pts, P.ctrl_raw, P.nbr, nn, P.K, P.ctrl_a);
+}
+__global__ __launch_bounds__(TPB) void k_arap_rhs_multi(const PartDev* __restrict__ parts, int parity, int it, double tol, double cg_tol, int prev_slot, int nl) {
+    const PartDev& P = parts[blockIdx.y];
+    const int ring_slot = (int)((long long)P.ctl[MVS_CTL_CUR] % MVS_RING);
+    const double* prev_scal = prev_slot >= 0 ? P.slots + (size_t)prev_slot * P.ss + 3 * (size_t)P.ras.NPpad : nullptr;
+    arap_rhs_body(P.sell, P.pts, parity ? P.x2 : P.sol, P.rot, it, tol, P.energy, nullptr, nullptr, P.b, cg_tol, P.ctl, ring_slot, prev_scal, P.bar, P.bpure, nl, 0);
+}
+__global__ __launch_bounds__(256) void k_arap_local_multi(const PartDev* __restrict__ parts, int parity, int it, double tol, int nfold) {
+    const PartDev& P = parts[blockIdx.y];
+    arap_local_body(P.sell, P.pts, parity ? P.x2 : P.sol, it, tol, P.energy, P.rot, P.bpure, nullptr, nfold);
+}
+__global__ void k_arap_finalize_multi(const PartDev* __restrict__ parts, int parity, int iters, double tol, int nb, double cg_tol, int last_slot, int nl) {
+    const PartDev& P = parts[blockIdx.y];
+    const int ring_slot = (int)((long long)P.ctl[MVS_CTL_CUR] % MVS_RING);
+    const double* last_scal = last_slot >= 0 ? P.slots + (size_t)last_slot * P.ss + 3 * (size_t)P.ras.NPpad : nullptr;
+    arap_finalize_body(P.sell, iters, tol, nb, P.energy, parity ? P.x2 : P.sol, P.pts, P.info, P.nrm, P.node_pts, P.node_nrm, cg_tol, P.ctl, ring_slot, P.host_ctl,
+                       last_scal, nl, 0, 0.0);
 }
 
 // exportOBJ's normals (R/Deformation/Deformation.h:86-128): unit facet normals summed, / sqrt(n.n)
@@ -727,6 +767,18 @@ void launch_arap_finalize(const SellDev& m, int iters, double tol, double* ered,
                           int nfold_local, int fused_local, double pass1) {
     k_arap_finalize<<<dim3((m.V + 255) / 256 + 1), dim3(256), 0, s>>>(m, iters, tol, arap_grid_blocks(m), ered, sol, pts, info, nrm, node_pts, node_nrm,
                                                                   cg_tol, ctl, ring_slot, host_ctl, last_solve_scalars, nfold_local, fused_local, pass1);
+}
+void launch_group_smooth(const PartDev* parts, const GroupDims& d, int nn, hipStream_t s) {
+    k_smooth_multi<<<dim3((d.Kmax + 255) / 256, d.n), dim3(256), 0, s>>>(parts, nn);
+}
+void launch_group_rhs(const PartDev* parts, const GroupDims& d, int parity, int it, double tol, double cg_tol, int prev_slot, hipStream_t s) {
+    k_arap_rhs_multi<<<dim3(d.Grow, d.n), dim3(TPB), 0, s>>>(parts, parity, it, tol, cg_tol, prev_slot, d.Grow);
+}
+void launch_group_local(const PartDev* parts, const GroupDims& d, int parity, int it, double tol, hipStream_t s) {
+    k_arap_local_multi<<<dim3(d.Grow, d.n), dim3(256), 0, s>>>(parts, parity, it, tol, d.Grow);
+}
+void launch_group_finalize(const PartDev* parts, const GroupDims& d, int parity, int iters, double tol, double cg_tol, int last_slot, hipStream_t s) {
+    k_arap_finalize_multi<<<dim3((d.Vmax + 255) / 256 + 1, d.n), dim3(256), 0, s>>>(parts, parity, iters, tol, d.Grow, cg_tol, last_slot, d.Grow);
 }
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf, int V,
                            double* out, hipStream_t s) {

@@ -1029,7 +1029,7 @@ __device__ inline void classify_node(const GridDev& g, const double* __restrict_
     else if (cls == CLS_HEAVY) heavy[1 + atomicAdd(&heavy[0], 1)] = node | HEAVY_DMIN_FLAG;
 }
 
-__global__ __launch_bounds__(1024) void k_assoc_prep(GridDev g, const double* __restrict__ node_pts, int K, const float* __restrict__ d2min_prev,
+__device__ __forceinline__ void assoc_prep_body(const GridDev& g, const double* __restrict__ node_pts, int K, const float* __restrict__ d2min_prev,
                                                      double* __restrict__ prev_node, float* __restrict__ lim_out, int32_t* __restrict__ heavy,
                                                      int32_t* __restrict__ mid, int with_grid, int NC, NgGeom* __restrict__ geo,
                                                      int* __restrict__ ng_start, float4* __restrict__ ng_sorted) {
@@ -1041,6 +1041,10 @@ __global__ __launch_bounds__(1024) void k_assoc_prep(GridDev g, const double* __
     const int node = ((int)blockIdx.x - (with_grid ? 1 : 0)) * 1024 + (int)threadIdx.x;
     if (node < K) classify_node(g, node_pts, node, d2min_prev, prev_node, lim_out, heavy, mid);
 }
+__global__ __launch_bounds__(1024) void k_assoc_prep(GridDev g, const double* __restrict__ node_pts, int K, const float* __restrict__ d2min_prev,
+                                                     double* __restrict__ prev_node, float* __restrict__ lim_out, int32_t* __restrict__ heavy,
+                                                     int32_t* __restrict__ mid, int with_grid, int NC, NgGeom* __restrict__ geo,
+                                                     int* __restrict__ ng_start, float4* __restrict__ ng_sorted) { assoc_prep_body(g, node_pts, K, d2min_prev, prev_node, lim_out, heavy, mid, with_grid, NC, geo, ng_start, ng_sorted); }
 
 // ---- 16-lane row helpers (DPP: row_shr:n = 0x110 + n with zero fill, row_ror:n = 0x120 + n)
 __device__ inline int row_incl_scan_i(int v) {
@@ -1670,16 +1674,17 @@ __device__ inline int assoc_all_sections(const GridDev& g, const double* __restr
                                                                 int HB, int MB, int NB, int GB, int nn, int graph_bounded,
                                                                 const NgGeom* __restrict__ geo, const int* __restrict__ cs,
                                                                 const float4* __restrict__ sorted, int32_t* __restrict__ nbr, const SellDev& m,
-                                                                const double* __restrict__ mesh_pts, int* items, AllLds& lds, const NgBuild& nb) {
+                                                                const double* __restrict__ mesh_pts, int* items, AllLds& lds, const NgBuild& nb,
+                                                                int vb /*this workgroup's number among the launch's `vg` for this node set*/, int vg) {
     const int wv = (int)(threadIdx.x >> 6);
-    if (nb.sync && blockIdx.x == 0) {                              // the node grid of this pass's graph queries (unless somebody took over)
+    if (nb.sync && vb == 0) {                              // the node grid of this pass's graph queries (unless somebody took over)
         __shared__ int s_mine;
         if (threadIdx.x == 0) s_mine = atomicMax(nb.sync, nb.pass) < nb.pass ? 1 : 0;
         __syncthreads();
         if (s_mine) ng_build_publish(node_pts, K, nb, reinterpret_cast<int*>(&lds));
         return 5;
     }
-    const int b = (int)blockIdx.x - (nb.sync ? 1 : 0);
+    const int b = vb - (nb.sync ? 1 : 0);
     if (b < HB) {
         const int n = min(heavy[0], K);
         for (int h = b; h < n; h += HB) {
@@ -1709,7 +1714,7 @@ __device__ inline int assoc_all_sections(const GridDev& g, const double* __restr
     }
     // (the weights before the graph queries: those wait for the node grid workgroup 0 builds meanwhile — as the LAST workgroups
     //  of the launch they find it done; in front of the weights they spun on a CU each: scripts/assoc_all_timeline.py)
-    const int CB = (int)gridDim.x - (nb.sync ? 1 : 0) - HB - MB - NB - GB;
+    const int CB = vg - (nb.sync ? 1 : 0) - HB - MB - NB - GB;
     if (b < HB + MB + NB + CB) {
         cot_weight_rows(m, mesh_pts, b - HB - MB - NB, CB, HEAVY_WAVES);
         return 4;
@@ -1720,6 +1725,29 @@ __device__ inline int assoc_all_sections(const GridDev& g, const double* __restr
     else if (w < K) ng_knn_query(w, node_pts, K, nn, geo, cs, sorted, nbr, nullptr, nullptr);
     return 3;
 }
+__device__ __forceinline__ void assoc_all_body(const GridDev& g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm,
+                                                                int K, int top_k, const float* __restrict__ lim, float* __restrict__ d2min,
+                                                                mvs_cand* __restrict__ rec, int32_t* __restrict__ counts,
+                                                                const int32_t* __restrict__ heavy, const int32_t* __restrict__ mid, const LocalMerge& lm,
+                                                                int32_t* __restrict__ heavy_next, int32_t* __restrict__ mid_next,
+                                                                int HB, int MB, int NB, int GB, int nn, int graph_bounded,
+                                                                const NgGeom* __restrict__ geo, const int* __restrict__ cs,
+                                                                const float4* __restrict__ sorted, int32_t* __restrict__ nbr, const SellDev& m,
+                                                                const double* __restrict__ mesh_pts, const NgBuild& nb, int vb, int vg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char all_dyn[];      // AllLds, or the cell counters of the node grid's builder
+    AllLds& lds = *reinterpret_cast<AllLds*>(all_dyn);
+    int items = 0;
+#ifdef MVS_STAMPS
+    unsigned long long t0_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory");
+#endif
+    const int section = assoc_all_sections(g, node_pts, node_nrm, K, top_k, lim, d2min, rec, counts, heavy, mid, lm, heavy_next, mid_next, HB, MB, NB, GB, nn,
+                                           graph_bounded, geo, cs, sorted, nbr, m, mesh_pts, &items, lds, nb, vb, vg);
+    (void)section;
+#ifdef MVS_STAMPS
+    unsigned long long t1_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory");
+    if (threadIdx.x == 0 && blockIdx.x < 4096) { g_all_stamps[4 * blockIdx.x] = t0_; g_all_stamps[4 * blockIdx.x + 1] = t1_; g_all_stamps[4 * blockIdx.x + 2] = (unsigned long long)section; g_all_stamps[4 * blockIdx.x + 3] = (unsigned long long)items; }
+#endif
+}
 __global__ __launch_bounds__(64 * HEAVY_WAVES, 4) void k_assoc_all(GridDev g, const double* __restrict__ node_pts, const double* __restrict__ node_nrm,
                                                                 int K, int top_k, const float* __restrict__ lim, float* __restrict__ d2min,
                                                                 mvs_cand* __restrict__ rec, int32_t* __restrict__ counts,
@@ -1728,20 +1756,25 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES, 4) void k_assoc_all(GridDev g, co
                                                                 int HB, int MB, int NB, int GB, int nn, int graph_bounded,
                                                                 const NgGeom* __restrict__ geo, const int* __restrict__ cs,
                                                                 const float4* __restrict__ sorted, int32_t* __restrict__ nbr, SellDev m,
-                                                                const double* __restrict__ mesh_pts, NgBuild nb) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char all_dyn[];      // AllLds, or the cell counters of the node grid's builder
-    AllLds& lds = *reinterpret_cast<AllLds*>(all_dyn);
-    int items = 0;
-#ifdef MVS_STAMPS
-    unsigned long long t0_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory");
-#endif
-    const int section = assoc_all_sections(g, node_pts, node_nrm, K, top_k, lim, d2min, rec, counts, heavy, mid, lm, heavy_next, mid_next, HB, MB, NB, GB, nn,
-                                           graph_bounded, geo, cs, sorted, nbr, m, mesh_pts, &items, lds, nb);
-    (void)section;
-#ifdef MVS_STAMPS
-    unsigned long long t1_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory");
-    if (threadIdx.x == 0 && blockIdx.x < 4096) { g_all_stamps[4 * blockIdx.x] = t0_; g_all_stamps[4 * blockIdx.x + 1] = t1_; g_all_stamps[4 * blockIdx.x + 2] = (unsigned long long)section; g_all_stamps[4 * blockIdx.x + 3] = (unsigned long long)items; }
-#endif
+                                                                const double* __restrict__ mesh_pts, NgBuild nb) { assoc_all_body(g, node_pts, node_nrm, K, top_k, lim, d2min, rec, counts, heavy, mid, lm, heavy_next, mid_next, HB, MB, NB, GB, nn, graph_bounded, geo, cs, sorted, nbr, m, mesh_pts, nb, (int)blockIdx.x, (int)gridDim.x); }
+
+// ---- group launches (engine.h, PartDev): grid (x, part); the sections of k_assoc_all are cut at the same x for every part
+__global__ __launch_bounds__(1024) void k_assoc_prep_multi(const PartDev* __restrict__ parts, int par) {
+    const PartDev& P = parts[blockIdx.y];
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctl[MVS_CTL_CUR] = P.ctl[MVS_CTL_SEQ];       // the pass in flight (its ring row), for the kernels behind
+    assoc_prep_body(P.grid, P.node_pts, P.K, P.d2min, P.near_prev, P.lim, P.heavy[par], P.mid[par], 0, 0, nullptr, nullptr, nullptr);
+}
+__global__ __launch_bounds__(64 * HEAVY_WAVES, 4) void k_assoc_all_multi(const PartDev* __restrict__ parts, int par, int top_k, double proj_len_err, double proj_dist_err,
+                                                                         double min_cos, int max_result, int HB, int MB, int NB, int GB, int nn,
+                                                                         unsigned long long pass) {
+    // grid (part, x): the workgroups are dealt x-major — every part's grid builder first, then every part's heavy nodes, ..., the graph
+    // queries of all parts last (with the parts along y a part's sections ran one part after the other, each behind its own
+    // builder and heavy nodes: 141 us for sixteen parts)
+    const PartDev& P = parts[blockIdx.x];
+    const LocalMerge lm{P.ctrl_raw, P.valid, P.top_idx, proj_len_err, proj_dist_err, min_cos, max_result, 0};
+    const NgBuild nb{P.ng_sync, pass, P.NC, (NgGeom*)P.ng_geo, P.ng_start, (float4*)P.ng_sorted};
+    assoc_all_body(P.grid, P.node_pts, P.node_nrm, P.K, top_k, P.lim, P.d2min, P.rec, P.counts, P.heavy[par], P.mid[par], lm, P.heavy[par ^ 1], P.mid[par ^ 1], HB, MB, NB, GB,
+                   nn, 1, (const NgGeom*)P.ng_geo, P.ng_start, (const float4*)P.ng_sorted, P.nbr, P.sell, P.pts, nb, (int)blockIdx.y, (int)gridDim.y);
 }
 
 // ----------------------------------------------------------------- merge ----
@@ -1942,6 +1975,32 @@ void launch_assoc_prep(const GridDev& g, const double* node_pts, int K, const fl
                                                                                 knn_ws ? knn_grid_cells_per_axis(K) : 0, (NgGeom*)geo, const_cast<int*>(cs),
                                                                                 (float4*)sorted);
 }
+// workgroups of k_assoc_all's sections for K nodes: heavy list | mid list | near nodes | weights | bounded graph queries
+void assoc_all_dims(int K, int cot_blocks, bool graph, int* HB, int* MB, int* NB, int* GB, int* CB) {
+    const int per = 4 * HEAVY_WAVES;                               // near nodes / bounded graph queries per workgroup
+    *HB = std::min(K, 256); *MB = 256 / HEAVY_WAVES; *NB = (K + per - 1) / per;
+    *GB = graph ? (K + per - 1) / per : 0;
+    *CB = cot_blocks * (16 / HEAVY_WAVES);
+}
+// dynamic LDS of k_assoc_all / k_assoc_all_multi: the sections' union, or the cell counters of the node grid's builder
+size_t assoc_all_lds_bytes(int K, bool build) {
+    size_t lds_bytes = sizeof(AllLds);
+    if (build) { const size_t NC = (size_t)knn_grid_cells_per_axis(K); lds_bytes = std::max(lds_bytes, sizeof(int) * ((NC * NC * NC + 3) / 4 * 4) + 16); }
+    if (lds_bytes > 64 * 1024) {                                   // (above the default limit of dynamic LDS: once per process)
+        static std::once_flag once;
+        std::call_once(once, [] {
+            (void)hipFuncSetAttribute((const void*)k_assoc_all, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+            (void)hipFuncSetAttribute((const void*)k_assoc_all_multi, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        });
+    }
+    return lds_bytes;
+}
+// a group's association: bounds + classes, then the searches, the graph queries and the weights of every part (two launches)
+void launch_group_assoc(const PartDev* parts, const GroupDims& d, int par, const mvs_deform_params& p, int nn, unsigned long long pass, hipStream_t s) {
+    k_assoc_prep_multi<<<dim3((d.Kmax + 1023) / 1024, d.n), dim3(1024), 0, s>>>(parts, par);
+    k_assoc_all_multi<<<dim3(d.n, 1 + d.HB + d.MB + d.NB + d.GB + d.CB), dim3(64 * HEAVY_WAVES), d.lds_all, s>>>(parts, par, p.top_k, p.proj_len_err, p.proj_dist_err, p.min_cos,
+                                                                                                              p.max_result, d.HB, d.MB, d.NB, d.GB, nn, pass);
+}
 bool assoc_all_builds_grid(int K) { return K <= 64 * HEAVY_WAVES * NG1_PPT && knn_grid_cells_per_axis(K) <= NG1_NC; }
 void launch_assoc_all(const GridDev& g, const double* node_pts, const double* node_nrm, int K, const mvs_deform_params& p, const float* lim,
                       float* d2min, mvs_cand* rec, int32_t* counts, const int32_t* heavy, const int32_t* mid, int32_t* heavy_next, int32_t* mid_next,
@@ -1953,19 +2012,13 @@ void launch_assoc_all(const GridDev& g, const double* node_pts, const double* no
     const void *geo = nullptr, *sorted = nullptr;
     const int* cs = nullptr;
     if (knn_ws) knn_grid_views(knn_ws, K, &geo, &cs, &sorted);
-    const int per = 4 * HEAVY_WAVES;                               // near nodes / bounded graph queries per workgroup
-    const int HB = std::min(K, 256), MB = 256 / HEAVY_WAVES, NB = (K + per - 1) / per;
-    const int GB = !knn_ws ? 0 : (graph_bounded ? (K + per - 1) / per : (K + HEAVY_WAVES - 1) / HEAVY_WAVES);
-    const int CB = mesh ? cot_blocks * (16 / HEAVY_WAVES) : 0;
+    int HB, MB, NB, GB, CB;
+    assoc_all_dims(K, mesh ? cot_blocks : 0, knn_ws != nullptr, &HB, &MB, &NB, &GB, &CB);
+    if (knn_ws && !graph_bounded) GB = (K + HEAVY_WAVES - 1) / HEAVY_WAVES;          // (no previous list: a wave per query)
     const bool build = ng_sync && knn_ws && GB > 0;
     const int NC = knn_ws ? knn_grid_cells_per_axis(K) : 0;
     const NgBuild nb{build ? ng_sync : nullptr, ng_pass, NC, (NgGeom*)geo, const_cast<int*>(cs), (float4*)sorted};
-    size_t lds_bytes = sizeof(AllLds);
-    if (build) lds_bytes = std::max(lds_bytes, sizeof(int) * (((size_t)NC * NC * NC + 3) / 4 * 4) + 16);
-    if (lds_bytes > 64 * 1024) {                                   // (above the default limit of dynamic LDS: once per process)
-        static std::once_flag once;
-        std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)k_assoc_all, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); });
-    }
+    const size_t lds_bytes = assoc_all_lds_bytes(K, build);
     k_assoc_all<<<dim3((build ? 1 : 0) + HB + MB + NB + GB + CB), dim3(64 * HEAVY_WAVES), lds_bytes, s>>>(g, node_pts, node_nrm, K, p.top_k, lim, d2min, rec, counts, heavy, mid, lm,
                                                                               heavy_next, mid_next, HB, MB, NB, GB, nn, graph_bounded ? 1 : 0, (const NgGeom*)geo, cs,
                                                                               (const float4*)sorted, nbr, mesh ? *mesh : SellDev{}, mesh_pts, nb);

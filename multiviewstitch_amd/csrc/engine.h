@@ -42,6 +42,8 @@ struct SellDev {               // "ELL-8 by row group" adjacency of the template
     const int32_t* is_ctrl;    // V
 };
 
+struct ChebCoef { double c0, c1[32], c2[32]; };      // Chebyshev steps of a patch sweep: d_0 = c0 D^-1 r ;  d_{k+1} = c1[k] d_k + c2[k] D^-1 r_{k+1}
+
 struct RasDev {                // patches of the restricted additive Schwarz solver (schwarz.hip)
     int32_t NP, NPpad, W, LS;  // patches, 4*NP partial sums rounded up to 64, entries per local row (8 / 12 / 16), rows per patch slot
     const int32_t* pnloc;      // NP: local rows of each patch (its slot holds LS >= nloc rows, the rest inert padding)
@@ -77,6 +79,8 @@ struct RasDev {                // patches of the restricted additive Schwarz sol
 #define MVS_BAR_STRIDE 32
 #define MVS_BAR_GROUPS 16
 #define MVS_BAR_WORDS  (2 + 2 * MVS_BAR_GROUPS)
+#define MVS_CTL_CUR    7     /* group passes (PartDev): the pass in flight = MVS_CTL_SEQ as the pass's first kernel found it (stable while
+                                the pass's last kernel advances MVS_CTL_SEQ) */
 #define MVS_CTL_PRED   5     /* patch solver: rel^2 PREDICTED for the solve in flight when its last sweep was stopped by
                                 prediction (0: it was not); the judge compares it with the true residual and clears it      */
 #define MVS_CTL_PSAFE  6     /* running max (slowly decaying) of (true / predicted) rel^2 over the predicted solves: the
@@ -90,6 +94,38 @@ struct RasDev {                // patches of the restricted additive Schwarz sol
 #define MVS_CTL_GAVEUP (MVS_CTL_LOCAL + 8)             /* [8]: pass number + 1 of the last pass in which the tail loop of solve `it` was abandoned
                                                           (a workgroup's bounded wait at the device-wide barrier expired): such a solve counts as a miss */
 #define MVS_CTL_SIZE   (MVS_CTL_GAVEUP + 8)
+
+// One part of a GROUP of handles (api_deform.cpp, mvs_deform_group_*): everything a bounded pass of that part's handle reads,
+// as one record in device memory.  The kernels of a pass are launched ONCE for all parts of a group — grid (x, part): a
+// workgroup takes its part's record and runs the same body a handle's own launch runs (blockIdx.x / gridDim.x are the x
+// dimension, common to the parts; a part that needs fewer workgroups lets the surplus ones return).  Every part keeps its own
+// control block, verdict ring, energies and launch-plan history: the arithmetic of a part is that of its handle stepping alone.
+struct PartDev {
+    SellDev sell; RasDev ras; GridDev grid;
+    int32_t K, V, ras_block, NC, ss, cheb_m, m2, pad0;
+    double *pts, *nrm, *sol, *x2, *rot, *b, *bpure, *pw, *pd, *slots, *energy, *ctl, *host_ctl;
+    int32_t *iters, *info;
+    unsigned* bar;
+    double *node_pts, *node_nrm, *ctrl_raw, *ctrl_a, *ctrl_b, *near_prev;
+    float *d2min, *lim;
+    int32_t *counts, *nbr, *heavy[2], *mid[2];
+    mvs_cand* rec; int64_t* top_idx; uint8_t* valid;
+    void* ng_geo; int* ng_start; void* ng_sorted; unsigned long long* ng_sync;
+    ChebCoef cc, cc2;
+};
+struct GroupDims { int n, W, block, Kmax, Vmax, NPmax, Grow, HB, MB, NB, GB, CB; size_t lds_all; };
+void launch_group_assoc(const PartDev* parts, const GroupDims& d, int par, const mvs_deform_params& p, int nn, unsigned long long pass, hipStream_t s);
+void launch_group_smooth(const PartDev* parts, const GroupDims& d, int nn, hipStream_t s);
+void launch_group_prepare(const PartDev* parts, const GroupDims& d, int nn, hipStream_t s);
+void launch_group_rhs(const PartDev* parts, const GroupDims& d, int parity, int it, double tol, double cg_tol, int prev_slot, hipStream_t s);
+void launch_group_sweep(const PartDev* parts, const GroupDims& d, int parity, int it, double arap_tol, int sweep, double cg_tol, double stop_margin, double predict,
+                        int slot, hipStream_t s);
+void launch_group_local(const PartDev* parts, const GroupDims& d, int parity, int it, double tol, hipStream_t s);
+void launch_group_finalize(const PartDev* parts, const GroupDims& d, int parity, int iters, double tol, double cg_tol, int last_slot, hipStream_t s);
+double ras_predict_margin(const mvs_deform_s* h, int it);                                      // margin of the predicted stops of ARAP iteration `it`
+void ras_cheb_sets(const mvs_deform_s* h, ChebCoef* cc, int* m, ChebCoef* cc2, int* m2);      // the coefficient sets launch_ras_sweep would pass
+size_t assoc_all_lds_bytes(int K, bool build);
+void assoc_all_dims(int K, int cot_blocks, bool graph, int* HB, int* MB, int* NB, int* GB, int* CB);
 
 // One hipMalloc, many arrays: a layout function is run twice over an Arena — first with base == NULL to learn the size,
 // then over the allocation to hand out the (256-byte aligned) pieces.  mvs_deform_create made ~30 hipMallocs before (3 ms).
@@ -228,6 +264,9 @@ struct mvs_deform_s {
     int dbg_maxspin = 0;            // polls a workgroup waits at the tail loop's barrier before it abandons the solve (0: default)
     int dbg_plan_cap = 0;           // at most this many launches per solve, the rest of its sweeps run inside the last one (0: no cap)
     int dbg_skip_wg = -1;           // the workgroup that never arrives at the tail loop's barrier (-1: none)
+    ChebCoef* d_cheb = nullptr;     // [2] the planned and the strong coefficient set of the sweeps, as last uploaded (launch_ras_sweep)
+    ChebCoef h_cheb[2];             // ... their host side (the source of the asynchronous upload)
+    double cheb_a_dev = -1.0; int cheb_m_dev = 0, cheb_m2_dev = 0;
     int32_t* d_deg = nullptr;       // [V] vertex degree (device build; the ELL-8 tables pad every row to a multiple of 8)
 };
 

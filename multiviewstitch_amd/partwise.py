@@ -146,11 +146,21 @@ class PartwiseDeformation:
         self._calibrated = False
         self._pool = None
         self.host_threads = 8
+        self._group = None
+        self.use_group = True            # step the parts as one sequence of launches when the library allows it
+        self.group_split = 2             # ... as this many groups side by side (each on its own stream and host thread)
+        self.group_declined = ""
+        self.group_passes = 0
 
     def close(self):
         if self._pool is not None:
             self._pool.shutdown()
             self._pool = None
+        if getattr(self, "_group", None) is not None:
+            from . import _lib as L
+            for g, _, _ in self._group:
+                L.lib().mvs_deform_group_destroy(g)
+            self._group = None
         for h in self.handles:
             if h is not None:
                 h.close()
@@ -194,6 +204,13 @@ class PartwiseDeformation:
             stats = [h.iterate(n_outer) for _, h in self.live]
             self._calibrated = True
             return stats
+        # The parts as ONE sequence of launches (include/mvs.h, mvs_deform_group_*: every kernel of an outer iteration once for
+        # all parts).  The library declines (MVS_E_STATE) until every part has stepped twice on its own — its first two
+        # associations search unbounded — or when a part runs the CG solver; the parts then go on as separate launch chains.
+        if self.use_group and len(self.live) > 1 and all(isinstance(h, Deformation) for _, h in self.live):
+            got = self._group_iterate(n_outer)
+            if got is not None:
+                return got
         # one host thread per part: the C-ABI call releases the GIL, and a single thread's launch rate (~3.5 us per
         # kernel) would otherwise cap 16 overlapping parts at the speed of ~4
         if self._pool is None:
@@ -201,6 +218,55 @@ class PartwiseDeformation:
             self._pool = ThreadPoolExecutor(max_workers=min(self.host_threads, max(1, len(self.live))))
         list(self._pool.map(lambda kh: kh[1].enqueue(n_outer), self.live))
         return [h.collect() for _, h in self.live]
+
+    def _group_iterate(self, n_outer: int):
+        """-> statistics per live part, or None when the library declines (see iterate).  The parts step as ``group_split`` groups,
+        each a sequence of launches of its own on its own stream and host thread: two groups of eight parts fill the chip better
+        than one of sixteen (a launch of ~500 workgroups leaves its last round half empty; the other group's launch runs beside
+        it) — 1.02 against 1.58 ms per outer iteration early in a config-5 fit, four groups 1.21 (scripts/config5_split.py)."""
+        import ctypes as C
+        from . import _lib as L
+        from .deformation import _stats
+        live = [h for _, h in self.live]
+        if self._group is None:
+            ng = max(1, min(int(self.group_split), len(live) // 2 or 1))
+            groups = []
+            for gi in range(ng):
+                idx = list(range(gi, len(live), ng))
+                arr = (C.c_void_p * len(idx))(*[live[i]._h for i in idx])
+                g = C.c_void_p()
+                L.check(L.lib().mvs_deform_group_create(C.cast(arr, C.c_void_p), len(idx), C.cast(C.byref(g), C.c_void_p)))
+                groups.append((g, idx, (L.CStats * len(idx))()))
+            self._group = groups
+
+        def run(item):
+            g, idx, st = item
+            rc = L.lib().mvs_deform_group_iterate(g, C.byref(live[idx[0]].params), n_outer, C.cast(st, C.c_void_p))
+            return rc, (L.lib().mvs_last_error().decode(errors="replace") if rc < 0 else "")
+
+        # (every group must be able to step: probe with zero outer iterations first, so that a decline leaves ALL parts untouched)
+        for g, idx, st in self._group:
+            rc = L.lib().mvs_deform_group_iterate(g, C.byref(live[idx[0]].params), 0, C.cast(st, C.c_void_p))
+            if rc == -8:                                         # MVS_E_STATE: not yet
+                self.group_declined = L.lib().mvs_last_error().decode(errors="replace")
+                return None
+            L.check(rc)
+        if len(self._group) == 1:
+            res = [run(self._group[0])]
+        else:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=min(self.host_threads, max(1, len(self.live))))
+            res = list(self._pool.map(run, self._group))
+        for rc, msg in res:
+            if rc < 0:
+                raise L.MvsError(rc, msg)
+        self.group_passes += n_outer
+        out = [None] * len(live)
+        for (g, idx, st) in self._group:
+            for i, s_ in zip(idx, st):
+                out[i] = _stats(s_, 1 if s_.unconverged_solves else 0)       # (a part's own verdict is in its statistics)
+        return out
 
     def vertices(self, comm_device=None) -> np.ndarray:
         """[V,3]: each part's vertices at their place; vertices of no sub-mesh (isolated by the split) stay at rest.

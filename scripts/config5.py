@@ -39,13 +39,24 @@ for _ in range(REPS):
         h.iterate(1)
 torch.cuda.synchronize()
 seq = (time.perf_counter() - a) / REPS
+pd.use_group = False
 a = time.perf_counter()
 stats = pd.iterate(REPS)                                        # every part: REPS outer iterations enqueued, then collected
 torch.cuda.synchronize()
 par = (time.perf_counter() - a) / REPS
+pd.use_group = True                                             # ... and as ONE sequence of launches (mvs_deform_group_*)
+pd.iterate(2)
+torch.cuda.synchronize()
+a = time.perf_counter()
+gstats = pd.iterate(REPS)
+torch.cuda.synchronize()
+grp = (time.perf_counter() - a) / REPS
+assert pd.group_passes == REPS + 2, pd.group_declined
 print(json.dumps({"config": 5, "points": int(len(tp)), "vertices": int(len(sc.verts)), "parts": len(pd.live), "nodes": int(K),
                   "vertices_per_part": [int(len(p["vid"])) for p in pd.parts],
                   "solver": sorted({h.solver_info()["kind"] for _, h in pd.live}),
                   "ms_per_outer_iteration_sequential": round(1e3 * seq, 4), "ms_per_outer_iteration_overlapped": round(1e3 * par, 4),
+                  "ms_per_outer_iteration_group": round(1e3 * grp, 4), "group_worst_rel_residual": max(s["worst_rel_residual_in_batch"] for s in gstats),
+                  "group_unconverged_solves": int(sum(s["unconverged_solves"] for s in gstats)), "groups": len(pd._group), "group_launches_per_outer_iteration": int(max(s["cg_launches"] for s in gstats)) + 19,
                   "worst_rel_residual": max(s["cg_rel_residual"] for s in stats),
                   "valid_nodes": int(sum(s["n_valid"] for s in stats))}))

@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported():
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
     assert sorted(_lib.EXPORTS) == decl, "multiviewstitch_amd/_lib.py signature table out of sync with include/*.h"
-    assert lib.mvs_abi_version() == 3
+    assert lib.mvs_abi_version() == 4
 
 
 def test_struct_layouts_match_the_header():

@@ -166,3 +166,55 @@ def test_abandoned_tail_loops_of_concurrent_parts_are_reported():
             assert np.array_equal(v, v_ref)
         else:
             assert s["unconverged_solves"] >= 1
+
+
+@pytest.mark.gpu
+def test_group_launches_give_the_bits_of_the_separate_handles(oracle):
+    """BASELINE config 5's pattern — several per-part handles stepping in lockstep — as ONE sequence of launches
+    (include/mvs.h, mvs_deform_group_*: every kernel of an outer iteration once for all parts, grid = workgroups x parts).  What a
+    part computes must be what its handle computes stepping alone: the metric workload's template cut into four parts of ~2 K nodes
+    (the node graph is searched on its grid from 1 K nodes on), stepped both ways — same vertices bit for bit, same integers, every
+    solve judged below cg_tol; one part also against the oracle."""
+    import torch
+    import bench
+    from multiviewstitch_amd import _lib, alignment, srt as srt_mod
+    if _lib.device_count() == 0:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box")
+    dev = torch.device("cuda", 0)
+    sc = S.make_scene(3, device=dev)
+    tp, tn = bench.build_target(torch, srt_mod, S, sc, range(8), dev)
+    tp, tn = tp.cpu().numpy(), tn.cpu().numpy()
+    labels = PW.sector_labels(sc.verts, 4)
+    tl = alignment.part_recog(sc.verts, labels, tp)
+    runs = {}
+    for grouped in (False, True):
+        pd = PW.PartwiseDeformation(sc.verts, sc.normals, sc.faces, labels, 4)
+        pd.use_group = grouped
+        assert pd.UniformSampling(16) > 4 * 1024
+        pd.set_target(tp, tn, tl)
+        assert all(h.solver_info()["kind"] == "patch" for _, h in pd.live)
+        hist = [pd.iterate(1), pd.iterate(1)]                    # every part alone: the calibration, the second unbounded pass
+        hist += [pd.iterate(3), pd.iterate(2), pd.iterate(1)]
+        if grouped:
+            assert pd._group is not None and len(pd._group) == 2 and pd.group_passes == 6, pd.group_declined      # (3 + 2 + 1 outer iterations as a group)
+        runs[grouped] = (pd.vertices(), hist, [h.nodes() for _, h in pd.live], [p["vid"] for p in pd.parts], [p["faces"] for p in pd.parts])
+        pd.close()
+    va, ha = runs[False][0], runs[False][1]
+    vb, hb = runs[True][0], runs[True][1]
+    tol = 1e-8
+    for step, (sa, sb) in enumerate(zip(ha, hb)):
+        for k, (a, b) in enumerate(zip(sa, sb)):
+            assert b["status"] == 0 and b["unconverged_solves"] == 0 and b["worst_rel_residual_in_batch"] <= tol, (step, k, b)
+            assert a["n_valid"] == b["n_valid"] and a["arap_iters_run"] == b["arap_iters_run"], (step, k)
+            assert np.allclose(a["energy"], b["energy"], rtol=1e-10, atol=1e-14), (step, k)
+    assert np.array_equal(va, vb)
+    # part 1 of the grouped run against the oracle's own eight outer iterations on the part's sub-mesh
+    k = 1
+    vid, faces = runs[True][3][k], runs[True][4][k]
+    o = oracle.Deform(sc.verts[vid], sc.normals[vid], faces)
+    o.set_nodes(runs[True][2][k])
+    sel = np.flatnonzero(tl == k)
+    o.set_target(tp[sel], tn[sel])
+    so = o.iterate(oracle.Params.default(), 8)
+    assert so["n_valid"] == hb[-1][k]["n_valid"] and so["arap_iters_run"] == hb[-1][k]["arap_iters_run"]
+    assert rms(vb[vid], o.vertices()) <= 1e-6
