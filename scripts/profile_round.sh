@@ -7,15 +7,15 @@
 #   3. the plain bench line                                      -> <tag>/bench.json
 # Raw traces stay in /tmp (too large to pull); only the summaries land under gpurun_out/<tag>/.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf /tmp/prof_$TAG /tmp/prof_cg_$TAG /tmp/pmcf_$TAG /tmp/pmcw_$TAG /tmp/prof_rows_$TAG      # (a box may be reused: stale traces would make the copies below ambiguous)
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 bench.py --no-cpu-baseline --no-alt-solver --no-single-solve > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 bench.py --warmup 5 --steps 20 --no-cpu-baseline --no-alt-solver --no-single-solve --no-cold-process --no-tolerance-headroom > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err || exit 1
 cp /tmp/prof_$TAG/*/*_kernel_stats.csv $OUT/kernel_stats_all.csv
 # the same command with the alternative solver (one kernel per CG iteration) as the main run: its own table
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_cg_$TAG -- python3 bench.py --no-cpu-baseline --only-alt-solver > $OUT/bench_cg_under_rocprof.json 2> $OUT/bench_cg_under_rocprof.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_cg_$TAG -- python3 bench.py --warmup 5 --steps 20 --no-cpu-baseline --only-alt-solver --no-cold-process --no-tolerance-headroom > $OUT/bench_cg_under_rocprof.json 2> $OUT/bench_cg_under_rocprof.err || exit 1
 cp /tmp/prof_cg_$TAG/*/*_kernel_stats.csv $OUT/kernel_stats_cg_all.csv
 python3 - "$OUT" <<'PY'
 import csv, sys
@@ -31,9 +31,9 @@ for src, dst in (("kernel_stats_all.csv", "kernel_stats.csv"), ("kernel_stats_cg
             w.writerow([r["Name"].replace("(anonymous namespace)::", "").split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
                         f"{100 * float(r['TotalDurationNs']) / tot:.2f}", r["MinNs"], r["MaxNs"], r["StdDev"]])
 PY
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmcf_$TAG -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-alt-solver > /dev/null 2> $OUT/pmc_fetch.err || exit 1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmcf_$TAG -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-alt-solver --no-cold-process --no-tolerance-headroom > /dev/null 2> $OUT/pmc_fetch.err || exit 1
 python3 scripts/pmc_summary.py /tmp/pmcf_$TAG > $OUT/pmc_fetch.txt
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmcw_$TAG -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-alt-solver > /dev/null 2> $OUT/pmc_write.err || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmcw_$TAG -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-alt-solver --no-cold-process --no-tolerance-headroom > /dev/null 2> $OUT/pmc_write.err || exit 1
 python3 scripts/pmc_summary.py /tmp/pmcw_$TAG > $OUT/pmc_write.txt
 python3 - "$OUT" <<'PY'
 import json, re, sys
@@ -60,7 +60,7 @@ json.dump({"kernel": "k_ras_sweep", "config": 3, "vertices": b["config"]["vertic
            "bytes_per_active_launch": int(1024 * (corr * f[1] + w[1])), "algorithmic_bytes_per_launch": b["roofline"]["bytes_per_launch"]},
           open(f"{out}/pmc_traffic_ras.json", "w"), indent=1)
 PY
-python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+python3 bench.py --warmup 5 --steps 20 > $OUT/bench.json 2> $OUT/bench.err || exit 1
 echo bench done
 # 4. the secondary rows at full size + the per-kernel table of the hot path -> <tag>/rows.md
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_rows_$TAG -- python3 scripts/bench_rows.py > $OUT/rows.json 2> $OUT/rows.err || exit 1

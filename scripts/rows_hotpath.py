@@ -14,9 +14,11 @@ E = 8 * V                                               # stored adjacency entri
 rl = b["roofline"]
 sweep_bytes = rl["bytes_per_launch"]
 alg = {   # kernel -> (bytes per launch, formula)
-    "k_assoc_local": (24 * P + 40 * K, "association as a whole, SURVEY 8(d): 24 P (every target point once) + 24 K read + 16 K written — the grid search visits a few hundred points per node, not all P"),
-    "k_assoc_heavy_knn": (None, "the far nodes of the association (its bytes are counted with k_assoc_local) + 9-NN graph + cotangent weights (24 V + 20 E read, 8 E + 8 V written)"),
-    "k_ng_build1": (24 * K + 16 * K, "24 K node positions read, 16 K sorted records written"),
+    "k_assoc_prep": (56 * K, "bounded passes: per node 24 B position + 24 B previous position + 4 B previous distance read, 4 B bound written (+ the lists of the few nodes a wave or a workgroup takes)"),
+    "k_assoc_all": (24 * P + 40 * K, "bounded passes, association as a whole (SURVEY 8(d): 24 P + 24 K read + 16 K written — the bounded search visits a few dozen points per node, not all P) + node grid build + 9-NN graph + cotangent weights (24 V + 20 E read, 8 E + 8 V written) in the same launch"),
+    "k_assoc_local": (24 * P + 40 * K, "the first two (unbounded) associations of a fit"),
+    "k_assoc_heavy_knn": (None, "the far nodes of the unbounded associations + 9-NN graph + cotangent weights"),
+    "k_ng_build1": (24 * K + 16 * K, "24 K node positions read, 16 K sorted records written (unbounded passes; bounded passes build the node grid inside k_assoc_all)"),
     "k_smooth": (144 * K, "one Jacobi sweep: 9 x (4 + 12) B gathered per node (SURVEY: 288 K for two)"),
     "k_ras_prepare": (None, "patch matrix: (8 W) B weights gathered + (8 W + 8) B written per patch-local row, 72 V rotations + 24 V start written"),
     "k_arap_rhs": ((72 + 24 + 24) * V + 12 * E + 48 * V, "(72 rotation + 24 rest + 24 x) V + 12 E (col, w) read, b and bpure (48 V) written; neighbour gathers are re-reads"),
