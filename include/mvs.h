@@ -270,7 +270,7 @@ int mvs_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t
 /* InitAlignment with the scan sharded over ranks by view: `tgt_local` holds this rank's share (may be empty), the
  * template `src` is replicated.  The scan's count / sums, bounding box, centred second moments (PointSetUtils.cpp:9-39) and its
  * extent along the first pivot (Alignment.cpp:281-296) are reduced over the ranks through the caller's all-reduce — four calls
- * of at most 6 doubles — so every rank returns the same R, t, scale; they equal mvs_init_alignment on the whole scan up to the
+ * of at most 7 doubles (the last one is the ranks' failure flag, see mvs_local_alignment_core_sharded) — so every rank returns the same R, t, scale; they equal mvs_init_alignment on the whole scan up to the
  * order of the floating-point sums.  `reduce(ctx, v, n, op)` all-reduces the n HOST doubles v in place, op 0 = sum, 1 = min,
  * and returns 0 on success; mvs_comm_reduce (ctx = an mvs_comm_t) is a ready one over RCCL. */
 typedef int (*mvs_reduce_fn)(void* ctx, double* v, int n, int op);
@@ -298,10 +298,19 @@ int mvs_local_alignment_core(const double* src, const int32_t* s_labels, int64_t
 
 /* LocalAlignmentCore with the scan sharded over ranks by view (template replicated): the scan's labelled moments, the labels
  * present (Alignment.cpp:475-477), its extent along the limb axis and the label at its far end (:519-528) are reduced through
- * `reduce`; every rank returns the same R, t, scale. */
+ * `reduce`; every rank returns the same R, t, scale.  When several points reach the largest projection the reference keeps the
+ * first of them (strict >, :521): here the lowest `rank` (= position of this share in the stitched scan) that reaches it, and within
+ * the rank the lowest index.
+ *
+ * All three sharded entries: a rank whose LOCAL stage fails (allocation, copy, kernel) still joins the next reduce, which carries one
+ * more element — the failure flag — so every rank returns an error from the same collective instead of waiting for the failed one
+ * (the failed rank returns its own code and message, the others MVS_E_STATE).  `reduce` must therefore accept any n <= 24.
+ * After mvs_remove_ground_sharded only ONE rank still holds points (RetainConnectRegion keeps one component and facets never join
+ * two ranks' points): the stages the reference runs next (InitAlignment, PartRecog, LocalAlignment) are then single-rank work with
+ * empty shares elsewhere — the sharded forms of those exist for scans sharded WITHOUT that trim (per-view parts, config 5). */
 int mvs_local_alignment_core_sharded(const double* src, const int32_t* s_labels, int64_t ns,
                                      const double* tgt_local, const int32_t* t_labels_local, int64_t nt_local,
-                                     uint32_t group_mask, int label, mvs_reduce_fn reduce, void* reduce_ctx,
+                                     uint32_t group_mask, int label, mvs_reduce_fn reduce, void* reduce_ctx, int rank,
                                      double* R /*9*/, double* t /*3*/, double* scale);
 
 /* Alignment::Align (Alignment.cpp:11-76; call site R/Processor/Processor.cpp:1130-1131) without its file I/O:
@@ -312,6 +321,12 @@ int mvs_local_alignment_core_sharded(const double* src, const int32_t* s_labels,
 int mvs_align(double* src, double* s_normals, int64_t ns, const int32_t* s_labels,
               double* tgt, double* t_normals, int64_t* nt, int32_t* t_faces, int64_t* nf,
               const double* view_ray, double dist_thres, int32_t* t_labels, double* ground_ray);
+/* The same with the scan resident in HBM (tgt_dev / t_normals_dev / t_faces_dev / t_labels_dev are DEVICE arrays, trimmed in
+ * place — what mvs_depth_to_model_dev / mvs_srt_apply_dev leave and mvs_deform_set_target_dev takes); the template stays a host
+ * argument.  The call waits for the device before it starts (the caller's arrays come from some other stream). */
+int mvs_align_dev(double* src, double* s_normals, int64_t ns, const int32_t* s_labels,
+                  double* tgt_dev, double* t_normals_dev, int64_t* nt, int32_t* t_faces_dev, int64_t* nf,
+                  const double* view_ray /*3*/, double dist_thres, int32_t* t_labels_dev, double* ground_ray /*3, optional*/);
 
 /* ------------------------------------------------------------------ tracing */
 /* SURVEY §8b "Side effects": the engine writes no files and prints nothing (the reference's only timer is a clock() pair around
@@ -495,7 +510,7 @@ typedef struct mvs_comm_s* mvs_comm_t;
 int mvs_comm_unique_id(uint8_t* id /*MVS_COMM_ID_BYTES*/);
 int mvs_comm_init(int rank, int nranks, const uint8_t* id /*MVS_COMM_ID_BYTES*/, mvs_comm_t* out);
 int mvs_comm_destroy(mvs_comm_t c);
-/* an mvs_reduce_fn over a communicator (ctx = the mvs_comm_t): n <= 16 host doubles, op 0 = sum, 1 = min */
+/* an mvs_reduce_fn over a communicator (ctx = the mvs_comm_t): n <= 24 host doubles, op 0 = sum, 1 = min */
 int mvs_comm_reduce(void* comm, double* v, int n, int op);
 int mvs_comm_info(mvs_comm_t c, int* rank, int* nranks);
 /* How the ranks' best-8 records meet in mvs_deform_iterate_sharded: AUTO = ALL_GATHER at every rank count; OWNER (on request)

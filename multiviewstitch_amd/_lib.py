@@ -106,10 +106,11 @@ _SIGS = {
     "mvs_init_alignment_sharded": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "mvs_comm_reduce": (C.c_int, [_VP, _VP, _I32, _I32]),
     "mvs_remove_ground_sharded": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _D, _VP, _VP, _I32, _VP]),
-    "mvs_local_alignment_core_sharded": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _I64, _U32, _I32, _VP, _VP, _VP, _VP, _VP]),
+    "mvs_local_alignment_core_sharded": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _I64, _U32, _I32, _VP, _VP, _I32, _VP, _VP, _VP]),
     "mvs_part_recog": (C.c_int, [_VP, _VP, _I64, _VP, _I64, _VP]),
     "mvs_local_alignment_core": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _I64, _U32, _I32, _VP, _VP, _VP]),
     "mvs_align": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _D, _VP, _VP]),
+    "mvs_align_dev": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _D, _VP, _VP]),
     "mvs_deform_default_params": (None, [_VP]),
     "mvs_deform_create": (C.c_int, [_I64, _VP, _VP, _I64, _VP, _VP]),
     "mvs_deform_destroy": (C.c_int, [_VP]),

@@ -96,12 +96,13 @@ class Alignment:
                                                   dist_thres, C.cast(reducer, C.c_void_p), None, rank, L.ptr(gr)))
         return gr, p[:V.value], (n[:V.value] if n is not None else None), f[:F.value]
 
-    def LocalAlignmentCoreSharded(self, src, s_labels, tgt_local, t_labels_local, group_mask: int, label: int, reducer):
+    def LocalAlignmentCoreSharded(self, src, s_labels, tgt_local, t_labels_local, group_mask: int, label: int, reducer, rank: int):
         s, t = L.arr(src, np.float64).reshape(-1, 3), L.arr(tgt_local, np.float64).reshape(-1, 3)
         sl, tl = L.arr(s_labels, np.int32), L.arr(t_labels_local, np.int32).reshape(-1)
         R, tr, sc = np.empty((3, 3)), np.empty(3), C.c_double()
         L.check(L.lib().mvs_local_alignment_core_sharded(L.ptr(s), L.ptr(sl), len(s), L.ptr(t) if len(t) else None, L.ptr(tl) if len(tl) else None,
-                                                         len(t), group_mask, label, C.cast(reducer, C.c_void_p), None, L.ptr(R), L.ptr(tr), C.byref(sc)))
+                                                         len(t), group_mask, label, C.cast(reducer, C.c_void_p), None, rank, L.ptr(R), L.ptr(tr),
+                                                         C.byref(sc)))
         return R, tr, sc.value
 
     def LocalAlignmentCore(self, src, s_labels, tgt, t_labels, group_mask: int, label: int):
@@ -126,3 +127,15 @@ class Alignment:
                                   L.ptr(v), dist_thres, L.ptr(tl), L.ptr(gr)))
         return dict(src=s, s_normals=sn, tgt=t[:nt.value], t_normals=tn[:nt.value], t_facets=tf[:nf.value],
                     t_labels=tl[:nt.value], ground_ray=gr)
+
+    def AlignDev(self, src, s_normals, s_labels, tgt_dev: int, t_normals_dev: int, n_t: int, t_facets_dev: int, n_f: int, t_labels_dev: int, viewRay,
+                 dist_thres: float = DIST_THRESHOLD):
+        """``Align`` with the scan resident in HBM (``mvs_align_dev``): device addresses of tgt (n_t x 3 doubles), its normals, its
+        facets (n_f x 3 int32) and room for n_t labels; all trimmed in place.  Returns dict(src, s_normals, n_t, n_f, ground_ray)."""
+        s, sn = L.arr(src, np.float64).reshape(-1, 3).copy(), L.arr(s_normals, np.float64).reshape(-1, 3).copy()
+        sl = L.arr(s_labels, np.int32)
+        v = L.arr(viewRay, np.float64)
+        nt, nf, gr = C.c_int64(n_t), C.c_int64(n_f), np.empty(3)
+        L.check(L.lib().mvs_align_dev(L.ptr(s), L.ptr(sn), len(s), L.ptr(sl), L.ptr(int(tgt_dev)), L.ptr(int(t_normals_dev)), C.byref(nt),
+                                      L.ptr(int(t_facets_dev)), C.byref(nf), L.ptr(v), dist_thres, L.ptr(int(t_labels_dev)), L.ptr(gr)))
+        return dict(src=s, s_normals=sn, n_t=nt.value, n_f=nf.value, ground_ray=gr)

@@ -361,26 +361,50 @@ void mv3(const double* M, const double* v, double* o) {
 struct Pca { double bary[3], lo[3], hi[3], axis[3][3], eval[3]; double cnt; uint32_t present; };
 struct Work {                 // per-call reduction scratch (device + pinned-size host mirror)
     Dev part;
-    std::vector<double> h;
-    int init() { h.resize((size_t)NBLK * 11); return part.alloc(sizeof(double) * NBLK * 11); }
+    std::vector<double> h = std::vector<double>((size_t)NBLK * 11, 0.0);   // (sized from the start: a bystander rank reads it without init())
+    int init() { return part.alloc(sizeof(double) * NBLK * 11); }
     int fetch(size_t n) { return mvs_check_hip(hipMemcpy(h.data(), part.p, sizeof(double) * n, hipMemcpyDeviceToHost), "memcpy"); }
 };
 
-// view-sharded form (mvs_init_alignment_sharded): the caller's all-reduce over the ranks on small host vectors, op 0 = sum, 1 = min
+// view-sharded form (mvs_init_alignment_sharded): the caller's all-reduce over the ranks on small host vectors, op 0 = sum, 1 = min.
+// A rank whose LOCAL stage fails (allocation, copy, kernel) must not leave its peers waiting in the next collective: local(rc)
+// remembers the first failure and lets the rank go on as a bystander (live() == false: device work is skipped); every run() carries
+// one more element, the failure flag of the ranks, and ALL ranks return an error from the same run().  close() is that flag alone,
+// for local stages after an entry's last collective.  Unsharded (fn == NULL): local(rc) is rc, run() / close() do nothing.
 struct Reducer {
     mvs_reduce_fn fn = nullptr; void* ctx = nullptr;
-    int run(double* v, int n, int op) const {
-        if (!fn) return MVS_OK;
-        if (fn(ctx, v, n, op) != 0) { mvs_set_error("the caller's all-reduce failed"); return MVS_E_STATE; }
+    mutable int dead = 0;
+    bool live() const { return dead == 0; }
+    int local(int rc) const {
+        if (!rc || !fn) return rc;
+        if (!dead) dead = rc;
         return MVS_OK;
     }
+    int run(double* v, int n, int op) const {
+        if (!fn) return MVS_OK;
+        double buf[24];
+        if (n > 23) { mvs_set_error("reduce of %d values", n); return MVS_E_STATE; }
+        for (int k = 0; k < n; ++k) buf[k] = dead ? 0.0 : v[k];
+        buf[n] = dead ? (op == 0 ? 1.0 : -1.0) : 0.0;               // sum: the number of failed ranks; min: -1 if any
+        if (fn(ctx, buf, n + 1, op) != 0) { mvs_set_error("the caller's all-reduce failed"); return MVS_E_STATE; }
+        if (buf[n] != 0.0) {
+            if (!dead) mvs_set_error("another rank failed in a local stage of this sharded call");
+            return dead ? dead : MVS_E_STATE;
+        }
+        for (int k = 0; k < n; ++k) v[k] = buf[k];
+        return MVS_OK;
+    }
+    int close() const { double none = 0; return run(&none, 0, 1); }
 };
+// a local stage of a function that takes `red`: skipped by a bystander; unsharded, its failure returns at once
+#define LOCAL(x) do { if (red.live()) { int rc_ = red.local(x); if (rc_) return rc_; } } while (0)
+#define LOCAL_HIP(x) LOCAL(mvs_check_hip((x), #x))
 
 // PointSetUtils::SetInput + CalcPivots on the selected device points
 int pca_dev(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, Work& w, Pca* out, const Reducer& red = Reducer()) {
-    k_moments1<<<dim3(NBLK), dim3(TPB)>>>(pts, n, labels, mask, w.part.as<double>());
-    int rc = w.fetch((size_t)NBLK * 11);
-    if (rc) return rc;
+    int rc;
+    if (red.live()) k_moments1<<<dim3(NBLK), dim3(TPB)>>>(pts, n, labels, mask, w.part.as<double>());
+    LOCAL(w.fetch((size_t)NBLK * 11));
     double cnt = 0, s[3] = {0, 0, 0};
     uint32_t present = 0;
     for (int c = 0; c < 3; ++c) { out->lo[c] = INFINITY; out->hi[c] = -INFINITY; }
@@ -401,7 +425,7 @@ int pca_dev(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, 
     if (cnt < 2) { mvs_set_error("PCA needs at least 2 points (got %.0f)", cnt); return MVS_E_DEGENERATE; }
     for (int c = 0; c < 3; ++c) out->bary[c] = s[c] / cnt;                    // PointSetUtils.cpp:43-47
     k_moments2<<<dim3(NBLK), dim3(TPB)>>>(pts, n, labels, mask, out->bary[0], out->bary[1], out->bary[2], w.part.as<double>());
-    if ((rc = w.fetch((size_t)NBLK * 6))) return rc;
+    LOCAL(w.fetch((size_t)NBLK * 6));
     double m[6] = {0, 0, 0, 0, 0, 0};
     for (int b = 0; b < NBLK; ++b) for (int k = 0; k < 6; ++k) m[k] += w.h[(size_t)b * 6 + k];
     if ((rc = red.run(m, 6, 0))) return rc;
@@ -476,24 +500,30 @@ int retain_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F,
     Dev parent, size, keep, flag, part;
     int rc;
     const int64_t n1 = std::max<int64_t>(*n, 1);
-    if ((rc = parent.alloc(sizeof(int32_t) * n1)) || (rc = size.alloc(sizeof(int32_t) * n1)) || (rc = keep.alloc(sizeof(int32_t) * (n1 + 1))) ||
-        (rc = flag.alloc(sizeof(int32_t))) || (rc = part.alloc(sizeof(long long) * 2 * NBLK))) return rc;
+    LOCAL(parent.alloc(sizeof(int32_t) * n1));
+    LOCAL(size.alloc(sizeof(int32_t) * n1));
+    LOCAL(keep.alloc(sizeof(int32_t) * (n1 + 1)));
+    LOCAL(flag.alloc(sizeof(int32_t)));
+    LOCAL(part.alloc(sizeof(long long) * 2 * NBLK));
     long long bs = -1, br = -1;
-    if (*n > 0) {
+    if (*n > 0 && red.live()) {
         k_cc_init<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n);
-        for (int round = 0; round < 64 && *F > 0; ++round) {             // O(log) rounds in practice; bounded
+        for (int round = 0; round < 64 && *F > 0 && red.live(); ++round) {             // O(log) rounds in practice; bounded
             int32_t changed = 0;
-            HIPCHK(hipMemset(flag.p, 0, sizeof(int32_t)));
+            LOCAL_HIP(hipMemset(flag.p, 0, sizeof(int32_t)));
+            if (!red.live()) break;
             k_cc_hook<<<blocks(*F), dim3(TPB)>>>(faces, *F, parent.as<int32_t>(), flag.as<int32_t>());
             k_cc_compress<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n);
-            HIPCHK(hipMemcpy(&changed, flag.p, sizeof changed, hipMemcpyDeviceToHost));
+            LOCAL_HIP(hipMemcpy(&changed, flag.p, sizeof changed, hipMemcpyDeviceToHost));
             if (!changed) break;
         }
-        HIPCHK(hipMemset(size.p, 0, sizeof(int32_t) * *n));
-        k_cc_sizes<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n, size.as<int32_t>());
-        k_cc_best<<<dim3(NBLK), dim3(TPB)>>>(size.as<int32_t>(), *n, part.as<long long>());
-        std::vector<long long> hp(2 * NBLK);
-        HIPCHK(hipMemcpy(hp.data(), part.p, sizeof(long long) * 2 * NBLK, hipMemcpyDeviceToHost));
+        LOCAL_HIP(hipMemset(size.p, 0, sizeof(int32_t) * *n));
+        std::vector<long long> hp(2 * NBLK, -1);
+        if (red.live()) {
+            k_cc_sizes<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n, size.as<int32_t>());
+            k_cc_best<<<dim3(NBLK), dim3(TPB)>>>(size.as<int32_t>(), *n, part.as<long long>());
+        }
+        LOCAL_HIP(hipMemcpy(hp.data(), part.p, sizeof(long long) * 2 * NBLK, hipMemcpyDeviceToHost));
         for (int b = 0; b < NBLK; ++b)
             if (hp[2 * b + 1] >= 0 && (hp[2 * b] > bs || (hp[2 * b] == bs && hp[2 * b + 1] < br))) { bs = hp[2 * b]; br = hp[2 * b + 1]; }
     }
@@ -502,12 +532,14 @@ int retain_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F,
         if ((rc = red.run(&g, 1, 1))) return rc;
         double win = (bs > 0 && (double)bs == -g) ? (double)rank : INFINITY;
         if ((rc = red.run(&win, 1, 1))) return rc;
-        if (win != (double)rank) { *n = 0; *F = 0; return MVS_OK; }
+        if (win != (double)rank) { *n = 0; *F = 0; return red.close(); }
     }
-    if (*n <= 0) return MVS_OK;
-    HIPCHK(hipMemset(keep.p, 0, sizeof(int32_t) * (*n + 1)));
-    k_cc_keep<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n, (int)br, keep.as<int32_t>());
-    return compact_dev(pts, nrm, n, faces, F, keep.as<int32_t>());
+    if (*n > 0) {                                                     // (after the last collective: a local failure is told by close())
+        LOCAL_HIP(hipMemset(keep.p, 0, sizeof(int32_t) * (*n + 1)));
+        if (red.live()) k_cc_keep<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n, (int)br, keep.as<int32_t>());
+        LOCAL(compact_dev(pts, nrm, n, faces, F, keep.as<int32_t>()));
+    }
+    return red.close();
 }
 
 // Alignment::RemoveGround on device arrays.  red.fn != NULL: the arrays hold this rank's share of a scan sharded by view; the
@@ -522,24 +554,26 @@ int remove_ground_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int6
     const double* pivot = p.axis[0];
     Dev t, side, dist, keep;
     const int64_t n1 = std::max<int64_t>(*n, 1);
-    if ((rc = t.alloc(sizeof(double) * n1)) || (rc = side.alloc((size_t)n1)) || (rc = dist.alloc(sizeof(double) * n1)) ||
-        (rc = keep.alloc(sizeof(int32_t) * (n1 + 1)))) return rc;
+    LOCAL(t.alloc(sizeof(double) * n1));
+    LOCAL(side.alloc((size_t)n1));
+    LOCAL(dist.alloc(sizeof(double) * n1));
+    LOCAL(keep.alloc(sizeof(int32_t) * (n1 + 1)));
     Range rr;
-    if ((rc = range_dev(pts, *n, nullptr, 0, pivot, p.bary, t.as<double>(), w, &rr))) return rc;   // t[i], Alignment.cpp:104
-    k_rg_tmax<<<dim3(NBLK), dim3(TPB)>>>(t.as<double>(), *n, w.part.as<double>());
-    if ((rc = w.fetch((size_t)NBLK * 2))) return rc;
+    LOCAL(range_dev(pts, *n, nullptr, 0, pivot, p.bary, t.as<double>(), w, &rr));   // t[i], Alignment.cpp:104
+    if (red.live()) k_rg_tmax<<<dim3(NBLK), dim3(TPB)>>>(t.as<double>(), *n, w.part.as<double>());
+    LOCAL(w.fetch((size_t)NBLK * 2));
     double tMax1 = DBL_MIN, tMax2 = DBL_MIN;
     for (int b = 0; b < NBLK; ++b) { tMax1 = std::max(tMax1, w.h[2 * b]); tMax2 = std::max(tMax2, w.h[2 * b + 1]); }
     if (red.fn) { double e[2] = {-tMax1, -tMax2}; if ((rc = red.run(e, 2, 1))) return rc; tMax1 = -e[0]; tMax2 = -e[1]; }
     k_rg_side<<<dim3(NBLK), dim3(TPB)>>>(t.as<double>(), *n, tMax1 * dist_thres, tMax2 * dist_thres, side.as<uint8_t>(), w.part.as<double>());
-    if ((rc = w.fetch((size_t)NBLK * 2))) return rc;
+    LOCAL(w.fetch((size_t)NBLK * 2));
     double c12[2] = {0, 0};
     for (int b = 0; b < NBLK; ++b) { c12[0] += w.h[2 * b]; c12[1] += w.h[2 * b + 1]; }
     if ((rc = red.run(c12, 2, 0))) return rc;
     const int which = c12[0] > c12[1] ? 1 : 2;                                  // :129-138
     for (int c = 0; c < 3; ++c) ground_ray[c] = which == 1 ? -pivot[c] : pivot[c];
     k_rg_plane<<<dim3(NBLK), dim3(TPB)>>>(pts, side.as<uint8_t>(), *n, which, w.part.as<double>());
-    if ((rc = w.fetch((size_t)NBLK * 9))) return rc;
+    LOCAL(w.fetch((size_t)NBLK * 9));
     double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int b = 0; b < NBLK; ++b) for (int k = 0; k < 9; ++k) m[k] += w.h[(size_t)b * 9 + k];
     if ((rc = red.run(m, 9, 0))) return rc;
@@ -553,14 +587,14 @@ int remove_ground_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int6
     for (int c = 0; c < 3; ++c) ans[c] /= len;
     if (dotp(ans, pivot) < 0) { for (int c = 0; c < 3; ++c) ans[c] = -ans[c]; d = -d; }   // :158-161
     k_rg_dist<<<dim3(NBLK), dim3(TPB)>>>(pts, side.as<uint8_t>(), *n, which, mk3(ans[0], ans[1], ans[2]), d, dist.as<double>(), w.part.as<double>());
-    if ((rc = w.fetch((size_t)NBLK))) return rc;
+    LOCAL(w.fetch((size_t)NBLK));
     double maxDist = DBL_MIN;
     for (int b = 0; b < NBLK; ++b) maxDist = std::max(maxDist, w.h[b]);
     if (red.fn) { double e = -maxDist; if ((rc = red.run(&e, 1, 1))) return rc; maxDist = -e; }
-    HIPCHK(hipMemset(keep.p, 0, sizeof(int32_t) * (n1 + 1)));
-    if (*n > 0) {
+    LOCAL_HIP(hipMemset(keep.p, 0, sizeof(int32_t) * (n1 + 1)));
+    if (*n > 0 && red.live()) {
         k_rg_keep<<<blocks(*n), dim3(TPB)>>>(dist.as<double>(), *n, maxDist * 0.28, keep.as<int32_t>());   // :187-193
-        if ((rc = compact_dev(pts, nrm, n, faces, F, keep.as<int32_t>()))) return rc;                      // :196-219
+        LOCAL(compact_dev(pts, nrm, n, faces, F, keep.as<int32_t>()));                                     // :196-219
     }
     return retain_dev(pts, nrm, n, faces, F, red, rank);                                                   // :227
 }
@@ -569,12 +603,13 @@ int init_alignment_dev(const double* src, int64_t ns, const double* tgt, int64_t
                        Work& w, double* R, double* t, double* scale, const Reducer& red = Reducer()) {
     Pca ps, pt;
     int rc;
-    if ((rc = pca_dev(src, ns, nullptr, 0, w, &ps)) || (rc = pca_dev(tgt, nt, nullptr, 0, w, &pt, red))) return rc;
+    LOCAL(pca_dev(src, ns, nullptr, 0, w, &ps));
+    if ((rc = pca_dev(tgt, nt, nullptr, 0, w, &pt, red))) return rc;
     if (dotp(ground_ray, pt.axis[0]) < 0) for (int c = 0; c < 3; ++c) pt.axis[0][c] = -pt.axis[0][c];   // :255
     if (dotp(view_ray, pt.axis[2]) < 0) for (int c = 0; c < 3; ++c) pt.axis[2][c] = -pt.axis[2][c];     // :256
     Range r1, r2;
-    if ((rc = range_dev(src, ns, nullptr, 0, ps.axis[0], ps.bary, nullptr, w, &r1)) ||
-        (rc = range_dev(tgt, nt, nullptr, 0, pt.axis[0], pt.bary, nullptr, w, &r2))) return rc;
+    LOCAL(range_dev(src, ns, nullptr, 0, ps.axis[0], ps.bary, nullptr, w, &r1));
+    LOCAL(range_dev(tgt, nt, nullptr, 0, pt.axis[0], pt.bary, nullptr, w, &r2));
     if (red.fn) {                                  // the scan's extent along its first pivot over all ranks (start values DBL_MAX / DBL_MIN included)
         double e[2] = {r2.lo, -r2.hi};
         if ((rc = red.run(e, 2, 1))) return rc;
@@ -608,12 +643,15 @@ void rotation_between(const double* before, const double* after, double* R) {   
 }
 
 // red.fn != NULL: tgt / t_labels hold this rank's share of the scan; its moments, the labels present, the extent along the
-// limb axis and the label at the far end are reduced over the ranks (the template is replicated)
+// limb axis and the label at the far end are reduced over the ranks (the template is replicated).  The far end: the reference's
+// loop keeps the FIRST point of the largest projection (Alignment.cpp:519-523, strict >), i.e. the lowest index of the stitched
+// scan — the lowest rank that reaches the extreme, and within it the lowest index (range_dev's rule).
 int local_core_dev(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels, int64_t nt,
-                   uint32_t group, int label, Work& w, double* R, double* t, double* scale, const Reducer& red = Reducer()) {
+                   uint32_t group, int label, Work& w, double* R, double* t, double* scale, const Reducer& red = Reducer(), int rank = 0) {
     Pca ps, pt;
     int rc;
-    if ((rc = pca_dev(src, ns, s_labels, group, w, &ps)) || (rc = pca_dev(tgt, nt, t_labels, group, w, &pt, red))) return rc;
+    LOCAL(pca_dev(src, ns, s_labels, group, w, &ps));
+    if ((rc = pca_dev(tgt, nt, t_labels, group, w, &pt, red))) return rc;
     if (dotp(ps.axis[0], pt.axis[0]) < 0) for (int c = 0; c < 3; ++c) pt.axis[0][c] = -pt.axis[0][c];   // :444-446
     if (red.fn) {                                 // labels present anywhere: OR over the ranks as a MIN of -bit, 16 labels per call
         uint32_t all = 0;
@@ -630,18 +668,26 @@ int local_core_dev(const double* src, const int32_t* s_labels, int64_t ns, const
     if (popc(sset) < popc(tset)) { const uint32_t e = tset & ~sset; tset &= ~(e & (~e + 1u)); }          // :479-488
     else if (popc(sset) > popc(tset)) { const uint32_t e = sset & ~tset; sset &= ~(e & (~e + 1u)); }     // :489-498
     Range r1, r2;
-    if ((rc = range_dev(src, ns, s_labels, sset, ps.axis[0], ps.bary, nullptr, w, &r1)) ||
-        (rc = range_dev(tgt, nt, t_labels, tset, pt.axis[0], pt.bary, nullptr, w, &r2))) return rc;
+    LOCAL(range_dev(src, ns, s_labels, sset, ps.axis[0], ps.bary, nullptr, w, &r1));
+    LOCAL(range_dev(tgt, nt, t_labels, tset, pt.axis[0], pt.bary, nullptr, w, &r2));
     int32_t lab1 = 0, lab2 = 0;
+    double far2[6] = {0, 0, 0, 0, 0, 0};                                 // the template's two end points (which one is used: below)
+    if (r1.ilo >= 0 && r1.ihi >= 0) {
+        LOCAL_HIP(hipMemcpy(&lab1, s_labels + r1.ihi, sizeof lab1, hipMemcpyDeviceToHost));
+        LOCAL_HIP(hipMemcpy(far2, src + 3 * r1.ilo, 3 * sizeof(double), hipMemcpyDeviceToHost));
+        LOCAL_HIP(hipMemcpy(far2 + 3, src + 3 * r1.ihi, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    }
     if (red.fn) {
-        // the scan's extent over all ranks, and the label of the point at its far end (the rank that holds it says which)
+        // the scan's extent over all ranks, and the label of the point at its far end (the lowest rank that holds it says which)
         int32_t mylab = 0;
-        if (r2.ihi >= 0) HIPCHK(hipMemcpy(&mylab, t_labels + r2.ihi, sizeof mylab, hipMemcpyDeviceToHost));
+        if (r2.ihi >= 0) LOCAL_HIP(hipMemcpy(&mylab, t_labels + r2.ihi, sizeof mylab, hipMemcpyDeviceToHost));
         double e[2] = {r2.lo, -r2.hi};
         const double myhi = r2.hi;
         if ((rc = red.run(e, 2, 1))) return rc;
         const bool any = -e[1] != DBL_MIN || e[0] != DBL_MAX;
-        double lv = (r2.ihi >= 0 && myhi == -e[1]) ? (double)mylab : INFINITY;
+        double who = (r2.ihi >= 0 && myhi == -e[1]) ? (double)rank : INFINITY;
+        if ((rc = red.run(&who, 1, 1))) return rc;
+        double lv = (who == (double)rank) ? (double)mylab : INFINITY;
         if ((rc = red.run(&lv, 1, 1))) return rc;
         if (!any || !(lv < INFINITY)) { mvs_set_error("limb group 0x%x has no extent", group); return MVS_E_DEGENERATE; }
         r2.lo = e[0]; r2.hi = -e[1]; r2.ilo = 0; r2.ihi = 0;
@@ -649,13 +695,12 @@ int local_core_dev(const double* src, const int32_t* s_labels, int64_t ns, const
     }
     if (r1.ilo < 0 || r1.ihi < 0 || r2.ilo < 0 || r2.ihi < 0) { mvs_set_error("limb group 0x%x has no extent", group); return MVS_E_DEGENERATE; }
     double far[3];
-    HIPCHK(hipMemcpy(&lab1, s_labels + r1.ihi, sizeof lab1, hipMemcpyDeviceToHost));
     if (!red.fn) HIPCHK(hipMemcpy(&lab2, t_labels + r2.ihi, sizeof lab2, hipMemcpyDeviceToHost));
+    std::memcpy(far, lab1 != label ? far2 + 3 : far2, sizeof far);                                      // src_[fidx1] + baryCenter1, :535
     if (lab1 != label) { std::swap(r1.lo, r1.hi); std::swap(r1.ilo, r1.ihi); }                          // :513-517
     if (lab2 != label) { std::swap(r2.lo, r2.hi); std::swap(r2.ilo, r2.ihi); }                          // :525-528
     *scale = (r2.hi - r2.lo) / (r1.hi - r1.lo);                                                         // :529
     rotation_between(ps.axis[0], pt.axis[0], R);                                                        // :532
-    HIPCHK(hipMemcpy(far, src + 3 * r1.ilo, sizeof far, hipMemcpyDeviceToHost));                        // src_[fidx1] + baryCenter1
     double sR[9], rf[3];
     for (int k = 0; k < 9; ++k) sR[k] = *scale * R[k];
     mv3(sR, far, rf);
@@ -754,15 +799,19 @@ int mvs_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t
 int mvs_init_alignment_sharded(const double* src, int64_t ns, const double* tgt_local, int64_t nt_local, const double* ground_ray,
                                const double* view_ray, mvs_reduce_fn reduce, void* reduce_ctx, double* R, double* t, double* scale) {
     MVS_TRACE();
-    if (!src || ns < 2 || nt_local < 0 || (nt_local > 0 && !tgt_local) || !ground_ray || !view_ray || !reduce || !R || !t || !scale) {
-        mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG;
-    }
-    int rc = need_device();
-    if (rc) return rc;
-    Dev ds, dt; Work w;
-    if ((rc = up(ds, src, (size_t)ns * 3)) || (rc = up(dt, tgt_local, (size_t)nt_local * 3, 3)) || (rc = w.init())) return rc;
+    if (!reduce) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     Reducer red;
     red.fn = reduce; red.ctx = reduce_ctx;
+    auto args_ok = [&]() {                         // (a local stage like the others: the peers must not wait for a rank that was called wrongly)
+        if (src && ns >= 2 && nt_local >= 0 && (nt_local == 0 || tgt_local) && ground_ray && view_ray && R && t && scale) return (int)MVS_OK;
+        mvs_set_error("bad arguments"); return (int)MVS_E_INVALID_ARG;
+    };
+    LOCAL(args_ok());
+    LOCAL(need_device());
+    Dev ds, dt; Work w;
+    LOCAL(up(ds, src, (size_t)ns * 3));
+    LOCAL(up(dt, tgt_local, (size_t)nt_local * 3, 3));
+    LOCAL(w.init());
     return init_alignment_dev(ds.as<double>(), ns, dt.as<double>(), nt_local, ground_ray, view_ray, w, R, t, scale, red);
 }
 
@@ -781,33 +830,49 @@ int mvs_part_recog(const double* tmpl_pts, const int32_t* tmpl_labels, int64_t V
 int mvs_remove_ground_sharded(int64_t* V, double* pts, double* normals, int64_t* F, int32_t* faces, double dist_thres,
                               mvs_reduce_fn reduce, void* reduce_ctx, int rank, double* ground_ray) {
     MVS_TRACE();
-    if (!V || !F || *V < 0 || *F < 0 || (*V > 0 && !pts) || (*F > 0 && !faces) || !ground_ray || !reduce || rank < 0) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
-    int rc = need_device();
-    if (rc) return rc;
-    Dev dp, dn, df; Work w;
-    if ((rc = up(dp, pts, (size_t)*V * 3)) || (normals && (rc = up(dn, normals, (size_t)*V * 3))) || (rc = up(df, faces, (size_t)*F * 3)) || (rc = w.init())) return rc;
+    if (!reduce || !V || !F || !ground_ray) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     Reducer red; red.fn = reduce; red.ctx = reduce_ctx;
+    int rc;
+    Dev dp, dn, df; Work w;
+    auto args_ok = [&]() {
+        if (*V >= 0 && *F >= 0 && (*V == 0 || pts) && (*F == 0 || faces) && rank >= 0) return (int)MVS_OK;
+        mvs_set_error("bad arguments"); return (int)MVS_E_INVALID_ARG;
+    };
+    LOCAL(args_ok());
+    LOCAL(need_device());
+    LOCAL(up(dp, pts, (size_t)*V * 3));
+    if (normals) LOCAL(up(dn, normals, (size_t)*V * 3));
+    LOCAL(up(df, faces, (size_t)*F * 3));
+    LOCAL(w.init());
     int64_t n = *V, f = *F;
     if ((rc = remove_ground_dev(dp.as<double>(), normals ? dn.as<double>() : nullptr, &n, df.as<int32_t>(), &f, dist_thres, ground_ray, w, red, rank))) return rc;
-    if ((rc = down(pts, dp, (size_t)n * 3)) || (normals && (rc = down(normals, dn, (size_t)n * 3))) || (rc = down(faces, df, (size_t)f * 3))) return rc;
+    LOCAL(down(pts, dp, (size_t)n * 3));
+    if (normals) LOCAL(down(normals, dn, (size_t)n * 3));
+    LOCAL(down(faces, df, (size_t)f * 3));
+    if ((rc = red.close())) return rc;
     *V = n; *F = f;
     return MVS_OK;
 }
 
 int mvs_local_alignment_core_sharded(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt_local, const int32_t* t_labels_local,
-                                     int64_t nt_local, uint32_t group_mask, int label, mvs_reduce_fn reduce, void* reduce_ctx,
+                                     int64_t nt_local, uint32_t group_mask, int label, mvs_reduce_fn reduce, void* reduce_ctx, int rank,
                                      double* R, double* t, double* scale) {
     MVS_TRACE();
-    if (!src || !s_labels || ns < 2 || nt_local < 0 || (nt_local > 0 && (!tgt_local || !t_labels_local)) || !reduce || !R || !t || !scale) {
-        mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG;
-    }
-    int rc = need_device();
-    if (rc) return rc;
-    Dev ds, dsl, dt, dtl; Work w;
-    if ((rc = up(ds, src, (size_t)ns * 3)) || (rc = up(dsl, s_labels, (size_t)ns)) || (rc = up(dt, tgt_local, (size_t)nt_local * 3)) ||
-        (rc = up(dtl, t_labels_local, (size_t)nt_local)) || (rc = w.init())) return rc;
+    if (!reduce) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     Reducer red; red.fn = reduce; red.ctx = reduce_ctx;
-    return local_core_dev(ds.as<double>(), dsl.as<int32_t>(), ns, dt.as<double>(), dtl.as<int32_t>(), nt_local, group_mask, label, w, R, t, scale, red);
+    Dev ds, dsl, dt, dtl; Work w;
+    auto args_ok = [&]() {
+        if (src && s_labels && ns >= 2 && nt_local >= 0 && (nt_local == 0 || (tgt_local && t_labels_local)) && rank >= 0 && R && t && scale) return (int)MVS_OK;
+        mvs_set_error("bad arguments"); return (int)MVS_E_INVALID_ARG;
+    };
+    LOCAL(args_ok());
+    LOCAL(need_device());
+    LOCAL(up(ds, src, (size_t)ns * 3));
+    LOCAL(up(dsl, s_labels, (size_t)ns));
+    LOCAL(up(dt, tgt_local, (size_t)nt_local * 3));
+    LOCAL(up(dtl, t_labels_local, (size_t)nt_local));
+    LOCAL(w.init());
+    return local_core_dev(ds.as<double>(), dsl.as<int32_t>(), ns, dt.as<double>(), dtl.as<int32_t>(), nt_local, group_mask, label, w, R, t, scale, red, rank);
 }
 
 int mvs_local_alignment_core(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels, int64_t nt,
@@ -821,6 +886,38 @@ int mvs_local_alignment_core(const double* src, const int32_t* s_labels, int64_t
     return local_core_dev(ds.as<double>(), dsl.as<int32_t>(), ns, dt.as<double>(), dtl.as<int32_t>(), nt, group_mask, label, w, R, t, scale);
 }
 
+// Alignment::Align on device arrays: the scan (tgt / normals / facets / labels) and the template (src / normals / labels) already in HBM
+static int align_core_dev(double* ds, double* dsn, const int32_t* dsl, int64_t ns, double* dt, double* dtn, int64_t* nt, int32_t* dtf, int64_t* nf,
+                          int32_t* dtl, const double* view_ray, double dist_thres, double* ground_ray, Work& w) {
+    enum { HEAD, NECK, LUA, LLA, LH, RUA, RLA, RH, LT, LS, LF, RT, RS, RF, TRUNCUS, HIP };   // PartRecognition.h:13-30
+    int rc;
+    int64_t n = *nt, f = *nf;
+    double gr[3], R[9], t[3], scale;
+    if ((rc = remove_ground_dev(dt, dtn, &n, dtf, &f, dist_thres, gr, w))) return rc;                                                  // Alignment.cpp:21
+    if (ground_ray) std::memcpy(ground_ray, gr, sizeof gr);
+    if ((rc = init_alignment_dev(ds, ns, dt, n, gr, view_ray, w, R, t, &scale))) return rc;                                           // :27
+    double M[9];
+    for (int k = 0; k < 9; ++k) M[k] = scale * R[k];
+    if ((rc = apply_masked_dev(ds, dsn, ns, nullptr, 0, M, R, t))) return rc;                                                         // :31-34
+    if ((rc = part_recog_dev(ds, dsl, ns, dt, n, dtl))) return rc;                                                                    // :38-49
+    Pca p1, p2;                                                                                                                       // :56-64 neck centroids
+    if ((rc = pca_dev(ds, ns, dsl, 1u << NECK, w, &p1)) || (rc = pca_dev(dt, n, dtl, 1u << NECK, w, &p2))) return rc;
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, off[3] = {p2.bary[0] - p1.bary[0], p2.bary[1] - p1.bary[1], p2.bary[2] - p1.bary[2]};
+    if ((rc = apply_masked_dev(ds, nullptr, ns, nullptr, 0, I, I, off))) return rc;
+    struct G { uint32_t group, apply; int label; };                                                                                  // :378-419
+    const G groups[4] = {{1u << LUA | 1u << LLA | 1u << LH, 1u << LUA | 1u << LLA | 1u << LH, LH},
+                         {1u << RUA | 1u << RLA | 1u << RH, 1u << RUA | 1u << RLA | 1u << RH, RH},
+                         {1u << LT | 1u << LS, 1u << LT | 1u << LS | 1u << LF, LS},
+                         {1u << RT | 1u << RS, 1u << RT | 1u << RS | 1u << RF, RS}};
+    for (const G& g : groups) {
+        if ((rc = local_core_dev(ds, dsl, ns, dt, dtl, n, g.group, g.label, w, R, t, &scale))) return rc;
+        for (int k = 0; k < 9; ++k) M[k] = scale * R[k];
+        if ((rc = apply_masked_dev(ds, dsn, ns, dsl, g.apply, M, R, t))) return rc;
+    }
+    *nt = n; *nf = f;
+    return MVS_OK;
+}
+
 int mvs_align(double* src, double* s_normals, int64_t ns, const int32_t* s_labels, double* tgt, double* t_normals, int64_t* nt,
               int32_t* t_faces, int64_t* nf, const double* view_ray, double dist_thres, int32_t* t_labels, double* ground_ray) {
     MVS_TRACE();
@@ -829,36 +926,37 @@ int mvs_align(double* src, double* s_normals, int64_t ns, const int32_t* s_label
     for (int64_t i = 0; i < ns; ++i) if (s_labels[i] < 0 || s_labels[i] > 31) { mvs_set_error("labels must be 0..31"); return MVS_E_INVALID_ARG; }
     int rc = need_device();
     if (rc) return rc;
-    enum { HEAD, NECK, LUA, LLA, LH, RUA, RLA, RH, LT, LS, LF, RT, RS, RF, TRUNCUS, HIP };   // PartRecognition.h:13-30
     Dev ds, dsn, dsl, dt, dtn, dtf, dtl; Work w;
     if ((rc = up(ds, src, (size_t)ns * 3)) || (rc = up(dsn, s_normals, (size_t)ns * 3)) || (rc = up(dsl, s_labels, (size_t)ns)) ||
         (rc = up(dt, tgt, (size_t)*nt * 3)) || (rc = up(dtn, t_normals, (size_t)*nt * 3)) || (rc = up(dtf, t_faces, (size_t)*nf * 3)) ||
         (rc = dtl.alloc(sizeof(int32_t) * *nt)) || (rc = w.init())) return rc;
     int64_t n = *nt, f = *nf;
-    double gr[3], R[9], t[3], scale;
-    if ((rc = remove_ground_dev(dt.as<double>(), dtn.as<double>(), &n, dtf.as<int32_t>(), &f, dist_thres, gr, w))) return rc;          // Alignment.cpp:21
-    if (ground_ray) std::memcpy(ground_ray, gr, sizeof gr);
-    if ((rc = init_alignment_dev(ds.as<double>(), ns, dt.as<double>(), n, gr, view_ray, w, R, t, &scale))) return rc;                  // :27
-    double M[9];
-    for (int k = 0; k < 9; ++k) M[k] = scale * R[k];
-    if ((rc = apply_masked_dev(ds.as<double>(), dsn.as<double>(), ns, nullptr, 0, M, R, t))) return rc;                                // :31-34
-    if ((rc = part_recog_dev(ds.as<double>(), dsl.as<int32_t>(), ns, dt.as<double>(), n, dtl.as<int32_t>()))) return rc;               // :38-49
-    Pca p1, p2;                                                                                                                       // :56-64 neck centroids
-    if ((rc = pca_dev(ds.as<double>(), ns, dsl.as<int32_t>(), 1u << NECK, w, &p1)) || (rc = pca_dev(dt.as<double>(), n, dtl.as<int32_t>(), 1u << NECK, w, &p2))) return rc;
-    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, off[3] = {p2.bary[0] - p1.bary[0], p2.bary[1] - p1.bary[1], p2.bary[2] - p1.bary[2]};
-    if ((rc = apply_masked_dev(ds.as<double>(), nullptr, ns, nullptr, 0, I, I, off))) return rc;
-    struct G { uint32_t group, apply; int label; };                                                                                  // :378-419
-    const G groups[4] = {{1u << LUA | 1u << LLA | 1u << LH, 1u << LUA | 1u << LLA | 1u << LH, LH},
-                         {1u << RUA | 1u << RLA | 1u << RH, 1u << RUA | 1u << RLA | 1u << RH, RH},
-                         {1u << LT | 1u << LS, 1u << LT | 1u << LS | 1u << LF, LS},
-                         {1u << RT | 1u << RS, 1u << RT | 1u << RS | 1u << RF, RS}};
-    for (const G& g : groups) {
-        if ((rc = local_core_dev(ds.as<double>(), dsl.as<int32_t>(), ns, dt.as<double>(), dtl.as<int32_t>(), n, g.group, g.label, w, R, t, &scale))) return rc;
-        for (int k = 0; k < 9; ++k) M[k] = scale * R[k];
-        if ((rc = apply_masked_dev(ds.as<double>(), dsn.as<double>(), ns, dsl.as<int32_t>(), g.apply, M, R, t))) return rc;
-    }
+    if ((rc = align_core_dev(ds.as<double>(), dsn.as<double>(), dsl.as<int32_t>(), ns, dt.as<double>(), dtn.as<double>(), &n, dtf.as<int32_t>(), &f,
+                             dtl.as<int32_t>(), view_ray, dist_thres, ground_ray, w))) return rc;
     if ((rc = down(src, ds, (size_t)ns * 3)) || (rc = down(s_normals, dsn, (size_t)ns * 3)) || (rc = down(tgt, dt, (size_t)n * 3)) ||
         (rc = down(t_normals, dtn, (size_t)n * 3)) || (rc = down(t_faces, dtf, (size_t)f * 3)) || (rc = down(t_labels, dtl, (size_t)n))) return rc;
+    *nt = n; *nf = f;
+    return MVS_OK;
+}
+
+// ... with the scan resident in HBM (as mvs_depth_to_model_dev / mvs_srt_apply_dev leave it, and as mvs_deform_set_target_dev takes it):
+// tgt / t_normals / t_faces / t_labels are DEVICE arrays, trimmed in place; the template (a few thousand vertices) stays a host
+// argument.  The host-pointer entry moves ~150 MB up and ~140 MB down for a 2 M-vertex scan: half of its 25 ms.
+int mvs_align_dev(double* src, double* s_normals, int64_t ns, const int32_t* s_labels, double* tgt_dev, double* t_normals_dev, int64_t* nt,
+                  int32_t* t_faces_dev, int64_t* nf, const double* view_ray, double dist_thres, int32_t* t_labels_dev, double* ground_ray) {
+    MVS_TRACE();
+    if (!src || !s_normals || !s_labels || !tgt_dev || !t_normals_dev || !nt || !nf || !view_ray || !t_labels_dev || ns < 2 || *nt < 2 || *nf < 0 ||
+        (*nf > 0 && !t_faces_dev)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    for (int64_t i = 0; i < ns; ++i) if (s_labels[i] < 0 || s_labels[i] > 31) { mvs_set_error("labels must be 0..31"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());                        // (the caller's arrays come from some other stream)
+    Dev ds, dsn, dsl; Work w;
+    if ((rc = up(ds, src, (size_t)ns * 3)) || (rc = up(dsn, s_normals, (size_t)ns * 3)) || (rc = up(dsl, s_labels, (size_t)ns)) || (rc = w.init())) return rc;
+    int64_t n = *nt, f = *nf;
+    if ((rc = align_core_dev(ds.as<double>(), dsn.as<double>(), dsl.as<int32_t>(), ns, tgt_dev, t_normals_dev, &n, t_faces_dev, &f, t_labels_dev, view_ray,
+                             dist_thres, ground_ray, w))) return rc;
+    if ((rc = down(src, ds, (size_t)ns * 3)) || (rc = down(s_normals, dsn, (size_t)ns * 3))) return rc;
     *nt = n; *nf = f;
     return MVS_OK;
 }

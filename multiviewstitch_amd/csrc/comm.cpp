@@ -67,7 +67,7 @@ int check_nccl(ncclResult_t e, const char* what) {
 struct mvs_comm_s {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1, device = 0;
-    double* scratch = nullptr;               // 16 doubles on the device (mvs_comm_reduce)
+    double* scratch = nullptr;               // 24 doubles on the device (mvs_comm_reduce)
     double* hscratch = nullptr;              // ... and their pinned host side
     hipStream_t stream = nullptr;            // the communicator's own stream (mvs_comm_reduce): never the legacy default stream
     int exchange = 0;                        // MVS_EXCHANGE_AUTO / _ALL_GATHER / _OWNER (mvs_comm_set_exchange)
@@ -120,11 +120,11 @@ int mvs_comm_destroy(mvs_comm_t c) {
 int mvs_comm_reduce(void* ctx, double* v, int n, int op) {
     MVS_TRACE();
     mvs_comm_t c = (mvs_comm_t)ctx;
-    if (!c || !v || n < 1 || n > 16 || (op != 0 && op != 1)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    if (!c || !v || n < 1 || n > 24 || (op != 0 && op != 1)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
     if (c->nranks == 1) return MVS_OK;
     HIPCHK(hipSetDevice(c->device));
     if (!c->stream) HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    if (!c->scratch) HIPCHK(hipMalloc(&c->scratch, sizeof(double) * 16));
+    if (!c->scratch) HIPCHK(hipMalloc(&c->scratch, sizeof(double) * 24));
     if (!c->hscratch) HIPCHK(hipHostMalloc((void**)&c->hscratch, sizeof(double) * 16, hipHostMallocDefault));
     // upload, all-reduce and download are ordered on the communicator's own stream; only that stream is waited for
     std::memcpy(c->hscratch, v, sizeof(double) * n);

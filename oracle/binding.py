@@ -438,15 +438,15 @@ def remove_ground_sharded(pts, nrm, faces, reducer, rank, dist_thres=0.81):
     return gr, p[:V.value], (n[:V.value] if n is not None else None), f[:F.value]
 
 
-def local_alignment_core_sharded(src, s_labels, tgt_local, t_labels_local, group_mask, label, reducer):
+def local_alignment_core_sharded(src, s_labels, tgt_local, t_labels_local, group_mask, label, reducer, rank):
     s, t = _c(src, np.float64), _c(np.asarray(tgt_local, np.float64).reshape(-1, 3), np.float64)
     sl, tl = _c(s_labels, np.int32), _c(np.asarray(t_labels_local, np.int32).reshape(-1), np.int32)
     R, tr, sc = np.empty((3, 3)), np.empty(3), C.c_double()
     fn = lib().orc_local_alignment_core_sharded
     fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p,
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                    C.c_void_p, C.c_void_p, C.c_void_p]
-    rc = fn(s.ctypes.data, sl.ctypes.data, len(s), t.ctypes.data, tl.ctypes.data, len(t), group_mask, label, C.cast(reducer, C.c_void_p), None,
+    rc = fn(s.ctypes.data, sl.ctypes.data, len(s), t.ctypes.data, tl.ctypes.data, len(t), group_mask, label, C.cast(reducer, C.c_void_p), None, rank,
             R.ctypes.data, tr.ctypes.data, C.addressof(sc))
     if rc:
         raise RuntimeError(f"orc_local_alignment_core_sharded -> {rc}")

@@ -140,7 +140,8 @@ typedef int (*orc_reduce_fn)(void* ctx, double* v, int n, int op);
 int  orc_remove_ground_sharded(int64_t* V, double* pts, double* nrm, int64_t* F, int32_t* faces, double dist_thres, orc_reduce_fn reduce,
                                void* ctx, int rank, double* ground_ray);
 int  orc_local_alignment_core_sharded(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels,
-                                      int64_t nt, uint32_t group_mask, int label, orc_reduce_fn reduce, void* ctx, double* R, double* t, double* scale);
+                                      int64_t nt, uint32_t group_mask, int label, orc_reduce_fn reduce, void* ctx, int rank, double* R, double* t,
+                                      double* scale);
 int  orc_init_alignment_sharded(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray,
                                 const double* view_ray, orc_reduce_fn reduce, void* ctx, double* R, double* t, double* scale);
 int  orc_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray,

@@ -359,7 +359,8 @@ void orc_part_recog(const double* tmpl, const int32_t* tmpl_labels, int64_t V, c
 // Alignment::LocalAlignmentCore (Alignment.cpp:423-546) on the points of src/tgt selected by group_mask;
 // slabel == tlabel == `label`.  Returns scale, R, translate.
 int orc_local_alignment_core_sharded(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels,
-                                     int64_t nt, uint32_t group_mask, int label, orc_reduce_fn reduce, void* ctx, double* R, double* t, double* scale) {
+                                     int64_t nt, uint32_t group_mask, int label, orc_reduce_fn reduce, void* ctx, int rank, double* R, double* t,
+                                     double* scale) {
     Reducer red;
     red.fn = reduce; red.ctx = ctx;
     Pca ps, pt;
@@ -395,7 +396,10 @@ int orc_local_alignment_core_sharded(const double* src, const int32_t* s_labels,
         double e[2] = {r2.lo, -r2.hi};
         const double myhi = r2.hi;
         if (!red.run(e, 2, 1)) return -8;
-        double lv = (r2.ihi >= 0 && myhi == -e[1]) ? (double)lab2 : INFINITY;
+        // the FIRST point of the largest projection in the stitched scan (strict >, :521): the lowest rank that reaches it says its label
+        double who = (r2.ihi >= 0 && myhi == -e[1]) ? (double)rank : INFINITY;
+        if (!red.run(&who, 1, 1)) return -8;
+        double lv = who == (double)rank ? (double)lab2 : INFINITY;
         if (!red.run(&lv, 1, 1)) return -8;
         if (!(lv < INFINITY)) return -9;
         r2.lo = e[0]; r2.hi = -e[1]; r2.ilo = r2.ihi = 0; lab2 = (int)lv;
@@ -412,7 +416,7 @@ int orc_local_alignment_core_sharded(const double* src, const int32_t* s_labels,
 }
 int orc_local_alignment_core(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels,
                              int64_t nt, uint32_t group_mask, int label, double* R, double* t, double* scale) {
-    return orc_local_alignment_core_sharded(src, s_labels, ns, tgt, t_labels, nt, group_mask, label, nullptr, nullptr, R, t, scale);
+    return orc_local_alignment_core_sharded(src, s_labels, ns, tgt, t_labels, nt, group_mask, label, nullptr, nullptr, 0, R, t, scale);
 }
 
 }  // extern "C"

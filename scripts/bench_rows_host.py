@@ -60,6 +60,21 @@ g, _ = best(lambda: A.Align(sc["src"], sc["s_nrm"], sc["s_labels"], sc["tgt"], s
 c, _ = best(lambda: O.align(sc["src"], sc["s_nrm"], sc["s_labels"], sc["tgt"], sc["t_nrm"], sc["t_faces"], sc["view_ray"], 0.81), 1)
 row("mvs_align", scan + f", {Vs} template vertices", g, c, "Alignment::Align, Alignment.cpp:11-76 (host pointers: ~150 MB up, ~140 MB down per call)")
 
+import torch
+dv = torch.device("cuda", 0)
+h = [torch.from_numpy(sc["tgt"]), torch.from_numpy(sc["t_nrm"]), torch.from_numpy(np.ascontiguousarray(sc["t_faces"], np.int32))]
+dt, dtn, dtf = (x.to(dv) for x in h)
+dl = torch.empty(Vt, dtype=torch.int32, device=dv)
+ts = []
+for _ in range(REPS):
+    dt.copy_(h[0]); dtn.copy_(h[1]); dtf.copy_(h[2])
+    torch.cuda.synchronize()
+    a = time.perf_counter()
+    A.AlignDev(sc["src"], sc["s_nrm"], sc["s_labels"], dt.data_ptr(), dtn.data_ptr(), Vt, dtf.data_ptr(), Ft, dl.data_ptr(), sc["view_ray"], 0.81)
+    ts.append(time.perf_counter() - a)
+row("mvs_align_dev", scan + f", {Vs} template vertices", 1e3 * min(ts), c, "the same with the scan resident in HBM (template up and down only)")
+del dt, dtn, dtf, dl
+
 # ---------------------------------------------------------------- SRT fit, RANSAC, RemoveOutliers
 sc0 = S.make_scene(1)
 s0, R0, t0 = sc0.srt[0]

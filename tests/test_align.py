@@ -199,3 +199,29 @@ def test_gpu_alignment_at_scan_scale_matches_oracle(al, oracle):
     assert np.array_equal(g["t_facets"], o["t_facets"]) and np.array_equal(g["t_labels"], o["t_labels"])
     assert np.abs(g["ground_ray"] - o["ground_ray"]).max() < 1e-9
     assert np.abs(g["src"] - o["src"]).max() < 1e-8 and np.abs(g["s_normals"] - o["s_normals"]).max() < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes", [(30, 60), (30, 450)])
+def test_gpu_align_on_device_arrays_gives_the_bits_of_the_host_entry(al, sizes):
+    """mvs_align_dev (include/mvs.h) — Alignment::Align (R/Alignment/Alignment.cpp:11-76) with the scan resident in HBM, as
+    mvs_depth_to_model_dev / mvs_srt_apply_dev leave it: trimmed scan arrays, labels, counts, moved template and ground ray are
+    the BITS of the host-pointer entry (which the tests above check against the oracle), at test and at scan scale."""
+    import torch
+    sc = body_scene(5, *sizes)
+    A = al.Alignment()
+    g = A.Align(sc["src"], sc["s_nrm"], sc["s_labels"], sc["tgt"], sc["t_nrm"], sc["t_faces"], sc["view_ray"], 0.81)
+    dev = torch.device("cuda", 0)
+    t, tn = torch.from_numpy(sc["tgt"]).to(dev), torch.from_numpy(sc["t_nrm"]).to(dev)
+    tf = torch.from_numpy(np.ascontiguousarray(sc["t_faces"], np.int32)).to(dev)
+    tl = torch.full((len(sc["tgt"]),), -7, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    d = A.AlignDev(sc["src"], sc["s_nrm"], sc["s_labels"], t.data_ptr(), tn.data_ptr(), len(sc["tgt"]), tf.data_ptr(), len(sc["t_faces"]), tl.data_ptr(),
+                   sc["view_ray"], 0.81)
+    n, f = d["n_t"], d["n_f"]
+    assert n == len(g["tgt"]) and f == len(g["t_facets"]) and n < len(sc["tgt"])
+    assert np.array_equal(t[:n].cpu().numpy(), g["tgt"]) and np.array_equal(tn[:n].cpu().numpy(), g["t_normals"])
+    assert np.array_equal(tf[:f].cpu().numpy(), g["t_facets"]) and np.array_equal(tl[:n].cpu().numpy(), g["t_labels"])
+    assert np.array_equal(d["src"], g["src"]) and np.array_equal(d["s_normals"], g["s_normals"]) and np.array_equal(d["ground_ray"], g["ground_ray"])
+    with pytest.raises(Exception):
+        A.AlignDev(sc["src"], sc["s_nrm"], sc["s_labels"], 0, tn.data_ptr(), n, tf.data_ptr(), f, tl.data_ptr(), sc["view_ray"], 0.81)

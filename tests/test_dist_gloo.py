@@ -348,10 +348,29 @@ def _ground_worker(rank, world, port, q, engine):
     sl = slice(cuts[rank], cuts[rank + 1])
     group, label = (1 << 2) | (1 << 3) | (1 << 4), 4                   # left arm, LeftHand
     if engine:
-        R, t, s = A.LocalAlignmentCoreSharded(b["src"], b["s_labels"], b["tgt"][sl], tl_full[sl], group, label, red)
+        R, t, s = A.LocalAlignmentCoreSharded(b["src"], b["s_labels"], b["tgt"][sl], tl_full[sl], group, label, red, rank)
     else:
-        R, t, s = O.local_alignment_core_sharded(b["src"], b["s_labels"], b["tgt"][sl], tl_full[sl], group, label, red)
-    q.put((rank, gr, p2, f2, R, t, s))
+        R, t, s = O.local_alignment_core_sharded(b["src"], b["s_labels"], b["tgt"][sl], tl_full[sl], group, label, red, rank)
+    # the far end is reached on two ranks at once (the arm's points on rank 0 AND, relabelled, on rank 1): the reference's loop
+    # keeps the first point of the stitched scan (strict >, Alignment.cpp:521), i.e. rank 0's label — not the smaller label
+    arm = np.isin(tl_full, (2, 3, 4))
+    tp_, tl_ = (b["tgt"][arm], tl_full[arm] if rank == 0 else np.full(int(arm.sum()), 3, np.int32)) if rank < 2 else (np.zeros((0, 3)), np.zeros(0, np.int32))
+    ties = []
+    for lab in (4, 2):
+        if engine:
+            ties.append(A.LocalAlignmentCoreSharded(b["src"], b["s_labels"], tp_, tl_, group, lab, red, rank))
+        else:
+            ties.append(O.local_alignment_core_sharded(b["src"], b["s_labels"], tp_, tl_, group, lab, red, rank))
+    # a rank that fails in a LOCAL stage (here: called with a negative rank) must not leave the others in the next reduce
+    failed = None
+    if engine:
+        try:
+            A.LocalAlignmentCoreSharded(b["src"], b["s_labels"], b["tgt"][sl], tl_full[sl], group, label, red, -1 if rank == 1 else rank)
+            failed = ""
+        except Exception as e:                                          # noqa: BLE001
+            failed = str(e)
+        A.LocalAlignmentCoreSharded(b["src"], b["s_labels"], b["tgt"][sl], tl_full[sl], group, label, red, rank)   # and the next call is in step again
+    q.put((rank, gr, p2, f2, R, t, s, ties, failed))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -389,8 +408,21 @@ def _run_ground(world, engine):
     tl_full = O.part_recog(b["src"], b["s_labels"], b["tgt"])
     want = O.local_alignment_core(b["src"], b["s_labels"], b["tgt"], tl_full, (1 << 2) | (1 << 3) | (1 << 4), 4)
     for r in range(1, world):
-        assert all(np.array_equal(np.asarray(a), np.asarray(c)) for a, c in zip(res[0][3:], res[r][3:]))
+        assert all(np.array_equal(np.asarray(a), np.asarray(c)) for a, c in zip(res[0][3:6], res[r][3:6]))
     assert np.abs(res[0][3] - want[0]).max() < 1e-9 and np.abs(res[0][4] - want[1]).max() < 1e-8 and abs(res[0][5] - want[2]) < 1e-10
+    arm = np.isin(tl_full, (2, 3, 4))
+    P2, L2 = np.concatenate([b["tgt"][arm], b["tgt"][arm]]), np.concatenate([tl_full[arm], np.full(int(arm.sum()), 3, np.int32)])
+    differ = 0
+    for k, lab in enumerate((4, 2)):
+        want = O.local_alignment_core(b["src"], b["s_labels"], P2, L2, (1 << 2) | (1 << 3) | (1 << 4), lab)
+        by_label = O.local_alignment_core(b["src"], b["s_labels"], P2[::-1].copy(), L2[::-1].copy(), (1 << 2) | (1 << 3) | (1 << 4), lab)   # label 3 first
+        differ += abs(want[2] - by_label[2]) > 1e-6
+        for r in range(world):
+            g = res[r][6][k]
+            assert np.abs(g[0] - want[0]).max() < 1e-9 and np.abs(g[1] - want[1]).max() < 1e-8 and abs(g[2] - want[2]) < 1e-10
+    assert differ >= 1                                                   # (the order of the tied points does decide one of the two)
+    if engine:
+        assert "bad arguments" in res[1][7] and "another rank failed" in res[0][7]
 
 
 @pytest.mark.parametrize("world", [2, 3])
