@@ -71,6 +71,10 @@ const char* mvs_last_error(void);     /* thread-local message of the last failur
 int  mvs_abi_version(void);
 int  mvs_device_count(void);          /* 0 when no GPU; never fails               */
 int  mvs_set_device(int device);      /* device used by handles created afterwards */
+/* The host-pointer entries (mvs_align, mvs_srt_*, mvs_depth_*, ...) keep the device scratch they used for the next call (up to
+ * MVS_SCRATCH_CACHE_MB megabytes, default 4096, 0 = keep nothing: a call on a 2 M-vertex scan makes ~40 allocations and releasing
+ * them was 40 % of its time).  mvs_trim() gives the kept blocks of every device back to the runtime. */
+int  mvs_trim(void);
 int  mvs_device_name(char* buf, int buflen);
 
 /* ---------------------------------------------------------------- camera -- */

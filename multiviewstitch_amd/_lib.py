@@ -78,6 +78,7 @@ _SIGS = {
     "mvs_abi_version": (C.c_int, []),
     "mvs_device_count": (C.c_int, []),
     "mvs_set_device": (C.c_int, [_I32]),
+    "mvs_trim": (C.c_int, []),
     "mvs_device_name": (C.c_int, [C.c_char_p, _I32]),
     "mvs_set_trace": (C.c_int, [_VP, _VP]),
     "mvs_set_trace_roctx": (C.c_int, [_I32]),

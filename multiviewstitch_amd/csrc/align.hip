@@ -236,40 +236,109 @@ __global__ void k_cc_init(int32_t* __restrict__ parent, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) parent[i] = (int32_t)i;
 }
-__device__ inline int cc_find(const int32_t* parent, int x) {
-    int p = parent[x];
-    while (p != x) { x = p; p = parent[x]; }                 // parents only ever decrease: terminates
-    return x;
+// Union-find without rounds (the shape of ECL-CC; round 3 ran hook / compress rounds with a host round trip each: 3 x 344 us +
+// 3 x 26 us on a 4 M-facet scan, the first round 1 ms on chains as long as a scan line):
+//   1. k_cc_low: every vertex under its LOWEST neighbour (one atomic minimum per edge, spread over all entries) — already a
+//      forest of the right components' parts; k_cc_flat makes every entry point at its tree's root;
+//   2. k_cc_union: an edge whose ends have different representatives puts the larger root under the smaller by
+//      compare-and-swap (a failed swap continues from the value it returned); few edges are left to do so after 1;
+//   3. k_cc_roots: every entry to its root.
+// Representatives are found with path HALVING (every visited entry is moved to its grandparent, plain stores).  Parents only
+// ever decrease along a path, every value an entry ever held is an ancestor of it, only non-roots are written by plain stores
+// and roots change through the swap alone, so a stale read (per-XCD L2s are not coherent) or a lost halving store costs steps,
+// never correctness.  Afterwards parent[v] = the LOWEST index of v's component — which representative UnionSet's Merge order
+// gives the reference is not observable (Alignment.cpp:628-653 only compares them).
+__device__ inline int cc_load(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // past this CU's L1
+__device__ inline int cc_rep(int32_t* parent, int x) {
+    int cur = cc_load(&parent[x]);
+    if (cur != x) {
+        int prev = x, next;
+        while (cur > (next = cc_load(&parent[cur]))) {
+            parent[prev] = next;
+            prev = cur;
+            cur = next;
+        }
+    }
+    return cur;
 }
-__global__ void k_cc_hook(const int32_t* __restrict__ faces, int64_t F, int32_t* parent, int32_t* __restrict__ changed) {
+__global__ void k_cc_low(const int32_t* __restrict__ faces, int64_t F, int32_t* parent) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
-    const int a = faces[3 * f];
-    for (int k = 1; k < 3; ++k) {                            // Merge(f0, f1), Merge(f0, f2)  (Alignment.cpp:623-626)
-        int ra = cc_find(parent, a), rb = cc_find(parent, faces[3 * f + k]);
-        if (ra == rb) continue;
-        if (ra > rb) { const int t = ra; ra = rb; rb = t; }
-        atomicMin(&parent[rb], ra);
-        *changed = 1;
-    }
+    const int a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
+    const int lo = min(a, min(b, c));
+    if (a != lo) atomicMin(&parent[a], lo);
+    if (b != lo) atomicMin(&parent[b], lo);
+    if (c != lo) atomicMin(&parent[c], lo);
 }
-__global__ void k_cc_compress(int32_t* parent, int64_t n) {
+__global__ void k_cc_flat(int32_t* parent, int64_t n) {                 // (between 1 and 2: shortens, need not be exact)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) parent[i] = cc_find(parent, (int)i);
+    if (i >= n) return;
+    const int r = cc_rep(parent, (int)i);
+    if (r != (int)i) parent[i] = r;                         // (a root's entry is left to the swaps)
 }
-__global__ void k_cc_sizes(const int32_t* __restrict__ parent, int64_t n, int32_t* __restrict__ size) {
+// the LAST pass writes nothing but a thread's own entry: a halving store of another thread (an ancestor, not the root) landing
+// behind it would leave the entry short of the root, and k_cc_keep compares entries with the root
+__global__ void k_cc_roots(int32_t* parent, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int root = i < n ? parent[i] : -1;
-    // one atomic per distinct root of the wave (a mesh has few components: usually one per wave)
-    unsigned long long todo = __ballot(root >= 0);
+    if (i >= n) return;
+    int x = (int)i, p = cc_load(&parent[x]);
+    while (p != x) { x = p; p = cc_load(&parent[x]); }
+    parent[i] = x;
+}
+__global__ void k_cc_union(const int32_t* __restrict__ faces, int64_t F, int32_t* parent) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = f < F;                                    // (no early return: the lanes of a wave vote below)
     const int lane = threadIdx.x & 63;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int r = __shfl(root, leader, 64);
-        const unsigned long long same = __ballot(root == r);
-        if (lane == leader) atomicAdd(&size[r], __popcll(same));
-        todo &= ~same;
+    const int a = in ? faces[3 * f] : 0;
+    for (int k = 1; k < 3; ++k) {                            // Merge(f0, f1), Merge(f0, f2)  (Alignment.cpp:623-626)
+        int ra = in ? cc_rep(parent, a) : 0, rb = in ? cc_rep(parent, faces[3 * f + k]) : 0;
+        bool need = ra != rb;
+        while (__any(need)) {
+            if (need && ra < rb) { const int t = ra; ra = rb; rb = t; }          // ra, the larger, goes under rb
+            // the facets of a wave lie side by side: where two trees meet, its lanes want the SAME swap (and thousands of waves
+            // want it at once — swaps on one word queue up behind each other): one lane per distinct pair tries it
+            unsigned long long todo = __ballot(need);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int la = __shfl(ra, leader, 64), lb = __shfl(rb, leader, 64);
+                const bool mine = need && ra == la && rb == lb;
+                int old = 0;
+                if (lane == leader) old = atomicCAS(&parent[la], la, lb);
+                old = __shfl(old, leader, 64);
+                if (mine) { if (old == la) need = false; else ra = old; }        // no root (any more): go on from its parent
+                todo &= ~__ballot(mine);
+            }
+            if (need) { ra = cc_rep(parent, ra); rb = cc_rep(parent, rb); need = ra != rb; }
+        }
     }
+}
+// component sizes: size[root] += members.  A mesh has few components (usually ONE holds nearly every vertex), and two million
+// adds to one word — even one per wave — queue up behind each other (341 us); a thread counts the run of equal roots along its
+// grid-stride walk and the wave adds ONE sum per distinct root it ends with: ~2 K adds to the big root.
+__global__ __launch_bounds__(TPB) void k_cc_sizes(const int32_t* __restrict__ parent, int64_t n, int32_t* __restrict__ size) {
+    int cur = -1, cnt = 0;
+    const int lane = threadIdx.x & 63;
+    auto flush = [&](bool want) {                            // the lanes that `want` add (cur, cnt): one add per distinct root of the wave
+        unsigned long long todo = __ballot(want);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int r = __shfl(cur, leader, 64);
+            const bool mine = want && cur == r;
+            int sum = mine ? cnt : 0;
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            if (lane == leader) atomicAdd(&size[r], sum);
+            todo &= ~__ballot(mine);
+        }
+    };
+    for (int64_t base = (int64_t)blockIdx.x * TPB; base < n; base += (int64_t)NBLK * TPB) {      // (uniform trip count per wave)
+        const int64_t i = base + threadIdx.x;
+        const int r = i < n ? parent[i] : cur;
+        const bool turn = cnt > 0 && r != cur;               // (the big component's run ends for EVERY thread where the next component starts)
+        if (__any(turn)) { flush(turn); if (turn) cnt = 0; }
+        cur = r;
+        if (i < n) ++cnt;
+    }
+    flush(cnt > 0);
 }
 // largest component, ties -> lowest root: part[b] = {size, root}
 __global__ __launch_bounds__(TPB) void k_cc_best(const int32_t* __restrict__ size, int64_t n, long long* __restrict__ part) {
@@ -307,10 +376,10 @@ __global__ void k_apply_masked(double* __restrict__ pts, double* __restrict__ nr
 }
 
 // ------------------------------------------------------------------------------------ host side ----
-struct Dev {                 // RAII scratch
+struct Dev {                 // RAII scratch from the pool (scratch.cpp): every launch of this file is on the legacy default stream
     void* p = nullptr;
-    int alloc(size_t b) { return mvs_check_hip(hipMalloc(&p, b ? b : 1), "hipMalloc"); }
-    ~Dev() { if (p) (void)hipFree(p); }
+    int alloc(size_t b) { return mvs_scratch_alloc(&p, b ? b : 1); }
+    ~Dev() { mvs_scratch_free(p); }
     template <class T> T* as() const { return (T*)p; }
 };
 inline dim3 blocks(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, (n + TPB - 1) / TPB)); }
@@ -497,30 +566,26 @@ int compact_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F
 // and every other rank keeps nothing.
 int retain_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F, const Reducer& red = Reducer(), int rank = 0) {
     if (*n <= 0 && !red.fn) return MVS_OK;
-    Dev parent, size, keep, flag, part;
+    Dev parent, size, keep, part;
     int rc;
     const int64_t n1 = std::max<int64_t>(*n, 1);
     LOCAL(parent.alloc(sizeof(int32_t) * n1));
     LOCAL(size.alloc(sizeof(int32_t) * n1));
     LOCAL(keep.alloc(sizeof(int32_t) * (n1 + 1)));
-    LOCAL(flag.alloc(sizeof(int32_t)));
     LOCAL(part.alloc(sizeof(long long) * 2 * NBLK));
     long long bs = -1, br = -1;
     if (*n > 0 && red.live()) {
         k_cc_init<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n);
-        for (int round = 0; round < 64 && *F > 0 && red.live(); ++round) {             // O(log) rounds in practice; bounded
-            int32_t changed = 0;
-            LOCAL_HIP(hipMemset(flag.p, 0, sizeof(int32_t)));
-            if (!red.live()) break;
-            k_cc_hook<<<blocks(*F), dim3(TPB)>>>(faces, *F, parent.as<int32_t>(), flag.as<int32_t>());
-            k_cc_compress<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n);
-            LOCAL_HIP(hipMemcpy(&changed, flag.p, sizeof changed, hipMemcpyDeviceToHost));
-            if (!changed) break;
+        if (*F > 0) {
+            k_cc_low<<<blocks(*F), dim3(TPB)>>>(faces, *F, parent.as<int32_t>());
+            k_cc_flat<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n);
+            k_cc_union<<<blocks(*F), dim3(TPB)>>>(faces, *F, parent.as<int32_t>());
+            k_cc_roots<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n);
         }
         LOCAL_HIP(hipMemset(size.p, 0, sizeof(int32_t) * *n));
         std::vector<long long> hp(2 * NBLK, -1);
         if (red.live()) {
-            k_cc_sizes<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n, size.as<int32_t>());
+            k_cc_sizes<<<dim3(NBLK), dim3(TPB)>>>(parent.as<int32_t>(), *n, size.as<int32_t>());
             k_cc_best<<<dim3(NBLK), dim3(TPB)>>>(size.as<int32_t>(), *n, part.as<long long>());
         }
         LOCAL_HIP(hipMemcpy(hp.data(), part.p, sizeof(long long) * 2 * NBLK, hipMemcpyDeviceToHost));

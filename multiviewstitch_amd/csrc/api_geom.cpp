@@ -18,10 +18,10 @@ int need_device() {
 }
 bool cam_ok(const mvs_camera* c) { return c && c->w > 0 && c->h > 0 && (int64_t)c->w * c->h < 0x7ffffff0LL; }
 
-struct DevBuf {               // RAII device scratch
+struct DevBuf {               // RAII device scratch from the pool (scratch.cpp; these entries launch on the legacy default stream and end in a blocking copy)
     void* p = nullptr;
-    int alloc(size_t bytes) { return mvs_check_hip(hipMalloc(&p, bytes ? bytes : 1), "hipMalloc"); }
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { return mvs_scratch_alloc(&p, bytes ? bytes : 1); }
+    ~DevBuf() { mvs_scratch_free(p); }
     template <class T> T* as() { return (T*)p; }
 };
 

@@ -146,14 +146,15 @@ int depth_to_model_dev(const float* dsp_dev, const mvs_camera* cam, double mn, d
     const int w = cam->w, h = cam->h, n = w * h;
     const double thr = (double)(float)(smooth * (mx - mn) / 100);        // `float threshold`, Depth2Model.cpp:45
     int32_t *flag = nullptr, *vstart = nullptr, *fcnt = nullptr, *fstart = nullptr;
-    HIPCHK(hipMalloc(&flag, sizeof(int32_t) * (n + 1)));
-    HIPCHK(hipMalloc(&vstart, sizeof(int32_t) * (n + 1)));
-    HIPCHK(hipMalloc(&fcnt, sizeof(int32_t) * (n + 1)));
-    HIPCHK(hipMalloc(&fstart, sizeof(int32_t) * (n + 1)));
+    int32_t* four = nullptr;                                             // one block of the scratch pool (scratch.cpp) for the four tables
+    const size_t stride = ((size_t)n + 1 + 63) / 64 * 64;
+    int rc = mvs_scratch_alloc((void**)&four, sizeof(int32_t) * 4 * stride);
+    if (rc) return rc;
+    flag = four; vstart = four + stride; fcnt = four + 2 * stride; fstart = four + 3 * stride;
     const dim3 g((n + TPB - 1) / TPB), b(TPB);
     k_depth_valid<<<g, b, 0, s>>>(dsp_dev, n, mn, mx, flag);
     k_quad_count<<<g, b, 0, s>>>(dsp_dev, w, h, mn, mx, thr, fcnt);
-    int rc = scan_exclusive_i32(flag, n, vstart, s);
+    rc = scan_exclusive_i32(flag, n, vstart, s);
     if (!rc) rc = scan_exclusive_i32(fcnt, n, fstart, s);
     int32_t tot[2] = {0, 0};
     if (!rc) rc = mvs_check_hip(hipMemcpyAsync(&tot[0], vstart + n, sizeof(int32_t), hipMemcpyDeviceToHost, s), "memcpy");
@@ -166,7 +167,8 @@ int depth_to_model_dev(const float* dsp_dev, const mvs_camera* cam, double mn, d
             rc = mvs_check_hip(hipStreamSynchronize(s), "depth_emit");
         }
     }
-    (void)hipFree(flag); (void)hipFree(vstart); (void)hipFree(fcnt); (void)hipFree(fstart);
+    if (rc) (void)hipStreamSynchronize(s);                               // (the block goes back behind the stream's work)
+    mvs_scratch_free(four);
     return rc;
 }
 

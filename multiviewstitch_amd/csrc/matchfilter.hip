@@ -45,9 +45,9 @@ __global__ void k_ssd(const int32_t* __restrict__ m, int n, const uint8_t* __res
 
 struct Buf {
     void* p = nullptr;
-    ~Buf() { if (p) (void)hipFree(p); }
+    ~Buf() { mvs_scratch_free(p); }            // (pool of scratch.cpp: every user below ends in a synchronisation)
     int alloc(size_t n) {
-        if (hipMalloc(&p, n ? n : 1) != hipSuccess) { mvs_set_error("hipMalloc(%zu) failed", n); return MVS_E_OOM; }
+        if (mvs_scratch_alloc(&p, n ? n : 1) != MVS_OK) { mvs_set_error("hipMalloc(%zu) failed", n); return MVS_E_OOM; }
         return MVS_OK;
     }
     template <class T> T* as() { return (T*)p; }
