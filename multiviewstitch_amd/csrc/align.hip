@@ -21,7 +21,7 @@
 
 int mvs_current_device();
 void knn_grid_build(const double* pts, int n, void* ws, hipStream_t s);
-size_t knn_grid_ws_bytes(int n);
+size_t label_grid_ws_bytes(int V);
 void launch_label_nn(const double* tmpl, int V, const int32_t* tmpl_labels, void* ws, const double* pts, int64_t P,
                      int32_t* out, int32_t* far_list, hipStream_t s);
 
@@ -787,7 +787,7 @@ int apply_masked_dev(double* pts, double* nrm, int64_t n, const int32_t* labels,
 int part_recog_dev(const double* tmpl, const int32_t* tmpl_labels, int64_t V, const double* pts, int64_t P, int32_t* out) {
     Dev ws, far;
     int rc;
-    if ((rc = ws.alloc(knn_grid_ws_bytes((int)V))) || (rc = far.alloc(sizeof(int32_t) * (size_t)(P + 1)))) return rc;
+    if ((rc = ws.alloc(label_grid_ws_bytes((int)V))) || (rc = far.alloc(sizeof(int32_t) * (size_t)(P + 1)))) return rc;
     launch_label_nn(tmpl, (int)V, tmpl_labels, ws.p, pts, P, out, far.as<int32_t>(), nullptr);
     return mvs_check_hip(hipDeviceSynchronize(), "part_recog");
 }

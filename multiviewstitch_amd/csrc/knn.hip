@@ -86,8 +86,11 @@ void launch_knn(const double* pts, int n, int k, int32_t* out, hipStream_t s) {
 namespace {
 
 
+// surf_c > 0 (the label grid of PartRecog): the cell edge from the surface the points lie on — h^2 = surf_c x (area of the
+// bounding box) / n, i.e. about surf_c points per cell the surface crosses whatever the box's proportions (an elongated body in
+// NC cells along its longest axis holds many more) — but never more than NC cells along an axis
 __global__ __launch_bounds__(1024) void k_ng_bbox(const double* __restrict__ pts, int n, int NC, NgGeom* __restrict__ geo,
-                                                  int* __restrict__ counts, int nclear) {
+                                                  int* __restrict__ counts, int nclear, float surf_c = 0.0f) {
     for (int i = threadIdx.x; i < nclear; i += 1024) counts[i] = 0;       // (saves the memset launch; the grid is rebuilt every outer iteration)
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = threadIdx.x; i < n; i += 1024)
@@ -111,7 +114,12 @@ __global__ __launch_bounds__(1024) void k_ng_bbox(const double* __restrict__ pts
         float ext = fmaxf(hi[0] - lo[0], fmaxf(hi[1] - lo[1], hi[2] - lo[2]));
         if (!(ext > 0.f)) ext = 1.f;
         NgGeom g;
-        g.h = ext / (float)NC * 1.0001f; g.inv_h = 1.0f / g.h;
+        g.h = ext / (float)NC * 1.0001f;
+        if (surf_c > 0.0f) {
+            const float a = hi[0] - lo[0], b = hi[1] - lo[1], c = hi[2] - lo[2];
+            g.h = fmaxf(g.h, sqrtf(surf_c * 2.0f * (a * b + b * c + c * a) / (float)n));
+        }
+        g.inv_h = 1.0f / g.h;
         g.minx = lo[0]; g.miny = lo[1]; g.minz = lo[2];
         g.nx = min(NC, (int)floorf((hi[0] - lo[0]) * g.inv_h) + 1);
         g.ny = min(NC, (int)floorf((hi[1] - lo[1]) * g.inv_h) + 1);
@@ -278,9 +286,9 @@ size_t knn_grid_ws_bytes(int n) {
 
 struct NgWs { NgGeom* geo; int* counts; int* start; int* tsum; int* cell_of; float4* sorted; int NC; size_t ncell; };
 static void ng_scan(const NgWs& w, hipStream_t s);
-static NgWs ng_carve(void* ws, int n) {
+static NgWs ng_carve(void* ws, int n, int NC = 0) {
     NgWs w;
-    w.NC = knn_grid_cap(n);
+    w.NC = NC ? NC : knn_grid_cap(n);
     w.ncell = (size_t)w.NC * w.NC * w.NC;
     char* p = (char*)ws;
     w.geo = (NgGeom*)p; p += 64;
@@ -303,9 +311,9 @@ static void ng_scan(const NgWs& w, hipStream_t s) {
     k_ng_scan_apply<<<dim3(ntiles), dim3(1024), 0, s>>>(w.counts, ncell, w.tsum, ntiles, w.start);
 }
 // build the point grid of `pts` in ws (device workspace of knn_grid_ws_bytes(n) bytes): 1 memset + 4 launches
-static void grid_build_ws(const double* pts, int n, const NgWs& w, hipStream_t s) {
-    if (n <= NG1_MAX && w.NC <= NG1_NC) { k_ng_build1<<<dim3(1), dim3(1024), 0, s>>>(pts, n, w.NC, w.geo, w.start, w.sorted); return; }
-    k_ng_bbox<<<dim3(1), dim3(1024), 0, s>>>(pts, n, w.NC, w.geo, w.counts, w.ncell <= 65536 ? (int)w.ncell + 1 : 0);
+static void grid_build_ws(const double* pts, int n, const NgWs& w, hipStream_t s, float surf_c = 0.0f) {
+    if (surf_c == 0.0f && n <= NG1_MAX && w.NC <= NG1_NC) { k_ng_build1<<<dim3(1), dim3(1024), 0, s>>>(pts, n, w.NC, w.geo, w.start, w.sorted); return; }
+    k_ng_bbox<<<dim3(1), dim3(1024), 0, s>>>(pts, n, w.NC, w.geo, w.counts, w.ncell <= 65536 ? (int)w.ncell + 1 : 0, surf_c);
     if (w.ncell > 65536) (void)hipMemsetAsync(w.counts, 0, sizeof(int) * (w.ncell + 1), s);
     k_ng_count<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pts, n, w.geo, w.counts, w.cell_of);
     ng_scan(w, s);
@@ -345,6 +353,12 @@ void launch_knn_grid(const double* pts, int n, int k, int32_t* out, void* ws, hi
 //                         a query whose search is not closed by then is appended to the far list
 //   pass 2 (k_label_far): a wave per far query: the shell walk continued 64 cells at a time, all V vertices only for a
 //                         query far outside the template's box
+// (Round 4 also tried the wave-cooperative form — the box of a wave's 64 queries grown by two cells, its template vertices staged
+//  in LDS once, every lane testing all of them: correct, not faster.  9 K-vertex template: 60-80 % of the waves stage (67-205
+//  vertices), but 20-50 % of their lanes are not closed by the box's faces and walk anyway; 216 K-vertex template: a wave's queries
+//  span ~20 cells, 5 % of the waves stage.  And the thread walk with shells 0 and 1 as ONE 27-cell block whose nine row ranges are
+//  fetched together before any point: 231 -> 292 us on the 216 K-vertex template.  What did pay is the label grid's cell edge from
+//  the SURFACE density (k_ng_bbox, surf_c): the 9 K-vertex elongated template 370 -> 230 us.  EXPERIMENTS r4-17.)
 namespace {
 constexpr int NEAR_SHELLS = 3;
 
@@ -377,7 +391,8 @@ __global__ __launch_bounds__(256) void k_label_nn(const NgGeom* __restrict__ geo
                 }
                 for (; k < B; ++k) take(sorted[k]);
             };
-            const int smax = min(NEAR_SHELLS, max(g.nx, max(g.ny, g.nz)));
+            const int nmax = max(g.nx, max(g.ny, g.nz));
+            const int smax = min(NEAR_SHELLS, nmax);
             open = true;
             for (int s = 0; s <= smax; ++s) {
                 for (int dz = -s; dz <= s; ++dz) {
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(256) void k_label_nn(const NgGeom* __restrict__ geo
                     }
                 }
                 const float bound = ((float)s + m - 0.01f) * g.h;
-                if ((bound > 0.0f && best <= bound * bound) || s >= max(g.nx, max(g.ny, g.nz))) { open = false; break; }
+                if ((bound > 0.0f && best <= bound * bound) || s >= nmax) { open = false; break; }
             }
         }
         if (!open) out[i] = labels[arg];
@@ -475,14 +490,23 @@ __global__ __launch_bounds__(256) void k_label_far(const NgGeom* __restrict__ ge
 }
 }  // namespace
 
-// far_list: P + 1 int32 on the device (scratch)
+// the label grid: cells per axis at most (3x the node grid's rule: the cell edge comes from the surface density, k_ng_bbox)
+int label_grid_cap(int V) {
+    const int nc = (int)(3.0f * sqrtf((float)V / 8.0f) + 0.5f);
+    return nc < 8 ? 8 : (nc > 128 ? 128 : nc);
+}
+size_t label_grid_ws_bytes(int V) {
+    const size_t nc = (size_t)label_grid_cap(V), ncell = nc * nc * nc;
+    return 64 + sizeof(int) * ((ncell + 1 + 3) / 4 * 4) * 2 + sizeof(int) * 1028 + sizeof(int) * (size_t)V + sizeof(float4) * (size_t)V + 64;
+}
+// ws: label_grid_ws_bytes(V); far_list: P + 1 int32 on the device (scratch)
 void launch_label_nn(const double* tmpl, int V, const int32_t* tmpl_labels, void* ws, const double* pts, int64_t P,
                      int32_t* out, int32_t* far_list, hipStream_t s) {
     if (P <= 0) return;
     // the default cell size (~1.3 template vertices per occupied cell) measured best: coarser cells (x4, x16 points
     // per cell) were 2x and 7x slower on 2 M scan points
-    const NgWs w = ng_carve(ws, V);
-    grid_build_ws(tmpl, V, w, s);
+    const NgWs w = ng_carve(ws, V, label_grid_cap(V));
+    grid_build_ws(tmpl, V, w, s, (float)MVS_KNOB("MVS_LABEL_SURF", 1.5, 0.05, 64.0));
     (void)hipMemsetAsync(far_list, 0, sizeof(int32_t), s);
     const unsigned nb = (unsigned)((P + 255) / 256);
     k_label_nn<<<dim3(nb), dim3(256), 0, s>>>(w.geo, w.start, w.sorted, tmpl_labels, pts, P, out, far_list);

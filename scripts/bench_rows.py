@@ -41,8 +41,9 @@ for _ in range(REPS):
 torch.cuda.synchronize()
 rows["k_srt_apply"] = {"bytes": 96 * npnt, "note": "48 B in + 48 B out per point", "points": npnt}
 
-# a10-a15: alignment of a 9 K-vertex labelled template to a 41 K-vertex scan mesh; a14 alone at 2 M scan points
-sc = body_scene(5, 30, 64)
+# a10-a15: alignment of a 9 K-vertex labelled template to a 2.03 M-vertex / 4.05 M-facet scan mesh (the size Processor.cpp:1119-1131
+# hands it; with a 41 K-vertex scan here, round 3's k_label_nn row was the mean of three small and three large calls)
+sc = body_scene(5, 30, 450)
 for _ in range(3):
     alignment.Alignment().Align(sc["src"], sc["s_nrm"], sc["s_labels"], sc["tgt"], sc["t_nrm"], sc["t_faces"], sc["view_ray"], 0.81)
 # a14 at BASELINE config 5's sizes: the scan of config 5 (2.06 M points) against its 216 K-vertex template with 16 sector labels
@@ -54,7 +55,7 @@ big = tp5.cpu().numpy()
 lab5 = PW.sector_labels(sc5.verts, 16)
 for _ in range(3):
     alignment.part_recog(sc5.verts, lab5, big)
-rows["k_label_nn"] = {"bytes": 28 * len(big), "note": f"24 B query + 4 B label per scan point, {len(sc5.verts)} template vertices (their grid stays in L2)", "points": len(big)}
+rows["k_label_nn"] = {"bytes": 28 * len(big), "note": f"24 B query + 4 B label per scan point; mean of three calls against the 9 K-vertex template (~1.9 M queries) and three against the {len(sc5.verts)}-vertex template ({len(big)} queries); the template grids stay in L2", "points": len(big)}
 # f3: render the 9 K-vertex template and a 314 K-vertex depth mesh back into a 1280x960 raster
 _, _, _, faces0 = srt_mod.depth_to_model(d[0], cams[0], S.MIN_DSP, S.MAX_DSP, S.SMOOTH)
 mesh_p = p
