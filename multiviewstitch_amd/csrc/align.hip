@@ -366,13 +366,14 @@ __global__ void k_cc_keep(const int32_t* __restrict__ parent, int64_t n, int roo
 }
 
 // masked similarity map p <- M p + t, n <- Rn n (Alignment.cpp:31-34,381-419); identity on the other points
+struct Similarity { double M[9], Rn[9], t[3]; };            // (a kernel argument read at constant offsets only: scalar registers)
 __global__ void k_apply_masked(double* __restrict__ pts, double* __restrict__ nrm, int64_t n, const int32_t* __restrict__ labels,
-                               uint32_t mask, const double* __restrict__ Mt /* M[9], Rn[9], t[3] */) {
+                               uint32_t mask, const Similarity S) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !sel(labels, mask, i)) return;
-    const d3 t = mk3(Mt[18], Mt[19], Mt[20]);
-    st3(pts + 3 * i, mulMv(Mt, ld3(pts + 3 * i)) + t);
-    if (nrm) st3(nrm + 3 * i, mulMv(Mt + 9, ld3(nrm + 3 * i)));
+    const d3 t = mk3(S.t[0], S.t[1], S.t[2]);
+    st3(pts + 3 * i, mulMv(S.M, ld3(pts + 3 * i)) + t);
+    if (nrm) st3(nrm + 3 * i, mulMv(S.Rn, ld3(nrm + 3 * i)));
 }
 
 // ------------------------------------------------------------------------------------ host side ----
@@ -774,14 +775,10 @@ int local_core_dev(const double* src, const int32_t* s_labels, int64_t ns, const
 }
 
 int apply_masked_dev(double* pts, double* nrm, int64_t n, const int32_t* labels, uint32_t mask, const double* M, const double* Rn, const double* t) {
-    double h[21];
-    std::memcpy(h, M, 72); std::memcpy(h + 9, Rn, 72); std::memcpy(h + 18, t, 24);
-    Dev d;
-    int rc = d.alloc(sizeof h);
-    if (rc) return rc;
-    HIPCHK(hipMemcpy(d.p, h, sizeof h, hipMemcpyHostToDevice));
-    k_apply_masked<<<blocks(n), dim3(TPB)>>>(pts, nrm, n, labels, mask, d.as<double>());
-    return mvs_check_hip(hipDeviceSynchronize(), "apply_masked");
+    Similarity S;                                            // (no scratch, no copy, no wait: the next stage is ordered behind it on the stream)
+    std::memcpy(S.M, M, 72); std::memcpy(S.Rn, Rn, 72); std::memcpy(S.t, t, 24);
+    k_apply_masked<<<blocks(n), dim3(TPB)>>>(pts, nrm, n, labels, mask, S);
+    return mvs_check_hip(hipGetLastError(), "apply_masked");
 }
 
 int part_recog_dev(const double* tmpl, const int32_t* tmpl_labels, int64_t V, const double* pts, int64_t P, int32_t* out) {

@@ -39,20 +39,44 @@ __global__ void k_bbox(const double* __restrict__ pts, int64_t P, float* __restr
     }
 }
 
+// A scan is written view after view, row after row: neighbours in the array are neighbours in space, and a wave's 64 points fall
+// into a handful of cells in RUNS of consecutive lanes.  One add per run instead of one per point (the first lane of a run adds
+// the run's length; in k_scatter it also fetches the run's first slot, so a run's points land side by side and their stores
+// coalesce).  Points in no order degrade to one add each, as before.
+struct Run { bool head; int len, first; };                // first = the lane the run starts at
+__device__ inline Run wave_run(int c) {
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(c, 1, 64);
+    Run r;
+    r.head = lane == 0 || c != prev;
+    const unsigned long long heads = __ballot(r.head);
+    const unsigned long long above = lane == 63 ? 0ull : heads & ~((2ull << lane) - 1ull);
+    r.len = (above ? __ffsll((long long)above) - 1 : 64) - lane;                       // (meaningful on a head lane)
+    r.first = 63 - __clzll((long long)(heads & ((lane == 63 ? 0ull : (2ull << lane)) - 1ull)));
+    return r;
+}
 __global__ void k_cell_count(const double* __restrict__ pts, int64_t P, GridGeom g, int32_t* __restrict__ counts,
                              int32_t* __restrict__ cell_of_pt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const int c = (int)grid_cell(g, (float)pts[3 * i], (float)pts[3 * i + 1], (float)pts[3 * i + 2]);
-    if (cell_of_pt) cell_of_pt[i] = c;
-    atomicAdd(&counts[c], 1);
+    const int c = i < P ? (int)grid_cell(g, (float)pts[3 * i], (float)pts[3 * i + 1], (float)pts[3 * i + 2]) : -1;   // (no early return: the lanes vote)
+    if (i < P && cell_of_pt) cell_of_pt[i] = c;
+    const Run r = wave_run(c);
+    if (r.head && c >= 0) atomicAdd(&counts[c], r.len);
 }
 
-__global__ void k_count_nonzero(const int32_t* __restrict__ counts, int64_t n, unsigned long long* out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nz = (i < n && counts[i] != 0) ? 1 : 0;
+// (one add per WORKGROUP of a fixed grid: one per wave of a grid as large as the cells was 39 K adds to one word = 78 us)
+__global__ __launch_bounds__(TPB) void k_count_nonzero(const int32_t* __restrict__ counts, int64_t n, unsigned long long* out) {
+    int nz = 0;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) nz += counts[i] != 0 ? 1 : 0;
     const int s = wave_sum_i(nz);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, (unsigned long long)s);
+    __shared__ int sm[TPB / 64];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < TPB / 64; ++w) t += sm[w];
+        if (t) atomicAdd(out, (unsigned long long)t);
+    }
 }
 
 // ---- exclusive scan of int32 counts (3 phases, 1024 elements per block) ----
@@ -107,9 +131,13 @@ __global__ void k_scatter(const double* __restrict__ pts, const double* __restri
                           int32_t* __restrict__ cursor, float4* __restrict__ spos, double* __restrict__ tpos,
                           double* __restrict__ tnrm) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = i < P ? cell_of_pt[i] : -1;
+    const Run r = wave_run(c);
+    int slot = 0;
+    if (r.head && c >= 0) slot = cell_start[c] + atomicAdd(&cursor[c], r.len);
+    slot = __shfl(slot, r.first, 64);
     if (i >= P) return;
-    const int c = cell_of_pt[i];
-    const int64_t d = (int64_t)cell_start[c] + atomicAdd(&cursor[c], 1);
+    const int64_t d = (int64_t)slot + ((threadIdx.x & 63) - r.first);
     const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
     spos[d] = make_float4((float)x, (float)y, (float)z, __int_as_float((int)i));
     tpos[3 * d] = x; tpos[3 * d + 1] = y; tpos[3 * d + 2] = z;
@@ -216,7 +244,7 @@ int grid_build(mvs_deform_s* h, int64_t P, const double* pts_dev, const double* 
         HIPCHK(hipMemsetAsync(d_probe, 0, sizeof(int32_t) * (ncells + 1), s));
         HIPCHK(hipMemsetAsync(d_nz, 0, sizeof(unsigned long long), s));
         k_cell_count<<<dim3((unsigned)((P + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(pts_dev, P, g, d_probe, nullptr);
-        k_count_nonzero<<<dim3((unsigned)((ncells + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(d_probe, ncells, d_nz);
+        k_count_nonzero<<<dim3((unsigned)std::min<int64_t>(1024, (ncells + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(d_probe, ncells, d_nz);
         unsigned long long nz = 0;
         HIPCHK(hipMemcpyAsync(&nz, d_nz, sizeof nz, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
