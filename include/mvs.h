@@ -529,13 +529,18 @@ int mvs_deform_iterate_sharded(mvs_deform_t h, mvs_comm_t c, const mvs_deform_pa
  * BASELINE config 5's per-part deformation graphs (R/PartRecognition/PartRecognition.cpp:50-77 labels, one Deformation per
  * part): every part is an ordinary handle — its own sub-mesh, nodes, target, control block and verdicts — but sixteen small
  * launch chains cost sixteen times the launch overhead.  A group launches every kernel of an outer iteration once for all its
- * handles (grid = workgroups x parts); what a part computes is what its handle computes stepping alone.
+ * handles (grid = workgroups x parts); what a part computes is what its handle computes stepping alone — bit for bit as long as
+ * every solve stops at the same sweep; the partial sums the stop rules read are grouped differently (a group's local step is a
+ * launch of its own), so over hundreds of solves one may stop a sweep apart: a difference at the solve tolerance (cg_tol).
  *   mvs_deform_group_create  : the handles (one device, no duplicates) stay owned by the caller and must outlive the group;
  *   mvs_deform_group_iterate : n_outer outer iterations of every handle, stats[n] per handle (may be NULL).  Returns
  *                              MVS_E_STATE having done nothing when the handles cannot step as a group yet — each must have
  *                              stepped twice on its own (mvs_deform_iterate: the unbounded first passes and the calibration of
  *                              its launch plan) with the overlapping-patch solver, smooth_sweeps = 2, update_normals = 0 —
- *                              mvs_last_error says which condition failed; the caller then steps the handles one by one. */
+ *                              mvs_last_error says which condition failed; the caller then steps the handles one by one.
+ *                              A handle that stops qualifying DURING a call (between two batches of 32 outer iterations: its
+ *                              solves begin to stall, a solve was abandoned) ends the group launches; the rest of the call's
+ *                              outer iterations are stepped handle by handle inside the call (same results, more launches). */
 typedef struct mvs_group_s* mvs_group_t;
 int mvs_deform_group_create(mvs_deform_t* handles, int n, mvs_group_t* out);
 int mvs_deform_group_iterate(mvs_group_t g, const mvs_deform_params* p, int n_outer, mvs_deform_stats* stats /*n, or NULL*/);

@@ -26,6 +26,11 @@ int mvs_test_preload_wait(void);
  *              other workgroup expires and the solve is abandoned — deterministically (-1: none). */
 int mvs_test_tail(mvs_deform_t h, int maxspin, int plan_cap, int skip_wg);
 
+/* mvs_deform_group_iterate re-checks between its batches (32 outer iterations) whether every handle still qualifies for group
+ * launches and otherwise finishes the call handle by handle: this makes THIS handle stop qualifying once it has been harvested
+ * `after_batches` times inside group calls (0: never). */
+int mvs_test_group_leave(mvs_deform_t h, int after_batches);
+
 /* Chebyshev steps every patch ran in the launch of sweep slot `slot` of the handle's last pass (slots are numbered through the
  * pass, solve 0's launches first) -> out[patches].  Equal numbers in every patch = every patch stopped at the same sweep. */
 int mvs_test_sweep_steps(mvs_deform_t h, int slot, int32_t* out);

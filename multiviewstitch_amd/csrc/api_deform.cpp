@@ -1570,6 +1570,14 @@ int mvs_test_tail(mvs_deform_t h, int maxspin, int plan_cap, int skip_wg) {
     return MVS_OK;
 }
 
+// The handle stops qualifying for group launches once it has been harvested `after_batches` times inside group calls (0: never):
+// forces the mid-call hand-over of mvs_deform_group_iterate to handle-by-handle stepping.
+int mvs_test_group_leave(mvs_deform_t h, int after_batches) {
+    if (!h) return MVS_E_INVALID_ARG;
+    h->dbg_group_leave = after_batches > 0 ? after_batches : 0;
+    return MVS_OK;
+}
+
 // Chebyshev steps every patch ran in the launch of sweep slot `slot` of the handle's last pass (slots are numbered through the
 // pass: solve 0's launches first) -> out[NP].  A tail launch that swept k times in the kernel reports k * steps-per-sweep.
 int mvs_test_sweep_steps(mvs_deform_t h, int slot, int32_t* out) {
@@ -1671,6 +1679,7 @@ static int group_member_ok(const mvs_deform_s* h, const mvs_deform_params& p, in
     if (h->grid.P <= 0) return bad("a part has no target points");
     if (h->timing) return bad("a part has timing enabled");
     if (h->saw_abandon) return bad("a part has seen an abandoned solve");
+    if (h->dbg_group_leave > 0 && h->group_batches >= h->dbg_group_leave) return bad("a part was told to leave the group (mvs_test_group_leave)");
     return 1;
 }
 
@@ -1723,7 +1732,15 @@ int mvs_deform_group_iterate(mvs_group_t g, const mvs_deform_params* pp, int n_o
     std::vector<mvs_deform_stats> acc(n);
     std::vector<double> worst(n, 0.0);
     std::vector<int> solves(n, 0), missed(n, 0), esc(n, 0);
-    for (int done = 0; done < n_outer;) {
+    int done = 0;
+    for (; done < n_outer;) {
+        if (done > 0) {
+            // the last harvest may have changed a part's regime (its solves stall: mixing sweeps; an abandoned solve): the group's
+            // launches do not serve those — the rest of this call is then stepped handle by handle, below
+            bool ok = true;
+            for (mvs_deform_s* h : g->h) { update_mix_state(h, p.arap_iters); if (!group_member_ok(h, p, nn, &why)) ok = false; }
+            if (!ok) break;
+        }
         const int batch = std::min(n_outer - done, MAX_BATCH);
         // ---- the parts' records (the coefficient sets and the plans move at every harvest) and the launch dimensions
         GroupDims d{};
@@ -1810,8 +1827,20 @@ int mvs_deform_group_iterate(mvs_group_t g, const mvs_deform_params* pp, int n_o
             worst[k] = std::max(worst[k], st.worst_rel_residual_in_batch);
             solves[k] += st.solves_in_batch; missed[k] += st.unconverged_solves; esc[k] |= st.escalated;
             acc[k] = st;
+            g->h[k]->group_batches++;
         }
         done += batch;
+    }
+    if (done < n_outer) {
+        for (int k = 0; k < n; ++k) {
+            mvs_deform_stats st{};
+            rc = mvs_deform_iterate(g->h[k], pp, n_outer - done, &st);
+            if (rc < 0) return rc;
+            if (rc > 0) status = rc;
+            worst[k] = std::max(worst[k], st.worst_rel_residual_in_batch);
+            solves[k] += st.solves_in_batch; missed[k] += st.unconverged_solves; esc[k] |= st.escalated;
+            acc[k] = st;
+        }
     }
     for (int k = 0; k < n; ++k) {
         mvs_deform_stats& st = acc[k];

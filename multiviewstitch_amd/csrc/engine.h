@@ -264,6 +264,8 @@ struct mvs_deform_s {
     int dbg_maxspin = 0;            // polls a workgroup waits at the tail loop's barrier before it abandons the solve (0: default)
     int dbg_plan_cap = 0;           // at most this many launches per solve, the rest of its sweeps run inside the last one (0: no cap)
     int dbg_skip_wg = -1;           // the workgroup that never arrives at the tail loop's barrier (-1: none)
+    int dbg_group_leave = 0;        // mvs_test_group_leave: the handle stops qualifying for group launches after this many harvests in a group (0: never)
+    int group_batches = 0;          // harvests of this handle inside group calls
     ChebCoef* d_cheb = nullptr;     // [2] the planned and the strong coefficient set of the sweeps, as last uploaded (launch_ras_sweep)
     ChebCoef h_cheb[2];             // ... their host side (the source of the asynchronous upload)
     double cheb_a_dev = -1.0; int cheb_m_dev = 0, cheb_m2_dev = 0;

@@ -218,3 +218,49 @@ def test_group_launches_give_the_bits_of_the_separate_handles(oracle):
     so = o.iterate(oracle.Params.default(), 8)
     assert so["n_valid"] == hb[-1][k]["n_valid"] and so["arap_iters_run"] == hb[-1][k]["arap_iters_run"]
     assert rms(vb[vid], o.vertices()) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_group_call_hands_over_when_a_part_stops_qualifying():
+    """mvs_deform_group_iterate re-checks between its batches (32 outer iterations) whether every handle still qualifies for group
+    launches — a part whose solves begin to stall needs the mixing sweeps, an abandoned solve the safe local step — and otherwise
+    finishes the call handle by handle.  Forced with mvs_test_group_leave on one part: 34 outer iterations in ONE call = 32 as a
+    group + 2 alone against 34 alone: every solve judged below cg_tol, the integers equal, the vertices equal to the solve tolerance
+    (a group's local step is a launch of its own, whose partial sums of |b| and of the energy are grouped differently from the fused
+    launch of a handle alone: over hundreds of solves one of them stops a sweep apart — 6 outer iterations are bit-equal, see above)."""
+    import torch
+    import bench
+    from multiviewstitch_amd import _lib, alignment, srt as srt_mod
+    if _lib.device_count() == 0:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box")
+    dev = torch.device("cuda", 0)
+    sc = S.make_scene(3, device=dev)
+    tp, tn = bench.build_target(torch, srt_mod, S, sc, range(8), dev)
+    tp, tn = tp.cpu().numpy(), tn.cpu().numpy()
+    labels = PW.sector_labels(sc.verts, 4)
+    tl = alignment.part_recog(sc.verts, labels, tp)
+    out = {}
+    for grouped in (False, True):
+        pd = PW.PartwiseDeformation(sc.verts, sc.normals, sc.faces, labels, 4)
+        pd.use_group = grouped
+        pd.group_split = 1
+        pd.UniformSampling(16)
+        pd.set_target(tp, tn, tl)
+        pd.iterate(1); pd.iterate(1)
+        if grouped:
+            _lib.check(_lib.lib().mvs_test_group_leave(pd.live[2][1]._h, 1))
+        st = pd.iterate(34)
+        if grouped:
+            assert pd._group is not None and pd.group_passes == 34, pd.group_declined
+            pd.iterate(1)                                        # the next call: the part does not qualify -> every part alone again
+            assert pd.group_passes == 34 and "leave" in pd.group_declined
+        else:
+            pd.iterate(1)
+        for x in st:
+            assert x["unconverged_solves"] == 0 and x["worst_rel_residual_in_batch"] <= 1e-8, (grouped, x["outer_done"], x["unconverged_solves"], x["worst_rel_residual_in_batch"])
+            assert not grouped or x["outer_done"] == 34, x["outer_done"]            # (enqueue + collect does not count)
+        out[grouped] = (pd.vertices(), [(x["n_valid"], x["arap_iters_run"]) for x in st])
+        pd.close()
+    assert out[False][1] == out[True][1]
+    d = rms(out[False][0], out[True][0])
+    assert d <= 1e-7, d
