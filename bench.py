@@ -95,6 +95,10 @@ def launch_ranks(args) -> int:
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", MVS_BENCH_CHILD="1")
+        # as torch.distributed.run does for its workers: without it every rank's torch / gloo host code spreads over all the
+        # host's cores, N ranks oversubscribe the box's CPU share and a 32 KB gloo all-reduce takes 30-60 ms instead of 0.3
+        # (two ranks on a one-GPU box: 130-170 ms per step against 3.1).  The oracle legs set their own thread count.
+        env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=out0 if r == 0 else subprocess.DEVNULL))
     # wait for all; a rank that dies takes the others down with it (they would wait for it in a collective for ever)

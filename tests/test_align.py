@@ -225,3 +225,24 @@ def test_gpu_align_on_device_arrays_gives_the_bits_of_the_host_entry(al, sizes):
     assert np.array_equal(d["src"], g["src"]) and np.array_equal(d["s_normals"], g["s_normals"]) and np.array_equal(d["ground_ray"], g["ground_ray"])
     with pytest.raises(Exception):
         A.AlignDev(sc["src"], sc["s_nrm"], sc["s_labels"], 0, tn.data_ptr(), n, tf.data_ptr(), f, tl.data_ptr(), sc["view_ray"], 0.81)
+
+
+@pytest.mark.gpu
+def test_scratch_pool_reuse_and_trim(al):
+    """The host-driven entries keep their device scratch for the next call (csrc/scratch.cpp; include/mvs.h: mvs_trim): the same
+    call three times — fresh blocks, reused blocks, blocks allocated again after mvs_trim — gives the same bits, and a smaller
+    request in between is served from (and does not corrupt) the kept blocks."""
+    from multiviewstitch_amd import _lib
+    sc = body_scene(5, 30, 60)
+    A = al.Alignment()
+    first = A.Align(sc["src"], sc["s_nrm"], sc["s_labels"], sc["tgt"], sc["t_nrm"], sc["t_faces"], sc["view_ray"], 0.81)
+    small = body_scene(5, 8, 12)
+    s1 = A.Align(small["src"], small["s_nrm"], small["s_labels"], small["tgt"], small["t_nrm"], small["t_faces"], small["view_ray"], 0.81)
+    again = A.Align(sc["src"], sc["s_nrm"], sc["s_labels"], sc["tgt"], sc["t_nrm"], sc["t_faces"], sc["view_ray"], 0.81)
+    assert _lib.lib().mvs_trim() == 0
+    assert _lib.lib().mvs_trim() == 0                                   # (nothing kept: still fine)
+    third = A.Align(sc["src"], sc["s_nrm"], sc["s_labels"], sc["tgt"], sc["t_nrm"], sc["t_faces"], sc["view_ray"], 0.81)
+    s2 = A.Align(small["src"], small["s_nrm"], small["s_labels"], small["tgt"], small["t_nrm"], small["t_faces"], small["view_ray"], 0.81)
+    for other in (again, third):
+        assert all(np.array_equal(first[k], other[k]) for k in first)
+    assert all(np.array_equal(s1[k], s2[k]) for k in s1)
