@@ -52,7 +52,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cold-process", action="store_true", help="skip the two child processes that time the call of a fresh process (scripts/cold_call.py)")
     ap.add_argument("--only-alt-solver", action="store_true", help="time the CG solver as the main run (profiles of the CG path alone)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "all_gather", "owner"],
-                    help="N > 1: how the ranks' best-8 records meet (auto: owner-merges from 4 ranks on, DESIGN.md §6)")
+                    help="N > 1: how the ranks' best-8 records meet (auto = all_gather at every N, as the C library's MVS_EXCHANGE_AUTO: the "
+                         "owner-merges form has never run on more than one GPU; DESIGN.md §7)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                                                       "the N > 1 code path with several ranks sharing one GPU)")
     ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal without a GPU: every rank joins the process group "
@@ -235,7 +236,7 @@ def main():
         shard = mdist.EngineShard(d, device)
         bufs = shard.buffers(K, world)
         exchange = "all_gather"
-        want = args.exchange if args.exchange != "auto" else ("owner" if world >= 4 else "all_gather")
+        want = args.exchange if args.exchange != "auto" else "all_gather"
         if want == "owner":
             # owner-merges exchange: checked once, before anything is timed, against the all-gather exchange on the
             # same records — identical node targets on this rank, and every rank must agree — else the all-gather form runs
