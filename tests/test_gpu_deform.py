@@ -67,6 +67,33 @@ def test_association_matches_oracle(eng, oracle, config):
         assert ref["valid"].sum() > 0.5 * len(nodes)
 
 
+def test_association_does_not_depend_on_the_order_of_the_target(eng, oracle):
+    """The target grid's histogram and scatter make one add per RUN of consecutive points that fall into one cell (grid.hip,
+    wave_run: a scan is written row after row).  A target in random order has runs of one, a target of fewer points than a wave
+    has idle lanes in its only wave: both must give the association of the scan order — point indices mapped back — and the
+    oracle's on the same arrays."""
+    sc, tp, tn, _ = scene_and_target(1)
+    nodes = oracle.uniform_sampling(sc.verts, 16)
+    rng = np.random.default_rng(11)
+    perm = rng.permutation(len(tp))
+    out = []
+    for P, N in ((tp, tn), (tp[perm], tn[perm]), (tp[:37], tn[:37])):
+        d = eng.Deformation(sc.verts, sc.normals, sc.faces)
+        d.set_nodes(nodes)
+        d.set_target(P, N)
+        d.iterate(1)
+        got = d.node_targets(smoothed=False)
+        ref = oracle.Target(P, N).associate(sc.verts[nodes], sc.normals[nodes], oracle.Params.default())
+        assert np.array_equal(got["d2min"], ref["d2min"]) and counts_match(got["counts"], ref["counts"])
+        assert np.array_equal(got["top_idx"], ref["top_idx"]) and np.array_equal(got["valid"], ref["valid"])
+        out.append(got)
+        d.close()
+    a, b = out[0], out[1]
+    assert np.array_equal(a["d2min"], b["d2min"]) and np.array_equal(a["valid"], b["valid"]) and np.array_equal(a["counts"], b["counts"])
+    back = np.where(b["top_idx"] >= 0, perm[np.maximum(b["top_idx"], 0)], -1)
+    assert np.array_equal(np.sort(back, axis=1), np.sort(a["top_idx"], axis=1))     # (ties in the order key are broken by index: compare as sets)
+
+
 @pytest.mark.parametrize("config", [1, 2])
 def test_bounded_association_and_graph_match_oracle(eng, oracle, config):
     """From the second association of a fit on the search is BOUNDED by the previous pass (assoc.hip: k_assoc_prep / k_assoc_all —
