@@ -10,12 +10,15 @@
 // control flow between stages.  Conventions for the unpinned bits are those of
 // oracle/orc_align.cpp (PCA axis sign, component tie-break, erased label).
 #include "engine.h"
+#include "knobs.h"
 #include "trace.h"
 #include "dev_common.h"
 #include "geom.h"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -261,10 +264,14 @@ __device__ inline int cc_rep(int32_t* parent, int x) {
     }
     return cur;
 }
-__global__ void k_cc_low(const int32_t* __restrict__ faces, int64_t F, int32_t* parent) {
+// (live != NULL: only the facets whose three vertices are live take part — RemoveGround's removal and RetainConnectRegion in one
+//  pass over the ORIGINAL numbering, compacted once: the vertex order, hence "lowest index", is the same before and after)
+__device__ inline bool cc_face_live(const int32_t* __restrict__ live, int a, int b, int c) { return !live || (live[a] && live[b] && live[c]); }
+__global__ void k_cc_low(const int32_t* __restrict__ faces, int64_t F, int32_t* parent, const int32_t* __restrict__ live) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
     const int a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
+    if (!cc_face_live(live, a, b, c)) return;
     const int lo = min(a, min(b, c));
     if (a != lo) atomicMin(&parent[a], lo);
     if (b != lo) atomicMin(&parent[b], lo);
@@ -285,11 +292,12 @@ __global__ void k_cc_roots(int32_t* parent, int64_t n) {
     while (p != x) { x = p; p = cc_load(&parent[x]); }
     parent[i] = x;
 }
-__global__ void k_cc_union(const int32_t* __restrict__ faces, int64_t F, int32_t* parent) {
+__global__ void k_cc_union(const int32_t* __restrict__ faces, int64_t F, int32_t* parent, const int32_t* __restrict__ live) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = f < F;                                    // (no early return: the lanes of a wave vote below)
+    bool in = f < F;                                          // (no early return: the lanes of a wave vote below)
     const int lane = threadIdx.x & 63;
     const int a = in ? faces[3 * f] : 0;
+    if (in && live) in = cc_face_live(live, a, faces[3 * f + 1], faces[3 * f + 2]);
     for (int k = 1; k < 3; ++k) {                            // Merge(f0, f1), Merge(f0, f2)  (Alignment.cpp:623-626)
         int ra = in ? cc_rep(parent, a) : 0, rb = in ? cc_rep(parent, faces[3 * f + k]) : 0;
         bool need = ra != rb;
@@ -315,7 +323,8 @@ __global__ void k_cc_union(const int32_t* __restrict__ faces, int64_t F, int32_t
 // component sizes: size[root] += members.  A mesh has few components (usually ONE holds nearly every vertex), and two million
 // adds to one word — even one per wave — queue up behind each other (341 us); a thread counts the run of equal roots along its
 // grid-stride walk and the wave adds ONE sum per distinct root it ends with: ~2 K adds to the big root.
-__global__ __launch_bounds__(TPB) void k_cc_sizes(const int32_t* __restrict__ parent, int64_t n, int32_t* __restrict__ size) {
+__global__ __launch_bounds__(TPB) void k_cc_sizes(const int32_t* __restrict__ parent, int64_t n, int32_t* __restrict__ size,
+                                                  const int32_t* __restrict__ live) {
     int cur = -1, cnt = 0;
     const int lane = threadIdx.x & 63;
     auto flush = [&](bool want) {                            // the lanes that `want` add (cur, cnt): one add per distinct root of the wave
@@ -332,11 +341,12 @@ __global__ __launch_bounds__(TPB) void k_cc_sizes(const int32_t* __restrict__ pa
     };
     for (int64_t base = (int64_t)blockIdx.x * TPB; base < n; base += (int64_t)NBLK * TPB) {      // (uniform trip count per wave)
         const int64_t i = base + threadIdx.x;
-        const int r = i < n ? parent[i] : cur;
+        const bool counts = i < n && (!live || live[i]);     // (a vertex that is not live belongs to no component)
+        const int r = counts ? parent[i] : cur;
         const bool turn = cnt > 0 && r != cur;               // (the big component's run ends for EVERY thread where the next component starts)
         if (__any(turn)) { flush(turn); if (turn) cnt = 0; }
         cur = r;
-        if (i < n) ++cnt;
+        if (counts) ++cnt;
     }
     flush(cnt > 0);
 }
@@ -360,12 +370,21 @@ __global__ __launch_bounds__(TPB) void k_cc_best(const int32_t* __restrict__ siz
         part[2 * blockIdx.x] = bs; part[2 * blockIdx.x + 1] = br;
     }
 }
-__global__ void k_cc_keep(const int32_t* __restrict__ parent, int64_t n, int root, int32_t* __restrict__ keep) {
+__global__ void k_cc_keep(const int32_t* __restrict__ parent, int64_t n, int root, int32_t* keep, const int32_t* live) {   // (live may BE keep)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keep[i] = parent[i] == root ? 1 : 0;
+    if (i < n) keep[i] = (parent[i] == root && (!live || live[i])) ? 1 : 0;
 }
 
 // masked similarity map p <- M p + t, n <- Rn n (Alignment.cpp:31-34,381-419); identity on the other points
+// the template's two end points along a limb axis and the labels at the far ends of template and scan: 8 doubles, one copy
+__global__ void k_ends(const double* __restrict__ src, const int32_t* __restrict__ s_labels, long long ilo, long long ihi,
+                       const int32_t* __restrict__ t_labels, long long t_ihi, double* __restrict__ out) {
+    const int t = threadIdx.x;
+    if (t < 3) out[t] = src[3 * ilo + t];
+    else if (t < 6) out[t] = src[3 * ihi + t - 3];
+    else if (t == 6) out[6] = (double)s_labels[ihi];
+    else if (t == 7) out[7] = (double)t_labels[t_ihi];
+}
 struct Similarity { double M[9], Rn[9], t[3]; };            // (a kernel argument read at constant offsets only: scalar registers)
 __global__ void k_apply_masked(double* __restrict__ pts, double* __restrict__ nrm, int64_t n, const int32_t* __restrict__ labels,
                                uint32_t mask, const Similarity S) {
@@ -431,9 +450,16 @@ void mv3(const double* M, const double* v, double* o) {
 struct Pca { double bary[3], lo[3], hi[3], axis[3][3], eval[3]; double cnt; uint32_t present; };
 struct Work {                 // per-call reduction scratch (device + pinned-size host mirror)
     Dev part;
-    std::vector<double> h = std::vector<double>((size_t)NBLK * 11, 0.0);   // (sized from the start: a bystander rank reads it without init())
-    int init() { return part.alloc(sizeof(double) * NBLK * 11); }
+    // SLOTS reductions can be in flight before ONE copy brings their partial sums (a blocking copy is ~20 us whatever its size:
+    // Alignment::Align made ~80 of them for 1.3 ms of kernels)
+    static constexpr int SLOTS = 8;
+    static constexpr size_t SLOT = (size_t)NBLK * 11;
+    std::vector<double> h = std::vector<double>(SLOT * SLOTS, 0.0);        // (sized from the start: a bystander rank reads it without init())
+    int init() { return part.alloc(sizeof(double) * SLOT * SLOTS); }
     int fetch(size_t n) { return mvs_check_hip(hipMemcpy(h.data(), part.p, sizeof(double) * n, hipMemcpyDeviceToHost), "memcpy"); }
+    double* dslot(int k) { return part.as<double>() + SLOT * k; }
+    const double* hslot(int k) const { return h.data() + SLOT * k; }
+    int fetch_slots(int n) { return fetch(SLOT * (size_t)n); }
 };
 
 // view-sharded form (mvs_init_alignment_sharded): the caller's all-reduce over the ranks on small host vectors, op 0 = sum, 1 = min.
@@ -470,37 +496,27 @@ struct Reducer {
 #define LOCAL(x) do { if (red.live()) { int rc_ = red.local(x); if (rc_) return rc_; } } while (0)
 #define LOCAL_HIP(x) LOCAL(mvs_check_hip((x), #x))
 
-// PointSetUtils::SetInput + CalcPivots on the selected device points
-int pca_dev(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, Work& w, Pca* out, const Reducer& red = Reducer()) {
-    int rc;
-    if (red.live()) k_moments1<<<dim3(NBLK), dim3(TPB)>>>(pts, n, labels, mask, w.part.as<double>());
-    LOCAL(w.fetch((size_t)NBLK * 11));
-    double cnt = 0, s[3] = {0, 0, 0};
+// host halves of the PCA: the blocks' partial sums folded in block order
+static void pca_fold1(const double* h, Pca* out, double* cnt_, double* s) {
+    double cnt = 0;
     uint32_t present = 0;
+    s[0] = s[1] = s[2] = 0;
     for (int c = 0; c < 3; ++c) { out->lo[c] = INFINITY; out->hi[c] = -INFINITY; }
     for (int b = 0; b < NBLK; ++b) {
-        const double* p = &w.h[(size_t)b * 11];
+        const double* p = &h[(size_t)b * 11];
         cnt += p[0]; s[0] += p[1]; s[1] += p[2]; s[2] += p[3];
         for (int c = 0; c < 3; ++c) { out->lo[c] = std::min(out->lo[c], p[4 + c]); out->hi[c] = std::max(out->hi[c], p[7 + c]); }
         present |= (uint32_t)p[10];
     }
-    if (red.fn) {                                  // counts, sums and the box over ALL ranks (a rank may hold no point: 0 / +-inf)
-        double a[4] = {cnt, s[0], s[1], s[2]};
-        double b[6] = {out->lo[0], out->lo[1], out->lo[2], -out->hi[0], -out->hi[1], -out->hi[2]};
-        if ((rc = red.run(a, 4, 0)) || (rc = red.run(b, 6, 1))) return rc;
-        cnt = a[0]; s[0] = a[1]; s[1] = a[2]; s[2] = a[3];
-        for (int c = 0; c < 3; ++c) { out->lo[c] = b[c]; out->hi[c] = -b[3 + c]; }
-    }
-    out->cnt = cnt; out->present = present;
-    if (cnt < 2) { mvs_set_error("PCA needs at least 2 points (got %.0f)", cnt); return MVS_E_DEGENERATE; }
-    for (int c = 0; c < 3; ++c) out->bary[c] = s[c] / cnt;                    // PointSetUtils.cpp:43-47
-    k_moments2<<<dim3(NBLK), dim3(TPB)>>>(pts, n, labels, mask, out->bary[0], out->bary[1], out->bary[2], w.part.as<double>());
-    LOCAL(w.fetch((size_t)NBLK * 6));
-    double m[6] = {0, 0, 0, 0, 0, 0};
-    for (int b = 0; b < NBLK; ++b) for (int k = 0; k < 6; ++k) m[k] += w.h[(size_t)b * 6 + k];
-    if ((rc = red.run(m, 6, 0))) return rc;
+    *cnt_ = cnt; out->present = present;
+}
+static void pca_fold2(const double* h, double* m) {
+    for (int k = 0; k < 6; ++k) m[k] = 0;
+    for (int b = 0; b < NBLK; ++b) for (int k = 0; k < 6; ++k) m[k] += h[(size_t)b * 6 + k];
+}
+static void pca_finish(double cnt, const double* m, Pca* out) {
     double C[9] = {m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5]};
-    for (int k = 0; k < 9; ++k) C[k] /= (cnt - 1.0);                          // :26
+    for (int k = 0; k < 9; ++k) C[k] /= (cnt - 1.0);                          // PointSetUtils.cpp:26
     double val[3], vec[9];
     eig3(C, val, vec);
     for (int i = 0; i < 3; ++i) {                                             // :36-39, sign convention Appendix A.5
@@ -513,10 +529,72 @@ int pca_dev(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, 
         std::memcpy(out->axis[i], a, sizeof a);
         out->eval[i] = val[2 - i];
     }
+}
+
+// PointSetUtils::SetInput + CalcPivots on the selected device points
+int pca_dev(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, Work& w, Pca* out, const Reducer& red = Reducer()) {
+    int rc;
+    if (red.live()) k_moments1<<<dim3(NBLK), dim3(TPB)>>>(pts, n, labels, mask, w.part.as<double>());
+    LOCAL(w.fetch((size_t)NBLK * 11));
+    double cnt = 0, s[3] = {0, 0, 0};
+    pca_fold1(w.h.data(), out, &cnt, s);
+    if (red.fn) {                                  // counts, sums and the box over ALL ranks (a rank may hold no point: 0 / +-inf)
+        double a[4] = {cnt, s[0], s[1], s[2]};
+        double b[6] = {out->lo[0], out->lo[1], out->lo[2], -out->hi[0], -out->hi[1], -out->hi[2]};
+        if ((rc = red.run(a, 4, 0)) || (rc = red.run(b, 6, 1))) return rc;
+        cnt = a[0]; s[0] = a[1]; s[1] = a[2]; s[2] = a[3];
+        for (int c = 0; c < 3; ++c) { out->lo[c] = b[c]; out->hi[c] = -b[3 + c]; }
+    }
+    out->cnt = cnt;
+    if (cnt < 2) { mvs_set_error("PCA needs at least 2 points (got %.0f)", cnt); return MVS_E_DEGENERATE; }
+    for (int c = 0; c < 3; ++c) out->bary[c] = s[c] / cnt;                    // PointSetUtils.cpp:43-47
+    k_moments2<<<dim3(NBLK), dim3(TPB)>>>(pts, n, labels, mask, out->bary[0], out->bary[1], out->bary[2], w.part.as<double>());
+    LOCAL(w.fetch((size_t)NBLK * 6));
+    double m[6];
+    pca_fold2(w.h.data(), m);
+    if ((rc = red.run(m, 6, 0))) return rc;
+    pca_finish(cnt, m, out);
+    return MVS_OK;
+}
+
+// ... of up to Work::SLOTS selections at once (one rank): all first passes, ONE copy, all second passes, ONE copy.  Every
+// selection's sums are what pca_dev computes for it alone (same kernels, same fold).
+struct PcaItem { const double* pts; int64_t n; const int32_t* labels; uint32_t mask; Pca* out; };
+int pca_batch(const PcaItem* it, int n, Work& w) {
+    if (n < 1 || n > Work::SLOTS) { mvs_set_error("pca_batch of %d", n); return MVS_E_STATE; }
+    int rc;
+    for (int k = 0; k < n; ++k) k_moments1<<<dim3(NBLK), dim3(TPB)>>>(it[k].pts, it[k].n, it[k].labels, it[k].mask, w.dslot(k));
+    if ((rc = w.fetch_slots(n))) return rc;
+    double cnt[Work::SLOTS];
+    for (int k = 0; k < n; ++k) {
+        double s[3];
+        pca_fold1(w.hslot(k), it[k].out, &cnt[k], s);
+        it[k].out->cnt = cnt[k];
+        if (cnt[k] < 2) { mvs_set_error("PCA needs at least 2 points (got %.0f)", cnt[k]); return MVS_E_DEGENERATE; }
+        for (int c = 0; c < 3; ++c) it[k].out->bary[c] = s[c] / cnt[k];
+    }
+    for (int k = 0; k < n; ++k)
+        k_moments2<<<dim3(NBLK), dim3(TPB)>>>(it[k].pts, it[k].n, it[k].labels, it[k].mask, it[k].out->bary[0], it[k].out->bary[1], it[k].out->bary[2], w.dslot(k));
+    if ((rc = w.fetch_slots(n))) return rc;
+    for (int k = 0; k < n; ++k) {
+        double m[6];
+        pca_fold2(w.hslot(k), m);
+        pca_finish(cnt[k], m, it[k].out);
+    }
     return MVS_OK;
 }
 
 struct Range { double lo = DBL_MAX, hi = DBL_MIN; int64_t ilo = -1, ihi = -1; };
+static void range_fold(const double* h, Range* out) {
+    Range r;                                                                   // the loops start from (DBL_MAX, DBL_MIN), Alignment.cpp:281-282
+    for (int b = 0; b < NBLK; ++b) {
+        const double* p = &h[(size_t)b * 4];
+        const int64_t il = (int64_t)p[1], ih = (int64_t)p[3];
+        if (il >= 0 && (p[0] < r.lo || (p[0] == r.lo && r.ilo >= 0 && il < r.ilo))) { r.lo = p[0]; r.ilo = il; }
+        if (ih >= 0 && (p[2] > r.hi || (p[2] == r.hi && r.ihi >= 0 && ih < r.ihi))) { r.hi = p[2]; r.ihi = ih; }
+    }
+    *out = r;
+}
 int range_dev(const double* pts, int64_t n, const int32_t* labels, uint32_t mask, const double* pivot, const double* c,
               double* tout, Work& w, Range* out) {
     const double den = nrm3(pivot) * nrm3(pivot);
@@ -524,14 +602,20 @@ int range_dev(const double* pts, int64_t n, const int32_t* labels, uint32_t mask
                                        w.part.as<double>());
     int rc = w.fetch((size_t)NBLK * 4);
     if (rc) return rc;
-    Range r;                                                                   // the loops start from (DBL_MAX, DBL_MIN), Alignment.cpp:281-282
-    for (int b = 0; b < NBLK; ++b) {
-        const double* p = &w.h[(size_t)b * 4];
-        const int64_t il = (int64_t)p[1], ih = (int64_t)p[3];
-        if (il >= 0 && (p[0] < r.lo || (p[0] == r.lo && r.ilo >= 0 && il < r.ilo))) { r.lo = p[0]; r.ilo = il; }
-        if (ih >= 0 && (p[2] > r.hi || (p[2] == r.hi && r.ihi >= 0 && ih < r.ihi))) { r.hi = p[2]; r.ihi = ih; }
+    range_fold(w.h.data(), out);
+    return MVS_OK;
+}
+struct RangeItem { const double* pts; int64_t n; const int32_t* labels; uint32_t mask; const double* pivot; const double* c; Range* out; };
+int range_batch(const RangeItem* it, int n, Work& w) {
+    if (n < 1 || n > Work::SLOTS) { mvs_set_error("range_batch of %d", n); return MVS_E_STATE; }
+    for (int k = 0; k < n; ++k) {
+        const double den = nrm3(it[k].pivot) * nrm3(it[k].pivot);
+        k_range<<<dim3(NBLK), dim3(TPB)>>>(it[k].pts, it[k].n, it[k].labels, it[k].mask, mk3(it[k].pivot[0], it[k].pivot[1], it[k].pivot[2]),
+                                           mk3(it[k].c[0], it[k].c[1], it[k].c[2]), den, nullptr, w.dslot(k));
     }
-    *out = r;
+    int rc = w.fetch_slots(n);
+    if (rc) return rc;
+    for (int k = 0; k < n; ++k) range_fold(w.hslot(k), it[k].out);
     return MVS_OK;
 }
 
@@ -565,28 +649,31 @@ int compact_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F
 // Alignment::RetainConnectRegion on device arrays.  red.fn != NULL (view-sharded scan, facets never join points of two ranks):
 // the largest component over ALL ranks stays — ties to the lower rank, as the lower vertex index wins in the stitched scan —
 // and every other rank keeps nothing.
-int retain_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F, const Reducer& red = Reducer(), int rank = 0) {
+// live (one rank only; n + 1 int32 on the device, the last one 0): the vertices that exist — the others and their facets take no
+// part and are removed by the same compaction (RemoveGround hands its removal over instead of compacting twice); overwritten.
+int retain_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F, const Reducer& red = Reducer(), int rank = 0, int32_t* live = nullptr) {
     if (*n <= 0 && !red.fn) return MVS_OK;
-    Dev parent, size, keep, part;
+    Dev parent, size, keep_own, part;
     int rc;
     const int64_t n1 = std::max<int64_t>(*n, 1);
     LOCAL(parent.alloc(sizeof(int32_t) * n1));
     LOCAL(size.alloc(sizeof(int32_t) * n1));
-    LOCAL(keep.alloc(sizeof(int32_t) * (n1 + 1)));
+    if (!live) LOCAL(keep_own.alloc(sizeof(int32_t) * (n1 + 1)));
+    int32_t* keep = live ? live : keep_own.as<int32_t>();
     LOCAL(part.alloc(sizeof(long long) * 2 * NBLK));
     long long bs = -1, br = -1;
     if (*n > 0 && red.live()) {
         k_cc_init<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n);
         if (*F > 0) {
-            k_cc_low<<<blocks(*F), dim3(TPB)>>>(faces, *F, parent.as<int32_t>());
+            k_cc_low<<<blocks(*F), dim3(TPB)>>>(faces, *F, parent.as<int32_t>(), live);
             k_cc_flat<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n);
-            k_cc_union<<<blocks(*F), dim3(TPB)>>>(faces, *F, parent.as<int32_t>());
+            k_cc_union<<<blocks(*F), dim3(TPB)>>>(faces, *F, parent.as<int32_t>(), live);
             k_cc_roots<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n);
         }
         LOCAL_HIP(hipMemset(size.p, 0, sizeof(int32_t) * *n));
         std::vector<long long> hp(2 * NBLK, -1);
         if (red.live()) {
-            k_cc_sizes<<<dim3(NBLK), dim3(TPB)>>>(parent.as<int32_t>(), *n, size.as<int32_t>());
+            k_cc_sizes<<<dim3(NBLK), dim3(TPB)>>>(parent.as<int32_t>(), *n, size.as<int32_t>(), live);
             k_cc_best<<<dim3(NBLK), dim3(TPB)>>>(size.as<int32_t>(), *n, part.as<long long>());
         }
         LOCAL_HIP(hipMemcpy(hp.data(), part.p, sizeof(long long) * 2 * NBLK, hipMemcpyDeviceToHost));
@@ -601,9 +688,10 @@ int retain_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int64_t* F,
         if (win != (double)rank) { *n = 0; *F = 0; return red.close(); }
     }
     if (*n > 0) {                                                     // (after the last collective: a local failure is told by close())
-        LOCAL_HIP(hipMemset(keep.p, 0, sizeof(int32_t) * (*n + 1)));
-        if (red.live()) k_cc_keep<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n, (int)br, keep.as<int32_t>());
-        LOCAL(compact_dev(pts, nrm, n, faces, F, keep.as<int32_t>()));
+        if (!live) LOCAL_HIP(hipMemset(keep, 0, sizeof(int32_t) * (*n + 1)));
+        if (bs <= 0) br = -1;                                         // (no live vertex at all: nothing stays)
+        if (red.live()) k_cc_keep<<<blocks(*n), dim3(TPB)>>>(parent.as<int32_t>(), *n, (int)br, keep, live);
+        LOCAL(compact_dev(pts, nrm, n, faces, F, keep));
     }
     return red.close();
 }
@@ -658,10 +746,9 @@ int remove_ground_dev(double* pts, double* nrm, int64_t* n, int32_t* faces, int6
     for (int b = 0; b < NBLK; ++b) maxDist = std::max(maxDist, w.h[b]);
     if (red.fn) { double e = -maxDist; if ((rc = red.run(&e, 1, 1))) return rc; maxDist = -e; }
     LOCAL_HIP(hipMemset(keep.p, 0, sizeof(int32_t) * (n1 + 1)));
-    if (*n > 0 && red.live()) {
-        k_rg_keep<<<blocks(*n), dim3(TPB)>>>(dist.as<double>(), *n, maxDist * 0.28, keep.as<int32_t>());   // :187-193
-        LOCAL(compact_dev(pts, nrm, n, faces, F, keep.as<int32_t>()));                                     // :196-219
-    }
+    if (*n > 0 && red.live()) k_rg_keep<<<blocks(*n), dim3(TPB)>>>(dist.as<double>(), *n, maxDist * 0.28, keep.as<int32_t>());   // :187-193
+    if (!red.fn) return retain_dev(pts, nrm, n, faces, F, red, rank, keep.as<int32_t>());                  // :196-219 + :227 with ONE compaction
+    if (*n > 0 && red.live()) LOCAL(compact_dev(pts, nrm, n, faces, F, keep.as<int32_t>()));               // :196-219
     return retain_dev(pts, nrm, n, faces, F, red, rank);                                                   // :227
 }
 
@@ -669,13 +756,23 @@ int init_alignment_dev(const double* src, int64_t ns, const double* tgt, int64_t
                        Work& w, double* R, double* t, double* scale, const Reducer& red = Reducer()) {
     Pca ps, pt;
     int rc;
-    LOCAL(pca_dev(src, ns, nullptr, 0, w, &ps));
-    if ((rc = pca_dev(tgt, nt, nullptr, 0, w, &pt, red))) return rc;
+    if (!red.fn) {                                 // one rank: template and scan together (two copies instead of four)
+        const PcaItem both[2] = {{src, ns, nullptr, 0, &ps}, {tgt, nt, nullptr, 0, &pt}};
+        if ((rc = pca_batch(both, 2, w))) return rc;
+    } else {
+        LOCAL(pca_dev(src, ns, nullptr, 0, w, &ps));
+        if ((rc = pca_dev(tgt, nt, nullptr, 0, w, &pt, red))) return rc;
+    }
     if (dotp(ground_ray, pt.axis[0]) < 0) for (int c = 0; c < 3; ++c) pt.axis[0][c] = -pt.axis[0][c];   // :255
     if (dotp(view_ray, pt.axis[2]) < 0) for (int c = 0; c < 3; ++c) pt.axis[2][c] = -pt.axis[2][c];     // :256
     Range r1, r2;
-    LOCAL(range_dev(src, ns, nullptr, 0, ps.axis[0], ps.bary, nullptr, w, &r1));
-    LOCAL(range_dev(tgt, nt, nullptr, 0, pt.axis[0], pt.bary, nullptr, w, &r2));
+    if (!red.fn) {
+        const RangeItem both[2] = {{src, ns, nullptr, 0, ps.axis[0], ps.bary, &r1}, {tgt, nt, nullptr, 0, pt.axis[0], pt.bary, &r2}};
+        if ((rc = range_batch(both, 2, w))) return rc;
+    } else {
+        LOCAL(range_dev(src, ns, nullptr, 0, ps.axis[0], ps.bary, nullptr, w, &r1));
+        LOCAL(range_dev(tgt, nt, nullptr, 0, pt.axis[0], pt.bary, nullptr, w, &r2));
+    }
     if (red.fn) {                                  // the scan's extent along its first pivot over all ranks (start values DBL_MAX / DBL_MIN included)
         double e[2] = {r2.lo, -r2.hi};
         if ((rc = red.run(e, 2, 1))) return rc;
@@ -712,12 +809,22 @@ void rotation_between(const double* before, const double* after, double* R) {   
 // limb axis and the label at the far end are reduced over the ranks (the template is replicated).  The far end: the reference's
 // loop keeps the FIRST point of the largest projection (Alignment.cpp:519-523, strict >), i.e. the lowest index of the stitched
 // scan — the lowest rank that reaches the extreme, and within it the lowest index (range_dev's rule).
+// pt_pre (one rank): the scan group's PCA, computed earlier with the other groups' (the scan does not move between them).
 int local_core_dev(const double* src, const int32_t* s_labels, int64_t ns, const double* tgt, const int32_t* t_labels, int64_t nt,
-                   uint32_t group, int label, Work& w, double* R, double* t, double* scale, const Reducer& red = Reducer(), int rank = 0) {
+                   uint32_t group, int label, Work& w, double* R, double* t, double* scale, const Reducer& red = Reducer(), int rank = 0,
+                   const Pca* pt_pre = nullptr) {
     Pca ps, pt;
     int rc;
-    LOCAL(pca_dev(src, ns, s_labels, group, w, &ps));
-    if ((rc = pca_dev(tgt, nt, t_labels, group, w, &pt, red))) return rc;
+    if (!red.fn && pt_pre) {
+        if ((rc = pca_dev(src, ns, s_labels, group, w, &ps))) return rc;
+        pt = *pt_pre;
+    } else if (!red.fn) {
+        const PcaItem both[2] = {{src, ns, s_labels, group, &ps}, {tgt, nt, t_labels, group, &pt}};
+        if ((rc = pca_batch(both, 2, w))) return rc;
+    } else {
+        LOCAL(pca_dev(src, ns, s_labels, group, w, &ps));
+        if ((rc = pca_dev(tgt, nt, t_labels, group, w, &pt, red))) return rc;
+    }
     if (dotp(ps.axis[0], pt.axis[0]) < 0) for (int c = 0; c < 3; ++c) pt.axis[0][c] = -pt.axis[0][c];   // :444-446
     if (red.fn) {                                 // labels present anywhere: OR over the ranks as a MIN of -bit, 16 labels per call
         uint32_t all = 0;
@@ -734,14 +841,26 @@ int local_core_dev(const double* src, const int32_t* s_labels, int64_t ns, const
     if (popc(sset) < popc(tset)) { const uint32_t e = tset & ~sset; tset &= ~(e & (~e + 1u)); }          // :479-488
     else if (popc(sset) > popc(tset)) { const uint32_t e = sset & ~tset; sset &= ~(e & (~e + 1u)); }     // :489-498
     Range r1, r2;
-    LOCAL(range_dev(src, ns, s_labels, sset, ps.axis[0], ps.bary, nullptr, w, &r1));
-    LOCAL(range_dev(tgt, nt, t_labels, tset, pt.axis[0], pt.bary, nullptr, w, &r2));
     int32_t lab1 = 0, lab2 = 0;
     double far2[6] = {0, 0, 0, 0, 0, 0};                                 // the template's two end points (which one is used: below)
-    if (r1.ilo >= 0 && r1.ihi >= 0) {
-        LOCAL_HIP(hipMemcpy(&lab1, s_labels + r1.ihi, sizeof lab1, hipMemcpyDeviceToHost));
-        LOCAL_HIP(hipMemcpy(far2, src + 3 * r1.ilo, 3 * sizeof(double), hipMemcpyDeviceToHost));
-        LOCAL_HIP(hipMemcpy(far2 + 3, src + 3 * r1.ihi, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (!red.fn) {
+        // one rank: both extents with one copy, then the two end points and the two end labels with one more (k_ends)
+        const RangeItem both[2] = {{src, ns, s_labels, sset, ps.axis[0], ps.bary, &r1}, {tgt, nt, t_labels, tset, pt.axis[0], pt.bary, &r2}};
+        if ((rc = range_batch(both, 2, w))) return rc;
+        if (r1.ilo >= 0 && r1.ihi >= 0 && r2.ilo >= 0 && r2.ihi >= 0) {
+            k_ends<<<dim3(1), dim3(64)>>>(src, s_labels, r1.ilo, r1.ihi, t_labels, r2.ihi, w.dslot(0));
+            if ((rc = w.fetch(8))) return rc;
+            std::memcpy(far2, w.h.data(), sizeof far2);
+            lab1 = (int32_t)w.h[6]; lab2 = (int32_t)w.h[7];
+        }
+    } else {
+        LOCAL(range_dev(src, ns, s_labels, sset, ps.axis[0], ps.bary, nullptr, w, &r1));
+        LOCAL(range_dev(tgt, nt, t_labels, tset, pt.axis[0], pt.bary, nullptr, w, &r2));
+        if (r1.ilo >= 0 && r1.ihi >= 0) {
+            LOCAL_HIP(hipMemcpy(&lab1, s_labels + r1.ihi, sizeof lab1, hipMemcpyDeviceToHost));
+            LOCAL_HIP(hipMemcpy(far2, src + 3 * r1.ilo, 3 * sizeof(double), hipMemcpyDeviceToHost));
+            LOCAL_HIP(hipMemcpy(far2 + 3, src + 3 * r1.ihi, 3 * sizeof(double), hipMemcpyDeviceToHost));
+        }
     }
     if (red.fn) {
         // the scan's extent over all ranks, and the label of the point at its far end (the lowest rank that holds it says which)
@@ -761,7 +880,6 @@ int local_core_dev(const double* src, const int32_t* s_labels, int64_t ns, const
     }
     if (r1.ilo < 0 || r1.ihi < 0 || r2.ilo < 0 || r2.ihi < 0) { mvs_set_error("limb group 0x%x has no extent", group); return MVS_E_DEGENERATE; }
     double far[3];
-    if (!red.fn) HIPCHK(hipMemcpy(&lab2, t_labels + r2.ihi, sizeof lab2, hipMemcpyDeviceToHost));
     std::memcpy(far, lab1 != label ? far2 + 3 : far2, sizeof far);                                      // src_[fidx1] + baryCenter1, :535
     if (lab1 != label) { std::swap(r1.lo, r1.hi); std::swap(r1.ilo, r1.ihi); }                          // :513-517
     if (lab2 != label) { std::swap(r2.lo, r2.hi); std::swap(r2.ilo, r2.ihi); }                          // :525-528
@@ -786,7 +904,7 @@ int part_recog_dev(const double* tmpl, const int32_t* tmpl_labels, int64_t V, co
     int rc;
     if ((rc = ws.alloc(label_grid_ws_bytes((int)V))) || (rc = far.alloc(sizeof(int32_t) * (size_t)(P + 1)))) return rc;
     launch_label_nn(tmpl, (int)V, tmpl_labels, ws.p, pts, P, out, far.as<int32_t>(), nullptr);
-    return mvs_check_hip(hipDeviceSynchronize(), "part_recog");
+    return mvs_check_hip(hipGetLastError(), "part_recog");       // (no wait: what follows is ordered behind it on the stream, the scratch goes back to the pool in that order)
 }
 
 int need_device() {
@@ -955,27 +1073,48 @@ static int align_core_dev(double* ds, double* dsn, const int32_t* dsl, int64_t n
     int rc;
     int64_t n = *nt, f = *nf;
     double gr[3], R[9], t[3], scale;
+    // MVS_DEBUG_CG >= 1: the stages' host laps on stderr (each closed by a device synchronisation: they add ~0.1 ms)
+    const bool laps = mvs_debug_level() >= 1;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!laps) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mvs align] %-16s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     if ((rc = remove_ground_dev(dt, dtn, &n, dtf, &f, dist_thres, gr, w))) return rc;                                                  // Alignment.cpp:21
+    lap("remove_ground");
     if (ground_ray) std::memcpy(ground_ray, gr, sizeof gr);
     if ((rc = init_alignment_dev(ds, ns, dt, n, gr, view_ray, w, R, t, &scale))) return rc;                                           // :27
     double M[9];
     for (int k = 0; k < 9; ++k) M[k] = scale * R[k];
     if ((rc = apply_masked_dev(ds, dsn, ns, nullptr, 0, M, R, t))) return rc;                                                         // :31-34
+    lap("init_alignment");
     if ((rc = part_recog_dev(ds, dsl, ns, dt, n, dtl))) return rc;                                                                    // :38-49
-    Pca p1, p2;                                                                                                                       // :56-64 neck centroids
-    if ((rc = pca_dev(ds, ns, dsl, 1u << NECK, w, &p1)) || (rc = pca_dev(dt, n, dtl, 1u << NECK, w, &p2))) return rc;
-    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, off[3] = {p2.bary[0] - p1.bary[0], p2.bary[1] - p1.bary[1], p2.bary[2] - p1.bary[2]};
-    if ((rc = apply_masked_dev(ds, nullptr, ns, nullptr, 0, I, I, off))) return rc;
+    lap("part_recog");
     struct G { uint32_t group, apply; int label; };                                                                                  // :378-419
     const G groups[4] = {{1u << LUA | 1u << LLA | 1u << LH, 1u << LUA | 1u << LLA | 1u << LH, LH},
                          {1u << RUA | 1u << RLA | 1u << RH, 1u << RUA | 1u << RLA | 1u << RH, RH},
                          {1u << LT | 1u << LS, 1u << LT | 1u << LS | 1u << LF, LS},
                          {1u << RT | 1u << RS, 1u << RT | 1u << RS | 1u << RF, RS}};
-    for (const G& g : groups) {
-        if ((rc = local_core_dev(ds, dsl, ns, dt, dtl, n, g.group, g.label, w, R, t, &scale))) return rc;
-        for (int k = 0; k < 9; ++k) M[k] = scale * R[k];
+    // the neck centroids (:56-64) and — the scan does not move any more — the scan side of the four limb groups: six PCAs, two copies
+    Pca p1, p2, ptg[4];
+    {
+        const PcaItem six[6] = {{ds, ns, dsl, 1u << NECK, &p1}, {dt, n, dtl, 1u << NECK, &p2}, {dt, n, dtl, groups[0].group, &ptg[0]},
+                                {dt, n, dtl, groups[1].group, &ptg[1]}, {dt, n, dtl, groups[2].group, &ptg[2]}, {dt, n, dtl, groups[3].group, &ptg[3]}};
+        if ((rc = pca_batch(six, 6, w))) return rc;
+    }
+    lap("six PCAs");
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, off[3] = {p2.bary[0] - p1.bary[0], p2.bary[1] - p1.bary[1], p2.bary[2] - p1.bary[2]};
+    if ((rc = apply_masked_dev(ds, nullptr, ns, nullptr, 0, I, I, off))) return rc;
+    for (int k = 0; k < 4; ++k) {
+        const G& g = groups[k];
+        if ((rc = local_core_dev(ds, dsl, ns, dt, dtl, n, g.group, g.label, w, R, t, &scale, Reducer(), 0, &ptg[k]))) return rc;
+        for (int j = 0; j < 9; ++j) M[j] = scale * R[j];
         if ((rc = apply_masked_dev(ds, dsn, ns, dsl, g.apply, M, R, t))) return rc;
     }
+    lap("4 limb groups");
     *nt = n; *nf = f;
     return MVS_OK;
 }
