@@ -80,8 +80,8 @@ __global__ __launch_bounds__(TPB) void k_check_seq(const float* __restrict__ dsp
 struct Buf {
     void* p = nullptr;
     ~Buf() { mvs_scratch_free(p); }            // (pool of scratch.cpp: every user below ends in a synchronisation)
-    int alloc(size_t n) {
-        if (mvs_scratch_alloc(&p, n ? n : 1) != MVS_OK) { mvs_set_error("hipMalloc(%zu) failed", n); return MVS_E_OOM; }
+    int alloc(size_t n, hipStream_t user = nullptr) {
+        if (mvs_scratch_alloc(&p, n ? n : 1, user) != MVS_OK) { mvs_set_error("hipMalloc(%zu) failed", n); return MVS_E_OOM; }
         return MVS_OK;
     }
     template <class T> T* as() { return (T*)p; }
@@ -113,7 +113,7 @@ int mvs_check_consistency_seq_dev(int32_t n_frames, const float* depths_dev, con
     std::vector<CamDev> hc((size_t)n_frames);
     for (int f = 0; f < n_frames; ++f) hc[f] = make_camdev(cams + f);
     Buf dc;
-    if ((rc = dc.alloc(sizeof(CamDev) * hc.size()))) return rc;
+    if ((rc = dc.alloc(sizeof(CamDev) * hc.size(), s))) return rc;
     HIPCHK(hipMemcpyAsync(dc.p, hc.data(), sizeof(CamDev) * hc.size(), hipMemcpyHostToDevice, s));
     const int npx = cams[0].w * cams[0].h;
     k_check_seq<<<dim3((npx + TPB - 1) / TPB, n_frames), dim3(TPB), 0, s>>>(depths_dev, dc.as<CamDev>(), n_frames, min_dsp, max_dsp, reproj_err, out_dev);

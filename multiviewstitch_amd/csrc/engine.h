@@ -374,7 +374,7 @@ int  ras_local_parts(const mvs_deform_s* h);      // partial sums per reduction 
 int  mvs_device_cus(int device);                  // compute units of a device (mutex-guarded table, one entry per device)
 #define MVS_MAX_DEVICES 64
 // scratch pool of the host-driven entries (scratch.cpp: blocks are kept for the next call; users launch on the legacy default stream)
-int  mvs_scratch_alloc(void** p, size_t bytes);
+int  mvs_scratch_alloc(void** p, size_t bytes, hipStream_t user = nullptr);   // user: the stream the block will be used on, when it is not the legacy default stream
 void mvs_scratch_free(void* p);
 void launch_vertex_normals(const double* pts, const int32_t* faces, const int32_t* vf_ptr, const int32_t* vf,
                            int V, double* out, hipStream_t s);

@@ -148,7 +148,7 @@ int depth_to_model_dev(const float* dsp_dev, const mvs_camera* cam, double mn, d
     int32_t *flag = nullptr, *vstart = nullptr, *fcnt = nullptr, *fstart = nullptr;
     int32_t* four = nullptr;                                             // one block of the scratch pool (scratch.cpp) for the four tables
     const size_t stride = ((size_t)n + 1 + 63) / 64 * 64;
-    int rc = mvs_scratch_alloc((void**)&four, sizeof(int32_t) * 4 * stride);
+    int rc = mvs_scratch_alloc((void**)&four, sizeof(int32_t) * 4 * stride, s);
     if (rc) return rc;
     flag = four; vstart = four + stride; fcnt = four + 2 * stride; fstart = four + 3 * stride;
     const dim3 g((n + TPB - 1) / TPB), b(TPB);

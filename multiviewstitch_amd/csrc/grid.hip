@@ -167,7 +167,7 @@ void scan_exclusive_i32_async(const int32_t* in, int64_t n, int32_t* out, int32_
 int scan_exclusive_i32(const int32_t* in, int64_t n, int32_t* out, hipStream_t s) {
     const int64_t nb = (n + 1 + SCAN_ELEMS - 1) / SCAN_ELEMS;
     int32_t* bsum = nullptr;
-    int rc = mvs_scratch_alloc((void**)&bsum, sizeof(int32_t) * nb);          // (pool of scratch.cpp; handed back behind the synchronisation)
+    int rc = mvs_scratch_alloc((void**)&bsum, sizeof(int32_t) * nb, s);          // (pool of scratch.cpp; handed back behind the synchronisation)
     if (rc) return rc;
     scan_exclusive_i32_async(in, n, out, bsum, s);
     rc = mvs_check_hip(hipStreamSynchronize(s), "scan");

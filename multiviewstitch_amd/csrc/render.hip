@@ -120,8 +120,8 @@ __global__ void k_rd_convert(const uint32_t* __restrict__ zbuf, int w, int h, do
 struct Buf {
     void* p = nullptr;
     ~Buf() { mvs_scratch_free(p); }            // (pool of scratch.cpp: every user below ends in a synchronisation)
-    int alloc(size_t n) {
-        if (mvs_scratch_alloc(&p, n ? n : 1) != MVS_OK) { mvs_set_error("hipMalloc(%zu) failed", n); return MVS_E_OOM; }
+    int alloc(size_t n, hipStream_t user = nullptr) {
+        if (mvs_scratch_alloc(&p, n ? n : 1, user) != MVS_OK) { mvs_set_error("hipMalloc(%zu) failed", n); return MVS_E_OOM; }
         return MVS_OK;
     }
     template <class T> T* as() { return (T*)p; }
@@ -143,7 +143,7 @@ int mvs_render_depth_dev(const double* pts_dev, int64_t V, const int32_t* faces_
     const int npx = cam->w * cam->h;
     Buf win, zb;
     int rc;
-    if ((rc = win.alloc(sizeof(float4) * (size_t)V)) || (rc = zb.alloc(sizeof(uint32_t) * (size_t)npx))) return rc;
+    if ((rc = win.alloc(sizeof(float4) * (size_t)V, s)) || (rc = zb.alloc(sizeof(uint32_t) * (size_t)npx, s))) return rc;
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)zb.p, 0x3f800000, (size_t)npx, s));           // glClearDepth(1.0f)
     k_rd_project<<<dim3((unsigned)((V + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(pts_dev, V, g, win.as<float4>());
     if (F) k_rd_raster<<<dim3((unsigned)((F + TPB - 1) / TPB)), dim3(TPB), 0, s>>>(win.as<float4>(), faces_dev, F, cam->w, cam->h, zb.as<uint32_t>());

@@ -2,9 +2,11 @@
 // makes ~40 device allocations, and hipFree alone was 4.3 of its 10 ms (rocprofv3 --hip-trace, profiles/r04/align_dev_hip_stats.csv:
 // 115 us per hipFree).  Blocks handed back are kept per device and given to the next request of a similar size.
 //
-// Ordering rule (why a cached block can be handed out at once): every user of this pool launches on the LEGACY default stream of
-// the device and hands a block back only behind its last use in that stream's order (most entries end in a blocking copy anyway),
-// so the next user's work on the block is ordered behind it.  Code on other streams (the deformation handles) has its own arenas.
+// Ordering rule (why a cached block can be handed out at once): a block is handed back either after its work has completed (the
+// entries that take a caller's stream wait for it first) or behind its last use in the order of the LEGACY default stream of the
+// device (Alignment's stages free scratch whose kernels are still queued there).  The next user on the legacy default stream is
+// ordered behind that by the stream itself; a user that names another stream (`user`) gets that stream ordered behind everything
+// the legacy stream has been given so far (one event) before it receives a cached block.  The deformation handles have their own arenas.
 // MVS_SCRATCH_CACHE_MB (default 4096; 0 = no caching) bounds what is kept; mvs_trim() releases it.
 #include <hip/hip_runtime.h>
 
@@ -24,6 +26,7 @@ struct Pool {
     std::unordered_map<void*, Info> out;               // blocks in use
     size_t kept = 0, cap = (size_t)4096 << 20;
     bool cap_read = false;
+    hipEvent_t fence[MVS_MAX_DEVICES] = {};             // "everything the legacy stream has been given" (created on first use)
 };
 Pool& pool() { static Pool* p = new Pool; return *p; }   // (never destroyed: entries may run during process teardown)
 size_t round_up(size_t b) {
@@ -34,7 +37,7 @@ size_t round_up(size_t b) {
 }
 }  // namespace
 
-int mvs_scratch_alloc(void** p, size_t bytes) {
+int mvs_scratch_alloc(void** p, size_t bytes, hipStream_t user) {
     Pool& P = pool();
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
@@ -48,6 +51,11 @@ int mvs_scratch_alloc(void** p, size_t bytes) {
         if (dev >= 0 && dev < MVS_MAX_DEVICES) {
             auto it = P.idle[dev].lower_bound(need);
             if (it != P.idle[dev].end() && it->first <= need + need / 4 + ((size_t)1 << 20)) {
+                if (user) {                                      // (under the lock: one event per device, recorded and waited for in one go)
+                    if (!P.fence[dev]) HIPCHK(hipEventCreateWithFlags(&P.fence[dev], hipEventDisableTiming));
+                    HIPCHK(hipEventRecord(P.fence[dev], nullptr));
+                    HIPCHK(hipStreamWaitEvent(user, P.fence[dev], 0));
+                }
                 *p = it->second;
                 P.out[*p] = {it->first, dev};
                 P.kept -= it->first;

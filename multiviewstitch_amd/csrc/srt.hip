@@ -282,13 +282,13 @@ int srt_ransac_round_batched(const double* m_all, const int64_t* off, int sets, 
 int srt_fit_dev(const double* matches_dev, int64_t n, const mvs_camera* c1, const mvs_camera* c2, int mode,
                 const int32_t* triples_dev, int iters, double* out_dev, hipStream_t s) {
     double *stats = nullptr, *hyp = nullptr;
-    int rc0 = mvs_scratch_alloc((void**)&stats, sizeof(double) * 16);            // (pool of scratch.cpp: the stream is waited for before the blocks go back)
+    int rc0 = mvs_scratch_alloc((void**)&stats, sizeof(double) * 16, s);            // (pool of scratch.cpp: the stream is waited for before the blocks go back)
     if (rc0) return rc0;
     k_srt_stats<<<dim3(1), dim3(256), 0, s>>>(matches_dev, n, stats);
     if (mode == MVS_SRT_CLOSED_FORM) {
         k_srt_closed<<<dim3(1), dim3(64), 0, s>>>(stats, out_dev);
     } else {
-        if ((rc0 = mvs_scratch_alloc((void**)&hyp, sizeof(double) * 13 * (size_t)iters))) { (void)hipStreamSynchronize(s); mvs_scratch_free(stats); return rc0; }
+        if ((rc0 = mvs_scratch_alloc((void**)&hyp, sizeof(double) * 13 * (size_t)iters, s))) { (void)hipStreamSynchronize(s); mvs_scratch_free(stats); return rc0; }
         k_srt_ransac<<<dim3((iters + 63) / 64), dim3(64), 0, s>>>(matches_dev, n, make_camdev(c1), make_camdev(c2), stats,
                                                                  triples_dev, iters, hyp);
         k_srt_pick<<<dim3(1), dim3(64), 0, s>>>(hyp, iters, stats, out_dev);
