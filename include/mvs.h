@@ -266,6 +266,12 @@ int mvs_retain_connect_region(int64_t* V, double* pts, double* normals, int64_t*
  * in place like the reference; ground_ray[3] out. */
 int mvs_remove_ground(int64_t* V, double* pts, double* normals, int64_t* F, int32_t* faces,
                       double dist_thres, double* ground_ray);
+/* The two on DEVICE arrays, trimmed in place — a view's mesh as mvs_depth_to_model_dev leaves it (R/Image3D/Image3D.cpp:87-88
+ * trims every view's mesh), the fused scan (Processor.cpp:1103-1104).  They wait for the device before they start (the arrays
+ * come from some other stream) and return with the arrays final; normals_dev may be NULL; ground_ray is a HOST array. */
+int mvs_retain_connect_region_dev(int64_t* V, double* pts_dev, double* normals_dev, int64_t* F, int32_t* faces_dev);
+int mvs_remove_ground_dev(int64_t* V, double* pts_dev, double* normals_dev, int64_t* F, int32_t* faces_dev,
+                          double dist_thres, double* ground_ray);
 
 /* Alignment::InitAlignment (Alignment.cpp:235-314): src -> tgt similarity from PCA axes and extents. */
 int mvs_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t nt,
@@ -294,6 +300,9 @@ int mvs_remove_ground_sharded(int64_t* V, double* pts, double* normals, int64_t*
 /* PartRecognition::PartRecog (R/PartRecognition/PartRecognition.cpp:50-77): label of the nearest template vertex. */
 int mvs_part_recog(const double* tmpl_pts, const int32_t* tmpl_labels, int64_t V,
                    const double* pts, int64_t P, int32_t* out_labels);
+/* ... with template, labels, queries and result on the device (same waiting rule as above). */
+int mvs_part_recog_dev(const double* tmpl_pts_dev, const int32_t* tmpl_labels_dev, int64_t V,
+                       const double* pts_dev, int64_t P, int32_t* out_labels_dev);
 
 /* Alignment::LocalAlignmentCore (Alignment.cpp:423-546) for one limb group (slabel == tlabel == label). */
 int mvs_local_alignment_core(const double* src, const int32_t* s_labels, int64_t ns,

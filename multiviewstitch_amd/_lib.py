@@ -102,13 +102,16 @@ _SIGS = {
     "mvs_srt_apply_dev": (C.c_int, [_VP, _VP, _I64, _D, _VP, _VP, _I32, _VP, _VP, _VP]),
     "mvs_pca": (C.c_int, [_VP, _I64, _VP, _U32, _VP, _VP, _VP, _VP]),
     "mvs_retain_connect_region": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "mvs_retain_connect_region_dev": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "mvs_remove_ground": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _D, _VP]),
+    "mvs_remove_ground_dev": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _D, _VP]),
     "mvs_init_alignment": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _VP]),
     "mvs_init_alignment_sharded": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "mvs_comm_reduce": (C.c_int, [_VP, _VP, _I32, _I32]),
     "mvs_remove_ground_sharded": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _D, _VP, _VP, _I32, _VP]),
     "mvs_local_alignment_core_sharded": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _I64, _U32, _I32, _VP, _VP, _I32, _VP, _VP, _VP]),
     "mvs_part_recog": (C.c_int, [_VP, _VP, _I64, _VP, _I64, _VP]),
+    "mvs_part_recog_dev": (C.c_int, [_VP, _VP, _I64, _VP, _I64, _VP]),
     "mvs_local_alignment_core": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _I64, _U32, _I32, _VP, _VP, _VP]),
     "mvs_align": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _D, _VP, _VP]),
     "mvs_align_dev": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _D, _VP, _VP]),

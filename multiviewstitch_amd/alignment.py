@@ -139,3 +139,23 @@ class Alignment:
         L.check(L.lib().mvs_align_dev(L.ptr(s), L.ptr(sn), len(s), L.ptr(sl), L.ptr(int(tgt_dev)), L.ptr(int(t_normals_dev)), C.byref(nt),
                                       L.ptr(int(t_facets_dev)), C.byref(nf), L.ptr(v), dist_thres, L.ptr(int(t_labels_dev)), L.ptr(gr)))
         return dict(src=s, s_normals=sn, n_t=nt.value, n_f=nf.value, ground_ray=gr)
+
+    # ---- the stages on device arrays (addresses; trimmed in place): mvs_retain_connect_region_dev / mvs_remove_ground_dev / mvs_part_recog_dev
+    def RetainConnectRegionDev(self, pts_dev: int, normals_dev: int, n_v: int, faces_dev: int, n_f: int):
+        """-> (n_v, n_f) after the trim; normals_dev may be 0."""
+        V, F = C.c_int64(n_v), C.c_int64(n_f)
+        L.check(L.lib().mvs_retain_connect_region_dev(C.byref(V), L.ptr(int(pts_dev)), L.ptr(int(normals_dev)) if normals_dev else None, C.byref(F),
+                                                      L.ptr(int(faces_dev))))
+        return V.value, F.value
+
+    def RemoveGroundDev(self, pts_dev: int, normals_dev: int, n_v: int, faces_dev: int, n_f: int, dist_thres: float = DIST_THRESHOLD):
+        """-> (ground_ray, n_v, n_f) after the trim."""
+        V, F, gr = C.c_int64(n_v), C.c_int64(n_f), np.empty(3)
+        L.check(L.lib().mvs_remove_ground_dev(C.byref(V), L.ptr(int(pts_dev)), L.ptr(int(normals_dev)) if normals_dev else None, C.byref(F),
+                                              L.ptr(int(faces_dev)), dist_thres, L.ptr(gr)))
+        return gr, V.value, F.value
+
+
+def part_recog_dev(tmpl_dev: int, tmpl_labels_dev: int, n_tmpl: int, pts_dev: int, n_pts: int, out_labels_dev: int) -> None:
+    """PartRecog with everything on the device (addresses): labels of the nearest template vertices into out_labels_dev."""
+    L.check(L.lib().mvs_part_recog_dev(L.ptr(int(tmpl_dev)), L.ptr(int(tmpl_labels_dev)), n_tmpl, L.ptr(int(pts_dev)), n_pts, L.ptr(int(out_labels_dev))))

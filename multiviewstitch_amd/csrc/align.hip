@@ -965,6 +965,47 @@ int mvs_remove_ground(int64_t* V, double* pts, double* normals, int64_t* F, int3
     return MVS_OK;
 }
 
+// ... on DEVICE arrays, trimmed in place (the mesh of a view as mvs_depth_to_model_dev leaves it: Image3D.cpp:87-88 trims every
+// view's mesh; the fused scan: Processor.cpp:1103-1104).  The calls wait for the device before they start (the arrays come from
+// some other stream) and return with the arrays final.
+int mvs_retain_connect_region_dev(int64_t* V, double* pts_dev, double* normals_dev, int64_t* F, int32_t* faces_dev) {
+    MVS_TRACE();
+    if (!V || !F || !pts_dev || *V < 0 || *F < 0 || (*F > 0 && !faces_dev)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    int64_t n = *V, f = *F;
+    if ((rc = retain_dev(pts_dev, normals_dev, &n, faces_dev, &f))) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    *V = n; *F = f;
+    return MVS_OK;
+}
+int mvs_remove_ground_dev(int64_t* V, double* pts_dev, double* normals_dev, int64_t* F, int32_t* faces_dev, double dist_thres, double* ground_ray) {
+    MVS_TRACE();
+    if (!V || !F || !pts_dev || !ground_ray || *V < 2 || *F < 0 || (*F > 0 && !faces_dev)) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    Work w;
+    if ((rc = w.init())) return rc;
+    int64_t n = *V, f = *F;
+    if ((rc = remove_ground_dev(pts_dev, normals_dev, &n, faces_dev, &f, dist_thres, ground_ray, w))) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    *V = n; *F = f;
+    return MVS_OK;
+}
+// PartRecog with template, labels, queries and result on the device
+int mvs_part_recog_dev(const double* tmpl_pts_dev, const int32_t* tmpl_labels_dev, int64_t V, const double* pts_dev, int64_t P, int32_t* out_labels_dev) {
+    MVS_TRACE();
+    if (!tmpl_pts_dev || !tmpl_labels_dev || V < 1 || P < 0 || (P > 0 && (!pts_dev || !out_labels_dev)) || V > 0x7ffffff0LL) { mvs_set_error("bad arguments"); return MVS_E_INVALID_ARG; }
+    int rc = need_device();
+    if (rc) return rc;
+    if (P == 0) return MVS_OK;
+    HIPCHK(hipDeviceSynchronize());
+    if ((rc = part_recog_dev(tmpl_pts_dev, tmpl_labels_dev, V, pts_dev, P, out_labels_dev))) return rc;
+    return mvs_check_hip(hipDeviceSynchronize(), "part_recog");
+}
+
 int mvs_init_alignment(const double* src, int64_t ns, const double* tgt, int64_t nt, const double* ground_ray, const double* view_ray,
                        double* R, double* t, double* scale) {
     MVS_TRACE();

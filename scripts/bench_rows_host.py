@@ -73,7 +73,27 @@ for _ in range(REPS):
     A.AlignDev(sc["src"], sc["s_nrm"], sc["s_labels"], dt.data_ptr(), dtn.data_ptr(), Vt, dtf.data_ptr(), Ft, dl.data_ptr(), sc["view_ray"], 0.81)
     ts.append(time.perf_counter() - a)
 row("mvs_align_dev", scan + f", {Vs} template vertices", 1e3 * min(ts), c, "the same with the scan resident in HBM (template up and down only)")
-del dt, dtn, dtf, dl
+# the stages on device arrays
+c_rc, _ = best(lambda: O.retain_connect_region(sc["tgt"], sc["t_nrm"], sc["t_faces"]), 1)
+c_rg, _ = best(lambda: O.remove_ground(sc["tgt"], sc["t_nrm"], sc["t_faces"], 0.81), 1)
+for name, call, cpu in (("mvs_retain_connect_region_dev", lambda: A.RetainConnectRegionDev(dt.data_ptr(), dtn.data_ptr(), Vt, dtf.data_ptr(), Ft), c_rc),
+                        ("mvs_remove_ground_dev", lambda: A.RemoveGroundDev(dt.data_ptr(), dtn.data_ptr(), Vt, dtf.data_ptr(), Ft, 0.81), c_rg)):
+    ts = []
+    for _ in range(REPS):
+        dt.copy_(h[0]); dtn.copy_(h[1]); dtf.copy_(h[2])
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        call()
+        ts.append(time.perf_counter() - a)
+    row(name, scan, 1e3 * min(ts), cpu, "on device arrays, trimmed in place")
+dq = torch.from_numpy(op).to(dv)
+dm, dml = torch.from_numpy(moved).to(dv), torch.from_numpy(np.ascontiguousarray(sc["s_labels"], np.int32)).to(dv)
+dout = torch.empty(len(op), dtype=torch.int32, device=dv)
+torch.cuda.synchronize()
+g, _ = best(lambda: alignment.part_recog_dev(dm.data_ptr(), dml.data_ptr(), Vs, dq.data_ptr(), len(op), dout.data_ptr()))
+c_pr, _ = best(lambda: O.part_recog(moved, sc["s_labels"], op), 1)
+row("mvs_part_recog_dev", f"{len(op)} scan points x {Vs} template vertices", g, c_pr, "template, labels, queries and result on the device")
+del dt, dtn, dtf, dl, dq, dm, dml, dout
 
 # ---------------------------------------------------------------- SRT fit, RANSAC, RemoveOutliers
 sc0 = S.make_scene(1)

@@ -246,3 +246,39 @@ def test_scratch_pool_reuse_and_trim(al):
     for other in (again, third):
         assert all(np.array_equal(first[k], other[k]) for k in first)
     assert all(np.array_equal(s1[k], s2[k]) for k in s1)
+
+
+@pytest.mark.gpu
+def test_gpu_stage_entries_on_device_arrays_give_the_bits_of_the_host_entries(al):
+    """mvs_retain_connect_region_dev / mvs_remove_ground_dev / mvs_part_recog_dev (include/mvs.h): the stages of Alignment on arrays
+    resident in HBM — what a view's mesh is after mvs_depth_to_model_dev (R/Image3D/Image3D.cpp:87-88) — trimmed in place: counts,
+    arrays, ground ray and labels are the BITS of the host-pointer entries (which the tests above check against the oracle)."""
+    import torch
+    sc = body_scene(5, 30, 60)
+    A = al.Alignment()
+    dev = torch.device("cuda", 0)
+
+    def up():
+        return (torch.from_numpy(sc["tgt"]).to(dev), torch.from_numpy(sc["t_nrm"]).to(dev),
+                torch.from_numpy(np.ascontiguousarray(sc["t_faces"], np.int32)).to(dev))
+
+    hp, hn, hf = A.RetainConnectRegion(sc["tgt"], sc["t_nrm"], sc["t_faces"])
+    p, n, f = up()
+    torch.cuda.synchronize()
+    nv, nf = A.RetainConnectRegionDev(p.data_ptr(), n.data_ptr(), len(sc["tgt"]), f.data_ptr(), len(sc["t_faces"]))
+    assert (nv, nf) == (len(hp), len(hf)) and nv < len(sc["tgt"])
+    assert np.array_equal(p[:nv].cpu().numpy(), hp) and np.array_equal(n[:nv].cpu().numpy(), hn) and np.array_equal(f[:nf].cpu().numpy(), hf)
+    hg, hp, hn, hf = A.RemoveGround(sc["tgt"], sc["t_nrm"], sc["t_faces"], 0.81)
+    p, n, f = up()
+    torch.cuda.synchronize()
+    g, nv, nf = A.RemoveGroundDev(p.data_ptr(), n.data_ptr(), len(sc["tgt"]), f.data_ptr(), len(sc["t_faces"]), 0.81)
+    assert (nv, nf) == (len(hp), len(hf)) and np.array_equal(g, hg)
+    assert np.array_equal(p[:nv].cpu().numpy(), hp) and np.array_equal(n[:nv].cpu().numpy(), hn) and np.array_equal(f[:nf].cpu().numpy(), hf)
+    nv2, nf2 = A.RetainConnectRegionDev(p.data_ptr(), 0, nv, f.data_ptr(), nf)         # (no normals; already one component: nothing goes)
+    assert (nv2, nf2) == (nv, nf)
+    hl = al.part_recog(sc["src"], sc["s_labels"], hp)
+    t, tl = torch.from_numpy(sc["src"]).to(dev), torch.from_numpy(np.ascontiguousarray(sc["s_labels"], np.int32)).to(dev)
+    out = torch.full((nv,), -3, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    al.part_recog_dev(t.data_ptr(), tl.data_ptr(), len(sc["src"]), p.data_ptr(), nv, out.data_ptr())
+    assert np.array_equal(out.cpu().numpy(), hl)
