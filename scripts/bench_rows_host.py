@@ -95,6 +95,24 @@ c_pr, _ = best(lambda: O.part_recog(moved, sc["s_labels"], op), 1)
 row("mvs_part_recog_dev", f"{len(op)} scan points x {Vs} template vertices", g, c_pr, "template, labels, queries and result on the device")
 del dt, dtn, dtf, dl, dq, dm, dml, dout
 
+# ---------------------------------------------------------------- the front of the pipeline on device arrays (a2, f2)
+from multiviewstitch_amd import processor
+cams8, d8 = S.make_sequence(8, 1280, 960, 2.0, device=dv)
+raster = torch.from_numpy(np.ascontiguousarray(d8[0])).to(dv)
+npnt, nfac = srt.depth_to_model_dev(raster.data_ptr(), cams8[0], S.MIN_DSP, S.MAX_DSP, S.SMOOTH)
+pp, pn = torch.empty((npnt, 3), dtype=torch.float64, device=dv), torch.empty((npnt, 3), dtype=torch.float64, device=dv)
+torch.cuda.synchronize()
+g, _ = best(lambda: srt.depth_to_model_dev(raster.data_ptr(), cams8[0], S.MIN_DSP, S.MAX_DSP, S.SMOOTH, pp.data_ptr(), pn.data_ptr()), 10)
+c, _ = best(lambda: O.depth_to_model(d8[0], cams8[0], S.MIN_DSP, S.MAX_DSP, S.SMOOTH), 1)
+row("mvs_depth_to_model_dev", f"one 1280 x 960 raster -> {npnt} points + normals ({nfac} facets counted)", g, c, "Depth2Model.cpp:7-81 (count pass + emit pass, one read-back of the two totals)")
+din = torch.from_numpy(d8).to(dv)
+dout8 = torch.empty_like(din)
+torch.cuda.synchronize()
+g, _ = best(lambda: (processor.CheckConsistency(cams8, din.data_ptr(), S.MIN_DSP, S.MAX_DSP, 4, out_dev=dout8.data_ptr()), torch.cuda.synchronize()), 10)
+c, _ = best(lambda: O.check_consistency_seq(d8, cams8, S.MIN_DSP, S.MAX_DSP, 4), 1)
+row("mvs_check_consistency_seq_dev", "8 frames of 1280 x 960", g, c, "Processor.cpp CheckConsistencyCore over a sequence")
+del raster, pp, pn, din, dout8
+
 # ---------------------------------------------------------------- SRT fit, RANSAC, RemoveOutliers
 sc0 = S.make_scene(1)
 s0, R0, t0 = sc0.srt[0]
