@@ -94,17 +94,22 @@ __global__ void k_scan_block_sums(const int32_t* __restrict__ in, int64_t n, int
     if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < TPB / 64; ++w) t += sm[w]; bsum[blockIdx.x] = t; }
 }
 
-__global__ void k_scan_sums_serial(int32_t* bsum, int64_t nb) {
-    // one wave; nb is small (ncells / 1024).  Chunked wave scan.
-    int carry = 0;
-    for (int64_t base = 0; base < nb; base += 64) {
-        const int64_t i = base + threadIdx.x;
-        int v = i < nb ? bsum[i] : 0;
-        int x = v;
-        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if ((int)threadIdx.x >= o) x += y; }
-        if (i < nb) bsum[i] = carry + x - v;
-        carry += __shfl(x, 63, 64);
-    }
+// exclusive scan of the nb block sums in place, ONE workgroup of 1024 threads: a thread owns a contiguous run of ceil(nb / 1024)
+// sums (a wave walking 64 at a time took 13-43 us for the 2-64 K block sums of a target grid or a 2 M-vertex compaction)
+__global__ __launch_bounds__(1024) void k_scan_sums_serial(int32_t* bsum, int64_t nb) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t per = (nb + 1023) / 1024, lo = (int64_t)t * per, hi = lo + per < nb ? lo + per : nb;
+    int sum = 0;
+    for (int64_t i = lo; i < hi; ++i) sum += bsum[i];
+    int x = sum;
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    __shared__ int sm[16];
+    if (lane == 63) sm[wv] = x;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wv; ++w) off += sm[w];
+    int run = off + x - sum;
+    for (int64_t i = lo; i < hi; ++i) { const int v = bsum[i]; bsum[i] = run; run += v; }
 }
 
 __global__ void k_scan_apply(const int32_t* __restrict__ in, int64_t n, const int32_t* __restrict__ bsum,
@@ -159,7 +164,7 @@ __global__ void k_coarse_start(const int32_t* __restrict__ cs, int64_t ncoarse, 
 void scan_exclusive_i32_async(const int32_t* in, int64_t n, int32_t* out, int32_t* bsum, hipStream_t s) {
     const int64_t nb = (n + 1 + SCAN_ELEMS - 1) / SCAN_ELEMS;
     k_scan_block_sums<<<dim3((unsigned)nb), dim3(TPB), 0, s>>>(in, n, bsum);
-    k_scan_sums_serial<<<dim3(1), dim3(64), 0, s>>>(bsum, nb);
+    k_scan_sums_serial<<<dim3(1), dim3(1024), 0, s>>>(bsum, nb);
     k_scan_apply<<<dim3((unsigned)nb), dim3(TPB), 0, s>>>(in, n, bsum, out);
 }
 
