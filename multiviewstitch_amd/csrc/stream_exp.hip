@@ -1,0 +1,152 @@
+// EXPERIMENT (make EXPERIMENTS=1; nothing of this file is in the product build): pass A of the POINT-STREAMING association that
+// VERDICT round 3 proposed — stream the cell-sorted target points once, tile by tile (a tile = one coarse cell = 8 x 8 x 8 fine
+// cells = one contiguous run of `spos`), against the nodes whose temporal search bound reaches the tile, and keep per node the
+// packed key (float bits of d^2 << 32 | point index): the exact nearest point with ties to the lower index in any arrival order.
+//   k_st_bin   : a thread per node: bound from the previous pass (temporal_limit2's formula), the coarse tiles its sphere's box
+//                touches, (tile, node) pairs into fixed-capacity tile lists; a node that touches more than ST_TILES tiles or
+//                meets a full list is left to the node-centric path (counted)
+//   k_st_stream: a workgroup per coarse tile: its nodes staged in LDS, its points streamed 256 at a time (one coalesced float4
+//                each), every lane tests its point against every staged node, wave minimum by DPP-style shuffles, the running
+//                best of node j kept by lane j, ONE atomicMin per (wave, node) at the end
+// scripts/stream_experiment.py compares the keys with the engine's next association and times both kernels.
+#ifdef MVS_EXPERIMENTS
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "../../include/mvs.h"
+#include "engine.h"
+#include "dev_common.h"
+
+namespace {
+constexpr int ST_CAP = 64;        // nodes per tile list (one per lane)
+constexpr int ST_TILES = 27;      // tiles a streamed node may touch
+
+__device__ inline float st_limit2(float prev_d2, const double* prev, const double* cur) {
+    const double dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
+    const double ulp = 4.0 * 1.1920929e-7 * (fabs(cur[0]) + fabs(cur[1]) + fabs(cur[2]));
+    const double r = sqrt((double)prev_d2) + sqrt(dx * dx + dy * dy + dz * dz) + ulp;
+    const double l2 = r * r * 1.001 + 1e-12;
+    return (l2 == l2 && l2 < 3.0e38) ? (float)l2 : INFINITY;
+}
+
+__global__ void k_st_bin(GridDev g, const double* __restrict__ node_pts, const double* __restrict__ prev_pts, const float* __restrict__ prev_d2, int K,
+                         float* __restrict__ lim, int32_t* __restrict__ tile_cnt, int32_t* __restrict__ tile_nodes, int32_t* __restrict__ handled,
+                         int32_t* __restrict__ counters /* [0] left to the node-centric path, [1] (tile, node) pairs */) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float l2 = st_limit2(prev_d2[k], prev_pts + 3 * (int64_t)k, node_pts + 3 * (int64_t)k);
+    lim[k] = l2;
+    handled[k] = 0;
+    if (!(l2 < INFINITY)) { atomicAdd(&counters[0], 1); return; }
+    const float qx = (float)node_pts[3 * (int64_t)k], qy = (float)node_pts[3 * (int64_t)k + 1], qz = (float)node_pts[3 * (int64_t)k + 2];
+    const float r = sqrtf(l2) * 1.0001f, tile = 8.0f * g.h;
+    auto lo = [&](float q, float mn, int n) { return max(0, min(n - 1, (int)floorf((q - r - mn) / tile))); };
+    auto hi = [&](float q, float mn, int n) { return max(0, min(n - 1, (int)floorf((q + r - mn) / tile))); };
+    const int x0 = lo(qx, g.minx, g.NX), x1 = hi(qx, g.minx, g.NX), y0 = lo(qy, g.miny, g.NY), y1 = hi(qy, g.miny, g.NY),
+              z0 = lo(qz, g.minz, g.NZ), z1 = hi(qz, g.minz, g.NZ);
+    if ((x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > ST_TILES) { atomicAdd(&counters[0], 1); return; }
+    bool ok = true;
+    int pairs = 0;
+    for (int z = z0; z <= z1 && ok; ++z)
+        for (int y = y0; y <= y1 && ok; ++y)
+            for (int x = x0; x <= x1 && ok; ++x) {
+                const int t = (z * g.NY + y) * g.NX + x;
+                if (g.coarse_start[t + 1] == g.coarse_start[t]) continue;          // no point in the tile
+                const int slot = atomicAdd(&tile_cnt[t], 1);
+                if (slot < ST_CAP) { tile_nodes[(int64_t)t * ST_CAP + slot] = k; ++pairs; }
+                else ok = false;
+            }
+    if (!ok) { atomicAdd(&counters[0], 1); return; }       // (its pairs stay in the lists: harmless, its key is ignored)
+    handled[k] = 1;
+    atomicAdd(&counters[1], pairs);
+}
+
+__global__ __launch_bounds__(256) void k_st_stream(GridDev g, const double* __restrict__ node_pts, const float* __restrict__ lim,
+                                                   const int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ tile_nodes,
+                                                   unsigned long long* __restrict__ key) {
+    const int t = blockIdx.x;
+    const int n = min(tile_cnt[t], ST_CAP);
+    if (n == 0) return;
+    __shared__ float s_q[ST_CAP][4];
+    __shared__ int s_id[ST_CAP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < n) {
+        const int k = tile_nodes[(int64_t)t * ST_CAP + tid];
+        s_id[tid] = k;
+        s_q[tid][0] = (float)node_pts[3 * (int64_t)k]; s_q[tid][1] = (float)node_pts[3 * (int64_t)k + 1]; s_q[tid][2] = (float)node_pts[3 * (int64_t)k + 2];
+        s_q[tid][3] = lim[k];
+    }
+    __syncthreads();
+    const int p0 = g.coarse_start[t], p1 = g.coarse_start[t + 1];
+    float best = INFINITY;                                   // lane j: the running best of staged node j in THIS wave
+    unsigned bidx = 0xffffffffu;
+    for (int base = p0; base < p1; base += 256) {
+        const int i = base + tid;
+        const bool in = i < p1;
+        const float4 p = in ? g.spos[i] : make_float4(0, 0, 0, 0);
+        const unsigned idx = (unsigned)__float_as_int(p.w);
+        for (int j = 0; j < n; ++j) {
+            float d = in ? d2f(s_q[j][0], s_q[j][1], s_q[j][2], p.x, p.y, p.z) : INFINITY;
+            if (!(d <= s_q[j][3])) d = INFINITY;
+            float m = d;
+            for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+            if (m < INFINITY) {                              // (wave-uniform)
+                unsigned w = d == m ? idx : 0xffffffffu;
+                for (int o = 32; o > 0; o >>= 1) w = min(w, (unsigned)__shfl_xor((int)w, o, 64));
+                if (lane == j && (m < best || (m == best && w < bidx))) { best = m; bidx = w; }
+            }
+        }
+    }
+    if (lane < n && best < INFINITY)
+        atomicMin(&key[s_id[lane]], ((unsigned long long)(unsigned)__float_as_int(best) << 32) | (unsigned long long)bidx);
+}
+}  // namespace
+
+extern "C" int mvs_experiment_stream_dmin(mvs_deform_t h, float* d2min_out, int32_t* idx_out, int32_t* handled_out, int32_t* counters_out,
+                                          double* us_bin, double* us_stream, int reps) {
+    if (!h || !d2min_out || !idx_out || !handled_out || !counters_out || h->K <= 0 || h->grid.P <= 0 || !h->d_near_prev || !h->d_d2min) return MVS_E_STATE;
+    const int K = (int)h->K;
+    const int64_t ntiles = (int64_t)h->grid.NX * h->grid.NY * h->grid.NZ;
+    float* lim = nullptr; int32_t *cnt = nullptr, *lists = nullptr, *handled = nullptr, *counters = nullptr; unsigned long long* key = nullptr;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMalloc(&lim, sizeof(float) * K)); HIPCHK(hipMalloc(&cnt, sizeof(int32_t) * ntiles)); HIPCHK(hipMalloc(&lists, sizeof(int32_t) * ntiles * ST_CAP));
+    HIPCHK(hipMalloc(&handled, sizeof(int32_t) * K)); HIPCHK(hipMalloc(&counters, sizeof(int32_t) * 2)); HIPCHK(hipMalloc(&key, sizeof(unsigned long long) * K));
+    hipEvent_t e0, e1, e2;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
+    double tb = 0, ts = 0;
+    hipStream_t s = h->stream;
+    for (int r = 0; r < reps + 1; ++r) {                     // (the first repetition is not timed)
+        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * ntiles, s));
+        HIPCHK(hipMemsetAsync(counters, 0, sizeof(int32_t) * 2, s));
+        HIPCHK(hipMemsetAsync(key, 0xff, sizeof(unsigned long long) * K, s));
+        HIPCHK(hipEventRecord(e0, s));
+        k_st_bin<<<dim3((K + 255) / 256), dim3(256), 0, s>>>(h->grid, h->d_node_pts, h->d_near_prev, h->d_d2min, K, lim, cnt, lists, handled, counters);
+        HIPCHK(hipEventRecord(e1, s));
+        k_st_stream<<<dim3((unsigned)ntiles), dim3(256), 0, s>>>(h->grid, h->d_node_pts, lim, cnt, lists, key);
+        HIPCHK(hipEventRecord(e2, s));
+        HIPCHK(hipStreamSynchronize(s));
+        float a = 0, b = 0;
+        HIPCHK(hipEventElapsedTime(&a, e0, e1)); HIPCHK(hipEventElapsedTime(&b, e1, e2));
+        if (r > 0) { tb += a; ts += b; }
+    }
+    std::vector<unsigned long long> hk(K);
+    HIPCHK(hipMemcpy(hk.data(), key, sizeof(unsigned long long) * K, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(handled_out, handled, sizeof(int32_t) * K, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(counters_out, counters, sizeof(int32_t) * 2, hipMemcpyDeviceToHost));
+    for (int k = 0; k < K; ++k) {
+        const unsigned hi = (unsigned)(hk[k] >> 32);
+        float f;
+        std::memcpy(&f, &hi, 4);
+        d2min_out[k] = hk[k] == ~0ull ? INFINITY : f;
+        idx_out[k] = hk[k] == ~0ull ? -1 : (int32_t)(hk[k] & 0xffffffffu);
+    }
+    if (us_bin) *us_bin = 1e3 * tb / reps;
+    if (us_stream) *us_stream = 1e3 * ts / reps;
+    (void)hipFree(lim); (void)hipFree(cnt); (void)hipFree(lists); (void)hipFree(handled); (void)hipFree(counters); (void)hipFree(key);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    return MVS_OK;
+}
+#endif
