@@ -63,44 +63,57 @@ __global__ void k_st_bin(GridDev g, const double* __restrict__ node_pts, const d
     atomicAdd(&counters[1], pairs);
 }
 
+// (second version; the first reduced over the wave for every node and every 256 points: 48.6 us, set by the densest tiles)
+// The tile's points are staged in LDS ST_PTS at a time; wave w takes the staged nodes j = w, w + 4, ...: every lane runs over its
+// share of the staged points with a running (distance, index) minimum in registers, ONE wave reduction per node and chunk, the
+// wave's result kept by lane j / 4; one atomicMin per (tile, node) at the end.
+constexpr int ST_PTS = 2048;
+__device__ inline float st_wave_min_f(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64)); return v; }
+__device__ inline unsigned st_wave_min_u(unsigned v) { for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o, 64)); return v; }
 __global__ __launch_bounds__(256) void k_st_stream(GridDev g, const double* __restrict__ node_pts, const float* __restrict__ lim,
                                                    const int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ tile_nodes,
                                                    unsigned long long* __restrict__ key) {
     const int t = blockIdx.x;
     const int n = min(tile_cnt[t], ST_CAP);
     if (n == 0) return;
+    __shared__ float4 s_p[ST_PTS];
     __shared__ float s_q[ST_CAP][4];
     __shared__ int s_id[ST_CAP];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < n) {
         const int k = tile_nodes[(int64_t)t * ST_CAP + tid];
         s_id[tid] = k;
         s_q[tid][0] = (float)node_pts[3 * (int64_t)k]; s_q[tid][1] = (float)node_pts[3 * (int64_t)k + 1]; s_q[tid][2] = (float)node_pts[3 * (int64_t)k + 2];
         s_q[tid][3] = lim[k];
     }
-    __syncthreads();
     const int p0 = g.coarse_start[t], p1 = g.coarse_start[t + 1];
-    float best = INFINITY;                                   // lane j: the running best of staged node j in THIS wave
+    float best = INFINITY;                                   // lane l of wave w: the running best of staged node 4 l + w
     unsigned bidx = 0xffffffffu;
-    for (int base = p0; base < p1; base += 256) {
-        const int i = base + tid;
-        const bool in = i < p1;
-        const float4 p = in ? g.spos[i] : make_float4(0, 0, 0, 0);
-        const unsigned idx = (unsigned)__float_as_int(p.w);
-        for (int j = 0; j < n; ++j) {
-            float d = in ? d2f(s_q[j][0], s_q[j][1], s_q[j][2], p.x, p.y, p.z) : INFINITY;
-            if (!(d <= s_q[j][3])) d = INFINITY;
-            float m = d;
-            for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
-            if (m < INFINITY) {                              // (wave-uniform)
-                unsigned w = d == m ? idx : 0xffffffffu;
-                for (int o = 32; o > 0; o >>= 1) w = min(w, (unsigned)__shfl_xor((int)w, o, 64));
-                if (lane == j && (m < best || (m == best && w < bidx))) { best = m; bidx = w; }
+    for (int base = p0; base < p1; base += ST_PTS) {
+        const int m = min(ST_PTS, p1 - base);
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) s_p[i] = g.spos[base + i];
+        __syncthreads();
+        for (int j = wv; j < n; j += 4) {
+            const float qx = s_q[j][0], qy = s_q[j][1], qz = s_q[j][2], l2 = s_q[j][3];
+            float d = INFINITY;
+            unsigned w = 0xffffffffu;
+            for (int i = lane; i < m; i += 64) {
+                const float4 p = s_p[i];
+                const float e = d2f(qx, qy, qz, p.x, p.y, p.z);
+                const unsigned ix = (unsigned)__float_as_int(p.w);
+                if (e <= l2 && (e < d || (e == d && ix < w))) { d = e; w = ix; }
+            }
+            const float mn = st_wave_min_f(d);
+            if (mn < INFINITY) {                             // (wave-uniform)
+                const unsigned wi = st_wave_min_u(d == mn ? w : 0xffffffffu);
+                if (lane == (j >> 2) && (mn < best || (mn == best && wi < bidx))) { best = mn; bidx = wi; }
             }
         }
     }
-    if (lane < n && best < INFINITY)
-        atomicMin(&key[s_id[lane]], ((unsigned long long)(unsigned)__float_as_int(best) << 32) | (unsigned long long)bidx);
+    const int mine = 4 * lane + wv;
+    if (mine < n && best < INFINITY)
+        atomicMin(&key[s_id[mine]], ((unsigned long long)(unsigned)__float_as_int(best) << 32) | (unsigned long long)bidx);
 }
 }  // namespace
 

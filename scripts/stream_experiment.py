@@ -41,6 +41,7 @@ print(f"streamed nodes: {int(took.sum())} ({100.0 * took.mean():.1f} %), left to
       f"= {counters[1] / max(1, took.sum()):.2f} tiles per streamed node")
 print(f"nearest distances of the streamed nodes equal to the engine's next association: {same_d}"
       + ("" if same_d else f" ({int((d2[took] != got['d2min'][took]).sum())} differ)"))
-print(f"k_st_bin {ub.value:.1f} us + k_st_stream {us.value:.1f} us (+ three memsets) = pass A alone (nearest distance only);")
+print(f"k_st_bin {ub.value:.1f} us + k_st_stream {us.value:.1f} us by HIP events (a pair adds ~4 us; rocprofv3 --kernel-trace --stats of this script has the kernels' own durations) "
+      "+ three memsets = pass A alone (nearest distance only);")
 print("the node-centric launch pair does the WHOLE association (nearest distance, ball members, best 8, node grid, 9-NN graph, cotangent weights): "
       "k_assoc_prep 5.6 us + k_assoc_all 36 us (profiles/r04/rows.md), of which the near nodes' section is 128 workgroups x 7.3 us beside the heavy nodes")
