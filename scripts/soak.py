@@ -9,12 +9,13 @@ from multiviewstitch_amd import deformation, srt as srt_mod, scene as S
 import bench
 
 dev = torch.device("cuda", 0)
-sc = S.make_scene(3, device=dev)
+cfg = next((int(a) for a in sys.argv[1:] if a.isdigit()), 3)         # `scripts/soak.py [config] [cg]`
+sc = S.make_scene(cfg, device=dev)
 d = deformation.Deformation(sc.verts, sc.normals, sc.faces)
-if len(sys.argv) > 1 and sys.argv[1] == "cg":
+if "cg" in sys.argv[1:]:
     d.params.solver = 1          # the one-kernel-per-iteration CG instead of the patch sweeps
 d.UniformSampling(16)
-tp, tn = bench.build_target(torch, srt_mod, S, sc, range(8), dev)
+tp, tn = bench.build_target(torch, srt_mod, S, sc, range(len(sc.cams)), dev)
 d.set_target_dev(tp.data_ptr(), tn.data_ptr(), tp.shape[0], 0)
 worst = 0.0
 reports = []
