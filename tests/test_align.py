@@ -282,3 +282,39 @@ def test_gpu_stage_entries_on_device_arrays_give_the_bits_of_the_host_entries(al
     torch.cuda.synchronize()
     al.part_recog_dev(t.data_ptr(), tl.data_ptr(), len(sc["src"]), p.data_ptr(), nv, out.data_ptr())
     assert np.array_equal(out.cpu().numpy(), hl)
+
+
+@pytest.mark.gpu
+def test_gpu_connected_components_on_odd_meshes_match_oracle(al, oracle):
+    """RetainConnectRegion (R/Alignment/Alignment.cpp:618-654) on meshes the union-find's shortcuts could trip over: no facet at all
+    (every vertex its own component: the lowest index stays), two components of EQUAL size (the one with the lowest vertex stays),
+    a long strip numbered against its adjacency (chains as long as the mesh for the path halving), one fan around a hub (every
+    facet wants the same two roots: the wave-deduplicated swaps), vertices that no facet uses, and PartRecog against a template
+    that lies in a plane (the label grid's cell edge comes from the box AREA) or in one point."""
+    rng = np.random.default_rng(3)
+    A = al.Alignment()
+
+    def check(p, f):
+        n = rng.normal(size=p.shape)
+        gp, gn, gf = A.RetainConnectRegion(p, n, f)
+        op, on, of = oracle.retain_connect_region(p, n, f)
+        assert np.array_equal(gp, op) and np.array_equal(gn, on) and np.array_equal(gf, of)
+        return len(gp)
+
+    pts = rng.normal(size=(300, 3))
+    assert check(pts, np.zeros((0, 3), np.int32)) == 1
+    tri = lambda a: np.stack([a, a + 1, a + 2], 1).astype(np.int32)                       # noqa: E731
+    two = np.concatenate([tri(np.arange(100, 148)), tri(np.arange(10, 58))])              # vertices 100..149 and 10..59: 50 each
+    assert check(pts, two) == 50
+    m = 4000
+    strip_pts = rng.normal(size=(m, 3))
+    perm = rng.permutation(m).astype(np.int32)                                            # a strip whose numbering ignores its adjacency
+    assert check(strip_pts, perm[tri(np.arange(0, m - 2))]) == m
+    hub = np.stack([np.zeros(m - 2, np.int32), np.arange(1, m - 1, dtype=np.int32), np.arange(2, m, dtype=np.int32)], 1)[::-1].copy()
+    assert check(strip_pts, hub) == m
+    assert check(strip_pts, hub[: m // 2]) < m                                            # the upper vertices are used by no facet
+    # PartRecog with a flat and with a one-point template
+    q = rng.normal(size=(5000, 3))
+    for tmpl in (np.concatenate([rng.normal(size=(400, 2)), np.zeros((400, 1))], 1), np.tile(rng.normal(size=(1, 3)), (50, 1))):
+        lab = rng.integers(0, 16, size=len(tmpl)).astype(np.int32)
+        assert np.array_equal(al.part_recog(tmpl, lab, q), oracle.part_recog(tmpl, lab, q))
