@@ -255,7 +255,16 @@ int mvs_select_keyframe_pair(int32_t n1, int32_t n2, const mvs_camera* cams1, co
         el.push_back(std::move(p));
     }
     const uint32_t start = *rand_state;
-    auto advance = [&](uint32_t st, int64_t draws) { for (int64_t d = 0; d < draws; ++d) (void)msvc_rand(&st); return st; };
+    // the state after `draws` calls of rand(): the n-fold composition of x -> 214013 x + 2531011 (mod 2^32) by squaring — the
+    // stream position of (pair, round) used to be WALKED from the start for every pair and round (64 pairs: 11 M steps per call)
+    auto advance = [&](uint32_t st, int64_t draws) {
+        uint32_t a = 214013u, c = 2531011u, A = 1u, Cc = 0u;    // (A, Cc): the map applied so far; (a, c): the map of 2^k steps
+        for (uint64_t n = (uint64_t)draws; n; n >>= 1) {
+            if (n & 1) { A = a * A; Cc = a * Cc + c; }
+            c = a * c + c; a = a * a;
+        }
+        return A * st + Cc;
+    };
     const int64_t per_round = (int64_t)iters * 3;
     // one filter step of RemoveOutliers on the host (:207-258) from the per-match pixel errors of the round
     auto filter = [&](Pair& p, const double* pm) {
