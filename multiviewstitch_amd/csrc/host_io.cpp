@@ -270,13 +270,9 @@ static void obj_line(const char* b, const char* e, int64_t nn_before, bool value
     }
 }
 
-int mvs_obj_read(const char* path, int64_t* n_vertices, int64_t* n_normals, int64_t* n_faces, double* points, double* normals,
-                 int32_t* faces) {
-    MVS_TRACE();
-    if (!path || !n_vertices || !n_normals || !n_faces) { mvs_set_error("mvs_obj_read: null argument"); return MVS_E_INVALID_ARG; }
-    errno = 0;
-    std::string text;
-    if (!read_whole(path, &text)) return io_fail("cannot open", path);
+// the text of an OBJ file -> counts (always) and arrays (those that are not NULL)
+static int obj_parse(const std::string& text, const char* path, int64_t* n_vertices, int64_t* n_normals, int64_t* n_faces, double* points,
+                     double* normals, int32_t* faces) {
     // line-aligned parts; pass 1 counts the lines of each kind per part (and finds the first line of more than 511 characters:
     // getline(line, 512) fails there and the reference's loop ends, PlyObj.cpp:40-41), pass 2 parses every part at its offsets
     const char* T = text.data();
@@ -363,6 +359,16 @@ int mvs_obj_read(const char* path, int64_t* n_vertices, int64_t* n_normals, int6
     for (int t = 0; t < parts; ++t)
         if (bad[t] != (size_t)-1) { errno = 0; return io_fail(bad_kind[t] == 3 ? "bad face line in" : "bad vertex line in", path); }
     return MVS_OK;
+}
+
+int mvs_obj_read(const char* path, int64_t* n_vertices, int64_t* n_normals, int64_t* n_faces, double* points, double* normals,
+                 int32_t* faces) {
+    MVS_TRACE();
+    if (!path || !n_vertices || !n_normals || !n_faces) { mvs_set_error("mvs_obj_read: null argument"); return MVS_E_INVALID_ARG; }
+    errno = 0;
+    std::string text;
+    if (!read_whole(path, &text)) return io_fail("cannot open", path);
+    return obj_parse(text, path, n_vertices, n_normals, n_faces, points, normals, faces);
 }
 
 int mvs_obj_write(const char* path, int64_t n_vertices, const double* points, const double* normals, int64_t n_faces,
@@ -634,14 +640,19 @@ int mvs_processor_deform(const char* model_obj, const char* template_obj, const 
     if (!model_obj || !template_obj || !parts_path || !cam_R || !out_obj) { mvs_set_error("mvs_processor_deform: null argument"); return MVS_E_INVALID_ARG; }
     int rc;
     int64_t nt, ntn, ntf, ns, nsn, nsf;
-    if ((rc = mvs_obj_read(model_obj, &nt, &ntn, &ntf, nullptr, nullptr, nullptr))) return rc;             // Processor.cpp:1121-1123
-    if ((rc = mvs_obj_read(template_obj, &ns, &nsn, &nsf, nullptr, nullptr, nullptr))) return rc;          // :1125-1127
+    errno = 0;
+    std::string model_text, template_text;                       // (each file is read ONCE: counted, then parsed into arrays of that size)
+    if (!read_whole(model_obj, &model_text)) return io_fail("cannot open", model_obj);
+    if (!read_whole(template_obj, &template_text)) return io_fail("cannot open", template_obj);
+    if ((rc = obj_parse(model_text, model_obj, &nt, &ntn, &ntf, nullptr, nullptr, nullptr))) return rc;             // Processor.cpp:1121-1123
+    if ((rc = obj_parse(template_text, template_obj, &ns, &nsn, &nsf, nullptr, nullptr, nullptr))) return rc;       // :1125-1127
     if (ntn != nt || nsn != ns) { mvs_set_error("mvs_processor_deform: both meshes need one normal per vertex (model %lld/%lld, template %lld/%lld)",
                                                 (long long)ntn, (long long)nt, (long long)nsn, (long long)ns); return MVS_E_INVALID_ARG; }
     std::vector<double> tgt((size_t)nt * 3), tnrm((size_t)nt * 3), src((size_t)ns * 3), snrm((size_t)ns * 3);
     std::vector<int32_t> tf((size_t)ntf * 3), sf((size_t)nsf * 3), s_labels((size_t)ns), t_labels((size_t)nt);
-    if ((rc = mvs_obj_read(model_obj, &nt, &ntn, &ntf, tgt.data(), tnrm.data(), tf.data()))) return rc;
-    if ((rc = mvs_obj_read(template_obj, &ns, &nsn, &nsf, src.data(), snrm.data(), sf.data()))) return rc;
+    if ((rc = obj_parse(model_text, model_obj, &nt, &ntn, &ntf, tgt.data(), tnrm.data(), tf.data()))) return rc;
+    if ((rc = obj_parse(template_text, template_obj, &ns, &nsn, &nsf, src.data(), snrm.data(), sf.data()))) return rc;
+    std::string().swap(model_text); std::string().swap(template_text);
     if ((rc = mvs_parts_read(parts_path, ns, s_labels.data()))) return rc;                                  // Alignment.cpp:38-41
     const double view_ray[3] = {cam_R[6], cam_R[7], cam_R[8]};                                             // R.transpose().col(2), :1133
     double ground[3];
