@@ -1981,6 +1981,9 @@ void assoc_all_dims(int K, int cot_blocks, bool graph, int* HB, int* MB, int* NB
     *HB = std::min(K, 256); *MB = 256 / HEAVY_WAVES; *NB = (K + per - 1) / per;
     *GB = graph ? (K + per - 1) / per : 0;
     *CB = cot_blocks * (16 / HEAVY_WAVES);
+    // (half as many workgroups for the weights, each taking twice the row groups: they are latency, not work — 256 x 4.2 us of CUs
+    //  became 128 x ~5 in front of the graph queries, which end the launch; 0.397-0.399 -> 0.394-0.396 ms, A/B on one box)
+    { const int div = (int)MVS_KNOB("MVS_COT_DIV", 2, 1, 16); if (div > 1 && *CB > 0) *CB = std::max(1, *CB / div); }
 }
 // dynamic LDS of k_assoc_all / k_assoc_all_multi: the sections' union, or the cell counters of the node grid's builder
 size_t assoc_all_lds_bytes(int K, bool build) {
