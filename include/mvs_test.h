@@ -26,6 +26,9 @@ int mvs_test_preload_wait(void);
  *              other workgroup expires and the solve is abandoned — deterministically (-1: none). */
 int mvs_test_tail(mvs_deform_t h, int maxspin, int plan_cap, int skip_wg);
 
+/* Geometry of the handle's target grid: out[0..2] = origin, [3] = cell edge, [4..6] = fine cells per axis, [7] = target points. */
+int mvs_test_grid(mvs_deform_t h, double* out /*8*/);
+
 /* mvs_deform_group_iterate re-checks between its batches (32 outer iterations) whether every handle still qualifies for group
  * launches and otherwise finishes the call handle by handle: this makes THIS handle stop qualifying once it has been harvested
  * `after_batches` times inside group calls (0: never). */

@@ -173,6 +173,7 @@ _SIGS = {
     "mvs_test_ctl": (C.c_int, [_VP, _VP, _I32]),
     "mvs_test_tail": (C.c_int, [_VP, _I32, _I32, _I32]),
     "mvs_test_group_leave": (C.c_int, [_VP, _I32]),
+    "mvs_test_grid": (C.c_int, [_VP, _VP]),
     "mvs_test_sweep_steps": (C.c_int, [_VP, _I32, _VP]),
     "mvs_test_heavy_count": (C.c_int, [_VP, _VP, _VP]),
     "mvs_test_mesh_table": (C.c_int, [_VP, _I32, _VP, _VP]),

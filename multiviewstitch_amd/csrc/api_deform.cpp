@@ -1570,6 +1570,14 @@ int mvs_test_tail(mvs_deform_t h, int maxspin, int plan_cap, int skip_wg) {
     return MVS_OK;
 }
 
+// Geometry of the handle's target grid: out[0..2] = origin, [3] = cell edge, [4..6] = fine cells per axis, [7] = target points.
+int mvs_test_grid(mvs_deform_t h, double* out) {
+    if (!h || !out) return MVS_E_INVALID_ARG;
+    out[0] = h->grid.minx; out[1] = h->grid.miny; out[2] = h->grid.minz; out[3] = h->grid.h;
+    out[4] = h->grid.nx; out[5] = h->grid.ny; out[6] = h->grid.nz; out[7] = (double)h->grid.P;
+    return MVS_OK;
+}
+
 // The handle stops qualifying for group launches once it has been harvested `after_batches` times inside group calls (0: never):
 // forces the mid-call hand-over of mvs_deform_group_iterate to handle-by-handle stepping.
 int mvs_test_group_leave(mvs_deform_t h, int after_batches) {
