@@ -365,7 +365,7 @@ constexpr int NEAR_SHELLS = 3;
 __global__ __launch_bounds__(256) void k_label_nn(const NgGeom* __restrict__ geo, const int* __restrict__ cs,
                                                   const float4* __restrict__ sorted, const int32_t* __restrict__ labels,
                                                   const double* __restrict__ pts, int64_t P, int32_t* __restrict__ out,
-                                                  int32_t* __restrict__ far /* [0] = count, [1..] = query ids */) {
+                                                  int32_t* __restrict__ far /* [0] = count, [1..] = query ids */, int near_shells) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool open = false;
     if (i < P) {
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void k_label_nn(const NgGeom* __restrict__ geo
                 for (; k < B; ++k) take(sorted[k]);
             };
             const int nmax = max(g.nx, max(g.ny, g.nz));
-            const int smax = min(NEAR_SHELLS, nmax);
+            const int smax = min(near_shells, nmax);
             open = true;
             for (int s = 0; s <= smax; ++s) {
                 for (int dz = -s; dz <= s; ++dz) {
@@ -509,7 +509,7 @@ void launch_label_nn(const double* tmpl, int V, const int32_t* tmpl_labels, void
     grid_build_ws(tmpl, V, w, s, (float)MVS_KNOB("MVS_LABEL_SURF", 1.5, 0.05, 64.0));
     (void)hipMemsetAsync(far_list, 0, sizeof(int32_t), s);
     const unsigned nb = (unsigned)((P + 255) / 256);
-    k_label_nn<<<dim3(nb), dim3(256), 0, s>>>(w.geo, w.start, w.sorted, tmpl_labels, pts, P, out, far_list);
+    k_label_nn<<<dim3(nb), dim3(256), 0, s>>>(w.geo, w.start, w.sorted, tmpl_labels, pts, P, out, far_list, (int)MVS_KNOB("MVS_LABEL_SHELLS", NEAR_SHELLS, 0, 8));
     k_label_far<<<dim3((unsigned)std::min<int64_t>((P + 3) / 4, 8192)), dim3(256), 0, s>>>(w.geo, w.start, w.sorted, V, tmpl_labels, pts, far_list, out);   // waves stride over the far list
 }
 

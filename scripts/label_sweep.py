@@ -17,6 +17,7 @@ from tests.util import body_scene
 import bench
 
 sc = body_scene(5, 30, 450)
+sc["tgt"] = sc["tgt"][: sc["n_body"]]                      # (as PartRecog sees it: after RemoveGround)
 o = O.init_alignment(sc["src"], sc["tgt"], np.array([0.0, 0.0, -1.0]), sc["view_ray"])
 moved = o[2] * sc["src"] @ o[0].T + o[1]
 for rep in range(3):

@@ -3,11 +3,11 @@
 R=$PWD
 mkdir -p $R/gpurun_out/r04
 cd /tmp && export TMPDIR=/tmp
-for c in "$@"; do
+for c in "$@"; do export MVS_LABEL_SHELLS=$c
   rm -rf /tmp/prof_label
-  MVS_LABEL_SURF=$c rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_label -o lab -- python3 $R/scripts/label_sweep.py > /tmp/label_run.log 2>&1 || { tail -5 /tmp/label_run.log; exit 1; }
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_label -o lab -- python3 $R/scripts/label_sweep.py > /tmp/label_run.log 2>&1 || { tail -5 /tmp/label_run.log; exit 1; }
   f=$(find /tmp/prof_label -name '*kernel_stats.csv' | head -1)
-  echo "== MVS_LABEL_SURF=$c"
+  echo "== MVS_LABEL_SHELLS=$c"
   t=$(find /tmp/prof_label -name '*kernel_trace.csv' | head -1)
   python3 - "$t" <<'PY'
 import csv, sys
