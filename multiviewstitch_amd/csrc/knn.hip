@@ -274,7 +274,8 @@ int knn_grid_cap(int n) {                                   // cells per axis: ~
     // and a query needs fewer shells; 8142 nodes: build 15.5 / 14.0 / 13.6 / 13.2 us, graph queries' launch 49.9 / 47.3 / 47.1 / 47.5 us
     // at n/8, n/12, n/16, n/24
     const float div_small = (float)MVS_KNOB("MVS_NG_DIV", 16.0, 1.0, 256.0);
-    int nc = (int)(sqrtf((float)n / (n <= 1024 * 20 ? div_small : 8.0f)) + 0.5f);
+    const float div_big = (float)MVS_KNOB("MVS_NG_DIV_BIG", 8.0, 1.0, 512.0);
+    int nc = (int)(sqrtf((float)n / (n <= 1024 * 20 ? div_small : div_big)) + 0.5f);
     if (n <= 1024 * 20) nc = nc > 32 ? 32 : nc;             // small sets: the one-launch build keeps its counters in LDS (k_ng_build1)
     return nc < 4 ? 4 : (nc > 128 ? 128 : nc);
 }
