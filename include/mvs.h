@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MVS_ABI_VERSION 4   /* 3: tracing hook, mvs_comm_set_exchange, view-sharded RemoveGround / LocalAlignmentCore; 4: mvs_deform_group_* (additive) */
+#define MVS_ABI_VERSION 4   /* 3: tracing hook, mvs_comm_set_exchange, view-sharded RemoveGround / LocalAlignmentCore; 4: mvs_deform_group_*, mvs_align_dev, mvs_retain_connect_region_dev / mvs_remove_ground_dev / mvs_part_recog_dev, mvs_trim (additive); mvs_local_alignment_core_sharded takes the rank */
 
 enum mvs_status {
     MVS_OK            =  0,
